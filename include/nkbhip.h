@@ -1,0 +1,103 @@
+/* libnkbhip — C ABI of the MI355X (gfx950) hot path behind nkb_classification's
+ * model.get_model() / engine.train_epoch() / losses.get_loss() / utils.get_optimizer().
+ *
+ * The reference (nkb-tech/nkb-classification) has no FFI of its own: every FLOP of its train step is
+ * issued by torch/timm from these Python call sites, which the entry points below replace:
+ *   nkb_classification/engine.py:48      preds = model(img)                 -> conv_gemm / bn_* / pool / im2row
+ *   nkb_classification/engine.py:51      loss = criterion(preds, target)    -> loss_forward
+ *   nkb_classification/engine.py:55-58   scaler.scale(loss).backward()      -> loss_backward / conv_gemm(mode=1) /
+ *                                                                              conv_wgrad / bn_backward / pool bwd
+ *   nkb_classification/engine.py:59      scaler.step(optimizer)             -> optim_step
+ *   nkb_classification/engine.py:62      epoch_logger.log_iter (softmax/argmax, logging.py:268-281) -> loss_forward
+ *   nkb_classification/engine.py:66-71   per-parameter grad.norm()          -> segment_sumsq
+ *   nkb_classification/model.py:41-43,114-116  classifier head(s)           -> conv_gemm (R=S=1) / colsum
+ *
+ * Conventions: all pointers are BORROWED device pointers (never freed or retained); no allocation and
+ * no synchronisation inside any call; kernels are enqueued on the caller's `stream`; every function
+ * returns 0 on success or a non-zero hipError_t-style code, with text in nkb_last_error().
+ * dtype codes: 0 = fp32 (parity mode, exact-fp32 MFMA), 1 = bf16 (fp32 accumulate).
+ * Activations are NHWC (channel-contiguous rows with leading dimension ld*); filters are
+ * [Cout][R][S][Cin] — the physical layout of a torch channels_last weight.
+ */
+#ifndef NKBHIP_H
+#define NKBHIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* nkb_stream_t; /* hipStream_t */
+
+#define NKB_DT_F32 0
+#define NKB_DT_BF16 1
+
+const char* nkb_last_error(void);
+int nkb_version(void);
+
+/* Implicit-GEMM convolution / linear layer on MFMA.
+ * mode 0 (forward):  y[n,p,q,co] = sum_{r,s,ci} x[n, p*stride+r-pad, q*stride+s-pad, ci] * w[co,r,s,ci]
+ * mode 1 (dgrad):    y[n,h,w,co] = sum_{r,s,ci} x[n, (h+pad-r)/stride, (w+pad-s)/stride, ci] * w[co,r,s,ci]
+ *                    (terms with a non-integral source coordinate are skipped; pass the [Cin][R][S][Cout] filter)
+ * Epilogue: + bias[co], + add[m][co], relu, optional fp32 output, optional per-row-tile channel sums
+ * stats[tile][0][co] = sum y, stats[tile][1][co] = sum y^2 (tile count: nkb_conv_gemm_stat_tiles).
+ * Cin must be a multiple of 64 (bf16) / 32 (fp32); stride in {1,2}. */
+int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add, const float* bias,
+                  float* stats, int N, int H, int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int ldadd,
+                  int R, int S, int stride, int pad, int relu, int out_f32, nkb_stream_t stream);
+int nkb_conv_gemm_stat_tiles(int M, int Cout);
+
+/* Weight gradient: dw[co][r][s][ci] += sum_{n,p,q} dy[n,p,q,co] * x[n, p*stride+r-pad, q*stride+s-pad, ci] (fp32 atomics) */
+int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int ldx, int P,
+                   int Q, int Cout, int lddy, int R, int S, int stride, int pad, nkb_stream_t stream);
+
+/* BatchNorm2d (torch semantics: biased var to normalise, unbiased var into running_var, momentum blend). */
+int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
+                    float* shift, float* save_mean, float* save_invstd, nkb_stream_t stream);
+int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, const float* scale, const float* shift,
+                 long long rows, int C, int relu, nkb_stream_t stream);
+int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const float* mean, const float* invstd,
+                    const float* gamma, long long rows, int C, float* dgamma, float* dbeta, void* dx, void* dy_masked,
+                    float* workspace, size_t workspace_floats, nkb_stream_t stream);
+size_t nkb_bn_backward_workspace_floats(long long rows, int C);
+
+/* MaxPool2d(3, 2, 1) and global average pool, forward (backward=0) / backward (backward=1), NHWC. */
+int nkb_maxpool3x3s2(int dtype, int backward, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C,
+                     nkb_stream_t stream);
+int nkb_avgpool(int dtype, int backward, const void* in, void* out, int N, int HW, int C, nkb_stream_t stream);
+
+/* NCHW fp32 image -> [N*P*Q][Kp] rows, k = (r*S+s)*Cin + c (stem conv / patch embedding as a GEMM). */
+int nkb_im2row(int dtype, const float* x, void* col, int N, int Cin, int H, int W, int R, int S, int stride, int pad,
+               int Kp, nkb_stream_t stream);
+
+/* fp32 master filter [A][B][C] -> compute-dtype copy (mode 0: rows padded to ld; mode 1: transposed [C][B][ld]). */
+int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int ld, int mode, nkb_stream_t stream);
+int nkb_add2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, nkb_stream_t stream);
+int nkb_colsum(int dtype, const void* x, float* out, int rows, int C, int ld, nkb_stream_t stream);
+int nkb_pad_cast(int dtype, const float* src, void* dst, int rows, int C, int ld_src, int ld_dst, float mul,
+                 nkb_stream_t stream);
+
+/* Losses (kind 0: CrossEntropyLoss(weight) mean; kind 1: FocalLoss(alpha, gamma) mean over un-ignored rows).
+ * out2[0] = loss, out2[1] = 1/normaliser.  probs/argmax double as the logger's softmax/argmax. */
+int nkb_loss_forward(int kind, const float* logits, int ld, const long long* target, int B, int C,
+                     const float* class_weight, float gamma, long long ignore_index, float* probs, int ldp,
+                     int* argmax, void* row_state, float* out2, nkb_stream_t stream);
+size_t nkb_loss_row_state_bytes(int B);
+int nkb_loss_backward(const float* probs, int ldp, const long long* target, const void* row_state, const float* out2,
+                      const float* grad_out, int B, int C, float* dlogits, int ldd, nkb_stream_t stream);
+
+/* Fused flat-arena optimizer step. kind: 0 adam, 1 nadam (decoupled wd), 2 radam, 3 sgd. */
+int nkb_optim_step(int kind, float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n, float lr,
+                   float wd, float beta1, float beta2, float eps, float grad_scale, float c0, float c1, float c2,
+                   float c3, nkb_stream_t stream);
+int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float* out, nkb_stream_t stream);
+
+/* Per-launch HIP-event profiler (bench.py's roofline leg). */
+void nkb_prof_enable(int on);
+int nkb_prof_collect(double* ms, long long* launches, double* work, int slots);
+const char* nkb_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+// C-ABI plumbing of libnkbhip: error string, version, and the per-launch HIP-event profiler that
+// bench.py uses to time the dominant kernel on the stream it is launched on.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <mutex>
+
+static thread_local char g_err[512] = "";
+
+void nkb_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int nkb_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        nkb_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" const char* nkb_last_error() { return g_err; }
+extern "C" int nkb_version() { return 100; }
+
+// ---- profiler ---------------------------------------------------------------------------
+struct ProfRec { int kid; hipEvent_t a, b; double work; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+static std::mutex g_prof_mu;
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+NkbProfScope::NkbProfScope(int kernel_id, hipStream_t s, double work) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.kid = kernel_id; r.work = work; r.a = get_event(); r.b = get_event();
+    hipEventRecord(r.a, s);
+    slot = (int)g_prof.size();
+    g_prof.push_back(r);
+}
+NkbProfScope::~NkbProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEventRecord(g_prof[slot].b, stream);
+}
+
+extern "C" void nkb_prof_enable(int on) { g_prof_on = on != 0; }
+
+// Synchronises the recorded events and returns, per kernel id (NKB_K_COUNT slots): total milliseconds,
+// number of launches and total algorithmic work (FLOPs where the launcher supplied them). Clears the log.
+extern "C" int nkb_prof_collect(double* ms, long long* launches, double* work, int slots) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < slots; ++i) { ms[i] = 0; launches[i] = 0; work[i] = 0; }
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.b);
+        float t = 0.f;
+        hipEventElapsedTime(&t, r.a, r.b);
+        if (r.kid < slots) { ms[r.kid] += t; launches[r.kid] += 1; work[r.kid] += r.work; }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_prof.clear();
+    return NKB_K_COUNT;
+}
+
+extern "C" const char* nkb_kernel_name(int kid) {
+    static const char* names[] = {"conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "bn_apply", "bn_bwd_reduce",
+                                  "bn_bwd_apply", "bn_finalize", "maxpool", "avgpool", "im2row", "wprep", "loss",
+                                  "optim", "misc", "layernorm", "attention", "gelu"};
+    return (kid >= 0 && kid < NKB_K_COUNT) ? names[kid] : "?";
+}

@@ -1,0 +1,563 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (CDNA4).
+//
+// One kernel family covers every contraction of the train step:
+//   conv fwd, conv dgrad (output-centric gather), Linear fwd/dgrad (R=S=1), stem conv via im2row.
+// A second family (wgrad) covers every weight-gradient contraction (reduction over pixels).
+//
+// Activations are NHWC ("pixel-major", channel-contiguous); weights are [Cout][R][S][Cin]
+// (K-contiguous), i.e. both GEMM operands are read as rows of contiguous K, 128 bytes per k-tile.
+//
+// MFMA orientation: D[cout][pixel] = W[cout][k] * X[pixel][k]^T, so each lane ends up holding
+// 4 consecutive output channels of one pixel.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+struct ConvParams {
+    const void* x;      // [N][H][W][ldx]   source activations (fwd: input, dgrad: dY)
+    const void* w;      // [Cout][R][S][Cin] (K-contiguous rows), same dtype as x
+    void* y;            // [M][ldy]          M = N*P*Q destination pixels
+    const void* add;    // optional [M][ldadd] tensor added in the epilogue (same dtype as y unless out_f32)
+    const float* bias;  // optional [Cout]
+    float* stats;       // optional per-row-tile partial sums: [tilesM][2][Cout]
+    int M;              // destination pixels
+    int H, W, Cin, ldx; // source geometry
+    int P, Q, Cout, ldy, ldadd;
+    int R, S, stride, pad;
+    int mode;           // 0: src = dst*stride + r - pad ; 1 (dgrad): src = (dst + pad - r)/stride when divisible
+    int relu;           // clamp at 0 in the epilogue
+    int out_f32;        // write fp32 regardless of the compute dtype
+    int tilesM, tilesN;
+    FastDiv divPQ, divQ;
+};
+
+template <typename T> struct MmaTraits;
+template <> struct MmaTraits<bf16_t> { static constexpr int KSTEPS = 2; };  // 2 x (16x16x32) per 128-byte k-tile
+template <> struct MmaTraits<float> { static constexpr int KSTEPS = 8; };   // 8 x (16x16x4)
+
+__device__ __forceinline__ int lds_swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <typename T, int TC, int TP>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int KTE = 128 / (int)sizeof(T);  // elements per k-tile row
+    constexpr int NWR = TC / 32;               // weight rows staged per thread
+    constexpr int NPR = TP / 32;               // pixel rows staged per thread
+    constexpr int MC = TC / 32;                // 16-row blocks along cout per wave
+    constexpr int MP = TP / 32;                // 16-col blocks along pixels per wave
+    constexpr int STAGE_BYTES = (TC + TP) * 128;
+    constexpr int EROW = TC * 4 + 16;          // epilogue tile row stride (fp32 + pad)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave >> 1, wp = wave & 1;
+
+    const unsigned nwg = gridDim.x;
+    const unsigned lid = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = lid % p.tilesN;
+    const int tile_m = lid / p.tilesN;
+    const int m0 = tile_m * TP;
+    const int c0 = tile_n * TC;
+
+    const T* __restrict__ X = (const T*)p.x;
+    const T* __restrict__ Wt = (const T*)p.w;
+    const int Ktot = p.R * p.S * p.Cin;
+    const int cpk = p.Cin / KTE;  // k-tiles per filter tap
+    const int KT = p.R * p.S * cpk;
+
+    // ---- per-thread staging coordinates -------------------------------------------------
+    const int cc = tid & 7;
+    const int srow = tid >> 3;
+    int hb[NPR], wb[NPR], nb[NPR];
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) {
+        const int m = m0 + srow + 32 * j;
+        if (m < p.M) {
+            const unsigned n = fdiv((unsigned)m, p.divPQ);
+            const unsigned rem = (unsigned)m - n * p.divPQ.d;
+            const unsigned pp = fdiv(rem, p.divQ);
+            const unsigned qq = rem - pp * p.divQ.d;
+            if (p.mode == 0) { hb[j] = (int)pp * p.stride - p.pad; wb[j] = (int)qq * p.stride - p.pad; }
+            else             { hb[j] = (int)pp + p.pad;            wb[j] = (int)qq + p.pad; }
+            nb[j] = (int)n * p.H * p.W;
+        } else {
+            hb[j] = -(1 << 28); wb[j] = 0; nb[j] = 0;
+        }
+    }
+    int wofs[NWR];
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+        const int co = c0 + srow + 32 * i;
+        wofs[i] = (co < p.Cout) ? co * Ktot + cc * EPC : -1;
+    }
+
+    u32x4 sw[NWR], sx[NPR];
+    int r = 0, s = 0, ck = 0;  // filter tap and channel-tile of the NEXT k-tile to load
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NWR; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (wofs[i] >= 0) v = *(const u32x4*)(Wt + (size_t)wofs[i] + (size_t)kt * KTE);
+            sw[i] = v;
+        }
+        const int cbase = ck * KTE + cc * EPC;
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            int hi, wi;
+            bool ok;
+            if (p.mode == 0) {
+                hi = hb[j] + r; wi = wb[j] + s;
+                ok = true;
+            } else {
+                const int th = hb[j] - r, tw = wb[j] - s;
+                ok = (th >= 0) && (tw >= 0) && (((th | tw) & (p.stride - 1)) == 0);
+                hi = th >> (p.stride >> 1); wi = tw >> (p.stride >> 1);  // stride in {1,2}
+            }
+            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *(const u32x4*)(X + ((size_t)(nb[j] + hi * p.W + wi)) * p.ldx + cbase);
+            sx[j] = v;
+        }
+        if (++ck == cpk) { ck = 0; if (++s == p.S) { s = 0; ++r; } }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NWR; ++i) *(u32x4*)(base + lds_swz(srow + 32 * i, cc)) = sw[i];
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) *(u32x4*)(base + lds_swz(TC + srow + 32 * j, cc)) = sx[j];
+    };
+
+    f32x4 acc[MC][MP];
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+#pragma unroll
+        for (int j = 0; j < MP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int arow0 = wc * (TC / 2) + frow;
+    const int brow0 = TC + wp * (TP / 2) + frow;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const unsigned char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < MmaTraits<T>::KSTEPS; ++ks) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 a[MC], b[MP];
+#pragma unroll
+                for (int i = 0; i < MC; ++i) a[i] = *(const bf16x8*)(base + lds_swz(arow0 + 16 * i, ks * 4 + fgrp));
+#pragma unroll
+                for (int j = 0; j < MP; ++j) b[j] = *(const bf16x8*)(base + lds_swz(brow0 + 16 * j, ks * 4 + fgrp));
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int j = 0; j < MP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                float a[MC], b[MP];
+#pragma unroll
+                for (int i = 0; i < MC; ++i) a[i] = *(const float*)(base + lds_swz(arow0 + 16 * i, ks) + fgrp * 4);
+#pragma unroll
+                for (int j = 0; j < MP; ++j) b[j] = *(const float*)(base + lds_swz(brow0 + 16 * j, ks) + fgrp * 4);
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int j = 0; j < MP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS [pixel][cout] fp32 -> coalesced global stores ------
+    // (the trailing __syncthreads of the k-loop guarantees nobody still reads the staging buffers)
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+#pragma unroll
+        for (int j = 0; j < MP; ++j) {
+            const int pix = wp * (TP / 2) + 16 * j + frow;
+            const int co = wc * (TC / 2) + 16 * i + fgrp * 4;
+            *(f32x4*)(smem + pix * EROW + co * 4) = acc[i][j];
+        }
+    __syncthreads();
+
+    constexpr int CPR = TC / 8;        // 8-channel groups per tile row
+    constexpr int RPP = 256 / CPR;     // rows per pass
+    const int eg = tid % CPR, er = tid / CPR;
+    const int co = c0 + eg * 8;
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+    const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
+
+    for (int row = er; row < TP; row += RPP) {
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        float v[8];
+        {
+            const f32x4 lo = *(const f32x4*)(smem + row * EROW + eg * 32);
+            const f32x4 hi = *(const f32x4*)(smem + row * EROW + eg * 32 + 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
+        }
+        if (p.add) {
+            if (p.out_f32 || sizeof(T) == 4) {
+                const float* a = (const float*)p.add + (size_t)m * p.ldadd + co;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (co + e < p.Cout) v[e] += a[e];
+            } else if (vec_ok) {
+                float fa[8];
+                unpack8(*(const u32x4*)((const bf16_t*)p.add + (size_t)m * p.ldadd + co), fa);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += fa[e];
+            } else {
+                const bf16_t* a = (const bf16_t*)p.add + (size_t)m * p.ldadd + co;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (co + e < p.Cout) v[e] += bf2f(a[e]);
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.out_f32 || sizeof(T) == 4) {
+            float* o = (float*)p.y + (size_t)m * p.ldy + co;
+            if (vec_ok) {
+                *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (co + e < p.Cout) o[e] = v[e];
+            }
+        } else {
+            bf16_t* o = (bf16_t*)p.y + (size_t)m * p.ldy + co;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));  // statistics see the stored value
+            if (vec_ok) {
+                *(u32x4*)o = pack8(v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (co + e < p.Cout) o[e] = f2bf(v[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+    }
+
+    if (p.stats) {  // deterministic per-tile partial sums (reduced later by bn_finalize)
+        __syncthreads();
+        float* red = (float*)smem;  // [RPP][CPR][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(er * CPR + eg) * 16 + e] = ssum[e];
+            red[(er * CPR + eg) * 16 + 8 + e] = ssq[e];
+        }
+        __syncthreads();
+        if (tid < TC * 2) {
+            const int which = tid / TC, ch = tid % TC;
+            float t = 0.f;
+            for (int rr = 0; rr < RPP; ++rr) t += red[(rr * CPR + (ch >> 3)) * 16 + which * 8 + (ch & 7)];
+            if (c0 + ch < p.Cout) p.stats[((size_t)tile_m * 2 + which) * p.Cout + c0 + ch] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: dW[cout][n] += sum_m dY[m][cout] * X[src(m, tap(n))][cin(n)],  n = (r,s,cin) flattened.
+// Both operands are pixel-major, so MFMA fragments come from LDS through the transposing read
+// (ds_read_b64_tr_b16) for bf16 and through plain ds_read_b32 for fp32.
+struct WgradParams {
+    const void* dy;   // [M][lddy]
+    const void* x;    // [N][H][W][ldx]
+    float* dw;        // [Cout][R*S*Cin] fp32, accumulated with atomics
+    float* dbias;     // optional [Cout]: column sums of dY (accumulated with atomics by tile_n == 0)
+    int M, H, W, Cin, ldx;
+    int P, Q, Cout, lddy;
+    int R, S, stride, pad;
+    int Ntot;         // R*S*Cin
+    int tilesC, tilesN, splits, rows_per_split;
+    FastDiv divPQ, divQ, divCin, divS;
+};
+
+__device__ __forceinline__ int lds_swz256(int row, int ch) {
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int TW = 256 / (int)sizeof(T);  // tile width in channels: 128 (bf16) / 64 (f32)
+    constexpr int PK = 64;                    // pixels per pipeline stage
+    constexpr int TILE_BYTES = PK * 256;
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int NB = TW / 32;               // 16-wide blocks per wave per dim (4 bf16 / 2 f32)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wn = wave & 1;
+    const int tile_c = blockIdx.x % p.tilesC;
+    const int tile_n = blockIdx.x / p.tilesC;
+    const int split = blockIdx.y;
+    const int c0 = tile_c * TW, n0 = tile_n * TW;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    const T* __restrict__ DY = (const T*)p.dy;
+    const T* __restrict__ X = (const T*)p.x;
+
+    const int cc = tid & 15, srow = tid >> 4;  // 16 chunks per 256-byte row, 16 rows per pass
+    // the tap and channel of this thread's X chunk are fixed for the whole kernel
+    const int ncol = n0 + cc * EPC;
+    int tr = 0, ts = 0, tc = 0;
+    const bool ncol_ok = ncol < p.Ntot;
+    if (ncol_ok) {
+        const unsigned tap = fdiv((unsigned)ncol, p.divCin);
+        tc = ncol - (int)tap * p.Cin;
+        tr = (int)fdiv(tap, p.divS);
+        ts = (int)tap - tr * p.S;
+    }
+    const int dycol = c0 + cc * EPC;
+    const bool dycol_ok = dycol < p.Cout;  // a chunk may run past Cout into the row padding (lddy >= roundup(Cout)); those rows are discarded
+    const bool direct = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
+
+    u32x4 sa[4], sb[4];
+    auto load_tile = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mb + srow + 16 * i;
+            u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+            if (m < m_end) {
+                if (dycol_ok) va = *(const u32x4*)(DY + (size_t)m * p.lddy + dycol);
+                if (ncol_ok) {
+                    if (direct) {
+                        vb = *(const u32x4*)(X + (size_t)m * p.ldx + tc);
+                    } else {
+                        const unsigned n = fdiv((unsigned)m, p.divPQ);
+                        const unsigned rem = (unsigned)m - n * p.divPQ.d;
+                        const unsigned pp = fdiv(rem, p.divQ);
+                        const unsigned qq = rem - pp * p.divQ.d;
+                        const int hi = (int)pp * p.stride - p.pad + tr, wi = (int)qq * p.stride - p.pad + ts;
+                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                            vb = *(const u32x4*)(X + ((size_t)n * p.H * p.W + (size_t)hi * p.W + wi) * p.ldx + tc);
+                    }
+                }
+            }
+            sa[i] = va; sb[i] = vb;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(u32x4*)(base + lds_swz256(srow + 16 * i, cc)) = sa[i];
+            *(u32x4*)(base + TILE_BYTES + lds_swz256(srow + 16 * i, cc)) = sb[i];
+        }
+    };
+
+    f32x4 acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+    const int nstage = (m_end > m_begin) ? (m_end - m_begin + PK - 1) / PK : 0;
+    if (nstage > 0) {
+        load_tile(m_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) load_tile(m_begin + (st + 1) * PK);
+        const unsigned char* A = smem + buf * STAGE_BYTES;
+        const unsigned char* B = A + TILE_BYTES;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[NB], b[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int blk = wr * NB + i;  // 16-channel block inside the 128-wide tile
+                    const int row = 32 * kk + 8 * g + q4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(A + lds_swz256(row, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(A + lds_swz256(row + 4, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+                    a[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int blk = wn * NB + j;
+                    const int row = 32 * kk + 8 * g + q4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(B + lds_swz256(row, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(B + lds_swz256(row + 4, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+                    b[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < PK / 4; ++ks) {
+                float a[NB], b[NB];
+                const int row = ks * 4 + g;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int col = (wr * NB + i) * 16 + li;
+                    a[i] = *(const float*)(A + lds_swz256(row, col >> 2) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int col = (wn * NB + j) * 16 + li;
+                    b[j] = *(const float*)(B + lds_swz256(row, col >> 2) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nstage) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    if (nstage == 0) return;
+
+    // epilogue: stage the fp32 tile [cout][n] in LDS, then row-contiguous float atomics (256 B per wave-instruction)
+    constexpr int EROW = TW * 4 + 16;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int rbase = (wr * NB + i) * 16 + g * 4;
+            const int col = (wn * NB + j) * 16 + li;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *(float*)(smem + (rbase + e) * EROW + col * 4) = acc[i][j][e];
+        }
+    __syncthreads();
+    for (int row = wave; row < TW; row += 4) {
+        const int co = c0 + row;
+        if (co >= p.Cout) break;
+        for (int col = lane; col < TW; col += 64) {
+            const int n = n0 + col;
+            if (n < p.Ntot) atomicAdd(p.dw + (size_t)co * p.Ntot + n, *(const float*)(smem + row * EROW + col * 4));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+template <typename T, int TC, int TP>
+static int launch_conv(ConvParams& p, hipStream_t stream) {
+    p.tilesM = (p.M + TP - 1) / TP;
+    p.tilesN = (p.Cout + TC - 1) / TC;
+    constexpr int stage = 2 * (TC + TP) * 128;
+    constexpr int epi = TP * (TC * 4 + 16);
+    constexpr int lds = stage > epi ? stage : epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TC, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)p.tilesM * (unsigned)p.tilesN;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TC, TP>), dim3(grid), dim3(256), lds, stream, p);
+    return nkb_check_launch("conv_igemm");
+}
+
+extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add,
+                             const float* bias, float* stats, int N, int H, int W, int Cin, int ldx, int P, int Q,
+                             int Cout, int ldy, int ldadd, int R, int S, int stride, int pad, int relu, int out_f32,
+                             hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int kte = 128 / esz;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_gemm: bad dtype %d", dtype); return 1; }
+    if (Cin % kte != 0 || ldx % (16 / esz) != 0) {
+        nkb_set_error("conv_gemm: Cin=%d must be a multiple of %d and ldx=%d of %d", Cin, kte, ldx, 16 / esz);
+        return 1;
+    }
+    if (stride != 1 && stride != 2) { nkb_set_error("conv_gemm: stride %d unsupported", stride); return 1; }
+    if ((long long)N * H * W * ldx >= (1ll << 31) || (long long)N * P * Q * ldy >= (1ll << 31) ||
+        (long long)Cout * R * S * Cin >= (1ll << 31)) {
+        nkb_set_error("conv_gemm: tensor exceeds 2^31 elements");
+        return 1;
+    }
+    ConvParams p;
+    p.x = x; p.w = w; p.y = y; p.add = add; p.bias = bias; p.stats = stats;
+    p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.ldy = ldy;
+    p.ldadd = ldadd; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.mode = mode; p.relu = relu;
+    p.out_f32 = out_f32;
+    p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
+    const double flops = 2.0 * p.M * (double)Cout * R * S * Cin;
+    NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops);
+    const bool narrow = Cout <= 64;
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
+    return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+}
+
+// number of row tiles the stats buffer must hold for a given launch: [tilesM][2][Cout] floats
+extern "C" int nkb_conv_gemm_stat_tiles(int M, int Cout) { return (M + (Cout <= 64 ? 256 : 128) - 1) / (Cout <= 64 ? 256 : 128); }
+
+extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
+                              int ldx, int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad,
+                              hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int epc = 16 / esz;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_wgrad: bad dtype %d", dtype); return 1; }
+    if (Cin % epc != 0 || ldx % epc != 0 || lddy % epc != 0 || lddy < (Cout + epc - 1) / epc * epc) {
+        nkb_set_error("conv_wgrad: Cin=%d ldx=%d lddy=%d must be multiples of %d and lddy >= roundup(Cout=%d)", Cin, ldx,
+                      lddy, epc, Cout);
+        return 1;
+    }
+    if ((long long)N * H * W * ldx >= (1ll << 31) || (long long)N * P * Q * lddy >= (1ll << 31)) {
+        nkb_set_error("conv_wgrad: tensor exceeds 2^31 elements");
+        return 1;
+    }
+    WgradParams p;
+    p.dy = dy; p.x = x; p.dw = dw; p.dbias = nullptr;
+    p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.lddy = lddy;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.Ntot = R * S * Cin;
+    const int TW = 256 / esz;
+    p.tilesC = (Cout + TW - 1) / TW;
+    p.tilesN = (p.Ntot + TW - 1) / TW;
+    const int tiles = p.tilesC * p.tilesN;
+    int splits = (1024 + tiles - 1) / tiles;
+    const int max_splits = (p.M + 255) / 256;  // at least 4 pipeline stages per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rps = (p.M + splits - 1) / splits;
+    rps = (rps + 63) / 64 * 64;
+    splits = (p.M + rps - 1) / rps;
+    p.splits = splits; p.rows_per_split = rps;
+    p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
+    p.divCin = make_fastdiv((unsigned)Cin); p.divS = make_fastdiv((unsigned)S);
+    const int lds = 2 * 2 * 64 * 256 > TW * (TW * 4 + 16) ? 2 * 2 * 64 * 256 : TW * (TW * 4 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (128 * 4 + 16));
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot);
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
+    return nkb_check_launch("conv_wgrad");
+}

@@ -1,0 +1,552 @@
+// HBM-bound kernels of the ResNet train step: BatchNorm (finalize / apply / backward), pooling,
+// stem im2row, weight re-layout.  All activations are NHWC, channel-contiguous, 16-byte vector I/O.
+#include "common.h"
+
+static inline unsigned grid_for(size_t work_items, int block = 256, unsigned cap = 256 * 16) {
+    size_t g = (work_items + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void load(const bf16_t* p, float* f) { unpack8(*(const u32x4*)p, f); }
+    __device__ static __forceinline__ void store(bf16_t* p, const float* f) { *(u32x4*)p = pack8(f); }
+};
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void load(const float* p, float* f) {
+        const f32x4 v = *(const f32x4*)p;
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+    }
+    __device__ static __forceinline__ void store(float* p, const float* f) { *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]}; }
+};
+
+// ------------------------------------------------------------------------------------------
+// bn_finalize: reduce the conv epilogue's per-tile partial sums -> batch mean / biased var,
+// fold gamma/beta into (scale, shift), update running stats (momentum, unbiased var).
+// eval mode (training == 0): scale/shift from the running statistics, nothing else touched.
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int tiles, int C, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, int training, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (training) {
+        // double accumulation keeps E[x^2]-E[x]^2 well conditioned and the result order-independent
+        double s = 0.0, ss = 0.0;
+        for (int t = 0; t < tiles; ++t) {
+            s += (double)partials[((size_t)t * 2) * C + c];
+            ss += (double)partials[((size_t)t * 2 + 1) * C + c];
+        }
+        const double m = s / count;
+        double v = ss / count - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m; var = (float)v;
+        const float unbiased = count > 1.f ? (float)(v * count / (count - 1.0)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    } else {
+        mean = running_mean[c]; var = running_var[c];
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = b - mean * g * invstd;
+    if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
+}
+
+extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               int training, float* scale, float* shift, float* save_mean, float* save_invstd,
+                               hipStream_t stream) {
+    NkbProfScope prof(NKB_K_BN_FINALIZE, stream, 0);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, partials, tiles, C, (float)count,
+                       gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, save_mean,
+                       save_invstd);
+    return nkb_check_launch("bn_finalize");
+}
+
+// ------------------------------------------------------------------------------------------
+// bn_apply: y = act(x*scale[c] + shift[c] (+ residual))
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                const float* __restrict__ scale, const float* __restrict__ shift, size_t nchunks, int C,
+                                int relu) {
+    constexpr int N = Chunk<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * N) % (size_t)C);
+        float v[N], r[N];
+        Chunk<T>::load(x + i * N, v);
+        if (res) Chunk<T>::load(res + i * N, r);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            float t = v[e] * scale[c + e] + shift[c + e];
+            if (res) t += r[e];
+            v[e] = relu ? fmaxf(t, 0.f) : t;
+        }
+        Chunk<T>::store(y + i * N, v);
+    }
+}
+
+extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, const float* scale, const float* shift,
+                            long long rows, int C, int relu, hipStream_t stream) {
+    const int n = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (C % n) { nkb_set_error("bn_apply: C=%d not a multiple of %d", C, n); return 1; }
+    const size_t nchunks = (size_t)rows * C / n;
+    NkbProfScope prof(NKB_K_BN_APPLY, stream, 0);
+    if (dtype == NKB_DT_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, stream, (const bf16_t*)x,
+                           (const bf16_t*)res, (bf16_t*)y, scale, shift, nchunks, C, relu);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, stream, (const float*)x,
+                           (const float*)res, (float*)y, scale, shift, nchunks, C, relu);
+    return nkb_check_launch("bn_apply");
+}
+
+// ------------------------------------------------------------------------------------------
+// bn backward, pass 1: per-channel sum(dy') and sum(dy' * xhat), dy' = dy * (yact > 0) when yact given.
+// Block b handles rows [b*rpb, (b+1)*rpb); thread t owns channel chunk t % (C/N) and walks rows with
+// stride blockDim/(C/N); block partials go to part[b][2][C] (deterministic), reduced by pass 1b.
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd, long long rows,
+                                     int C, int rpb, float* __restrict__ part) {
+    constexpr int N = Chunk<T>::N;
+    extern __shared__ float red[];
+    const int cpr = C / N;                       // chunks per row
+    const int tpc = blockDim.x / cpr;            // threads sharing one chunk column (>=1 by host construction)
+    const int cg = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float s1[N], s2[N], mu[N], is[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (rl < tpc) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) { mu[e] = mean[cg * N + e]; is[e] = invstd[cg * N + e]; }
+        const long long r0 = (long long)blockIdx.x * rpb;
+        const long long r1 = min(rows, r0 + rpb);
+        for (long long r = r0 + rl; r < r1; r += tpc) {
+            const size_t off = (size_t)r * C + cg * N;
+            float g[N], xv[N], ya[N];
+            Chunk<T>::load(dy + off, g);
+            Chunk<T>::load(x + off, xv);
+            if (yact) Chunk<T>::load(yact + off, ya);
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                float gg = g[e];
+                if (yact && !(ya[e] > 0.f)) gg = 0.f;
+                s1[e] += gg;
+                s2[e] += gg * (xv[e] - mu[e]) * is[e];
+            }
+        }
+    }
+    // cross-thread reduce through LDS: red[2][tpc][C]
+    if (rl < tpc) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            red[(0 * tpc + rl) * C + cg * N + e] = s1[e];
+            red[(1 * tpc + rl) * C + cg * N + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        const int which = i / C, c = i % C;
+        float t = 0.f;
+        for (int k = 0; k < tpc; ++k) t += red[(which * tpc + k) * C + c];
+        part[((size_t)blockIdx.x * 2 + which) * C + c] = t;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < blocks; ++t) {
+        a += (double)part[((size_t)t * 2) * C + c];
+        b += (double)part[((size_t)t * 2 + 1) * C + c];
+    }
+    sums[c] = (float)a;       // sum dy
+    sums[C + c] = (float)b;   // sum dy*xhat
+    if (dbeta) dbeta[c] += (float)a;
+    if (dgamma) dgamma[c] += (float)b;
+}
+
+// pass 2: dx = gamma*invstd * (dy' - sum_dy/M - xhat*sum_dy_xhat/M); optionally writes dy' back (masked grad).
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ sums, float inv_count,
+                                    size_t nchunks, int C, T* __restrict__ dx, T* __restrict__ dy_masked) {
+    constexpr int N = Chunk<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * N) % (size_t)C);
+        float g[N], xv[N], ya[N], o[N];
+        Chunk<T>::load(dy + i * N, g);
+        Chunk<T>::load(x + i * N, xv);
+        if (yact) Chunk<T>::load(yact + i * N, ya);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            float gg = g[e];
+            if (yact && !(ya[e] > 0.f)) gg = 0.f;
+            g[e] = gg;
+            const float is = invstd[c + e];
+            const float xhat = (xv[e] - mean[c + e]) * is;
+            const float ga = gamma ? gamma[c + e] : 1.f;
+            o[e] = ga * is * (gg - sums[c + e] * inv_count - xhat * sums[C + c + e] * inv_count);
+        }
+        Chunk<T>::store(dx + i * N, o);
+        if (dy_masked) Chunk<T>::store(dy_masked + i * N, g);
+    }
+}
+
+// eval-mode / frozen-stat backward is not needed: frozen backbones skip backward entirely.
+extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const float* mean,
+                               const float* invstd, const float* gamma, long long rows, int C, float* dgamma,
+                               float* dbeta, void* dx, void* dy_masked, float* workspace, size_t workspace_floats,
+                               hipStream_t stream) {
+    const int n = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (C % n || C / n > 1024) { nkb_set_error("bn_backward: unsupported C=%d", C); return 1; }
+    const int cpr = C / n;
+    int threads = 256;
+    while (threads < cpr) threads *= 2;
+    const int tpc = threads / cpr;
+    int blocks = (int)((rows + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const int rpb = (int)((rows + blocks - 1) / blocks);
+    blocks = (int)((rows + rpb - 1) / rpb);
+    const size_t need = (size_t)blocks * 2 * C + 2 * C;
+    if (workspace_floats < need) { nkb_set_error("bn_backward: workspace %zu < %zu floats", workspace_floats, need); return 1; }
+    float* part = workspace;
+    float* sums = workspace + (size_t)blocks * 2 * C;
+    const size_t lds = (size_t)2 * tpc * C * sizeof(float);
+    {
+        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0);
+        if (dtype == NKB_DT_BF16)
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(threads), lds, stream, (const bf16_t*)dy,
+                               (const bf16_t*)x, (const bf16_t*)yact, mean, invstd, rows, C, rpb, part);
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(threads), lds, stream, (const float*)dy,
+                               (const float*)x, (const float*)yact, mean, invstd, rows, C, rpb, part);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, part, blocks, C, dgamma,
+                           dbeta, sums);
+    }
+    if (int rc = nkb_check_launch("bn_bwd_reduce")) return rc;
+    if (dx) {
+        const size_t nchunks = (size_t)rows * C / n;
+        NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0);
+        if (dtype == NKB_DT_BF16)
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, stream,
+                               (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)yact, mean, invstd, gamma, sums,
+                               1.0f / (float)rows, nchunks, C, (bf16_t*)dx, (bf16_t*)dy_masked);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, stream,
+                               (const float*)dy, (const float*)x, (const float*)yact, mean, invstd, gamma, sums,
+                               1.0f / (float)rows, nchunks, C, (float*)dx, (float*)dy_masked);
+    }
+    return nkb_check_launch("bn_bwd_apply");
+}
+
+extern "C" size_t nkb_bn_backward_workspace_floats(long long rows, int C) {
+    long long blocks = (rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return (size_t)blocks * 2 * C + 2 * C;
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool 3x3 / stride 2 / pad 1 (NHWC).  Padding is -inf; on ties the first window element in
+// row-major order wins (torch CPU semantics).  The winner's window slot (0..8) is kept for backward.
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx, int N,
+                                   int H, int W, int C, int P, int Q) {
+    constexpr int NC = Chunk<T>::N;
+    const int cpr = C / NC;
+    const size_t total = (size_t)N * P * Q * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % cpr);
+        size_t pix = i / cpr;
+        const int q = (int)(pix % Q); pix /= Q;
+        const int pp = (int)(pix % P);
+        const int n = (int)(pix / P);
+        float best[NC];
+        int bi[NC];
+#pragma unroll
+        for (int e = 0; e < NC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        bool first = true;
+        for (int r = 0; r < 3; ++r) {
+            const int h = 2 * pp - 1 + r;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int w = 2 * q - 1 + s;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float v[NC];
+                Chunk<T>::load(x + (((size_t)n * H + h) * W + w) * C + cg * NC, v);
+#pragma unroll
+                for (int e = 0; e < NC; ++e) {
+                    // NaN propagates like torch: (v > best) || isnan(v)
+                    if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }
+                }
+                first = false;
+            }
+        }
+        const size_t o = ((((size_t)n * P + pp) * Q + q) * C) + cg * NC;
+        Chunk<T>::store(y + o, best);
+#pragma unroll
+        for (int e = 0; e < NC; ++e) idx[o + e] = (unsigned char)bi[e];
+    }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, T* __restrict__ dx,
+                                   int N, int H, int W, int C, int P, int Q) {
+    constexpr int NC = Chunk<T>::N;
+    const int cpr = C / NC;
+    const size_t total = (size_t)N * H * W * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % cpr);
+        size_t pix = i / cpr;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const int n = (int)(pix / H);
+        float acc[NC];
+#pragma unroll
+        for (int e = 0; e < NC; ++e) acc[e] = 0.f;
+        const int p0 = h >> 1, p1 = (h + 1) >> 1, q0 = w >> 1, q1 = (w + 1) >> 1;
+        for (int pp = p0; pp <= p1; ++pp) {
+            if (pp >= P) continue;
+            const int r = h - (2 * pp - 1);
+            for (int q = q0; q <= q1; ++q) {
+                if (q >= Q) continue;
+                const int s = w - (2 * q - 1);
+                const int slot = r * 3 + s;
+                const size_t o = ((((size_t)n * P + pp) * Q + q) * C) + cg * NC;
+                float g[NC];
+                Chunk<T>::load(dy + o, g);
+#pragma unroll
+                for (int e = 0; e < NC; ++e) if (idx[o + e] == slot) acc[e] += g[e];
+            }
+        }
+        Chunk<T>::store(dx + ((((size_t)n * H + h) * W + w) * C) + cg * NC, acc);
+    }
+}
+
+extern "C" int nkb_maxpool3x3s2(int dtype, int backward, const void* in, void* out, unsigned char* idx, int N, int H,
+                                int W, int C, hipStream_t stream) {
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const int n = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (C % n) { nkb_set_error("maxpool: C=%d not a multiple of %d", C, n); return 1; }
+    NkbProfScope prof(NKB_K_MAXPOOL, stream, 0);
+    if (!backward) {
+        const size_t total = (size_t)N * P * Q * (C / n);
+        if (dtype == NKB_DT_BF16)
+            hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)in,
+                               (bf16_t*)out, idx, N, H, W, C, P, Q);
+        else
+            hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)in,
+                               (float*)out, idx, N, H, W, C, P, Q);
+    } else {
+        const size_t total = (size_t)N * H * W * (C / n);
+        if (dtype == NKB_DT_BF16)
+            hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)in,
+                               idx, (bf16_t*)out, N, H, W, C, P, Q);
+        else
+            hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)in,
+                               idx, (float*)out, N, H, W, C, P, Q);
+    }
+    return nkb_check_launch("maxpool");
+}
+
+// ------------------------------------------------------------------------------------------
+// Global average pool [N][HW][C] -> [N][C] and its backward (broadcast of g/HW).
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C) {
+    constexpr int NC = Chunk<T>::N;
+    const int cpr = C / NC;
+    const size_t total = (size_t)N * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % cpr), n = (int)(i / cpr);
+        float acc[NC];
+#pragma unroll
+        for (int e = 0; e < NC; ++e) acc[e] = 0.f;
+        for (int k = 0; k < HW; ++k) {
+            float v[NC];
+            Chunk<T>::load(x + ((size_t)n * HW + k) * C + cg * NC, v);
+#pragma unroll
+            for (int e = 0; e < NC; ++e) acc[e] += v[e];
+        }
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < NC; ++e) acc[e] *= inv;
+        Chunk<T>::store(y + (size_t)n * C + cg * NC, acc);
+    }
+}
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ g, T* __restrict__ dx, int N, int HW, int C) {
+    constexpr int NC = Chunk<T>::N;
+    const int cpr = C / NC;
+    const size_t total = (size_t)N * HW * cpr;
+    const float inv = 1.f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % cpr);
+        const int n = (int)(i / ((size_t)cpr * HW));
+        float v[NC];
+        Chunk<T>::load(g + (size_t)n * C + cg * NC, v);
+#pragma unroll
+        for (int e = 0; e < NC; ++e) v[e] *= inv;
+        Chunk<T>::store(dx + i * NC, v);
+    }
+}
+extern "C" int nkb_avgpool(int dtype, int backward, const void* in, void* out, int N, int HW, int C, hipStream_t stream) {
+    const int n = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (C % n) { nkb_set_error("avgpool: C=%d not a multiple of %d", C, n); return 1; }
+    NkbProfScope prof(NKB_K_AVGPOOL, stream, 0);
+    const size_t total = backward ? (size_t)N * HW * (C / n) : (size_t)N * (C / n);
+    const unsigned grid = backward ? grid_for(total) : grid_for(total, 64);
+    const int blk = backward ? 256 : 64;
+    if (dtype == NKB_DT_BF16) {
+        if (!backward) hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(grid), dim3(blk), 0, stream, (const bf16_t*)in, (bf16_t*)out, N, HW, C);
+        else hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(grid), dim3(blk), 0, stream, (const bf16_t*)in, (bf16_t*)out, N, HW, C);
+    } else {
+        if (!backward) hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid), dim3(blk), 0, stream, (const float*)in, (float*)out, N, HW, C);
+        else hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid), dim3(blk), 0, stream, (const float*)in, (float*)out, N, HW, C);
+    }
+    return nkb_check_launch("avgpool");
+}
+
+// ------------------------------------------------------------------------------------------
+// Stem im2row: NCHW fp32 image -> [N*P*Q][Kp] rows with k = (r*S + s)*Cin + c (zero beyond R*S*Cin),
+// the K order of a channels-last [Cout][R][S][Cin] filter.  Generic in (R,S,stride,pad,Cin): also the
+// ViT patch embedding (k=s=16).
+template <typename T>
+__global__ void im2row_kernel(const float* __restrict__ x, T* __restrict__ col, int N, int Cin, int H, int W, int P,
+                              int Q, int R, int S, int stride, int pad, int Kp) {
+    constexpr int NC = Chunk<T>::N;
+    const int cpr = Kp / NC;
+    const int K = R * S * Cin;
+    const size_t total = (size_t)N * P * Q * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % cpr);
+        size_t pix = i / cpr;
+        const int q = (int)(pix % Q); pix /= Q;
+        const int pp = (int)(pix % P);
+        const int n = (int)(pix / P);
+        float v[NC];
+#pragma unroll
+        for (int e = 0; e < NC; ++e) {
+            const int k = cg * NC + e;
+            float t = 0.f;
+            if (k < K) {
+                const int c = k % Cin, tap = k / Cin;
+                const int r = tap / S, s = tap % S;
+                const int h = pp * stride - pad + r, w = q * stride - pad + s;
+                if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) t = x[(((size_t)n * Cin + c) * H + h) * W + w];
+            }
+            v[e] = t;
+        }
+        Chunk<T>::store(col + i * NC, v);
+    }
+}
+extern "C" int nkb_im2row(int dtype, const float* x, void* col, int N, int Cin, int H, int W, int R, int S, int stride,
+                          int pad, int Kp, hipStream_t stream) {
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    const int n = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (Kp % n || Kp < R * S * Cin) { nkb_set_error("im2row: bad Kp=%d", Kp); return 1; }
+    const size_t total = (size_t)N * P * Q * (Kp / n);
+    NkbProfScope prof(NKB_K_IM2COL, stream, 0);
+    if (dtype == NKB_DT_BF16)
+        hipLaunchKernelGGL(im2row_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, x, (bf16_t*)col, N, Cin, H, W, P, Q, R, S, stride, pad, Kp);
+    else
+        hipLaunchKernelGGL(im2row_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, x, (float*)col, N, Cin, H, W, P, Q, R, S, stride, pad, Kp);
+    return nkb_check_launch("im2row");
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight re-layout from the fp32 master [A][B][C] (= [Cout][R*S][Cin]):
+//   mode 0: dst[a][ldd] = cast(src[a][0..B*C))   (row copy with zero padding up to ldd)
+//   mode 1: dst[c][b][a .. lda) = cast(src[a][b][c])  (dgrad layout, [Cin][R*S][lda], zero padded beyond A)
+template <typename T>
+__global__ void wprep_kernel(const float* __restrict__ src, T* __restrict__ dst, int A, int B, int C, int ld, int mode) {
+    if (mode == 0) {
+        const size_t total = (size_t)A * ld;
+        const int K = B * C;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const int k = (int)(i % ld), a = (int)(i / ld);
+            DT<T>::st(dst + i, k < K ? src[(size_t)a * K + k] : 0.f);
+        }
+    } else {
+        const size_t total = (size_t)C * B * ld;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const int a = (int)(i % ld);
+            const int b = (int)((i / ld) % B);
+            const int c = (int)(i / ((size_t)ld * B));
+            DT<T>::st(dst + i, a < A ? src[((size_t)a * B + b) * C + c] : 0.f);
+        }
+    }
+}
+extern "C" int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int ld, int mode, hipStream_t stream) {
+    const size_t total = mode == 0 ? (size_t)A * ld : (size_t)C * B * ld;
+    NkbProfScope prof(NKB_K_WPREP, stream, 0);
+    if (dtype == NKB_DT_BF16)
+        hipLaunchKernelGGL(wprep_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, src, (bf16_t*)dst, A, B, C, ld, mode);
+    else
+        hipLaunchKernelGGL(wprep_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, (float*)dst, A, B, C, ld, mode);
+    return nkb_check_launch("wprep");
+}
+
+// strided 2-D fp32 copy-add: dst[r][0..cols) (ld_dst) += src[r][0..cols) (ld_src); used to fold the padded stem
+// weight gradient back into the parameter gradient.
+__global__ void add2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int ld_src, int ld_dst) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols), r = (int)(i / cols);
+        dst[(size_t)r * ld_dst + c] += src[(size_t)r * ld_src + c];
+    }
+}
+extern "C" int nkb_add2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t stream) {
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    hipLaunchKernelGGL(add2d_kernel, dim3(grid_for((size_t)rows * cols)), dim3(256), 0, stream, src, dst, rows, cols, ld_src, ld_dst);
+    return nkb_check_launch("add2d");
+}
+
+// column sums of a [rows][ld] matrix (first C columns) into fp32 out[C] (+=): bias gradients.
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int C, int ld) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;  // 4 row partitions per block
+    __shared__ float red[4][64];
+    float t = 0.f;
+    if (c < C) for (int r = part; r < rows; r += 4) t += DT<T>::ld(x + (size_t)r * ld + c);
+    red[part][threadIdx.x & 63] = t;
+    __syncthreads();
+    if (part == 0 && c < C) out[c] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+extern "C" int nkb_colsum(int dtype, const void* x, float* out, int rows, int C, int ld, hipStream_t stream) {
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((C + 63) / 64), dim3(256), 0, stream, (const bf16_t*)x, out, rows, C, ld);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)x, out, rows, C, ld);
+    return nkb_check_launch("colsum");
+}
+
+// fp32 [rows][C] (ld_src) -> T [rows][ld_dst] with zero padding: packs loss gradients for the head GEMMs.
+template <typename T>
+__global__ void pad_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int C, int ld_src, int ld_dst, float mul) {
+    const size_t total = (size_t)rows * ld_dst;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld_dst), r = (int)(i / ld_dst);
+        DT<T>::st(dst + i, c < C ? src[(size_t)r * ld_src + c] * mul : 0.f);
+    }
+}
+extern "C" int nkb_pad_cast(int dtype, const float* src, void* dst, int rows, int C, int ld_src, int ld_dst, float mul, hipStream_t stream) {
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    const size_t total = (size_t)rows * ld_dst;
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(pad_cast_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, src, (bf16_t*)dst, rows, C, ld_src, ld_dst, mul);
+    else hipLaunchKernelGGL(pad_cast_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, (float*)dst, rows, C, ld_src, ld_dst, mul);
+    return nkb_check_launch("pad_cast");
+}

@@ -1,0 +1,182 @@
+"""Backbone definitions for the HIP engine.
+
+The reference builds its backbone with `timm.create_model(name, pretrained=..., num_classes=0)`
+(/root/reference/nkb_classification/model.py:82).  timm is a third-party dependency that is not part of the
+reference tree; the modules below keep timm's parameter names and shapes (so `state_dict()` checkpoints are
+interchangeable, train.py:70-72 / model.py:172) but hold parameters only — their arithmetic is executed by
+HipEngine through libnkbhip, never by torch.nn forward methods.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from .hipnet import HipEngine
+
+
+class _ParamOnly(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("this module only stores parameters; it is executed by the owning HIP classifier "
+                           "(call the classifier returned by get_model, on a cuda device)")
+
+
+class _Basic(_ParamOnly):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def stages(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+
+    def last_bn(self):
+        return self.bn2
+
+
+class _Bottle(_ParamOnly):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def stages(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+
+    def last_bn(self):
+        return self.bn3
+
+
+class HipResNet(_ParamOnly):
+    """timm `resnet*` parameter layout: conv1/bn1, layer1..4.{i}.conv{j}/bn{j}/downsample.{0,1}."""
+
+    family = "resnet"
+
+    def __init__(self, block, layers: Sequence[int], zero_init_last: bool = True):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for i, (planes, n) in enumerate(zip((64, 128, 256, 512), layers)):
+            stride = 1 if i == 0 else 2
+            blocks = []
+            for b in range(n):
+                s = stride if b == 0 else 1
+                down = None
+                if s != 1 or inplanes != planes * block.expansion:
+                    down = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, s, bias=False),
+                                         nn.BatchNorm2d(planes * block.expansion))
+                blocks.append(block(inplanes, planes, s, down))
+                inplanes = planes * block.expansion
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.num_features = inplanes
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if zero_init_last:
+            for m in self.modules():
+                if isinstance(m, (_Basic, _Bottle)):
+                    nn.init.zeros_(m.last_bn().weight)
+
+    def blocks(self):
+        for i in range(1, 5):
+            for j, blk in enumerate(getattr(self, f"layer{i}")):
+                yield f"layer{i}.{j}", blk
+
+    def gemm_convs(self) -> List[nn.Conv2d]:
+        """Convolutions executed by the generic implicit-GEMM kernel (everything but the im2row stem)."""
+        out = []
+        for _, blk in self.blocks():
+            out += [c for c, _ in blk.stages()]
+            if blk.downsample is not None:
+                out.append(blk.downsample[0])
+        return out
+
+    def stem_convs(self) -> List[nn.Conv2d]:
+        return [self.conv1]
+
+    # ---- execution plan ---------------------------------------------------------------
+    def run_forward(self, eng: HipEngine, img: torch.Tensor, train: bool) -> torch.Tensor:
+        from . import hip
+        N, C, H, W = img.shape
+        conv = self.conv1
+        R, st, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        P, Q = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+        kp = eng.kpad(C * R * R)
+        col = eng.ws.get("stem.col", (N, P, Q, kp), eng.T)
+        hip.im2row(eng.d, img, col, N, C, H, W, R, R, st, pad, kp)
+        x = eng.conv_bn("stem", col, conv, self.bn1, True, None, train, col_input=True)
+        x = eng.maxpool("pool", x, train)
+        for name, blk in self.blocks():
+            inp = x
+            stages = blk.stages()
+            for k, (cv, bn) in enumerate(stages[:-1]):
+                x = eng.conv_bn(f"{name}.{k}", x, cv, bn, True, None, train)
+            short = inp
+            if blk.downsample is not None:
+                short = eng.conv_bn(f"{name}.ds", inp, blk.downsample[0], blk.downsample[1], False, None, train)
+            cv, bn = stages[-1]
+            x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train)
+        return eng.avgpool("gap", x)
+
+    def run_backward(self, eng: HipEngine, g_emb: torch.Tensor):
+        g = eng.avgpool_backward("gap", g_emb, "g0")
+        flip = 1
+        for name, blk in reversed(list(self.blocks())):
+            n = len(blk.stages())
+            # last stage: ReLU(bn(conv) + shortcut); the masked incoming gradient also feeds the shortcut
+            gc = eng.bn_backward(f"{name}.{n - 1}", g, "t0", write_masked=True)
+            for k in range(n - 1, 0, -1):
+                ga = eng.conv_backward(f"{name}.{k}", gc, f"a{k}")
+                gc = eng.bn_backward(f"{name}.{k - 1}", ga, f"c{k}")
+            add = g
+            if blk.downsample is not None:
+                gcd = eng.bn_backward(f"{name}.ds", g, "t5")
+                add = eng.conv_backward(f"{name}.ds", gcd, "t6")
+            g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add)
+            flip ^= 1
+        g = eng.maxpool_backward("pool", g, "mp")
+        gc = eng.bn_backward("stem", g, "t0")
+        eng.conv_backward("stem", gc, None)
+
+
+_RESNETS = {
+    "resnet18": (_Basic, (2, 2, 2, 2)),
+    "resnet34": (_Basic, (3, 4, 6, 3)),
+    "resnet50": (_Bottle, (3, 4, 6, 3)),
+    "resnet101": (_Bottle, (3, 4, 23, 3)),
+    "resnet152": (_Bottle, (3, 8, 36, 3)),
+    # reduced members of the family used by the fast parity tests (same blocks, one per stage)
+    "resnet_tiny_basic": (_Basic, (1, 1, 1, 1)),
+    "resnet_tiny_bottleneck": (_Bottle, (1, 1, 1, 1)),
+}
+
+
+def create_backbone(name: str, pretrained: bool = False) -> nn.Module:
+    """Counterpart of timm.create_model(name, pretrained=..., num_classes=0) for the families this engine runs."""
+    key = name.lower()
+    if pretrained:
+        raise RuntimeError(f"pretrained=True needs timm's weight hub, which this offline engine does not ship; "
+                           f"load a timm-format state_dict through cfg.model['checkpoint'] instead ({name})")
+    if key in _RESNETS:
+        blk, layers = _RESNETS[key]
+        return HipResNet(blk, layers)
+    from .vit import create_vit
+    m = create_vit(key)
+    if m is None:
+        raise NotImplementedError(f"backbone {name!r} is not implemented by the HIP engine "
+                                  f"(available: {sorted(_RESNETS)} + vit_base_patch16_224)")
+    return m

@@ -1,0 +1,145 @@
+"""Train / validation epoch drivers — drop-in for /root/reference/nkb_classification/engine.py:20-117.
+
+Same positional signatures and the same step order (zero_grad -> forward -> loss -> backward -> optimizer
+step -> log; scheduler stepped once per epoch), the same returned dict.  Differences are confined to where the
+host waits for the device:
+  * the image batch is uploaded with a non-blocking copy,
+  * the progress bar prints the PREVIOUS step's loss, so `loss.item()` (engine.py:13-17, issued between
+    forward and backward in the reference) never stalls the step that is being enqueued,
+  * the logger keeps its per-step tensors on the device (logging.py in this package).
+Mixed precision: `cfg.enable_mixed_presicion` selects bf16 compute (fp32 accumulate / statistics / master
+weights) through torch.autocast, the mechanism the reference uses for its fp16 mode (engine.py:43-47).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+
+import torch
+from tqdm import tqdm
+
+from . import hip
+
+
+class TrainPbar(tqdm):
+    def __init__(self, train_loader, leave, desc, cfg):
+        super().__init__(train_loader, leave=leave, desc=desc)
+        self.cfg = cfg
+        self._pending = None
+
+    def update_loss(self, loss):
+        prev, self._pending = self._pending, loss
+        if prev is None:
+            return
+        if self.cfg.task == "multi" and self.cfg.show_full_current_loss_in_terminal:
+            self.set_postfix_str(", ".join(f"loss {k}: {v:.4f}" for k, v in prev.items()), refresh=False)
+        elif self.cfg.task == "multi":
+            self.set_postfix_str(f"Loss: {prev['loss'].item():.4f}", refresh=False)
+        else:
+            self.set_postfix_str(f"Loss: {prev.item():.4f}", refresh=False)
+
+
+def _amp_dtype(cfg):
+    return getattr(cfg, "amp_dtype", torch.bfloat16)
+
+
+def _grad_norms(model, log):
+    """engine.py:64-73: per-parameter gradient L2 norms + their sum, computed by one segmented HIP reduction
+    over the flat gradient arena when the model has one."""
+    arena = getattr(model, "arena", None)
+    named = [(tag, p) for tag, p in model.named_parameters() if p.grad is not None]
+    for tag, _ in named:
+        assert tag != "Total"
+    if arena is not None and arena.packed and all(arena.owns(p) for _, p in named) and named:
+        offs = []
+        for _, p in named:
+            o = arena.offset_of(p)
+            offs += [o, o + p.numel()]
+        dev = arena.flat_grad.device
+        # segments are [o_i, o_i + n_i); encoded as consecutive pairs -> 2k-1 segments, odd ones are the gaps
+        offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
+        out = torch.empty(len(offs) - 1, device=dev, dtype=torch.float32)
+        hip.segment_sumsq(arena.flat_grad, offsets, len(offs) - 1, out)
+        norms = out[0::2].sqrt()
+    else:
+        norms = torch.stack([p.grad.norm() for _, p in named]) if named else torch.zeros(0)
+    total = norms.sum() if named else 0
+    for i, (tag, _) in enumerate(named):
+        log[f"Gradients/{tag}"].append(norms[i])
+    log["Gradients/Total"].append(total)
+
+
+def train_epoch(
+    model,
+    train_loader,
+    optimizer,
+    scheduler,
+    scaler,
+    criterion,
+    device,
+    cfg,
+    epoch_logger,
+):
+    model.train()
+    epoch_logger.init_iter_logs()
+    metrics_grad_log = defaultdict(list) if cfg.log_gradients else None
+    pbar = TrainPbar(train_loader, leave=False, desc="Training", cfg=cfg)
+
+    for img, target in pbar:
+        img = img.to(device, non_blocking=True)
+        optimizer.zero_grad()
+
+        with torch.autocast(device_type="cuda", dtype=_amp_dtype(cfg), enabled=cfg.enable_mixed_presicion):
+            preds = model(img)
+            if isinstance(target, torch.Tensor):
+                target = target.to(device, non_blocking=True)
+            loss = criterion(preds, target)
+
+        pbar.update_loss(loss)
+
+        scaler.scale(loss["loss"] if isinstance(loss, dict) else loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+
+        if isinstance(target, dict):
+            target = {k: v.to(device, non_blocking=True) for k, v in target.items()}
+        epoch_logger.log_iter(preds, target, loss)
+
+        if metrics_grad_log is not None:
+            _grad_norms(model, metrics_grad_log)
+
+        epoch_logger.log_images_if_needed(img)
+
+    if scheduler is not None:
+        scheduler.step()
+
+    results = epoch_logger.get_epoch_results()
+    if metrics_grad_log is not None:
+        results["metrics_grad_log"] = metrics_grad_log
+    return results
+
+
+@torch.no_grad()
+def val_epoch(
+    model,
+    val_loader,
+    criterion,
+    device,
+    cfg,
+    epoch_logger,
+):
+    model.eval()
+    epoch_logger.init_iter_logs()
+
+    for img, target in tqdm(val_loader, leave=False, desc="Evaluating"):
+        img = img.to(device, non_blocking=True)
+        with torch.autocast(device_type="cuda", dtype=_amp_dtype(cfg), enabled=cfg.enable_mixed_presicion):
+            preds = model(img)
+            if isinstance(target, torch.Tensor):
+                target = target.to(device, non_blocking=True)
+            loss = criterion(preds, target)
+        if isinstance(target, dict):
+            target = {k: v.to(device, non_blocking=True) for k, v in target.items()}
+        epoch_logger.log_iter(preds, target, loss)
+        epoch_logger.log_images_if_needed(img)
+
+    return epoch_logger.get_epoch_results()

@@ -1,0 +1,201 @@
+"""ctypes binding of libnkbhip.so (include/nkbhip.h) — the only compute backend of this package.
+
+There is deliberately no CPU or eager-torch fallback: if the shared library is missing or a call
+fails, the caller gets a RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+F32, BF16 = 0, 1
+_TORCH_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+_LIB = None
+_LIB_PATH = Path(__file__).resolve().parents[1] / "lib" / "libnkbhip.so"
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+_SIGS = {
+    "nkb_version": (i32, []),
+    "nkb_last_error": (C.c_char_p, []),
+    "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp]),
+    "nkb_conv_gemm_stat_tiles": (i32, [i32, i32]),
+    "nkb_conv_wgrad": (i32, [i32, vp, vp, vp] + [i32] * 13 + [vp]),
+    "nkb_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
+    "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
+    "nkb_maxpool3x3s2": (i32, [i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "nkb_avgpool": (i32, [i32, i32, vp, vp, i32, i32, i32, vp]),
+    "nkb_im2row": (i32, [i32, vp, vp] + [i32] * 9 + [vp]),
+    "nkb_wprep": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nkb_add2d": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "nkb_colsum": (i32, [i32, vp, vp, i32, i32, i32, vp]),
+    "nkb_pad_cast": (i32, [i32, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "nkb_loss_forward": (i32, [i32, vp, i32, vp, i32, i32, vp, f32, i64, vp, i32, vp, vp, vp, vp]),
+    "nkb_loss_row_state_bytes": (sz, [i32]),
+    "nkb_loss_backward": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
+    "nkb_optim_step": (i32, [i32, vp, vp, vp, vp, vp, i64] + [f32] * 10 + [vp]),
+    "nkb_segment_sumsq": (i32, [vp, vp, i32, vp, vp]),
+    "nkb_prof_enable": (None, [i32]),
+    "nkb_prof_collect": (i32, [vp, vp, vp, i32]),
+    "nkb_kernel_name": (C.c_char_p, [i32]),
+}
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("NKBHIP_LIB", _LIB_PATH))
+
+
+def load():
+    """Load libnkbhip.so once; raise loudly when it is absent (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not path.exists():
+        raise RuntimeError(
+            f"libnkbhip.so not found at {path}: build it with `make -C nkb-classification_amd/csrc` "
+            "(or __graft_entry__.build()). This package has no CPU / eager fallback."
+        )
+    lib = C.CDLL(str(path))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def dt(t) -> int:
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    if d not in _TORCH_DT:
+        raise RuntimeError(f"nkbhip: unsupported dtype {d}")
+    return _TORCH_DT[d]
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"nkbhip {what} failed (code {rc}): {load().nkb_last_error().decode()}")
+
+
+def require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the HIP engine runs on cuda devices only "
+                           "(there is no CPU fallback)")
+
+
+# ------------------------------------------------------------------ thin typed wrappers ----
+def conv_gemm(dtype, mode, x, w, y, *, N, H, W, Cin, ldx, P, Q, Cout, ldy, R=1, S=1, stride=1, pad=0, add=None,
+              ldadd=0, bias=None, stats=None, relu=False, out_f32=False):
+    check(load().nkb_conv_gemm(dtype, mode, ptr(x), ptr(w), ptr(y), ptr(add), ptr(bias), ptr(stats), N, H, W, Cin, ldx,
+                               P, Q, Cout, ldy, ldadd, R, S, stride, pad, int(relu), int(out_f32), stream()), "conv_gemm")
+
+
+def stat_tiles(M, Cout):
+    return load().nkb_conv_gemm_stat_tiles(M, Cout)
+
+
+def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0):
+    check(load().nkb_conv_wgrad(dtype, ptr(dy), ptr(x), ptr(dw), N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad,
+                                stream()), "conv_wgrad")
+
+
+def bn_finalize(partials, tiles, C_, count, gamma, beta, rm, rv, momentum, eps, training, scale, shift, mean, invstd):
+    check(load().nkb_bn_finalize(ptr(partials), tiles, C_, count, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), momentum, eps,
+                                 int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream()), "bn_finalize")
+
+
+def bn_apply(dtype, x, res, y, scale, shift, rows, C_, relu):
+    check(load().nkb_bn_apply(dtype, ptr(x), ptr(res), ptr(y), ptr(scale), ptr(shift), rows, C_, int(relu), stream()),
+          "bn_apply")
+
+
+def bn_backward(dtype, dy, x, yact, mean, invstd, gamma, rows, C_, dgamma, dbeta, dx, dy_masked, workspace):
+    check(load().nkb_bn_backward(dtype, ptr(dy), ptr(x), ptr(yact), ptr(mean), ptr(invstd), ptr(gamma), rows, C_,
+                                 ptr(dgamma), ptr(dbeta), ptr(dx), ptr(dy_masked), ptr(workspace), workspace.numel(),
+                                 stream()), "bn_backward")
+
+
+def bn_backward_ws(rows, C_):
+    return load().nkb_bn_backward_workspace_floats(rows, C_)
+
+
+def maxpool(dtype, backward, src, dst, idx, N, H, W, C_):
+    check(load().nkb_maxpool3x3s2(dtype, int(backward), ptr(src), ptr(dst), ptr(idx), N, H, W, C_, stream()), "maxpool")
+
+
+def avgpool(dtype, backward, src, dst, N, HW, C_):
+    check(load().nkb_avgpool(dtype, int(backward), ptr(src), ptr(dst), N, HW, C_, stream()), "avgpool")
+
+
+def im2row(dtype, x, col, N, Cin, H, W, R, S, stride, pad, Kp):
+    check(load().nkb_im2row(dtype, ptr(x), ptr(col), N, Cin, H, W, R, S, stride, pad, Kp, stream()), "im2row")
+
+
+def wprep(dtype, src, dst, A, B, C_, ld, mode):
+    check(load().nkb_wprep(dtype, ptr(src), ptr(dst), A, B, C_, ld, mode, stream()), "wprep")
+
+
+def add2d(src, dst, rows, cols, ld_src, ld_dst):
+    check(load().nkb_add2d(ptr(src), ptr(dst), rows, cols, ld_src, ld_dst, stream()), "add2d")
+
+
+def colsum(dtype, x, out, rows, C_, ld):
+    check(load().nkb_colsum(dtype, ptr(x), ptr(out), rows, C_, ld, stream()), "colsum")
+
+
+def pad_cast(dtype, src, dst, rows, C_, ld_src, ld_dst, mul=1.0):
+    check(load().nkb_pad_cast(dtype, ptr(src), ptr(dst), rows, C_, ld_src, ld_dst, mul, stream()), "pad_cast")
+
+
+def loss_forward(kind, logits, ld, target, B, C_, class_weight, gamma, ignore_index, probs, ldp, argmax, row_state, out2):
+    check(load().nkb_loss_forward(kind, ptr(logits), ld, ptr(target), B, C_, ptr(class_weight), gamma, ignore_index,
+                                  ptr(probs), ldp, ptr(argmax), ptr(row_state), ptr(out2), stream()), "loss_forward")
+
+
+def loss_backward(probs, ldp, target, row_state, out2, grad_out, B, C_, dlogits, ldd):
+    check(load().nkb_loss_backward(ptr(probs), ldp, ptr(target), ptr(row_state), ptr(out2), ptr(grad_out), B, C_,
+                                   ptr(dlogits), ldd, stream()), "loss_backward")
+
+
+def optim_step(kind, p, g, m, v, shadow, n, lr, wd, beta1, beta2, eps, grad_scale, c0=0.0, c1=0.0, c2=0.0, c3=0.0):
+    check(load().nkb_optim_step(kind, ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, lr, wd, beta1, beta2, eps,
+                                grad_scale, c0, c1, c2, c3, stream()), "optim_step")
+
+
+def segment_sumsq(x, offsets, nseg, out):
+    check(load().nkb_segment_sumsq(ptr(x), ptr(offsets), nseg, ptr(out), stream()), "segment_sumsq")
+
+
+def prof_enable(on: bool):
+    load().nkb_prof_enable(int(on))
+
+
+def prof_collect():
+    n = 32
+    ms = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    work = (C.c_double * n)()
+    k = load().nkb_prof_collect(ms, cnt, work, n)
+    out = {}
+    for i in range(k):
+        if cnt[i]:
+            out[load().nkb_kernel_name(i).decode()] = dict(ms=ms[i], launches=cnt[i], work=work[i])
+    return out

@@ -1,0 +1,232 @@
+"""Layer-level executor over libnkbhip: forward / backward of conv+BN(+ReLU,+residual) stages, pooling and
+the classifier head(s), with persistent NHWC activation buffers.  This is the host side of
+`preds = model(img)` (engine.py:48) and of `loss.backward()` (engine.py:55-58) for ResNet-family backbones
+(timm layout, /root/reference/nkb_classification/model.py:82).
+
+Nothing here computes: every method only sizes buffers and enqueues libnkbhip kernels on the current stream.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import hip
+from .runtime import ParamArena, Workspace, _round_up
+
+
+class HipEngine:
+    """One instance per (model, compute dtype).  dtype: torch.float32 (parity mode) or torch.bfloat16."""
+
+    def __init__(self, arena: ParamArena, device, dtype: torch.dtype):
+        self.arena = arena
+        self.device = device
+        self.T = dtype
+        self.d = hip.dt(dtype)
+        self.esz = 2 if dtype == torch.bfloat16 else 4
+        self.kte = 128 // self.esz          # K elements per k-tile (Cin granularity of the GEMM kernels)
+        self.ws = Workspace(device)
+        self.saved: Dict[str, dict] = {}
+        self._wver = -1
+        self._wd: Dict[int, torch.Tensor] = {}     # id(conv/linear weight) -> dgrad-layout shadow
+        self._wpad: Dict[int, torch.Tensor] = {}   # id(stem weight) -> K-padded forward shadow
+        self._convs: List[nn.Module] = []
+        self._stems: List[nn.Module] = []
+        self._heads = None
+        self._bn_scratch_off = 0
+
+    # ------------------------------------------------------------------ weights ----
+    def register(self, convs, stems, head_weights, head_biases):
+        self._convs, self._stems = list(convs), list(stems)
+        self._heads = (list(head_weights), list(head_biases))
+
+    def kpad(self, k: int) -> int:
+        return _round_up(k, self.kte)
+
+    def refresh_weights(self, need_dgrad: bool):
+        a = self.arena
+        a.poll_external_writes()
+        if self._wver == a.version and (not need_dgrad or self._dgrad_ready):
+            return
+        if self.T == torch.bfloat16:
+            a.ensure_shadow()
+            hip.wprep(self.d, a.flat_param, a.shadow, 1, 1, a.total, a.total, 0)
+        for conv in self._stems:
+            w = conv.weight
+            K = w.shape[1] * w.shape[2] * w.shape[3]
+            buf = self._wpad.get(id(w))
+            if buf is None:
+                buf = self._wpad[id(w)] = torch.empty(w.shape[0], self.kpad(K), device=self.device, dtype=self.T)
+            hip.wprep(self.d, a.param_flat(w), buf, w.shape[0], 1, K, buf.shape[1], 0)
+        if need_dgrad:
+            for conv in self._convs:
+                w = conv.weight
+                co, ci, r, s = w.shape
+                buf = self._wd.get(id(w))
+                if buf is None:
+                    buf = self._wd[id(w)] = torch.empty(ci, r, s, co, device=self.device, dtype=self.T)
+                hip.wprep(self.d, a.param_flat(w), buf, co, r * s, ci, co, 1)
+            hw, _ = self._heads
+            ctot = sum(w.shape[0] for w in hw)
+            E = hw[0].shape[1]
+            cp = self.kpad(ctot)
+            buf = self._wd.get("head")
+            if buf is None:
+                buf = self._wd["head"] = torch.empty(E, cp, device=self.device, dtype=self.T)
+            lo = a.offset_of(hw[0])
+            hip.wprep(self.d, a.flat_param[lo:lo + ctot * E], buf, ctot, 1, E, cp, 1)
+        self._dgrad_ready = need_dgrad
+        self._wver = a.version
+
+    _dgrad_ready = False
+
+    def w_fwd(self, w: torch.Tensor) -> torch.Tensor:
+        if id(w) in self._wpad:
+            return self._wpad[id(w)]
+        return self.arena.shadow_flat(w) if self.T == torch.bfloat16 else self.arena.param_flat(w)
+
+    # ------------------------------------------------------------------ forward ops ----
+    def conv_bn(self, key: str, x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool,
+                res: Optional[torch.Tensor], train: bool, col_input: bool = False) -> torch.Tensor:
+        """y = act(bn(conv(x)) (+ res)).  x: [N,H,W,Cin] in the compute dtype (or the im2row matrix of the stem)."""
+        w = conv.weight
+        co, ci, R, S = w.shape
+        st, pad = conv.stride[0], conv.padding[0]
+        if col_input:
+            N, P, Q, kp = x.shape
+            geom = dict(N=N * P * Q, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, ldy=co, R=1, S=1, stride=1, pad=0)
+        else:
+            N, H, W, _ = x.shape
+            P, Q = (H + 2 * pad - R) // st + 1, (W + 2 * pad - S) // st + 1
+            geom = dict(N=N, H=H, W=W, Cin=ci, ldx=ci, P=P, Q=Q, Cout=co, ldy=co, R=R, S=S, stride=st, pad=pad)
+        rows = N * P * Q
+        c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
+        tiles = hip.stat_tiles(rows, co)
+        stats = self.ws.get(key + ".stats", (tiles, 2, co), torch.float32) if train else None
+        hip.conv_gemm(self.d, 0, x, self.w_fwd(w), c, stats=stats, **geom)
+        sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
+        scale, shift, mean, invstd = sc[0], sc[1], sc[2], sc[3]
+        hip.bn_finalize(stats, tiles, co, rows, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                        bn.momentum if bn.momentum is not None else 0.1, bn.eps, train, scale, shift, mean, invstd)
+        y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
+        hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu)
+        if train:
+            self.saved[key] = dict(x=x, c=c, y=y, mean=mean, invstd=invstd, relu=relu, geom=geom, conv=conv, bn=bn,
+                                   rows=rows, col_input=col_input)
+        return y
+
+    def maxpool(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:
+        N, H, W, C = x.shape
+        P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = self.ws.get(key + ".y", (N, P, Q, C), self.T)
+        idx = self.ws.get(key + ".idx", (N, P, Q, C), torch.uint8)
+        hip.maxpool(self.d, False, x, y, idx, N, H, W, C)
+        if train:
+            self.saved[key] = dict(idx=idx, in_shape=(N, H, W, C))
+        return y
+
+    def avgpool(self, key: str, x: torch.Tensor) -> torch.Tensor:
+        N, H, W, C = x.shape
+        y = self.ws.get(key + ".y", (N, C), self.T)
+        hip.avgpool(self.d, False, x, y, N, H * W, C)
+        self.saved[key] = dict(in_shape=(N, H, W, C))
+        return y
+
+    def head(self, emb: torch.Tensor, train: bool) -> torch.Tensor:
+        """Fused classifier heads: logits[B][sum C_t] (fp32) = emb @ W_all^T + b_all."""
+        hw, hb = self._heads
+        ctot = sum(w.shape[0] for w in hw)
+        B, E = emb.shape
+        a = self.arena
+        lo = a.offset_of(hw[0])
+        wall = (a.shadow if self.T == torch.bfloat16 else a.flat_param)[lo:lo + ctot * E]
+        bo = a.offset_of(hb[0])
+        ball = a.flat_param[bo:bo + ctot]
+        logits = torch.empty(B, ctot, device=self.device, dtype=torch.float32)
+        hip.conv_gemm(self.d, 0, emb, wall, logits, N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1, Cout=ctot, ldy=ctot,
+                      bias=ball, out_f32=True)
+        if train:
+            self.saved["head"] = dict(emb=emb, ctot=ctot)
+        return logits
+
+    # ------------------------------------------------------------------ backward ops ----
+    def scratch(self, slot: str, shape) -> torch.Tensor:
+        return self.ws.get("grad.%s.%s" % (slot, "x".join(str(int(v)) for v in shape)), shape, self.T)
+
+    def head_backward(self, glogits: torch.Tensor, need_demb: bool) -> Optional[torch.Tensor]:
+        sv = self.saved["head"]
+        emb, ctot = sv["emb"], sv["ctot"]
+        hw, hb = self._heads
+        B, E = emb.shape
+        cp = self.kpad(ctot)
+        a = self.arena
+        dl = self.ws.get("head.dl", (B, cp), self.T)
+        if not glogits.is_contiguous():
+            glogits = glogits.contiguous()
+        hip.pad_cast(self.d, glogits, dl, B, ctot, ctot, cp)
+        lo = a.offset_of(hw[0])
+        hip.conv_wgrad(self.d, dl, emb, a.flat_grad[lo:lo + ctot * E], N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1,
+                       Cout=ctot, lddy=cp)
+        bo = a.offset_of(hb[0])
+        hip.colsum(self.d, dl, a.flat_grad[bo:bo + ctot], B, ctot, cp)
+        if not need_demb:
+            return None
+        g = self.ws.get("head.demb", (B, E), self.T)
+        hip.conv_gemm(self.d, 0, dl, self._wd["head"], g, N=B, H=1, W=1, Cin=cp, ldx=cp, P=1, Q=1, Cout=E, ldy=E)
+        return g
+
+    def avgpool_backward(self, key: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        N, H, W, C = self.saved[key]["in_shape"]
+        dx = self.scratch(slot, (N, H, W, C))
+        hip.avgpool(self.d, True, g, dx, N, H * W, C)
+        return dx
+
+    def maxpool_backward(self, key: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        sv = self.saved[key]
+        N, H, W, C = sv["in_shape"]
+        dx = self.scratch(slot, (N, H, W, C))
+        hip.maxpool(self.d, True, g, dx, sv["idx"], N, H, W, C)
+        return dx
+
+    def bn_backward(self, key: str, g_y: torch.Tensor, slot: str, write_masked: bool = False) -> torch.Tensor:
+        """g_y: gradient w.r.t. the stage output y.  Returns the gradient w.r.t. the raw conv output.
+        With write_masked the ReLU-masked g_y is written back in place (it then is the gradient that flows
+        into the residual branch)."""
+        sv = self.saved[key]
+        bn, rows = sv["bn"], sv["rows"]
+        co = sv["c"].shape[-1]
+        a = self.arena
+        gc = self.scratch(slot, sv["c"].shape)
+        work = self.ws.at_least("bn.work", hip.bn_backward_ws(rows, co), torch.float32)
+        hip.bn_backward(self.d, g_y, sv["c"], sv["y"] if sv["relu"] else None, sv["mean"], sv["invstd"], bn.weight, rows,
+                        co, a.grad_flat(bn.weight), a.grad_flat(bn.bias), gc, g_y if (write_masked and sv["relu"]) else None,
+                        work)
+        return gc
+
+    def conv_backward(self, key: str, g_c: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None):
+        """Weight gradient into the arena; input gradient (optionally + add) when slot is given."""
+        sv = self.saved[key]
+        geom, conv = sv["geom"], sv["conv"]
+        w = conv.weight
+        a = self.arena
+        if sv["col_input"]:
+            kp = geom["Cin"]
+            co = geom["Cout"]
+            K = w.shape[1] * w.shape[2] * w.shape[3]
+            dwp = self.ws.get(key + ".dwpad", (co, kp), torch.float32)
+            dwp.zero_()
+            hip.conv_wgrad(self.d, g_c, sv["x"], dwp, N=geom["N"], H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, lddy=co)
+            hip.add2d(dwp, a.grad_flat(w), co, K, kp, K)
+            return None
+        hip.conv_wgrad(self.d, g_c, sv["x"], a.grad_flat(w), N=geom["N"], H=geom["H"], W=geom["W"], Cin=geom["Cin"],
+                       ldx=geom["ldx"], P=geom["P"], Q=geom["Q"], Cout=geom["Cout"], lddy=geom["Cout"], R=geom["R"],
+                       S=geom["S"], stride=geom["stride"], pad=geom["pad"])
+        if slot is None:
+            return None
+        N, H, W, ci = geom["N"], geom["H"], geom["W"], geom["Cin"]
+        dx = self.scratch(slot, (N, H, W, ci))
+        hip.conv_gemm(self.d, 1, g_c, self._wd[id(w)], dx, N=N, H=geom["P"], W=geom["Q"], Cin=geom["Cout"],
+                      ldx=geom["Cout"], P=H, Q=W, Cout=ci, ldy=ci, R=geom["R"], S=geom["S"], stride=geom["stride"],
+                      pad=geom["pad"], add=add, ldadd=ci if add is not None else 0)
+        return dx

@@ -1,0 +1,260 @@
+"""Classifier wrappers and `get_model` — drop-in for /root/reference/nkb_classification/model.py.
+
+`SingletaskClassifier` / `MultitaskClassifier` keep the reference's constructor arguments, attributes
+(`emb_model`, `emb_size`, `classifier`), methods (`set_backbone_state`, `set_dropout`,
+`initialize_classifier[s]`) and state-dict key names (model.py:17-159).  `forward` does not run torch
+modules: the whole network (backbone + fused heads) is ONE autograd node whose forward and backward enqueue
+libnkbhip kernels on the current HIP stream and whose parameter gradients land in the flat gradient arena.
+
+Compute dtype: fp32 (exact-fp32 MFMA; the parity mode, equal to the reference's CPU path) unless the call
+happens under `torch.autocast` (what engine.train_epoch does when cfg.enable_mixed_presicion is set), in
+which case activations / GEMM operands are bf16 with fp32 accumulation, statistics, logits and master weights.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Union
+
+import torch
+from torch import nn
+
+from . import hip
+from .backbones import create_backbone
+from .hipnet import HipEngine
+from .runtime import ParamArena
+
+
+class _NetFn(torch.autograd.Function):
+    """model(img) as a single autograd node.  Parameters are passed only so autograd schedules backward; their
+    gradients are written straight into the arena (returned as None here) — see ParamArena.publish_grads."""
+
+    @staticmethod
+    def forward(ctx, owner, img, *params):
+        ctx.owner = owner
+        ctx.token = owner._fwd_token
+        return owner._forward_impl(img)
+
+    @staticmethod
+    def backward(ctx, glogits):
+        owner = ctx.owner
+        if ctx.token != owner._fwd_token:
+            raise RuntimeError("HIP engine: backward() called after a newer forward overwrote the saved "
+                               "activations (only the most recent forward can be differentiated)")
+        owner._backward_impl(glogits)
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class _HipClassifier(nn.Module):
+    def __init__(self, cfg_model: dict):
+        super().__init__()
+        self.emb_model, self.emb_size = self.get_emb_model(cfg_model)
+        self.set_dropout(self.emb_model, cfg_model["backbone_dropout"])
+        self.arena = ParamArena()
+        self._engines: Dict[torch.dtype, HipEngine] = {}
+        self._fwd_token = 0
+        self._active: HipEngine = None
+        self._nbt_flat = None
+        self.grad_ready_hook = None   # set by parallel.GradReducer: called as hook(lo, hi) while backward runs
+
+    # ---- reference API -------------------------------------------------------------------
+    @staticmethod
+    def get_emb_model(cfg_model: dict):
+        name = cfg_model["model"]
+        if name.lower().startswith("unicom"):
+            raise NotImplementedError("unicom backbones are not available offline (model.py:77-79 loads them "
+                                      "from the unicom package's weight hub)")
+        emb_model = create_backbone(name, pretrained=cfg_model.get("pretrained", False))
+        return emb_model, emb_model.num_features
+
+    @staticmethod
+    def set_dropout(model: nn.Module, drop_rate: float = 0.2) -> None:
+        for child in model.children():
+            if isinstance(child, nn.Dropout):
+                child.p = drop_rate
+            _HipClassifier.set_dropout(child, drop_rate=drop_rate)
+
+    def set_backbone_state(self, state: str):
+        for p in self.emb_model.parameters():
+            if state == "freeze":
+                p.requires_grad = False
+            elif state == "unfreeze":
+                p.requires_grad = True
+
+    @staticmethod
+    def _init_params(params, strategy: str):
+        for p in params:
+            if p.ndim >= 2:
+                if strategy == "kaiming_normal_":
+                    nn.init.kaiming_normal_(p, nonlinearity="relu")
+                elif strategy == "kaiming_uniform_":
+                    nn.init.kaiming_uniform_(p, nonlinearity="relu")
+                elif strategy in ("xavier_normal_", "xavier_uniform_"):
+                    # model.py:52-55 passes nonlinearity= to xavier_*, which torch rejects with this TypeError
+                    raise TypeError(f"{strategy}() got an unexpected keyword argument 'nonlinearity'")
+            else:
+                nn.init.zeros_(p)
+
+    # ---- packing / engines ------------------------------------------------------------------
+    def _heads(self) -> List[nn.Linear]:
+        raise NotImplementedError
+
+    def _pack(self, device):
+        heads = self._heads()
+        blocks = [[p] for p in self.emb_model.parameters()]
+        blocks += [[h.weight] for h in heads]
+        blocks.append([h.bias for h in heads])
+        self.arena.pack(blocks, device)
+        # one int64 word per BatchNorm for num_batches_tracked, bumped by a single add per step
+        bns = [m for m in self.emb_model.modules() if isinstance(m, nn.BatchNorm2d)]
+        if bns:
+            flat = torch.stack([m.num_batches_tracked.to(device).reshape(()) for m in bns]).contiguous()
+            for i, m in enumerate(bns):
+                m._buffers["num_batches_tracked"] = flat[i]
+            self._nbt_flat = flat
+        self._engines.clear()
+
+    def _engine(self, device, dtype) -> HipEngine:
+        if not self.arena.still_packed() or self.arena.device != device:
+            self._pack(device)
+        eng = self._engines.get(dtype)
+        if eng is None:
+            eng = HipEngine(self.arena, device, dtype)
+            heads = self._heads()
+            em = self.emb_model
+            eng.register(em.gemm_convs(), em.stem_convs(), [h.weight for h in heads], [h.bias for h in heads])
+            self._engines[dtype] = eng
+        return eng
+
+    def _apply(self, fn, *a, **k):
+        # module.to()/cuda()/float() re-create parameter storage: drop the arena, it is rebuilt on the next forward
+        out = super()._apply(fn, *a, **k)
+        self.arena.packed = False
+        return out
+
+    def _load_from_state_dict(self, *a, **k):
+        out = super()._load_from_state_dict(*a, **k)
+        self.arena.mark_dirty()
+        return out
+
+    # ---- execution -----------------------------------------------------------------------------
+    def _compute_dtype(self) -> torch.dtype:
+        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+    def _classifier_dropout_p(self) -> float:
+        raise NotImplementedError
+
+    def _forward_impl(self, img: torch.Tensor) -> torch.Tensor:
+        eng = self._active
+        train = self.training
+        need_dgrad = train and any(p.requires_grad for p in self.emb_model.parameters())
+        eng.refresh_weights(need_dgrad=need_dgrad)
+        emb = self.emb_model.run_forward(eng, img, train)
+        if train and self._nbt_flat is not None:
+            self._nbt_flat.add_(1)
+        return eng.head(emb, train)
+
+    def _backward_impl(self, glogits: torch.Tensor):
+        eng = self._active
+        arena = self.arena
+        heads = self._heads()
+        head_params = [h.weight for h in heads] + [h.bias for h in heads]
+        bb_params = [p for p in self.emb_model.parameters() if p.requires_grad]
+        wanted = [p for p in head_params if p.requires_grad] + bb_params
+        arena.begin_backward(wanted)
+        g_emb = eng.head_backward(glogits, need_demb=bool(bb_params))
+        hook = self.grad_ready_hook
+        if hook is not None:
+            lo = arena.offset_of(heads[0].weight)
+            hook(lo, arena.total)
+        if bb_params:
+            self.emb_model.run_backward(eng, g_emb)
+            if hook is not None:
+                hook(0, arena.offset_of(heads[0].weight))
+        arena.publish_grads(wanted)
+
+    def _logits(self, x: torch.Tensor) -> torch.Tensor:
+        hip.require_device(x, "model.forward")
+        if x.dim() != 4 or x.dtype != torch.float32:
+            raise RuntimeError(f"expected a float32 NCHW image batch, got {tuple(x.shape)} {x.dtype}")
+        if self.training and self._classifier_dropout_p() > 0:
+            raise NotImplementedError("classifier_dropout > 0 is not implemented by the HIP engine yet; set it to 0")
+        x = x.contiguous()
+        self._active = self._engine(x.device, self._compute_dtype())
+        self._fwd_token += 1
+        params = [p for p in self.parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and self.training and params:
+            return _NetFn.apply(self, x, *params)
+        with torch.no_grad():
+            return self._forward_impl(x)
+
+
+class SingletaskClassifier(_HipClassifier):
+    """Single task classification model (model.py:17-85)."""
+
+    def __init__(self, cfg_model: dict, classes: list):
+        super().__init__(cfg_model)
+        self.classifier = nn.Sequential(
+            nn.Dropout(cfg_model["classifier_dropout"]),
+            nn.Linear(self.emb_size, len(classes)),
+        )
+        self.initialize_classifier(strategy=cfg_model["classifier_initialization"])
+
+    def initialize_classifier(self, strategy="kaiming_normal_"):
+        self._init_params(self.classifier.parameters(), strategy)
+
+    def _heads(self):
+        return [self.classifier[1]]
+
+    def _classifier_dropout_p(self):
+        return float(self.classifier[0].p)
+
+    def forward(self, x: torch.Tensor):
+        return self._logits(x)
+
+
+class MultitaskClassifier(_HipClassifier):
+    """Shared backbone + one Dropout->Linear head per task (model.py:88-159); heads run as one fused GEMM."""
+
+    def __init__(self, cfg_model: dict, classes: dict):
+        super().__init__(cfg_model)
+        self.classifier = nn.ModuleDict()
+        for target_name in classes:
+            self.classifier[target_name] = nn.Sequential(
+                nn.Dropout(cfg_model["classifier_dropout"]),
+                nn.Linear(self.emb_size, len(classes[target_name])),
+            )
+        self.initialize_classifiers(strategy=cfg_model["classifier_initialization"])
+
+    def initialize_classifiers(self, strategy="kaiming_normal_"):
+        for head in self.classifier.values():
+            self._init_params(head.parameters(), strategy)
+
+    def _heads(self):
+        return [head[1] for head in self.classifier.values()]
+
+    def _classifier_dropout_p(self):
+        return max(float(head[0].p) for head in self.classifier.values())
+
+    def forward(self, x: torch.Tensor):
+        fused = self._logits(x)
+        out, lo = {}, 0
+        for name, head in self.classifier.items():
+            n = head[1].out_features
+            out[name] = fused[:, lo:lo + n]
+            lo += n
+        return out
+
+
+def get_model(cfg_model, classes, device="cpu", compile: bool = False):
+    if cfg_model.get("scripted", False):
+        model = torch.jit.load(cfg_model["checkpoint"], map_location="cpu")
+    else:
+        if cfg_model["task"] == "single":
+            model = SingletaskClassifier(cfg_model, classes)
+        elif cfg_model["task"] == "multi":
+            model = MultitaskClassifier(cfg_model, classes)
+        chkpt = cfg_model.get("checkpoint", None)
+        if chkpt is not None:
+            model.load_state_dict(torch.load(chkpt, map_location="cpu"))
+    model.to(device)
+    # `compile` is accepted for signature parity (model.py:174-175); the HIP engine has no tracing compiler.
+    return model

@@ -1,0 +1,28 @@
+import sys, torch
+sys.path.insert(0, "."); sys.path.insert(0, "nkb-classification_amd")
+from nkb_classification.model import get_model
+from nkb_classification.losses import get_loss
+from oracle.torch_models import OracleClassifier
+backbone = sys.argv[1]; hw = int(sys.argv[2])
+cfg_model = dict(model=backbone, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0, classifier_initialization="kaiming_normal_", task="single")
+torch.manual_seed(0)
+oracle = OracleClassifier(cfg_model, ["a","b","c"]).double()
+model = get_model(cfg_model, ["a","b","c"], "cuda:0")
+g = torch.Generator().manual_seed(5)
+with torch.no_grad():
+    for p in oracle.parameters():
+        if p.dim() == 1: p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.5)
+model.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in oracle.state_dict().items()})
+o32 = OracleClassifier(cfg_model, ["a","b","c"]); o32.load_state_dict(model.state_dict())
+x = torch.randn(4, 3, hw, hw, generator=g); y = torch.randint(0, 3, (4,), generator=g)
+oracle.train(); model.train(); o32.train()
+torch.nn.functional.cross_entropy(oracle(x.double()), y).backward()
+torch.nn.functional.cross_entropy(o32(x), y).backward()
+crit = get_loss(dict(task="single", type="CrossEntropyLoss"), "cuda:0")
+crit(model(x.cuda()), y.cuda()).backward()
+rp = dict(oracle.named_parameters()); r32 = dict(o32.named_parameters())
+for n, p in model.named_parameters():
+    ref = rp[n].grad
+    e_hip = ((p.grad.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    e_cpu = ((r32[n].grad.double() - ref).abs().max() / ref.abs().max()).item()
+    print(f"{n:45s} max|ref| {ref.abs().max().item():.3e}  hip-vs-f64 {e_hip:.2e}  cpu32-vs-f64 {e_cpu:.2e}")

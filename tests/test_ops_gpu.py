@@ -1,0 +1,324 @@
+"""Op-level parity of every HIP kernel (through the C ABI) against stock torch CPU fp32 ops.
+
+fp32 mode must match to ~1e-5 (exact-fp32 MFMA, different summation order only); bf16 mode is compared
+against the same torch op evaluated on bf16-rounded inputs, within bf16 output rounding.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from nkb_classification import hip  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, k=1):
+    return dict(rtol=2e-5, atol=2e-5 * math.sqrt(k)) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2 * math.sqrt(k) / 4)
+
+
+def nhwc(t):  # NCHW logical -> contiguous NHWC storage
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def rnd(t, dtype):
+    return t.to(dtype).float()
+
+
+CONV_CASES = [
+    # N, H, Cin, Cout, k, stride, pad
+    (2, 14, 64, 64, 3, 1, 1),
+    (2, 14, 64, 128, 3, 2, 1),
+    (3, 7, 128, 256, 1, 1, 0),
+    (2, 14, 128, 64, 1, 2, 0),
+    (1, 9, 64, 192, 3, 1, 1),
+    (4, 8, 256, 40, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    N, H, Cin, Cout, k, st, pad = case
+    torch.manual_seed(0)
+    x = rnd(torch.randn(N, Cin, H, H), dtype).requires_grad_(True)
+    w = rnd(torch.randn(Cout, Cin, k, k) / math.sqrt(Cin * k * k), dtype).requires_grad_(True)
+    y = F.conv2d(x, w, stride=st, padding=pad)
+    P = y.shape[2]
+    dy = rnd(torch.randn_like(y), dtype)
+    y.backward(dy)
+    d = hip.dt(dtype)
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    wd = nhwc(w.detach()).to(DEV, dtype)                      # [Cout][R][S][Cin]
+    yd = torch.empty(N, P, P, Cout, device=DEV, dtype=dtype)
+    tiles = hip.stat_tiles(N * P * P, Cout)
+    stats = torch.zeros(tiles, 2, Cout, device=DEV)
+    hip.conv_gemm(d, 0, xd, wd, yd, N=N, H=H, W=H, Cin=Cin, ldx=Cin, P=P, Q=P, Cout=Cout, ldy=Cout, R=k, S=k,
+                  stride=st, pad=pad, stats=stats)
+    torch.cuda.synchronize()
+    K = Cin * k * k
+    torch.testing.assert_close(yd.float().cpu(), nhwc(y.detach()), **tol(dtype, K))
+    # epilogue statistics see the stored values
+    got = yd.float().reshape(-1, Cout)
+    torch.testing.assert_close(stats.sum(0)[0].cpu(), got.sum(0).cpu(), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(stats.sum(0)[1].cpu(), (got * got).sum(0).cpu(), rtol=1e-4, atol=1e-2)
+
+    # dgrad: gather form with the [Cin][R][S][Cout] filter
+    if Cout % (64 if dtype == torch.bfloat16 else 32) == 0:
+        wt = w.detach().permute(1, 2, 3, 0).contiguous().to(DEV, dtype)
+        dyd = nhwc(dy).to(DEV, dtype)
+        dxd = torch.empty(N, H, H, Cin, device=DEV, dtype=dtype)
+        hip.conv_gemm(d, 1, dyd, wt, dxd, N=N, H=P, W=P, Cin=Cout, ldx=Cout, P=H, Q=H, Cout=Cin, ldy=Cin, R=k, S=k,
+                      stride=st, pad=pad)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(dxd.float().cpu(), nhwc(x.grad), **tol(dtype, Cout * k * k))
+
+    # wgrad (fp32 accumulate with atomics into a zeroed buffer)
+    dyd = nhwc(dy).to(DEV, dtype)
+    dwd = torch.zeros(Cout, k, k, Cin, device=DEV)
+    hip.conv_wgrad(d, dyd, xd, dwd, N=N, H=H, W=H, Cin=Cin, ldx=Cin, P=P, Q=P, Cout=Cout, lddy=Cout, R=k, S=k,
+                   stride=st, pad=pad)
+    torch.cuda.synchronize()
+    t = tol(torch.float32, N * P * P)
+    if dtype == torch.bfloat16:
+        t = dict(rtol=1e-3, atol=1e-3 * math.sqrt(N * P * P))
+    torch.testing.assert_close(dwd.cpu(), nhwc(w.grad), **t)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_head_epilogue(dtype):
+    """R=S=1 GEMM with bias, fp32 output, Cout not a multiple of 8 (scalar store path)."""
+    torch.manual_seed(1)
+    B, E = 24, 512
+    for Cout in (2, 10, 1000):
+        x = rnd(torch.randn(B, E), dtype)
+        w = rnd(torch.randn(Cout, E) / math.sqrt(E), dtype)
+        b = torch.randn(Cout)
+        ref = x @ w.t() + b
+        out = torch.empty(B, Cout, device=DEV)
+        hip.conv_gemm(hip.dt(dtype), 0, x.to(DEV, dtype), w.to(DEV, dtype), out, N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1,
+                      Cout=Cout, ldy=Cout, bias=b.to(DEV), out_f32=True)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.cpu(), ref, **tol(dtype, E))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_epilogue_add_relu(dtype):
+    torch.manual_seed(2)
+    N, H, Cin, Cout = 2, 6, 64, 128
+    x = rnd(torch.randn(N, H, H, Cin), dtype)
+    w = rnd(torch.randn(Cout, Cin) / 8, dtype)
+    add = rnd(torch.randn(N, H, H, Cout), dtype)
+    ref = torch.relu(x.reshape(-1, Cin) @ w.t() + add.reshape(-1, Cout)).reshape(N, H, H, Cout)
+    y = torch.empty(N, H, H, Cout, device=DEV, dtype=dtype)
+    hip.conv_gemm(hip.dt(dtype), 0, x.to(DEV, dtype), w.to(DEV, dtype), y, N=N, H=H, W=H, Cin=Cin, ldx=Cin, P=H, Q=H,
+                  Cout=Cout, ldy=Cout, add=add.to(DEV, dtype), ldadd=Cout, relu=True)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.float().cpu(), ref, **tol(dtype, Cin))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [64, 256, 2048])
+def test_batchnorm_train_fwd_bwd(dtype, C):
+    torch.manual_seed(3)
+    N, H = 4, 6
+    rows = N * H * H
+    x = rnd(torch.randn(N, C, H, H) * 2 + 0.5, dtype).requires_grad_(True)
+    res = rnd(torch.randn(N, C, H, H), dtype)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    y = torch.relu(bn(x) + res)
+    dy = rnd(torch.randn_like(y), dtype)
+    y.backward(dy)
+
+    d = hip.dt(dtype)
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    # emulate the conv epilogue's partial sums with two row tiles
+    xf = xd.float().reshape(rows, C)
+    half = rows // 2
+    partials = torch.stack([torch.stack([xf[:half].sum(0), (xf[:half] ** 2).sum(0)]),
+                            torch.stack([xf[half:].sum(0), (xf[half:] ** 2).sum(0)])]).contiguous()
+    gamma, beta = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    scale, shift, mean, invstd = (torch.empty(C, device=DEV) for _ in range(4))
+    hip.bn_finalize(partials, 2, C, rows, gamma, beta, rm, rv, 0.1, 1e-5, True, scale, shift, mean, invstd)
+    yd = torch.empty_like(xd)
+    hip.bn_apply(d, xd, nhwc(res).to(DEV, dtype), yd, scale, shift, rows, C, True)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(rm.cpu(), bn.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv.cpu(), bn.running_var, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(yd.float().cpu(), nhwc(y.detach()), **tol(dtype))
+
+    dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = torch.empty_like(xd)
+    dym = torch.empty_like(xd)
+    ws = torch.empty(hip.bn_backward_ws(rows, C), device=DEV)
+    # mask from the torch activation so both sides agree on borderline zeros in bf16
+    yact = nhwc(y.detach()).to(DEV, dtype)
+    hip.bn_backward(d, nhwc(dy).to(DEV, dtype), xd, yact, mean, invstd, gamma, rows, C, dgamma, dbeta, dx, dym, ws)
+    torch.cuda.synchronize()
+    t = tol(dtype, rows)
+    torch.testing.assert_close(dbeta.cpu(), bn.bias.grad, **t)
+    torch.testing.assert_close(dgamma.cpu(), bn.weight.grad, **t)
+    torch.testing.assert_close(dx.float().cpu(), nhwc(x.grad), **tol(dtype, 4))
+    torch.testing.assert_close(dym.float().cpu(), nhwc(dy * (y.detach() > 0)), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm_eval(dtype):
+    torch.manual_seed(4)
+    C, rows = 128, 50
+    x = rnd(torch.randn(rows, C), dtype)
+    rm, rv = torch.randn(C), torch.rand(C) + 0.5
+    g, b = torch.rand(C) + 0.5, torch.randn(C)
+    ref = (x - rm) / torch.sqrt(rv + 1e-5) * g + b
+    scale, shift = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    hip.bn_finalize(None, 0, C, rows, g.to(DEV), b.to(DEV), rmd, rvd, 0.1, 1e-5, False, scale, shift, None, None)
+    y = torch.empty(rows, C, device=DEV, dtype=dtype)
+    hip.bn_apply(hip.dt(dtype), x.to(DEV, dtype), None, y, scale, shift, rows, C, False)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.float().cpu(), ref, **tol(dtype))
+    torch.testing.assert_close(rmd.cpu(), rm)  # eval leaves running stats untouched
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_maxpool_fwd_bwd_and_ties(dtype):
+    torch.manual_seed(5)
+    N, C, H = 2, 64, 12
+    x = rnd(torch.randn(N, C, H, H), dtype)
+    x[0, :, :4, :4] = 0.0  # tie block: first element in row-major window order must win
+    x.requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = rnd(torch.randn_like(y), dtype)
+    y.backward(dy)
+    P = y.shape[2]
+    d = hip.dt(dtype)
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    yd = torch.empty(N, P, P, C, device=DEV, dtype=dtype)
+    idx = torch.empty(N, P, P, C, device=DEV, dtype=torch.uint8)
+    hip.maxpool(d, False, xd, yd, idx, N, H, H, C)
+    dx = torch.empty_like(xd)
+    hip.maxpool(d, True, nhwc(dy).to(DEV, dtype), dx, idx, N, H, H, C)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(yd.float().cpu(), nhwc(y.detach()), rtol=0, atol=0)
+    torch.testing.assert_close(dx.float().cpu(), nhwc(x.grad), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_avgpool_fwd_bwd(dtype):
+    torch.manual_seed(6)
+    N, C, HW = 3, 512, 49
+    x = rnd(torch.randn(N, HW, C), dtype)
+    y = torch.empty(N, C, device=DEV, dtype=dtype)
+    hip.avgpool(hip.dt(dtype), False, x.to(DEV, dtype), y, N, HW, C)
+    g = rnd(torch.randn(N, C), dtype)
+    dx = torch.empty(N, HW, C, device=DEV, dtype=dtype)
+    hip.avgpool(hip.dt(dtype), True, g.to(DEV, dtype), dx, N, HW, C)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.float().cpu(), x.mean(1), **tol(dtype))
+    torch.testing.assert_close(dx.float().cpu(), (g / HW)[:, None, :].expand(N, HW, C), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_im2row_stem_matches_conv(dtype):
+    torch.manual_seed(7)
+    N, H = 2, 32
+    x = torch.randn(N, 3, H, H)
+    w = torch.randn(64, 3, 7, 7) / 12
+    Kp = 192 if dtype == torch.bfloat16 else 160
+    P = H // 2
+    col = torch.empty(N * P * P, Kp, device=DEV, dtype=dtype)
+    hip.im2row(hip.dt(dtype), x.to(DEV), col, N, 3, H, H, 7, 7, 2, 3, Kp)
+    wp = torch.empty(64, Kp, device=DEV, dtype=dtype)
+    hip.wprep(hip.dt(dtype), nhwc(w).to(DEV), wp, 64, 49, 3, Kp, 0)
+    y = torch.empty(N * P * P, 64, device=DEV, dtype=dtype)
+    hip.conv_gemm(hip.dt(dtype), 0, col, wp, y, N=N * P * P, H=1, W=1, Cin=Kp, ldx=Kp, P=1, Q=1, Cout=64, ldy=64)
+    torch.cuda.synchronize()
+    ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), stride=2, padding=3)
+    torch.testing.assert_close(y.float().cpu().reshape(N, P, P, 64), nhwc(ref), **tol(dtype, 147))
+
+
+def test_wprep_transpose():
+    w = torch.randn(10, 9, 64)
+    out = torch.empty(64, 9, 32, device=DEV, dtype=torch.bfloat16)
+    hip.wprep(hip.BF16, w.to(DEV), out, 10, 9, 64, 32, 1)
+    torch.cuda.synchronize()
+    ref = torch.zeros(64, 9, 32)
+    ref[:, :, :10] = w.permute(2, 1, 0)
+    torch.testing.assert_close(out.float().cpu(), ref.bfloat16().float())
+
+
+def test_loss_kernels_match_golden(golden):
+    g1 = golden("g1_losses")
+    for case in g1["cases"]:
+        cfg = case["cfg"]
+        if cfg["task"] != "single":
+            continue
+        x = torch.tensor(case["x"], dtype=torch.float32, device=DEV)
+        y = torch.tensor(case["y"], dtype=torch.int64, device=DEV)
+        B, Cn = x.shape
+        kind = 0 if cfg["type"] == "CrossEntropyLoss" else 1
+        cw = cfg.get("weight", cfg.get("alpha"))
+        cw = torch.tensor(cw, dtype=torch.float32, device=DEV) if cw is not None else None
+        gamma = float(cfg.get("gamma", 2.0))
+        probs = torch.empty(B, Cn, device=DEV)
+        am = torch.empty(B, dtype=torch.int32, device=DEV)
+        rows = torch.empty(hip.load().nkb_loss_row_state_bytes(B), dtype=torch.uint8, device=DEV)
+        out2 = torch.empty(2, device=DEV)
+        hip.loss_forward(kind, x, Cn, y, B, Cn, cw, gamma, -100, probs, Cn, am, rows, out2)
+        dl = torch.empty(B, Cn, device=DEV)
+        hip.loss_backward(probs, Cn, y, rows, out2, torch.ones(1, device=DEV), B, Cn, dl, Cn)
+        torch.cuda.synchronize()
+        assert abs(out2[0].item() - case["loss"]) <= 2e-6 + 2e-6 * abs(case["loss"]), case["name"]
+        if case["grad"] is not None:
+            torch.testing.assert_close(dl.cpu(), torch.tensor(case["grad"]), rtol=2e-5, atol=2e-7, msg=case["name"])
+        torch.testing.assert_close(probs.cpu(), torch.softmax(x.cpu(), -1), rtol=1e-5, atol=1e-7)
+        assert am.cpu().tolist() == x.cpu().argmax(-1).tolist()
+
+
+@pytest.mark.parametrize("kind", ["adam", "nadam", "radam", "sgd"])
+def test_optimizer_kernel_matches_torch(kind):
+    torch.manual_seed(8)
+    n = 10007
+    p0 = torch.randn(n)
+    ref_p = p0.clone().requires_grad_(True)
+    lr, wd = 1e-2, 0.05
+    if kind == "adam":
+        opt = torch.optim.Adam([ref_p], lr=lr, weight_decay=wd)
+    elif kind == "nadam":
+        opt = torch.optim.NAdam([ref_p], lr=lr, weight_decay=wd, decoupled_weight_decay=True)
+    elif kind == "radam":
+        opt = torch.optim.RAdam([ref_p], lr=lr, weight_decay=wd)
+    else:
+        opt = torch.optim.SGD([ref_p], lr=lr, weight_decay=wd)
+    from nkb_classification.utils import _step_scalars
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    state = {}
+    for step in range(1, 9):
+        g = torch.randn(n)
+        ref_p.grad = g.clone()
+        opt.step()
+        k, sc = _step_scalars(kind, state, lr=lr, beta1=0.9, beta2=0.999, eps=1e-8, momentum_decay=4e-3)
+        hip.optim_step(k, p, g.to(DEV), m, v, shadow, n, lr, wd, 0.9, 0.999, 1e-8, 1.0, *sc)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=1e-5, atol=2e-6, msg=f"{kind} step {step}")
+    torch.testing.assert_close(shadow.float().cpu(), p.cpu().bfloat16().float())
+
+
+def test_segment_sumsq():
+    x = torch.randn(5000, device=DEV)
+    offs = torch.tensor([0, 10, 10, 3000, 5000], dtype=torch.int64, device=DEV)
+    out = torch.empty(4, device=DEV)
+    hip.segment_sumsq(x, offs, 4, out)
+    torch.cuda.synchronize()
+    ref = torch.stack([(x[a:b] ** 2).sum() for a, b in ((0, 10), (10, 10), (10, 3000), (3000, 5000))])
+    torch.testing.assert_close(out.cpu(), ref.cpu(), rtol=1e-5, atol=1e-6)
