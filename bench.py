@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the full train step (engine.train_epoch's per-batch body) on synthetic
+3x224x224 batches, ResNet-50 single-task, bs=256 per GPU, bf16 compute with fp32 master weights
+(BASELINE.json configs[1]) — one process per GPU, RCCL gradient all-reduce over xGMI for N>1.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = images/sec over all ranks with inputs resident in HBM;
+`roofline` = the dominant kernel family timed with HIP events on its own stream (libnkbhip profiler);
+`cpu_baseline` = the CPU oracle (torch fp32 restatement of the reference path) timed on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "nkb-classification_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic FLOPs per image of one train step (fwd + dgrad + wgrad MACs x2), SURVEY.md §8(d)
+TRAIN_GFLOP_PER_IMG = {"resnet18": 10.645, "resnet50": 24.287, "vit_base_patch16_224": 105.147}
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def usable_cpus() -> int:
+    """Host cores this process may really use: affinity mask, cgroup quota, and the GPU box's 16-core share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cap = int(os.environ.get("NKB_CPU_THREADS", "16"))
+    return max(1, min(n, cap))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=1000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def build(args, device):
+    from nkb_classification.losses import get_loss
+    from nkb_classification.model import get_model
+    from nkb_classification.utils import get_optimizer
+    torch.manual_seed(0)
+    cfg_model = dict(task="single", model=args.model, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_")
+    classes = [str(i) for i in range(args.classes)]
+    model = get_model(cfg_model, classes, device)
+    # optimizer settings of configs/singletask_config.py:235-243 (NAdam, per-group lr / decoupled wd)
+    opt = get_optimizer(model, dict(type="nadam", lr=1e-4, backbone_lr=1e-5, classifier_lr=1e-4, weight_decay=0.01,
+                                    backbone_weight_decay=0.01, classifier_weight_decay=0.2))
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), device)
+    return model, opt, crit
+
+
+def cpu_baseline(args):
+    """Oracle (kind 'port'): torch-CPU fp32 restatement of the same train step, bounded sample."""
+    from oracle.torch_engine import Criterion, make_optimizer
+    from oracle.torch_models import OracleClassifier
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    log(f"cpu baseline on {threads} threads (os.cpu_count()={os.cpu_count()})")
+    torch.manual_seed(0)
+    m = OracleClassifier(dict(model=args.model, backbone_dropout=0.0, classifier_dropout=0.0),
+                         [str(i) for i in range(args.classes)])
+    opt = make_optimizer(m, dict(type="nadam", lr=1e-4, backbone_lr=1e-5, classifier_lr=1e-4, weight_decay=0.01,
+                                 backbone_weight_decay=0.01, classifier_weight_decay=0.2))
+    crit = Criterion(dict(task="single", type="CrossEntropyLoss"))
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(args.cpu_batch, 3, 224, 224, generator=g)
+    y = torch.randint(0, args.classes, (args.cpu_batch,), generator=g)
+    m.train()
+
+    def step():
+        opt.zero_grad()
+        crit(m(x), y).backward()
+        opt.step()
+
+    step()  # warm-up
+    log("cpu warm-up step done")
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        step()
+        log(f"cpu step done at {time.perf_counter() - t0:.1f}s")
+    dt = time.perf_counter() - t0
+    return dict(value=round(args.cpu_batch * args.cpu_steps / dt, 2), unit="images/sec", cores=torch.get_num_threads(),
+                kind="port", sample=f"{args.model} fp32 train step, bs={args.cpu_batch}, {args.cpu_steps} timed steps "
+                                   f"after 1 warm-up, torch {torch.__version__} CPU")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from nkb_classification import hip
+    from nkb_classification.logging import softmax_argmax
+    model, opt, crit = build(args, device)
+    reducer = None
+    if world > 1:
+        from nkb_classification.parallel import GradReducer
+        reducer = GradReducer(model, opt)
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(args.batch, 3, 224, 224, generator=g).to(device)
+    tgt = torch.randint(0, args.classes, (args.batch,), generator=g).to(device)
+    amp = args.dtype == "bf16"
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=amp):
+            preds = model(img)
+            loss = crit(preds, tgt)
+        loss.backward()
+        opt.step()
+        softmax_argmax(preds)       # the logger's per-step by-products (device side, no host sync)
+        return loss
+
+    # first step packs the arena; broadcast rank-0 state afterwards so all ranks start identical
+    log("model built; first step")
+    step()
+    torch.cuda.synchronize()
+    log("first step done")
+    if reducer is not None:
+        reducer.broadcast_state(model.arena.flat_param, [b for b in model.buffers() if b.is_floating_point()])
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    sync()
+    log("warm-up done; timing")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = float(loss.item())
+    log(f"timed region: {dt:.3f}s for {args.steps} steps")
+
+    roofline = None
+    prof = {}
+    if rank == 0 and not args.no_roofline:
+        # same step, re-run with one HIP-event pair per launch on the launch stream (perturbs wall time, so it is
+        # kept out of the timed region above)
+        nprof = min(args.steps, 5)
+        hip.prof_enable(True)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        hip.prof_enable(False)
+        prof = hip.prof_collect()
+        mfma = {k: v for k, v in prof.items() if v["work"] > 0}
+        if mfma:
+            name = max(mfma, key=lambda k: mfma[k]["ms"])
+            v = mfma[name]
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.dtype]
+            total_ms = sum(x["ms"] for x in prof.values())
+            roofline = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                            traffic=None, kernel=name, launches_per_step=v["launches"] // nprof,
+                            avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
+                            share_of_gpu_time=round(v["ms"] / total_ms, 3),
+                            gflop_per_launch=round(v["work"] / v["launches"] / 1e9, 3))
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        ips = args.batch * world * args.steps / dt
+        gflop = TRAIN_GFLOP_PER_IMG.get(args.model)
+        out = {
+            "metric": "images/sec train step (3x224x224)",
+            "value": round(ips, 1),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic randn images resident in HBM, random-init weights",
+            "config": {"workload": f"{args.model} single-task train step, {args.classes} classes, bs={args.batch}/GPU, "
+                                   f"{args.dtype} compute + fp32 master weights, NAdam, 3x224x224",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "step_tflops": round(ips * gflop / 1e3, 1) if gflop else None,
+            "step_mfma_frac": round(ips * gflop / 1e3 / PEAK_TFLOPS[args.dtype], 4) if gflop else None,
+            "final_loss": round(final_loss, 4),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernel_ms_per_step": {k: round(v["ms"] / max(min(args.steps, 5), 1), 3) for k, v in
+                                   sorted(prof.items(), key=lambda kv: -kv[1]["ms"])} if prof else None,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

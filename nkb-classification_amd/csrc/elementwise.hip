@@ -34,16 +34,26 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int tiles
                                    float momentum, float eps, int training, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float mean, var;
-    if (training) {
-        // double accumulation keeps E[x^2]-E[x]^2 well conditioned and the result order-independent
-        double s = 0.0, ss = 0.0;
-        for (int t = 0; t < tiles; ++t) {
+    // block = 64 channels x 16 tile-partitions; partition sums are combined through LDS in a fixed order
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s = 0.0, ss = 0.0;
+    if (training && c < C) {
+        // double accumulation keeps E[x^2]-E[x]^2 well conditioned
+        for (int t = py; t < tiles; t += 16) {
             s += (double)partials[((size_t)t * 2) * C + c];
             ss += (double)partials[((size_t)t * 2 + 1) * C + c];
         }
+    }
+    red[0][py][cx] = s;
+    red[1][py][cx] = ss;
+    __syncthreads();
+    if (py != 0 || c >= C) return;
+    float mean, var;
+    if (training) {
+        s = 0.0; ss = 0.0;
+        for (int k = 0; k < 16; ++k) { s += red[0][k][cx]; ss += red[1][k][cx]; }
         const double m = s / count;
         double v = ss / count - m * m;
         if (v < 0.0) v = 0.0;
@@ -66,7 +76,7 @@ extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long lon
                                int training, float* scale, float* shift, float* save_mean, float* save_invstd,
                                hipStream_t stream) {
     NkbProfScope prof(NKB_K_BN_FINALIZE, stream, 0);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, partials, tiles, C, (float)count,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, tiles, C, (float)count,
                        gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, save_mean,
                        save_invstd);
     return nkb_check_launch("bn_finalize");
@@ -74,38 +84,60 @@ extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long lon
 
 // ------------------------------------------------------------------------------------------
 // bn_apply: y = act(x*scale[c] + shift[c] (+ residual))
+// Thread t owns channel chunk (t % cpr) for the whole launch: scale/shift live in registers and the row loop has
+// no integer division.  Host guarantees (gridDim*blockDim) % cpr == 0.
+static inline unsigned grid_cols(size_t rows, int cpr, unsigned want_blocks = 256 * 8) {
+    auto gcd = [](unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; };
+    const unsigned g0 = (unsigned)cpr / gcd((unsigned)cpr, 256u);   // grid must be a multiple of this
+    size_t need = (rows * (size_t)cpr + 255) / 256;
+    unsigned g = (unsigned)(need < want_blocks ? need : want_blocks);
+    g = (g + g0 - 1) / g0 * g0;
+    return g ? g : g0;
+}
+
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-                                const float* __restrict__ scale, const float* __restrict__ shift, size_t nchunks, int C,
-                                int relu) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                       T* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, unsigned rows, int C, int relu) {
     constexpr int N = Chunk<T>::N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * N) % (size_t)C);
-        float v[N], r[N];
-        Chunk<T>::load(x + i * N, v);
-        if (res) Chunk<T>::load(res + i * N, r);
+    const unsigned cpr = (unsigned)C / N;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned cg = t % cpr, r0 = t / cpr, rs = (gridDim.x * blockDim.x) / cpr;
+    float sc[N], sh[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { sc[e] = scale[cg * N + e]; sh[e] = shift[cg * N + e]; }
+    for (unsigned r = r0; r < rows; r += 2 * rs) {
+        const size_t o0 = (size_t)r * C + cg * N;
+        const bool two = r + rs < rows;
+        const size_t o1 = two ? (size_t)(r + rs) * C + cg * N : o0;
+        float v0[N], v1[N], q0[N], q1[N];
+        Chunk<T>::load(x + o0, v0);
+        Chunk<T>::load(x + o1, v1);
+        if (res) { Chunk<T>::load(res + o0, q0); Chunk<T>::load(res + o1, q1); }
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            float t = v[e] * scale[c + e] + shift[c + e];
-            if (res) t += r[e];
-            v[e] = relu ? fmaxf(t, 0.f) : t;
+            float a = v0[e] * sc[e] + sh[e], b = v1[e] * sc[e] + sh[e];
+            if (res) { a += q0[e]; b += q1[e]; }
+            v0[e] = relu ? fmaxf(a, 0.f) : a;
+            v1[e] = relu ? fmaxf(b, 0.f) : b;
         }
-        Chunk<T>::store(y + i * N, v);
+        Chunk<T>::store(y + o0, v0);
+        if (two) Chunk<T>::store(y + o1, v1);
     }
 }
 
 extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, const float* scale, const float* shift,
                             long long rows, int C, int relu, hipStream_t stream) {
     const int n = dtype == NKB_DT_BF16 ? 8 : 4;
-    if (C % n) { nkb_set_error("bn_apply: C=%d not a multiple of %d", C, n); return 1; }
-    const size_t nchunks = (size_t)rows * C / n;
+    if (C % n || rows >= (1ll << 31)) { nkb_set_error("bn_apply: C=%d not a multiple of %d (or too many rows)", C, n); return 1; }
     NkbProfScope prof(NKB_K_BN_APPLY, stream, 0);
+    const unsigned grid = grid_cols((size_t)rows, C / n);
     if (dtype == NKB_DT_BF16)
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, stream, (const bf16_t*)x,
-                           (const bf16_t*)res, (bf16_t*)y, scale, shift, nchunks, C, relu);
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x,
+                           (const bf16_t*)res, (bf16_t*)y, scale, shift, (unsigned)rows, C, relu);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, stream, (const float*)x,
-                           (const float*)res, (float*)y, scale, shift, nchunks, C, relu);
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x,
+                           (const float*)res, (float*)y, scale, shift, (unsigned)rows, C, relu);
     return nkb_check_launch("bn_apply");
 }
 
@@ -164,13 +196,22 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     double a = 0.0, b = 0.0;
-    for (int t = 0; t < blocks; ++t) {
-        a += (double)part[((size_t)t * 2) * C + c];
-        b += (double)part[((size_t)t * 2 + 1) * C + c];
+    if (c < C) {
+        for (int t = py; t < blocks; t += 16) {
+            a += (double)part[((size_t)t * 2) * C + c];
+            b += (double)part[((size_t)t * 2 + 1) * C + c];
+        }
     }
+    red[0][py][cx] = a;
+    red[1][py][cx] = b;
+    __syncthreads();
+    if (py != 0 || c >= C) return;
+    a = 0.0; b = 0.0;
+    for (int k = 0; k < 16; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
     sums[c] = (float)a;       // sum dy
     sums[C + c] = (float)b;   // sum dy*xhat
     if (dbeta) dbeta[c] += (float)a;
@@ -179,29 +220,44 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 
 // pass 2: dx = gamma*invstd * (dy' - sum_dy/M - xhat*sum_dy_xhat/M); optionally writes dy' back (masked grad).
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ sums, float inv_count,
-                                    size_t nchunks, int C, T* __restrict__ dx, T* __restrict__ dy_masked) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ yact, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, float inv_count,
+                                                           unsigned rows, int C, T* __restrict__ dx,
+                                                           T* __restrict__ dy_masked) {
     constexpr int N = Chunk<T>::N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * N) % (size_t)C);
-        float g[N], xv[N], ya[N], o[N];
-        Chunk<T>::load(dy + i * N, g);
-        Chunk<T>::load(x + i * N, xv);
-        if (yact) Chunk<T>::load(yact + i * N, ya);
+    const unsigned cpr = (unsigned)C / N;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned cg = t % cpr, r0 = t / cpr, rs = (gridDim.x * blockDim.x) / cpr;
+    // dx = k1*dy' + k2*x + k3 with per-channel constants
+    float k1[N], k2[N], k3[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const int c = cg * N + e;
+        const float is = invstd[c], ga = gamma ? gamma[c] : 1.f, mu = mean[c];
+        const float a = ga * is;
+        const float sdy = sums[c] * inv_count, sdyx = sums[C + c] * inv_count;
+        k1[e] = a;
+        k2[e] = -a * is * sdyx;
+        k3[e] = -a * sdy + a * is * sdyx * mu;
+    }
+    for (unsigned r = r0; r < rows; r += rs) {
+        const size_t o = (size_t)r * C + cg * N;
+        float g[N], xv[N], ya[N], out[N];
+        Chunk<T>::load(dy + o, g);
+        Chunk<T>::load(x + o, xv);
+        if (yact) Chunk<T>::load(yact + o, ya);
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             float gg = g[e];
             if (yact && !(ya[e] > 0.f)) gg = 0.f;
             g[e] = gg;
-            const float is = invstd[c + e];
-            const float xhat = (xv[e] - mean[c + e]) * is;
-            const float ga = gamma ? gamma[c + e] : 1.f;
-            o[e] = ga * is * (gg - sums[c + e] * inv_count - xhat * sums[C + c + e] * inv_count);
+            out[e] = k1[e] * gg + (k2[e] * xv[e] + k3[e]);
         }
-        Chunk<T>::store(dx + i * N, o);
-        if (dy_masked) Chunk<T>::store(dy_masked + i * N, g);
+        Chunk<T>::store(dx + o, out);
+        if (dy_masked) Chunk<T>::store(dy_masked + o, g);
     }
 }
 
@@ -216,7 +272,7 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
     int threads = 256;
     while (threads < cpr) threads *= 2;
     const int tpc = threads / cpr;
-    int blocks = (int)((rows + 255) / 256);
+    int blocks = (int)((rows + 63) / 64);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     const int rpb = (int)((rows + blocks - 1) / blocks);
@@ -234,27 +290,27 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
         else
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(threads), lds, stream, (const float*)dy,
                                (const float*)x, (const float*)yact, mean, invstd, rows, C, rpb, part);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, part, blocks, C, dgamma,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, part, blocks, C, dgamma,
                            dbeta, sums);
     }
     if (int rc = nkb_check_launch("bn_bwd_reduce")) return rc;
     if (dx) {
-        const size_t nchunks = (size_t)rows * C / n;
         NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0);
+        const unsigned grid = grid_cols((size_t)rows, cpr);
         if (dtype == NKB_DT_BF16)
-            hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, stream,
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream,
                                (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)yact, mean, invstd, gamma, sums,
-                               1.0f / (float)rows, nchunks, C, (bf16_t*)dx, (bf16_t*)dy_masked);
+                               1.0f / (float)rows, (unsigned)rows, C, (bf16_t*)dx, (bf16_t*)dy_masked);
         else
-            hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, stream,
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream,
                                (const float*)dy, (const float*)x, (const float*)yact, mean, invstd, gamma, sums,
-                               1.0f / (float)rows, nchunks, C, (float*)dx, (float*)dy_masked);
+                               1.0f / (float)rows, (unsigned)rows, C, (float*)dx, (float*)dy_masked);
     }
     return nkb_check_launch("bn_bwd_apply");
 }
 
 extern "C" size_t nkb_bn_backward_workspace_floats(long long rows, int C) {
-    long long blocks = (rows + 255) / 256;
+    long long blocks = (rows + 63) / 64;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     return (size_t)blocks * 2 * C + 2 * C;

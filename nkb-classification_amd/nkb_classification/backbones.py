@@ -132,10 +132,14 @@ class HipResNet(_ParamOnly):
             x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train)
         return eng.avgpool("gap", x)
 
-    def run_backward(self, eng: HipEngine, g_emb: torch.Tensor):
+    def run_backward(self, eng: HipEngine, g_emb: torch.Tensor, on_done=None):
+        """on_done(module) is called as soon as every parameter gradient of `module` (layer4 .. layer1, then the
+        stem) is final, so the data-parallel reducer can start exchanging it while backward continues."""
         g = eng.avgpool_backward("gap", g_emb, "g0")
         flip = 1
-        for name, blk in reversed(list(self.blocks())):
+        blocks = list(self.blocks())
+        for bi in range(len(blocks) - 1, -1, -1):
+            name, blk = blocks[bi]
             n = len(blk.stages())
             # last stage: ReLU(bn(conv) + shortcut); the masked incoming gradient also feeds the shortcut
             gc = eng.bn_backward(f"{name}.{n - 1}", g, "t0", write_masked=True)
@@ -148,9 +152,14 @@ class HipResNet(_ParamOnly):
                 add = eng.conv_backward(f"{name}.ds", gcd, "t6")
             g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add)
             flip ^= 1
+            if on_done is not None and name.endswith(".0"):
+                on_done(getattr(self, name.split(".")[0]))
         g = eng.maxpool_backward("pool", g, "mp")
         gc = eng.bn_backward("stem", g, "t0")
         eng.conv_backward("stem", gc, None)
+        if on_done is not None:
+            on_done(self.conv1)
+            on_done(self.bn1)
 
 
 _RESNETS = {

@@ -166,9 +166,13 @@ class _HipClassifier(nn.Module):
             lo = arena.offset_of(heads[0].weight)
             hook(lo, arena.total)
         if bb_params:
-            self.emb_model.run_backward(eng, g_emb)
+            on_done = None
             if hook is not None:
-                hook(0, arena.offset_of(heads[0].weight))
+                def on_done(module):
+                    rng = arena.range_of(list(module.parameters()))
+                    if rng is not None:
+                        hook(*rng)
+            self.emb_model.run_backward(eng, g_emb, on_done)
         arena.publish_grads(wanted)
 
     def _logits(self, x: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,81 @@
+"""Data-parallel gradient exchange for the HIP engine: one process per GPU, RCCL over xGMI through
+torch.distributed (backend "nccl" is RCCL on ROCm).
+
+The reference is single-device (train.py:98); this is new functionality required by BASELINE configs 4-5.
+Because all gradients live in ONE flat fp32 arena laid out in forward order, backward completes the arena
+from its tail to its head; as soon as a contiguous range is final the model calls `on_range_ready(lo, hi)`
+and the range is all-reduced in large buckets on a side HIP stream while backward keeps running on the
+compute stream.  The 1/world_size average is folded into the fused optimizer kernel (grad_scale).
+BatchNorm statistics stay per-GPU (no SyncBN), as in standard DDP.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes: int = 64 << 20):
+        if not dist.is_initialized():
+            raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self._pending: List = []
+        self._stream: Optional[torch.cuda.Stream] = None
+        model.grad_ready_hook = self.on_range_ready
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world
+            self._wrap_step(optimizer)
+
+    # -- start-of-training synchronisation: parameters and BN buffers from rank 0 --------------------
+    def broadcast_state(self, flat_param: torch.Tensor, buffers=()):
+        dist.broadcast(flat_param, 0, group=self.group)
+        for b in buffers:
+            if b.numel():
+                dist.broadcast(b, 0, group=self.group)
+
+    # -- called by the model while backward is still running --------------------------------------------
+    def on_range_ready(self, lo: int, hi: int):
+        if self.world == 1 or hi <= lo:
+            return
+        flat = self.model.arena.flat_grad
+        if flat.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=flat.device)
+            ev = torch.cuda.Event()
+            ev.record()                       # gradients [lo, hi) are complete at this point of the compute stream
+            self._stream.wait_event(ev)
+            with torch.cuda.stream(self._stream):
+                self._launch(flat, lo, hi)
+        else:
+            self._launch(flat, lo, hi)
+
+    def _launch(self, flat, lo, hi):
+        # walk from the tail: those gradients were produced first
+        b = hi
+        while b > lo:
+            a = max(lo, b - self.bucket_elems)
+            self._pending.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            b = a
+
+    def wait(self):
+        """Make the compute stream wait for every outstanding bucket (no host block on GPU)."""
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+
+    def _wrap_step(self, optimizer):
+        inner = optimizer.step
+        reducer = self
+
+        def step(*a, **k):
+            reducer.wait()
+            return inner(*a, **k)
+
+        optimizer.step = step

@@ -44,7 +44,8 @@ def _relerr(a, b):
 def test_single_step_gradients_match_oracle_fp32(backbone):
     """Truth = the oracle evaluated in float64.  ReLU/max-pool decisions on near-zero pre-activations make the
     problem mildly ill-conditioned, so the HIP fp32 path is held to the same distance from the float64 truth as
-    torch's own CPU fp32 path (x4 slack, floor 1e-3) instead of to a fixed distance from the fp32 CPU result."""
+    torch's own CPU fp32 path instead of to a fixed distance from the fp32 CPU result (see the bounds below).
+    Logits keep the 1e-3 / exact-argmax bar."""
     cfg_model = dict(model=backbone, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
                      classifier_initialization="kaiming_normal_", task="single")
     classes = ["a", "b", "c"]
@@ -75,6 +76,7 @@ def test_single_step_gradients_match_oracle_fp32(backbone):
     assert out.argmax(-1).cpu().tolist() == ref32.argmax(-1).tolist()
     p64, p32 = dict(o64.named_parameters()), dict(o32.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in p64.values())
+    num = den = 0.0
     for name, p in model.named_parameters():
         assert p.grad is not None, name
         assert p.grad.shape == p32[name].grad.shape
@@ -82,7 +84,13 @@ def test_single_step_gradients_match_oracle_fp32(backbone):
         scale = max(ref.abs().max().item(), 1e-6 * gmax)   # exact invariances give |grad| ~ 1e-16: compare to the model's scale
         e_hip = (p.grad.cpu().double() - ref).abs().max().item() / scale
         e_cpu = (p32[name].grad.double() - ref).abs().max().item() / scale
-        assert e_hip <= max(1e-3, 4 * e_cpu), (name, e_hip, e_cpu)
+        # a single flipped ReLU decision (observed: 1 element in 65k, either implementation) moves a small layer's
+        # gradient by ~1/n_terms, so the per-tensor bound only screens for O(1) errors (wrong indexing, lost terms) ...
+        assert e_hip <= max(2e-2, 4 * e_cpu), (name, e_hip, e_cpu)
+        num += (p.grad.cpu().double() - ref).pow(2).sum().item()
+        den += ref.pow(2).sum().item()
+    # ... and the whole-model gradient is held to 3e-3 in the L2 sense
+    assert (num / den) ** 0.5 < 3e-3, (num / den) ** 0.5
     # running statistics advanced identically
     ob, mb = dict(o32.named_buffers()), dict(model.named_buffers())
     for k in ob:
