@@ -13,6 +13,7 @@ import math
 import sys
 from pathlib import Path
 
+import numpy as np
 import torch
 from torch.optim import lr_scheduler
 
@@ -38,7 +39,8 @@ def _step_scalars(kind: str, state: dict, *, lr: float, beta1: float, beta2: flo
     if kind == "nadam":
         mu = beta1 * (1.0 - 0.5 * (0.96 ** (step * momentum_decay)))
         mu_next = beta1 * (1.0 - 0.5 * (0.96 ** ((step + 1) * momentum_decay)))
-        mu_product = state["mu_product"] = state.get("mu_product", 1.0) * mu
+        # torch keeps mu_product in a float32 state tensor (NAdam._init_group), so it is rounded to fp32 every step
+        mu_product = state["mu_product"] = float(np.float32(state.get("mu_product", 1.0)) * np.float32(mu))
         return 1, (bc2, lr * (1.0 - mu) / (1.0 - mu_product), lr * mu_next / (1.0 - mu_product * mu_next), 0.0)
     if kind == "radam":
         rho_inf = 2.0 / (1.0 - beta2) - 1.0
@@ -60,11 +62,16 @@ class FusedOptimizer(torch.optim.Optimizer):
 
     def __init__(self, params, kind: str, arena=None):
         self.kind = kind
-        defaults = dict(lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, momentum_decay=4e-3)
+        # hyper-parameter keys and defaults of the torch optimizer the reference instantiates (utils.py:29-39)
         if kind == "sgd":
-            defaults = dict(lr=1e-3, weight_decay=0.0, momentum=0, dampening=0, nesterov=False)
-        elif kind == "nadam":
-            defaults["decoupled_weight_decay"] = True
+            defaults = dict(lr=1e-3, weight_decay=0.0, momentum=0, dampening=0, nesterov=False, maximize=False)
+        else:
+            defaults = dict(lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, maximize=False,
+                            decoupled_weight_decay=(kind == "nadam"))
+            if kind == "nadam":
+                defaults["momentum_decay"] = 4e-3
+            if kind == "adam":
+                defaults["amsgrad"] = False
         super().__init__(params, defaults)
         self.arena = arena
         self.grad_scale = 1.0

@@ -1,0 +1,173 @@
+"""CPU-side checks of the drop-in API: factories, parameter groups, error behaviour, result-dict contract,
+state-dict compatibility, and that the HIP product path refuses to run without a GPU (no fallback)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from nkb_classification import losses, metrics, utils
+from nkb_classification.logging import BaseLogger
+from nkb_classification.model import MultitaskClassifier, SingletaskClassifier, get_model
+from oracle.torch_models import OracleClassifier
+
+CFG = dict(model="resnet_tiny_bottleneck", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+           classifier_initialization="kaiming_normal_", task="single")
+
+
+def test_get_model_surface_and_state_dict_keys():
+    m = get_model(CFG, ["a", "b"], "cpu")
+    assert isinstance(m, SingletaskClassifier) and m.emb_size == 2048
+    o = OracleClassifier(CFG, ["a", "b"])
+    assert list(m.state_dict()) == list(o.state_dict())
+    m.load_state_dict(o.state_dict())
+    assert {"classifier.1.weight", "classifier.1.bias", "emb_model.conv1.weight"} <= set(m.state_dict())
+    mm = get_model({**CFG, "task": "multi"}, {"t1": ["a", "b"], "t2": ["x", "y", "z"]}, "cpu")
+    assert isinstance(mm, MultitaskClassifier)
+    assert {"classifier.t1.1.weight", "classifier.t2.1.bias"} <= set(mm.state_dict())
+    m.set_backbone_state("freeze")
+    assert not any(p.requires_grad for p in m.emb_model.parameters()) and all(p.requires_grad for p in m.classifier.parameters())
+    m.set_backbone_state("unfreeze")
+    assert all(p.requires_grad for p in m.emb_model.parameters())
+    with pytest.raises(UnboundLocalError):          # model.py:162-177 has no else branch for an unknown task
+        get_model({**CFG, "task": "nope"}, ["a"], "cpu")
+    with pytest.raises(TypeError, match="nonlinearity"):   # model.py:52-55 behaviour at reference HEAD
+        get_model({**CFG, "classifier_initialization": "xavier_normal_"}, ["a", "b"], "cpu")
+    with pytest.raises(NotImplementedError):
+        get_model({**CFG, "model": "mobilenetv3_large_100"}, ["a"], "cpu")
+
+
+def test_head_init_matches_reference_rule():
+    torch.manual_seed(0)
+    m = get_model({**CFG, "model": "resnet50"}, [str(i) for i in range(64)], "cpu")
+    w = m.classifier[1].weight
+    assert abs(w.std().item() - (2 / 2048) ** 0.5) < 2e-3 and float(m.classifier[1].bias.abs().sum()) == 0.0
+
+
+def test_no_cpu_fallback():
+    m = get_model(CFG, ["a", "b"], "cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        losses.get_loss(dict(task="single", type="CrossEntropyLoss"), "cpu")(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="only stores parameters"):
+        m.emb_model(torch.zeros(1, 3, 64, 64))
+
+
+def test_get_optimizer_groups_match_reference(golden):
+    g2 = golden("g2_optim")
+    m = get_model(CFG, ["a", "b", "c"], "cpu")
+    for traj in g2["trajectories"]:
+        opt = utils.get_optimizer(m, traj["cfg"])
+        assert len(opt.param_groups) == 2
+        assert len(opt.param_groups[0]["params"]) == len(list(m.emb_model.parameters()))
+        assert len(opt.param_groups[1]["params"]) == 2
+        for grp, gold in zip(opt.param_groups, g2["group_defaults"][traj["name"]]):
+            for k in ("lr", "weight_decay", "betas", "eps", "momentum_decay", "decoupled_weight_decay", "momentum"):
+                if k in gold:
+                    got = grp[k]
+                    assert (list(got) if isinstance(got, tuple) else got) == gold[k], (traj["name"], k)
+    with pytest.raises(NotImplementedError, match="Unknown optimizer in config: lion"):
+        utils.get_optimizer(m, dict(type="lion"))
+    d = utils.get_optimizer(m, dict(type="adam")).param_groups
+    assert d[0]["lr"] == 0.001 and d[0]["weight_decay"] == 0.0
+
+
+def test_get_scheduler_sequences(golden):
+    g2 = golden("g2_optim")
+    m = get_model(CFG, ["a", "b"], "cpu")
+    for name, rec in g2["lr_sequences"].items():
+        opt = utils.get_optimizer(m, dict(type="sgd", lr=1.0))
+        sch = utils.get_scheduler(opt, rec["policy"])
+        seq = []
+        for _ in range(5):
+            seq.append(opt.param_groups[0]["lr"])
+            sch.step()
+        assert seq == pytest.approx(rec["lrs"], rel=1e-12, abs=1e-15), name
+    assert utils.get_scheduler(utils.get_optimizer(m, dict(type="sgd")), {}) is None
+    with pytest.raises(NotImplementedError, match="Learning rate policy poly not implemented."):
+        utils.get_scheduler(utils.get_optimizer(m, dict(type="sgd")), dict(type="poly"))
+
+
+def test_step_scalars_reproduce_torch_coefficients():
+    """The host-side scalars fed to nkb_optim_step, checked by replaying torch's formulas on one element."""
+    for kind, mk in (("adam", lambda p: torch.optim.Adam([p], lr=1e-2, weight_decay=0.1)),
+                     ("nadam", lambda p: torch.optim.NAdam([p], lr=1e-2, weight_decay=0.1, decoupled_weight_decay=True)),
+                     ("radam", lambda p: torch.optim.RAdam([p], lr=1e-2, weight_decay=0.1)),
+                     ("sgd", lambda p: torch.optim.SGD([p], lr=1e-2, weight_decay=0.1))):
+        p = torch.tensor([0.7], dtype=torch.float64, requires_grad=True)
+        opt = mk(p)
+        w, m, v, state = 0.7, 0.0, 0.0, {}
+        for step in range(1, 12):
+            g = 0.3 * ((-1) ** step) + 0.05 * step
+            p.grad = torch.tensor([g], dtype=torch.float64)
+            opt.step()
+            k, (c0, c1, c2, _) = utils._step_scalars(kind, state, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+            lr, wd, b1, b2, eps = 1e-2, 0.1, 0.9, 0.999, 1e-8
+            if kind == "sgd":
+                w = w - lr * (g + wd * w)
+            else:
+                if kind == "nadam":
+                    w = w * (1 - lr * wd)
+                else:
+                    g = g + wd * w
+                m = m + (g - m) * (1 - b1)
+                v = v * b2 + (1 - b2) * g * g
+                if kind == "adam":
+                    w = w - c0 * (m / (v ** 0.5 / c1 + eps))
+                elif kind == "nadam":
+                    den = (v / c0) ** 0.5 + eps
+                    w = w - c1 * (g / den) - c2 * (m / den)
+                else:
+                    w = w - lr * (m / c0) * c2 * (c1 / (v ** 0.5 + eps)) if c2 > 0 else w - lr * (m / c0)
+            assert w == pytest.approx(p.item(), rel=1e-12), (kind, step)
+
+
+def test_get_loss_factory(golden):
+    assert isinstance(losses.get_loss(dict(task="single", type="CrossEntropyLoss", weight=[1, 2]), "cpu"), losses.CrossEntropyLoss)
+    f = losses.get_loss(dict(task="single", type="FocalLoss", gamma=1, alpha=[1, 2, .5]), "cpu")
+    assert isinstance(f, losses.FocalLoss) and f.gamma == 1 and f.alpha.tolist() == [1, 2, .5]
+    assert losses.get_loss(dict(task="single", type="FocalLoss"), "cpu").gamma == losses.DEFAULT_FOCAL_GAMMA == 2.0
+    assert isinstance(losses.get_loss(dict(task="multi", type="FocalLoss"), "cpu"), losses.MultitaskCriterion)
+    with pytest.raises(NotImplementedError, match=golden("g1_losses")["unknown_type_error"]):
+        losses.get_loss(dict(task="single", type="Nope"), "cpu")
+    with pytest.raises(ValueError):
+        losses.FocalLoss(reduction="avg")
+
+
+def test_compute_metrics_matches_reference(golden):
+    g3 = golden("g3_metrics")
+    for name in ("single_C2", "single_C5"):
+        got = metrics.compute_metrics(types.SimpleNamespace(task="single"), dict(g3[name]["inputs"]))
+        gold = g3[name]["metrics"]
+        assert got["epoch_acc"] == pytest.approx(gold["epoch_acc"]) and got["epoch_loss"] == pytest.approx(gold["epoch_loss"])
+        np.testing.assert_allclose(got["epoch_roc_auc"], gold["epoch_roc_auc"])
+        assert got["loss"] == gold["loss"]
+    got = metrics.compute_metrics(types.SimpleNamespace(task="multi", target_names=["a", "b"]), g3["multi"]["inputs"])
+    gold = g3["multi"]["metrics"]
+    assert got["epoch_acc"] == pytest.approx(gold["epoch_acc"]) and got["loss"] == gold["loss"]
+    for t in ("a", "b"):
+        assert got[t]["epoch_acc"] == pytest.approx(gold[t]["epoch_acc"])
+        np.testing.assert_allclose(got[t]["epoch_roc_auc"], gold[t]["epoch_roc_auc"])
+    with pytest.raises(ValueError):
+        metrics.compute_metrics(types.SimpleNamespace(task="x"), {})
+
+
+def test_logger_construction_and_contract():
+    lg = BaseLogger(types.SimpleNamespace(task="multi"), {"b": ["x"], "a": ["y", "z"]})
+    assert lg.target_names == ["a", "b"]            # logging.py:243 crashes here at reference HEAD; intent = sorted names
+    res = lg.get_epoch_results()
+    assert set(res) == {"running_loss", "confidences", "predictions", "ground_truth", "images"}
+    with pytest.raises(AssertionError):
+        BaseLogger(types.SimpleNamespace(task="other"), [])
+
+
+def test_read_py_config(tmp_path):
+    p = tmp_path / "my_cfg.py"
+    p.write_text("device = 'cuda:0'\n")
+    line = utils.read_py_config(str(p))
+    assert line == "import my_cfg as cfg"
+    ns = {}
+    exec(line, ns, ns)
+    assert ns["cfg"].device == "cuda:0"
+    assert utils.get_classes_configs(["a", "b"]) == ({"a": 0, "b": 1}, {0: "a", 1: "b"})

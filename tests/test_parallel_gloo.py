@@ -1,0 +1,57 @@
+"""world_size-2 rehearsal of the data-parallel path on CPU (gloo): bucketed all-reduce of flat-arena ranges
+issued while 'backward' is still producing gradients, then the 1/world average through grad_scale."""
+import os
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nkb_classification.parallel import GradReducer
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 10_000
+        arena = types.SimpleNamespace(flat_grad=torch.zeros(n))
+        model = types.SimpleNamespace(arena=arena, grad_ready_hook=None)
+        calls = []
+        opt = types.SimpleNamespace(grad_scale=1.0, step=lambda: calls.append(arena.flat_grad.clone()))
+        red = GradReducer(model, opt, bucket_bytes=4 * 1500)       # several buckets per range
+        assert model.grad_ready_hook is not None and opt.grad_scale == 0.5
+        flat_param = torch.full((8,), float(rank + 1))
+        red.broadcast_state(flat_param, [torch.zeros(0)])
+        assert flat_param.tolist() == [1.0] * 8
+        # backward produces the tail of the arena first, then the head
+        arena.flat_grad[6000:] = torch.arange(6000, n, dtype=torch.float32) * (rank + 1)
+        model.grad_ready_hook(6000, n)
+        arena.flat_grad[:6000] = torch.arange(0, 6000, dtype=torch.float32) * (rank + 1)
+        model.grad_ready_hook(0, 6000)
+        opt.step()                                                   # wrapped: waits for every bucket first
+        expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        ok = torch.equal(calls[0], expect) and not red._pending
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_reducer_requires_process_group():
+    with pytest.raises(RuntimeError, match="process group"):
+        GradReducer(types.SimpleNamespace(arena=None, grad_ready_hook=None))
