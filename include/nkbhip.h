@@ -56,9 +56,12 @@ int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, co
                     float* shift, float* save_mean, float* save_invstd, nkb_stream_t stream);
 int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, const float* scale, const float* shift,
                  long long rows, int C, int relu, nkb_stream_t stream);
-int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const float* mean, const float* invstd,
-                    const float* gamma, long long rows, int C, float* dgamma, float* dbeta, void* dx, void* dy_masked,
-                    float* workspace, size_t workspace_floats, nkb_stream_t stream);
+/* ReLU mask: from yact (> 0) when given, else recomputed as x*fscale+fshift > 0 when fscale is given, else none. */
+int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const float* fscale,
+                    const float* fshift, const float* mean, const float* invstd, const float* gamma, long long rows,
+                    int C, float* dgamma, float* dbeta, void* dx, void* dy_masked, float* workspace,
+                    size_t workspace_floats, nkb_stream_t stream);
+size_t nkb_bn_stats_floats(int tiles, int C); /* size of the `partials` buffer nkb_bn_finalize expects */
 size_t nkb_bn_backward_workspace_floats(long long rows, int C);
 
 /* MaxPool2d(3, 2, 1) and global average pool, forward (backward=0) / backward (backward=1), NHWC. */
@@ -95,6 +98,7 @@ int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float*
 /* Per-launch HIP-event profiler (bench.py's roofline leg). */
 void nkb_prof_enable(int on);
 int nkb_prof_collect(double* ms, long long* launches, double* work, int slots);
+int nkb_prof_collect_raw(int* kernel_id, double* ms, double* work, int cap);
 const char* nkb_kernel_name(int kernel_id);
 
 #ifdef __cplusplus

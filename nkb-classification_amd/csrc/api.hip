@@ -76,6 +76,22 @@ extern "C" int nkb_prof_collect(double* ms, long long* launches, double* work, i
     return NKB_K_COUNT;
 }
 
+// Raw per-launch records (kernel id, milliseconds, work) in launch order; clears the log. Returns the count written.
+extern "C" int nkb_prof_collect_raw(int* kid, double* ms, double* work, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.b);
+        float t = 0.f;
+        hipEventElapsedTime(&t, r.a, r.b);
+        if (n < cap) { kid[n] = r.kid; ms[n] = t; work[n] = r.work; ++n; }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_prof.clear();
+    return n;
+}
+
 extern "C" const char* nkb_kernel_name(int kid) {
     static const char* names[] = {"conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "bn_apply", "bn_bwd_reduce",
                                   "bn_bwd_apply", "bn_finalize", "maxpool", "avgpool", "im2row", "wprep", "loss",

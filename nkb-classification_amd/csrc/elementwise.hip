@@ -28,7 +28,30 @@ template <> struct Chunk<float> {
 // bn_finalize: reduce the conv epilogue's per-tile partial sums -> batch mean / biased var,
 // fold gamma/beta into (scale, shift), update running stats (momentum, unbiased var).
 // eval mode (training == 0): scale/shift from the running statistics, nothing else touched.
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int tiles, int C, float count,
+// stage A (only for many tiles): grid (C/64, 16) blocks of 64 channels x 16 partitions -> dpart[16][2][C] doubles
+__global__ void bn_partial_reduce_kernel(const float* __restrict__ partials, int tiles, int C, double* __restrict__ dpart) {
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s = 0.0, ss = 0.0;
+    if (c < C) {
+        for (int t = blockIdx.y * 16 + py; t < tiles; t += 256) {
+            s += (double)partials[((size_t)t * 2) * C + c];
+            ss += (double)partials[((size_t)t * 2 + 1) * C + c];
+        }
+    }
+    red[0][py][cx] = s;
+    red[1][py][cx] = ss;
+    __syncthreads();
+    if (py != 0 || c >= C) return;
+    s = 0.0; ss = 0.0;
+    for (int k = 0; k < 16; ++k) { s += red[0][k][cx]; ss += red[1][k][cx]; }
+    dpart[((size_t)blockIdx.y * 2) * C + c] = s;
+    dpart[((size_t)blockIdx.y * 2 + 1) * C + c] = ss;
+}
+
+template <typename PT>
+__global__ void bn_finalize_kernel(const PT* __restrict__ partials, int tiles, int C, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, int training, float* __restrict__ scale,
@@ -71,16 +94,26 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int tiles
     if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
 }
 
+// `partials` must have room for 64*C extra floats behind the [tiles][2][C] block when tiles > 128 (stage-A scratch).
 extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                int training, float* scale, float* shift, float* save_mean, float* save_invstd,
                                hipStream_t stream) {
     NkbProfScope prof(NKB_K_BN_FINALIZE, stream, 0);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, tiles, C, (float)count,
-                       gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, save_mean,
-                       save_invstd);
+    if (training && tiles > 128) {
+        double* dpart = (double*)(partials + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, 16), dim3(1024), 0, stream, partials, tiles, C, dpart);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream, (const double*)dpart, 16, C,
+                           (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
+                           save_mean, save_invstd);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, tiles, C,
+                           (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
+                           save_mean, save_invstd);
+    }
     return nkb_check_launch("bn_finalize");
 }
+extern "C" size_t nkb_bn_stats_floats(int tiles, int C) { return (size_t)tiles * 2 * C + 2 + (tiles > 128 ? (size_t)64 * C : 0); }
 
 // ------------------------------------------------------------------------------------------
 // bn_apply: y = act(x*scale[c] + shift[c] (+ residual))
@@ -142,11 +175,14 @@ extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, 
 }
 
 // ------------------------------------------------------------------------------------------
-// bn backward, pass 1: per-channel sum(dy') and sum(dy' * xhat), dy' = dy * (yact > 0) when yact given.
+// ReLU mask of a BN+ReLU stage: from the stored activation (yact > 0, residual stages) or recomputed from the raw
+// conv output as x*scale+shift > 0 (same expression, same rounding as bn_apply), which saves one tensor read.
+// bn backward, pass 1: per-channel sum(dy') and sum(dy' * xhat), dy' = dy * mask.
 // Block b handles rows [b*rpb, (b+1)*rpb); thread t owns channel chunk t % (C/N) and walks rows with
 // stride blockDim/(C/N); block partials go to part[b][2][C] (deterministic), reduced by pass 1b.
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
+                                     const float* __restrict__ fscale, const float* __restrict__ fshift,
                                      const float* __restrict__ mean, const float* __restrict__ invstd, long long rows,
                                      int C, int rpb, float* __restrict__ part) {
     constexpr int N = Chunk<T>::N;
@@ -154,12 +190,16 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
     const int cpr = C / N;                       // chunks per row
     const int tpc = blockDim.x / cpr;            // threads sharing one chunk column (>=1 by host construction)
     const int cg = threadIdx.x % cpr, rl = threadIdx.x / cpr;
-    float s1[N], s2[N], mu[N], is[N];
+    float s1[N], s2[N], mu[N], is[N], fs[N], fb[N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int e = 0; e < N; ++e) { s1[e] = 0.f; s2[e] = 0.f; fs[e] = 0.f; fb[e] = 1.f; }
     if (rl < tpc) {
 #pragma unroll
         for (int e = 0; e < N; ++e) { mu[e] = mean[cg * N + e]; is[e] = invstd[cg * N + e]; }
+        if (fscale) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) { fs[e] = fscale[cg * N + e]; fb[e] = fshift[cg * N + e]; }
+        }
         const long long r0 = (long long)blockIdx.x * rpb;
         const long long r1 = min(rows, r0 + rpb);
         for (long long r = r0 + rl; r < r1; r += tpc) {
@@ -172,6 +212,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
             for (int e = 0; e < N; ++e) {
                 float gg = g[e];
                 if (yact && !(ya[e] > 0.f)) gg = 0.f;
+                if (fscale && !(DT<T>::rnd(xv[e] * fs[e] + fb[e]) > 0.f)) gg = 0.f;
                 s1[e] += gg;
                 s2[e] += gg * (xv[e] - mu[e]) * is[e];
             }
@@ -221,7 +262,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 // pass 2: dx = gamma*invstd * (dy' - sum_dy/M - xhat*sum_dy_xhat/M); optionally writes dy' back (masked grad).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                           const T* __restrict__ yact, const float* __restrict__ mean,
+                                                           const T* __restrict__ yact, const float* __restrict__ fscale,
+                                                           const float* __restrict__ fshift, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, float inv_count,
@@ -232,10 +274,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned cg = t % cpr, r0 = t / cpr, rs = (gridDim.x * blockDim.x) / cpr;
     // dx = k1*dy' + k2*x + k3 with per-channel constants
-    float k1[N], k2[N], k3[N];
+    float k1[N], k2[N], k3[N], fs[N], fb[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) {
         const int c = cg * N + e;
+        fs[e] = fscale ? fscale[c] : 0.f;
+        fb[e] = fscale ? fshift[c] : 1.f;
         const float is = invstd[c], ga = gamma ? gamma[c] : 1.f, mu = mean[c];
         const float a = ga * is;
         const float sdy = sums[c] * inv_count, sdyx = sums[C + c] * inv_count;
@@ -253,6 +297,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int e = 0; e < N; ++e) {
             float gg = g[e];
             if (yact && !(ya[e] > 0.f)) gg = 0.f;
+            if (fscale && !(DT<T>::rnd(xv[e] * fs[e] + fb[e]) > 0.f)) gg = 0.f;
             g[e] = gg;
             out[e] = k1[e] * gg + (k2[e] * xv[e] + k3[e]);
         }
@@ -262,7 +307,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // eval-mode / frozen-stat backward is not needed: frozen backbones skip backward entirely.
-extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const float* mean,
+extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const float* fscale,
+                               const float* fshift, const float* mean,
                                const float* invstd, const float* gamma, long long rows, int C, float* dgamma,
                                float* dbeta, void* dx, void* dy_masked, float* workspace, size_t workspace_floats,
                                hipStream_t stream) {
@@ -273,7 +319,7 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
     while (threads < cpr) threads *= 2;
     const int tpc = threads / cpr;
     int blocks = (int)((rows + 63) / 64);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     const int rpb = (int)((rows + blocks - 1) / blocks);
     blocks = (int)((rows + rpb - 1) / rpb);
@@ -286,10 +332,10 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
         NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0);
         if (dtype == NKB_DT_BF16)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(threads), lds, stream, (const bf16_t*)dy,
-                               (const bf16_t*)x, (const bf16_t*)yact, mean, invstd, rows, C, rpb, part);
+                               (const bf16_t*)x, (const bf16_t*)yact, fscale, fshift, mean, invstd, rows, C, rpb, part);
         else
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(threads), lds, stream, (const float*)dy,
-                               (const float*)x, (const float*)yact, mean, invstd, rows, C, rpb, part);
+                               (const float*)x, (const float*)yact, fscale, fshift, mean, invstd, rows, C, rpb, part);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, part, blocks, C, dgamma,
                            dbeta, sums);
     }
@@ -299,11 +345,11 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
         const unsigned grid = grid_cols((size_t)rows, cpr);
         if (dtype == NKB_DT_BF16)
             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream,
-                               (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)yact, mean, invstd, gamma, sums,
+                               (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)yact, fscale, fshift, mean, invstd, gamma, sums,
                                1.0f / (float)rows, (unsigned)rows, C, (bf16_t*)dx, (bf16_t*)dy_masked);
         else
             hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream,
-                               (const float*)dy, (const float*)x, (const float*)yact, mean, invstd, gamma, sums,
+                               (const float*)dy, (const float*)x, (const float*)yact, fscale, fshift, mean, invstd, gamma, sums,
                                1.0f / (float)rows, (unsigned)rows, C, (float*)dx, (float*)dy_masked);
     }
     return nkb_check_launch("bn_bwd_apply");
@@ -311,7 +357,7 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
 
 extern "C" size_t nkb_bn_backward_workspace_floats(long long rows, int C) {
     long long blocks = (rows + 63) / 64;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     return (size_t)blocks * 2 * C + 2 * C;
 }

@@ -27,7 +27,8 @@ _SIGS = {
     "nkb_conv_wgrad": (i32, [i32, vp, vp, vp] + [i32] * 13 + [vp]),
     "nkb_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
-    "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "nkb_bn_stats_floats": (sz, [i32, i32]),
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
     "nkb_maxpool3x3s2": (i32, [i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nkb_avgpool": (i32, [i32, i32, vp, vp, i32, i32, i32, vp]),
@@ -43,6 +44,7 @@ _SIGS = {
     "nkb_segment_sumsq": (i32, [vp, vp, i32, vp, vp]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, i32]),
+    "nkb_prof_collect_raw": (i32, [vp, vp, vp, i32]),
     "nkb_kernel_name": (C.c_char_p, [i32]),
 }
 
@@ -127,8 +129,14 @@ def bn_apply(dtype, x, res, y, scale, shift, rows, C_, relu):
           "bn_apply")
 
 
-def bn_backward(dtype, dy, x, yact, mean, invstd, gamma, rows, C_, dgamma, dbeta, dx, dy_masked, workspace):
-    check(load().nkb_bn_backward(dtype, ptr(dy), ptr(x), ptr(yact), ptr(mean), ptr(invstd), ptr(gamma), rows, C_,
+def bn_stats_floats(tiles, C_):
+    return load().nkb_bn_stats_floats(tiles, C_)
+
+
+def bn_backward(dtype, dy, x, yact, mean, invstd, gamma, rows, C_, dgamma, dbeta, dx, dy_masked, workspace,
+                fscale=None, fshift=None):
+    check(load().nkb_bn_backward(dtype, ptr(dy), ptr(x), ptr(yact), ptr(fscale), ptr(fshift), ptr(mean), ptr(invstd),
+                                 ptr(gamma), rows, C_,
                                  ptr(dgamma), ptr(dbeta), ptr(dx), ptr(dy_masked), ptr(workspace), workspace.numel(),
                                  stream()), "bn_backward")
 
@@ -199,3 +207,12 @@ def prof_collect():
         if cnt[i]:
             out[load().nkb_kernel_name(i).decode()] = dict(ms=ms[i], launches=cnt[i], work=work[i])
     return out
+
+
+def prof_collect_raw(cap: int = 1 << 16):
+    """[(kernel name, ms, work)] per launch, in launch order."""
+    kid = (C.c_int * cap)()
+    ms = (C.c_double * cap)()
+    work = (C.c_double * cap)()
+    n = load().nkb_prof_collect_raw(kid, ms, work, cap)
+    return [(load().nkb_kernel_name(kid[i]).decode(), ms[i], work[i]) for i in range(n)]

@@ -103,7 +103,7 @@ class HipEngine:
         rows = N * P * Q
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
         tiles = hip.stat_tiles(rows, co)
-        stats = self.ws.get(key + ".stats", (tiles, 2, co), torch.float32) if train else None
+        stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
         hip.conv_gemm(self.d, 0, x, self.w_fwd(w), c, stats=stats, **geom)
         sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
         scale, shift, mean, invstd = sc[0], sc[1], sc[2], sc[3]
@@ -113,7 +113,7 @@ class HipEngine:
         hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu)
         if train:
             self.saved[key] = dict(x=x, c=c, y=y, mean=mean, invstd=invstd, relu=relu, geom=geom, conv=conv, bn=bn,
-                                   rows=rows, col_input=col_input)
+                                   rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None)
         return y
 
     def maxpool(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:
@@ -199,9 +199,12 @@ class HipEngine:
         a = self.arena
         gc = self.scratch(slot, sv["c"].shape)
         work = self.ws.at_least("bn.work", hip.bn_backward_ws(rows, co), torch.float32)
-        hip.bn_backward(self.d, g_y, sv["c"], sv["y"] if sv["relu"] else None, sv["mean"], sv["invstd"], bn.weight, rows,
+        # ReLU mask: stages without a residual recompute it from the raw conv output (one tensor read less)
+        from_y = sv["relu"] and sv["has_res"]
+        from_x = sv["relu"] and not sv["has_res"]
+        hip.bn_backward(self.d, g_y, sv["c"], sv["y"] if from_y else None, sv["mean"], sv["invstd"], bn.weight, rows,
                         co, a.grad_flat(bn.weight), a.grad_flat(bn.bias), gc, g_y if (write_masked and sv["relu"]) else None,
-                        work)
+                        work, fscale=sv["scale"] if from_x else None, fshift=sv["shift"] if from_x else None)
         return gc
 
     def conv_backward(self, key: str, g_c: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None):

@@ -144,6 +144,12 @@ def test_batchnorm_train_fwd_bwd(dtype, C):
     half = rows // 2
     partials = torch.stack([torch.stack([xf[:half].sum(0), (xf[:half] ** 2).sum(0)]),
                             torch.stack([xf[half:].sum(0), (xf[half:] ** 2).sum(0)])]).contiguous()
+    # many-tile path (two-stage reduction): same sums spread over 300 row tiles + the scratch tail the API asks for
+    big = torch.zeros(hip.bn_stats_floats(300, C), device=DEV)
+    big[:300 * 2 * C].view(300, 2, C)[:2] = partials
+    sc2, sh2, mean2, inv2 = (torch.empty(C, device=DEV) for _ in range(4))
+    hip.bn_finalize(big, 300, C, rows, bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), torch.zeros(C, device=DEV),
+                    torch.ones(C, device=DEV), 0.1, 1e-5, True, sc2, sh2, mean2, inv2)
     gamma, beta = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     scale, shift, mean, invstd = (torch.empty(C, device=DEV) for _ in range(4))
@@ -151,6 +157,8 @@ def test_batchnorm_train_fwd_bwd(dtype, C):
     yd = torch.empty_like(xd)
     hip.bn_apply(d, xd, nhwc(res).to(DEV, dtype), yd, scale, shift, rows, C, True)
     torch.cuda.synchronize()
+    torch.testing.assert_close(sc2.cpu(), scale.cpu(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(mean2.cpu(), mean.cpu(), rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(rm.cpu(), bn.running_mean, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rv.cpu(), bn.running_var, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(yd.float().cpu(), nhwc(y.detach()), **tol(dtype))
@@ -168,6 +176,20 @@ def test_batchnorm_train_fwd_bwd(dtype, C):
     torch.testing.assert_close(dgamma.cpu(), bn.weight.grad, **t)
     torch.testing.assert_close(dx.float().cpu(), nhwc(x.grad), **tol(dtype, 4))
     torch.testing.assert_close(dym.float().cpu(), nhwc(dy * (y.detach() > 0)), **tol(dtype))
+
+    # no-residual stage: the mask is recomputed from x*scale+shift instead of being read from the activation
+    x2 = x.detach().clone().requires_grad_(True)
+    bn.zero_grad()
+    y2 = torch.relu(torch.nn.functional.batch_norm(x2, None, None, bn.weight, bn.bias, True, 0.1, 1e-5))
+    y2.backward(dy)
+    dgamma.zero_(); dbeta.zero_()
+    hip.bn_backward(d, nhwc(dy).to(DEV, dtype), xd, None, mean, invstd, gamma, rows, C, dgamma, dbeta, dx, None, ws,
+                    fscale=scale, fshift=shift)
+    torch.cuda.synchronize()
+    if dtype == torch.float32:   # in bf16 the torch reference masks on unrounded values; borderline zeros may differ
+        torch.testing.assert_close(dbeta.cpu(), bn.bias.grad, **t)
+        torch.testing.assert_close(dgamma.cpu(), bn.weight.grad, **t)
+        torch.testing.assert_close(dx.float().cpu(), nhwc(x2.grad), **tol(dtype, 4))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
