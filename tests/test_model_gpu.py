@@ -200,3 +200,22 @@ def test_cpu_forward_fails_loudly():
     model = get_model(cfg_model, ["a", "b"], "cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(torch.randn(1, 3, 64, 64))
+
+
+def test_train_py_end_to_end(tmp_path):
+    """The config-driven entry point (train.py -cfg ...) runs two epochs and writes the checkpoint files."""
+    import subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1] / "nkb-classification_amd"
+    cfg = (root / "configs" / "synthetic_singletask_config.py").read_text().replace(
+        '"runs/synthetic_single"', repr(str(tmp_path / "exp")))
+    (tmp_path / "cfg_e2e.py").write_text(cfg)
+    r = subprocess.run([sys.executable, str(root / "train.py"), "-cfg", str(tmp_path / "cfg_e2e.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exp = tmp_path / "exp"
+    assert (exp / "weights" / "last.pth").exists() and (exp / "classes.json").exists()
+    lines = (exp / "metrics.csv").read_text().strip().splitlines()
+    assert len(lines) == 3 and "\t" in lines[0]
+    sd = torch.load(exp / "weights" / "last.pth", map_location="cpu")
+    assert "emb_model.layer4.1.bn2.running_var" in sd and "classifier.1.weight" in sd
