@@ -80,6 +80,31 @@ int nkb_colsum(int dtype, const void* x, float* out, int rows, int C, int ld, nk
 int nkb_pad_cast(int dtype, const float* src, void* dst, int rows, int C, int ld_src, int ld_dst, float mul,
                  nkb_stream_t stream);
 
+/* ---- transformer (timm VisionTransformer) ------------------------------------------------------------------ */
+/* Batched GEMM y[z][m][n] = sum_k x[z][m][k] w[z][n][k] and its transposed-A form out[z][a][b] = sum_m A[z][m][a] B[z][m][b];
+ * z = zo*inner + zi, element offsets zo*s?o + zi*s?i (attention products over all image x head pairs). */
+int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y, int M, int N, int K, int ldx, int ldw, int ldy,
+                     int outer, int inner, long long sxo, long long sxi, long long swo, long long swi, long long syo,
+                     long long syi, int out_f32, nkb_stream_t stream);
+int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int M, int Na, int Nb, int lda, int ldb,
+                        int ldo, int outer, int inner, long long sao, long long sai, long long sbo, long long sbi,
+                        long long soo, long long soi, nkb_stream_t stream);
+/* LayerNorm over the last dim (biased variance). backward=0: in = x -> out = y, writes mean/rstd.
+ * backward=1: in = dy, x = saved input -> out = dx (+ add), dgamma/dbeta accumulated with atomics. Strides in elements. */
+int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
+                  const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
+                  long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps, nkb_stream_t stream);
+/* exact-erf GELU: dy == NULL -> out = gelu(x); else out = dy * gelu'(x) */
+int nkb_gelu(int dtype, const void* x, const void* dy, void* out, long long n, nkb_stream_t stream);
+/* softmax over fp32 score rows (forward: p = softmax(scale*s); backward: ds = scale*p*(dp - sum dp*p)), zero padded to ldp */
+int nkb_attn_softmax(int dtype, int backward, const float* s, int lds, const void* p_in, void* out, int ldp,
+                     long long rows, int cols, float scale, nkb_stream_t stream);
+int nkb_head_transpose(int dtype, const void* in, int ld_in, long long sio, long long sii, int outer, int inner, void* out,
+                       int T, int dh, int ldt, nkb_stream_t stream);
+int nkb_vit_assemble(int dtype, int backward, void* tok, const float* cls, const float* pos, void* x, int B, int Tn, int D,
+                     nkb_stream_t stream);
+int nkb_colsum2d(int dtype, const void* x, float* out, long long rows, int C, long long ld, nkb_stream_t stream);
+
 /* Losses (kind 0: CrossEntropyLoss(weight) mean; kind 1: FocalLoss(alpha, gamma) mean over un-ignored rows).
  * out2[0] = loss, out2[1] = 1/normaliser.  probs/argmax double as the logger's softmax/argmax. */
 int nkb_loss_forward(int kind, const float* logits, int ld, const long long* target, int B, int C,

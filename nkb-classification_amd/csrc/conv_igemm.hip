@@ -28,6 +28,10 @@ struct ConvParams {
     int out_f32;        // write fp32 regardless of the compute dtype
     int tilesM, tilesN;
     FastDiv divPQ, divQ;
+    // batched GEMM (attention): blockIdx.y = zo*inner + zi; element offsets zo*s?o + zi*s?i on x / w / y
+    int ldw;            // row stride of w in elements (R*S*Cin unless batched)
+    int inner;
+    long long sxo, sxi, swo, swi, syo, syi;
 };
 
 template <typename T> struct MmaTraits;
@@ -60,9 +64,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int m0 = tile_m * TP;
     const int c0 = tile_n * TC;
 
-    const T* __restrict__ X = (const T*)p.x;
-    const T* __restrict__ Wt = (const T*)p.w;
-    const int Ktot = p.R * p.S * p.Cin;
+    const int zo = blockIdx.y / p.inner, zi = blockIdx.y - zo * p.inner;
+    const T* __restrict__ X = (const T*)p.x + (zo * p.sxo + zi * p.sxi);
+    const T* __restrict__ Wt = (const T*)p.w + (zo * p.swo + zi * p.swi);
+    const size_t yoff = (size_t)(zo * p.syo + zi * p.syi);
     const int cpk = p.Cin / KTE;  // k-tiles per filter tap
     const int KT = p.R * p.S * cpk;
 
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
         const int co = c0 + srow + 32 * i;
-        wofs[i] = (co < p.Cout) ? co * Ktot + cc * EPC : -1;
+        wofs[i] = (co < p.Cout) ? co * p.ldw + cc * EPC : -1;
     }
 
     u32x4 sw[NWR], sx[NPR];
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.out_f32 || sizeof(T) == 4) {
-            float* o = (float*)p.y + (size_t)m * p.ldy + co;
+            float* o = (float*)p.y + yoff + (size_t)m * p.ldy + co;
             if (vec_ok) {
                 *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
                 *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 for (int e = 0; e < 8; ++e) if (co + e < p.Cout) o[e] = v[e];
             }
         } else {
-            bf16_t* o = (bf16_t*)p.y + (size_t)m * p.ldy + co;
+            bf16_t* o = (bf16_t*)p.y + yoff + (size_t)m * p.ldy + co;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));  // statistics see the stored value
             if (vec_ok) {
@@ -289,6 +294,11 @@ struct WgradParams {
     int Ntot;         // R*S*Cin
     int tilesC, tilesN, splits, rows_per_split;
     FastDiv divPQ, divQ, divCin, divS;
+    // batched / direct-store form (attention dV, dK): blockIdx.z = zo*inner + zi; when out_t is set the single split
+    // stores its tile in the compute dtype at out_t[z-offset + cout*ldo + n] instead of adding to dw
+    void* out_t;
+    int ldo, inner;
+    long long sdo, sdi, sxo, sxi, soo, soi;
 };
 
 __device__ __forceinline__ int lds_swz256(int row, int ch) {
@@ -314,8 +324,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
 
-    const T* __restrict__ DY = (const T*)p.dy;
-    const T* __restrict__ X = (const T*)p.x;
+    const int zo = blockIdx.z / p.inner, zi = blockIdx.z - zo * p.inner;
+    const T* __restrict__ DY = (const T*)p.dy + (zo * p.sdo + zi * p.sdi);
+    const T* __restrict__ X = (const T*)p.x + (zo * p.sxo + zi * p.sxi);
 
     const int cc = tid & 15, srow = tid >> 4;  // 16 chunks per 256-byte row, 16 rows per pass
     // the tap and channel of this thread's X chunk are fixed for the whole kernel
@@ -453,6 +464,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             for (int e = 0; e < 4; ++e) *(float*)(smem + (rbase + e) * EROW + col * 4) = acc[i][j][e];
         }
     __syncthreads();
+    if (p.out_t) {
+        T* out = (T*)p.out_t + (zo * p.soo + zi * p.soi);
+        for (int row = wave; row < TW; row += 4) {
+            const int co = c0 + row;
+            if (co >= p.Cout) break;
+            for (int col = lane; col < TW; col += 64) {
+                const int n = n0 + col;
+                if (n < p.Ntot) DT<T>::st(out + (size_t)co * p.ldo + n, *(const float*)(smem + row * EROW + col * 4));
+            }
+        }
+        return;
+    }
     for (int row = wave; row < TW; row += 4) {
         const int co = c0 + row;
         if (co >= p.Cout) break;
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // ------------------------------------------------------------------------------------------
 // host launchers
 template <typename T, int TC, int TP>
-static int launch_conv(ConvParams& p, hipStream_t stream) {
+static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
     p.tilesM = (p.M + TP - 1) / TP;
     p.tilesN = (p.Cout + TC - 1) / TC;
     constexpr int stage = 2 * (TC + TP) * 128;
@@ -478,7 +501,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const unsigned grid = (unsigned)p.tilesM * (unsigned)p.tilesN;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, TC, TP>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TC, TP>), dim3(grid, batch), dim3(256), lds, stream, p);
     return nkb_check_launch("conv_igemm");
 }
 
@@ -505,11 +528,38 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     p.ldadd = ldadd; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.mode = mode; p.relu = relu;
     p.out_f32 = out_f32;
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
+    p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     const double flops = 2.0 * p.M * (double)Cout * R * S * Cin;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops);
     const bool narrow = Cout <= 64;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+}
+
+// Batched row-major GEMM  y[z][m][n] = sum_k x[z][m][k] * w[z][n][k]  (both operands K-contiguous rows with leading
+// dimensions ldx / ldw), z = zo*inner + zi with element offsets zo*s?o + zi*s?i: the attention products
+// (Q K^T, P V, dO V^T, dS K) over all (image, head) pairs in one launch.
+extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y, int M, int N, int K, int ldx, int ldw,
+                                int ldy, int outer, int inner, long long sxo, long long sxi, long long swo,
+                                long long swi, long long syo, long long syi, int out_f32, hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int kte = 128 / esz;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("gemm_batched: bad dtype %d", dtype); return 1; }
+    if (K % kte != 0 || ldx % (16 / esz) != 0 || ldw % (16 / esz) != 0 || outer * inner > 65535 || outer * inner < 1) {
+        nkb_set_error("gemm_batched: K=%d must be a multiple of %d, ldx/ldw of %d, batch <= 65535", K, kte, 16 / esz);
+        return 1;
+    }
+    ConvParams p;
+    p.x = x; p.w = w; p.y = y; p.add = nullptr; p.bias = nullptr; p.stats = nullptr;
+    p.M = M; p.H = M; p.W = 1; p.Cin = K; p.ldx = ldx; p.P = M; p.Q = 1; p.Cout = N; p.ldy = ldy; p.ldadd = 0;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 0; p.relu = 0; p.out_f32 = out_f32;
+    p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
+    p.ldw = ldw; p.inner = inner; p.sxo = sxo; p.sxi = sxi; p.swo = swo; p.swi = swi; p.syo = syo; p.syi = syi;
+    NkbProfScope prof(NKB_K_ATTN, stream, 2.0 * M * (double)N * K * outer * inner);
+    const bool narrow = N <= 64;
+    const int batch = outer * inner;
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream, batch) : launch_conv<bf16_t, 128, 128>(p, stream, batch);
+    return narrow ? launch_conv<float, 64, 256>(p, stream, batch) : launch_conv<float, 128, 128>(p, stream, batch);
 }
 
 // number of row tiles the stats buffer must hold for a given launch: [tilesM][2][Cout] floats
@@ -548,6 +598,7 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     p.splits = splits; p.rows_per_split = rps;
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.divCin = make_fastdiv((unsigned)Cin); p.divS = make_fastdiv((unsigned)S);
+    p.out_t = nullptr; p.ldo = 0; p.inner = 1; p.sdo = p.sdi = p.sxo = p.sxi = p.soo = p.soi = 0;
     const int lds = 2 * 2 * 64 * 256 > TW * (TW * 4 + 16) ? 2 * 2 * 64 * 256 : TW * (TW * 4 + 16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -560,4 +611,40 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
     return nkb_check_launch("conv_wgrad");
+}
+
+// Batched "transposed-A" GEMM  out[z][a][b] = sum_m A[z][m][a] * B[z][m][b]  (both operands m-major, e.g. attention
+// dV = P^T dO and dK = dS^T Q), stored in the compute dtype with leading dimension ldo.  One split per batch.
+extern "C" int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int M, int Na, int Nb, int lda,
+                                   int ldb, int ldo, int outer, int inner, long long sao, long long sai, long long sbo,
+                                   long long sbi, long long soo, long long soi, hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int epc = 16 / esz;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("gemm_tn_batched: bad dtype %d", dtype); return 1; }
+    if (Nb % epc != 0 || lda % epc != 0 || ldb % epc != 0 || lda < (Na + epc - 1) / epc * epc || outer * inner > 65535) {
+        nkb_set_error("gemm_tn_batched: Nb=%d lda=%d ldb=%d must be multiples of %d, lda >= roundup(Na=%d)", Nb, lda, ldb, epc, Na);
+        return 1;
+    }
+    WgradParams p;
+    p.dy = a; p.x = b; p.dw = nullptr; p.dbias = nullptr;
+    p.M = M; p.H = M; p.W = 1; p.Cin = Nb; p.ldx = ldb; p.P = M; p.Q = 1; p.Cout = Na; p.lddy = lda;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.Ntot = Nb;
+    const int TW = 256 / esz;
+    p.tilesC = (Na + TW - 1) / TW; p.tilesN = (Nb + TW - 1) / TW;
+    p.splits = 1; p.rows_per_split = (M + 63) / 64 * 64;
+    p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
+    p.divCin = make_fastdiv((unsigned)Nb); p.divS = make_fastdiv(1u);
+    p.out_t = out; p.ldo = ldo; p.inner = inner; p.sdo = sao; p.sdi = sai; p.sxo = sbo; p.sxi = sbi; p.soo = soo; p.soi = soi;
+    const int lds = 2 * 2 * 64 * 256 > TW * (TW * 4 + 16) ? 2 * 2 * 64 * 256 : TW * (TW * 4 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (128 * 4 + 16));
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    NkbProfScope prof(NKB_K_ATTN, stream, 2.0 * M * (double)Na * Nb * outer * inner);
+    dim3 grid((unsigned)(p.tilesC * p.tilesN), 1, (unsigned)(outer * inner));
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
+    return nkb_check_launch("gemm_tn_batched");
 }

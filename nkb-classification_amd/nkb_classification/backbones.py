@@ -187,5 +187,5 @@ def create_backbone(name: str, pretrained: bool = False) -> nn.Module:
     m = create_vit(key)
     if m is None:
         raise NotImplementedError(f"backbone {name!r} is not implemented by the HIP engine "
-                                  f"(available: {sorted(_RESNETS)} + vit_base_patch16_224)")
+                                  f"(available: {sorted(_RESNETS)} + vit_{{small,base,large}}_patch16_224)")
     return m

@@ -37,6 +37,14 @@ _SIGS = {
     "nkb_add2d": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "nkb_colsum": (i32, [i32, vp, vp, i32, i32, i32, vp]),
     "nkb_pad_cast": (i32, [i32, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "nkb_gemm_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [i32, vp]),
+    "nkb_gemm_tn_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [vp]),
+    "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
+    "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
+    "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
+    "nkb_head_transpose": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, i32, i32, i32, vp]),
+    "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "nkb_colsum2d": (i32, [i32, vp, vp, i64, i32, i64, vp]),
     "nkb_loss_forward": (i32, [i32, vp, i32, vp, i32, i32, vp, f32, i64, vp, i32, vp, vp, vp, vp]),
     "nkb_loss_row_state_bytes": (sz, [i32]),
     "nkb_loss_backward": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
@@ -216,3 +224,46 @@ def prof_collect_raw(cap: int = 1 << 16):
     work = (C.c_double * cap)()
     n = load().nkb_prof_collect_raw(kid, ms, work, cap)
     return [(load().nkb_kernel_name(kid[i]).decode(), ms[i], work[i]) for i in range(n)]
+
+
+# ---- transformer ----------------------------------------------------------------------------------
+def gemm_batched(dtype, x, w, y, M, N, K, ldx, ldw, ldy, outer, inner, sx, sw, sy, out_f32=False):
+    check(load().nkb_gemm_batched(dtype, ptr(x), ptr(w), ptr(y), M, N, K, ldx, ldw, ldy, outer, inner, sx[0], sx[1],
+                                  sw[0], sw[1], sy[0], sy[1], int(out_f32), stream()), "gemm_batched")
+
+
+def gemm_tn_batched(dtype, a, b, out, M, Na, Nb, lda, ldb, ldo, outer, inner, sa, sb, so):
+    check(load().nkb_gemm_tn_batched(dtype, ptr(a), ptr(b), ptr(out), M, Na, Nb, lda, ldb, ldo, outer, inner, sa[0], sa[1],
+                                     sb[0], sb[1], so[0], so[1], stream()), "gemm_tn_batched")
+
+
+def layernorm_fwd(dtype, x, x_stride, gamma, beta, y, y_stride, mean, rstd, rows, D, eps):
+    check(load().nkb_layernorm(dtype, 0, ptr(x), x_stride, None, 0, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), None,
+                               ptr(y), y_stride, None, None, rows, D, eps, stream()), "layernorm_fwd")
+
+
+def layernorm_bwd(dtype, dy, dy_stride, x, x_stride, gamma, mean, rstd, add, dx, dx_stride, dgamma, dbeta, rows, D):
+    check(load().nkb_layernorm(dtype, 1, ptr(dy), dy_stride, ptr(x), x_stride, ptr(gamma), None, ptr(mean), ptr(rstd),
+                               ptr(add), ptr(dx), dx_stride, ptr(dgamma), ptr(dbeta), rows, D, 0.0, stream()), "layernorm_bwd")
+
+
+def gelu(dtype, x, dy, out, n):
+    check(load().nkb_gelu(dtype, ptr(x), ptr(dy), ptr(out), n, stream()), "gelu")
+
+
+def attn_softmax(dtype, backward, s, lds, p_in, out, ldp, rows, cols, scale):
+    check(load().nkb_attn_softmax(dtype, int(backward), ptr(s), lds, ptr(p_in), ptr(out), ldp, rows, cols, scale, stream()),
+          "attn_softmax")
+
+
+def head_transpose(dtype, src, ld_in, sio, sii, outer, inner, out, T, dh, ldt):
+    check(load().nkb_head_transpose(dtype, ptr(src), ld_in, sio, sii, outer, inner, ptr(out), T, dh, ldt, stream()),
+          "head_transpose")
+
+
+def vit_assemble(dtype, backward, tok, cls, pos, x, B, Tn, D):
+    check(load().nkb_vit_assemble(dtype, int(backward), ptr(tok), ptr(cls), ptr(pos), ptr(x), B, Tn, D, stream()), "vit_assemble")
+
+
+def colsum2d(dtype, x, out, rows, C_, ld):
+    check(load().nkb_colsum2d(dtype, ptr(x), ptr(out), rows, C_, ld, stream()), "colsum2d")

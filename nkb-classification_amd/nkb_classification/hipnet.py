@@ -62,7 +62,7 @@ class HipEngine:
         if need_dgrad:
             for conv in self._convs:
                 w = conv.weight
-                co, ci, r, s = w.shape
+                co, ci, r, s = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
                 buf = self._wd.get(id(w))
                 if buf is None:
                     buf = self._wd[id(w)] = torch.empty(ci, r, s, co, device=self.device, dtype=self.T)
@@ -233,3 +233,112 @@ class HipEngine:
                       ldx=geom["Cout"], P=H, Q=W, Cout=ci, ldy=ci, R=geom["R"], S=geom["S"], stride=geom["stride"],
                       pad=geom["pad"], add=add, ldadd=ci if add is not None else 0)
         return dx
+
+    # ------------------------------------------------------------------ transformer ops ----
+    def linear(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """y = x @ W^T + b (+ add); x: [M, K] in the compute dtype."""
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        y = self.ws.get(key + ".y", (M, N), self.T)
+        hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
+                      bias=self.arena.param_flat(lin.bias) if lin.bias is not None else None, add=add,
+                      ldadd=N if add is not None else 0)
+        if train:
+            self.saved[key] = dict(x=x, lin=lin)
+        return y
+
+    def linear_backward(self, key: str, g: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None):
+        sv = self.saved[key]
+        x, lin = sv["x"], sv["lin"]
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        a = self.arena
+        hip.conv_wgrad(self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N)
+        if lin.bias is not None:
+            hip.colsum2d(self.d, g, a.grad_flat(lin.bias), M, N, N)
+        if slot is None:
+            return None
+        dx = self.scratch(slot, (M, K))
+        hip.conv_gemm(self.d, 0, g, self._wd[id(lin.weight)], dx, N=M, H=1, W=1, Cin=N, ldx=N, P=1, Q=1, Cout=K, ldy=K,
+                      add=add, ldadd=K if add is not None else 0)
+        return dx
+
+    def layernorm(self, key: str, x: torch.Tensor, ln: nn.LayerNorm, train: bool, rows: Optional[int] = None,
+                  x_stride: Optional[int] = None) -> torch.Tensor:
+        D = ln.weight.shape[0]
+        rows = x.shape[0] if rows is None else rows
+        xs = D if x_stride is None else x_stride
+        y = self.ws.get(key + ".y", (rows, D), self.T)
+        st = self.ws.get(key + ".stat", (2, rows), torch.float32)
+        a = self.arena
+        hip.layernorm_fwd(self.d, x, xs, a.param_flat(ln.weight), a.param_flat(ln.bias), y, D, st[0], st[1], rows, D, ln.eps)
+        if train:
+            self.saved[key] = dict(x=x, xs=xs, rows=rows, ln=ln, mean=st[0], rstd=st[1])
+        return y
+
+    def layernorm_backward(self, key: str, g: torch.Tensor, out: torch.Tensor, out_stride: int,
+                           add: Optional[torch.Tensor] = None):
+        """dx (+ add) is written into `out` rows with stride out_stride (elements)."""
+        sv = self.saved[key]
+        ln = sv["ln"]
+        D = ln.weight.shape[0]
+        a = self.arena
+        hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
+                          out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), sv["rows"], D)
+        return out
+
+    def gelu(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:
+        y = self.ws.get(key + ".y", x.shape, self.T)
+        hip.gelu(self.d, x, None, y, x.numel())
+        if train:
+            self.saved[key] = dict(x=x)
+        return y
+
+    def gelu_backward(self, key: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        x = self.saved[key]["x"]
+        dx = self.scratch(slot, x.shape)
+        hip.gelu(self.d, x, g, dx, x.numel())
+        return dx
+
+    def attention(self, key: str, qkv: torch.Tensor, B: int, T: int, H: int, train: bool) -> torch.Tensor:
+        """softmax(q k^T / sqrt(dh)) v over all (image, head) pairs; qkv: [B*T, 3*D] laid out [which][head][dh]."""
+        D = qkv.shape[1] // 3
+        dh = D // H
+        Tp = _round_up(T, self.kte)
+        S = self.ws.get("attn.S", (B * H, T, Tp), torch.float32)
+        P = self.ws.get(key + ".P", (B * H, T, Tp), self.T)
+        Vt = self.ws.get("attn.Vt", (B * H, dh, Tp), self.T)
+        o = self.ws.get(key + ".o", (B * T, D), self.T)
+        q, k, v = qkv, qkv[:, D:], qkv[:, 2 * D:]
+        sq = (T * 3 * D, dh)
+        hip.gemm_batched(self.d, q, k, S, T, T, dh, 3 * D, 3 * D, Tp, B, H, sq, sq, (H * T * Tp, T * Tp), out_f32=True)
+        hip.attn_softmax(self.d, False, S, Tp, None, P, Tp, B * H * T, T, dh ** -0.5)
+        hip.head_transpose(self.d, v, 3 * D, T * 3 * D, dh, B, H, Vt, T, dh, Tp)
+        hip.gemm_batched(self.d, P, Vt, o, T, dh, Tp, Tp, Tp, D, B, H, (H * T * Tp, T * Tp), (H * dh * Tp, dh * Tp),
+                         (T * D, dh))
+        if train:
+            self.saved[key] = dict(qkv=qkv, P=P, B=B, T=T, H=H)
+        return o
+
+    def attention_backward(self, key: str, d_o: torch.Tensor, slot: str) -> torch.Tensor:
+        sv = self.saved[key]
+        qkv, P, B, T, H = sv["qkv"], sv["P"], sv["B"], sv["T"], sv["H"]
+        D = qkv.shape[1] // 3
+        dh = D // H
+        Tp = P.shape[2]
+        dqkv = self.scratch(slot, qkv.shape)
+        dP = self.ws.get("attn.S", (B * H, T, Tp), torch.float32)
+        dS = self.ws.get("attn.dS", (B * H, T, Tp), self.T)
+        Kt = self.ws.get("attn.Vt", (B * H, dh, Tp), self.T)
+        q, k, v = qkv, qkv[:, D:], qkv[:, 2 * D:]
+        sq, sp, so = (T * 3 * D, dh), (H * T * Tp, T * Tp), (T * D, dh)
+        # dV = P^T dO
+        hip.gemm_tn_batched(self.d, P, d_o, dqkv[:, 2 * D:], T, T, dh, Tp, D, 3 * D, B, H, sp, so, sq)
+        # dP = dO V^T ; dS = softmax'(P, dP)
+        hip.gemm_batched(self.d, d_o, v, dP, T, T, dh, D, 3 * D, Tp, B, H, so, sq, sp, out_f32=True)
+        hip.attn_softmax(self.d, True, dP, Tp, P, dS, Tp, B * H * T, T, dh ** -0.5)
+        # dQ = dS K ; dK = dS^T Q
+        hip.head_transpose(self.d, k, 3 * D, T * 3 * D, dh, B, H, Kt, T, dh, Tp)
+        hip.gemm_batched(self.d, dS, Kt, dqkv, T, dh, Tp, Tp, Tp, 3 * D, B, H, sp, (H * dh * Tp, dh * Tp), sq)
+        hip.gemm_tn_batched(self.d, dS, q, dqkv[:, D:], T, T, dh, Tp, 3 * D, 3 * D, B, H, sp, sq, sq)
+        return dqkv

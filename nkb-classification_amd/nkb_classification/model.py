@@ -169,7 +169,7 @@ class _HipClassifier(nn.Module):
             on_done = None
             if hook is not None:
                 def on_done(module):
-                    rng = arena.range_of(list(module.parameters()))
+                    rng = arena.range_of(list(module.parameters()) if isinstance(module, nn.Module) else list(module))
                     if rng is not None:
                         hook(*rng)
             self.emb_model.run_backward(eng, g_emb, on_done)

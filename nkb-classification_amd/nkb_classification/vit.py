@@ -1,6 +1,173 @@
-"""timm VisionTransformer family for the HIP engine (filled in once the ResNet path is parity-green)."""
+"""timm VisionTransformer family (vit_base_patch16_224 layout, num_classes=0, class-token pooling) for the HIP
+engine: parameter containers with timm's state-dict names + the forward / backward execution plan.
+
+Reference call site: timm.create_model("vit_base_patch16_224", ...) at
+/root/reference/nkb_classification/model.py:82; architecture per SURVEY.md §8 A8 (LayerNorm eps 1e-6, qkv with
+bias, exact-erf GELU, pre-norm residual blocks, x[:, 0] of the final norm as the embedding).
+"""
 from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import hip
+from .backbones import _ParamOnly
+from .hipnet import HipEngine
+
+
+class _PatchEmbed(_ParamOnly):
+    def __init__(self, patch, in_chans, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, dim, patch, patch)
+
+
+class _Attention(_ParamOnly):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.attn_drop = nn.Dropout(0.0)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(0.0)
+
+
+class _Mlp(_ParamOnly):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.drop1 = nn.Dropout(0.0)
+        self.fc2 = nn.Linear(hidden, dim)
+        self.drop2 = nn.Dropout(0.0)
+
+
+class _Block(_ParamOnly):
+    def __init__(self, dim, heads, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class HipViT(_ParamOnly):
+    family = "vit"
+
+    def __init__(self, img=224, patch=16, dim=768, depth=12, heads=12, mlp_ratio=4.0):
+        super().__init__()
+        self.num_features = dim
+        self.img, self.patch, self.heads = img, patch, heads
+        self.patch_embed = _PatchEmbed(patch, 3, dim)
+        n_tok = (img // patch) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, n_tok + 1, dim) * 0.02)
+        self.pos_drop = nn.Dropout(0.0)
+        self.blocks = nn.Sequential(*[_Block(dim, heads, mlp_ratio) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def gemm_convs(self):
+        return [m for m in self.modules() if isinstance(m, nn.Linear)]
+
+    def stem_convs(self):
+        return [self.patch_embed.proj]
+
+    def _check_dropout(self, train):
+        if train and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
+            raise NotImplementedError("backbone_dropout > 0 is not implemented by the HIP engine yet; set it to 0")
+
+    def run_forward(self, eng: HipEngine, img: torch.Tensor, train: bool) -> torch.Tensor:
+        self._check_dropout(train)
+        B, C, Hh, Ww = img.shape
+        if Hh != self.img or Ww != self.img:
+            raise RuntimeError(f"this ViT expects {self.img}x{self.img} inputs (pos_embed is fixed), got {Hh}x{Ww}")
+        pr = self.patch_embed.proj
+        D, ps = self.num_features, self.patch
+        gh = Hh // ps
+        npatch = gh * gh
+        T = npatch + 1
+        K = C * ps * ps
+        kp = eng.kpad(K)
+        col = eng.ws.get("pe.col", (B * npatch, kp), eng.T)
+        hip.im2row(eng.d, img, col, B, C, Hh, Ww, ps, ps, ps, 0, kp)
+        tok = eng.ws.get("pe.tok", (B * npatch, D), eng.T)
+        a = eng.arena
+        hip.conv_gemm(eng.d, 0, col, eng.w_fwd(pr.weight), tok, N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D,
+                      ldy=D, bias=a.param_flat(pr.bias))
+        x = eng.ws.get("pe.x", (B * T, D), eng.T)
+        hip.vit_assemble(eng.d, False, tok, a.param_flat(self.cls_token), a.param_flat(self.pos_embed), x, B, T, D)
+        if train:
+            eng.saved["pe"] = dict(col=col, B=B, T=T, kp=kp, K=K)
+        for i, blk in enumerate(self.blocks):
+            h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train)
+            qkv = eng.linear(f"b{i}.qkv", h, blk.attn.qkv, train)
+            o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train)
+            x = eng.linear(f"b{i}.proj", o, blk.attn.proj, train, add=x)
+            h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train)
+            u = eng.linear(f"b{i}.fc1", h, blk.mlp.fc1, train)
+            u = eng.gelu(f"b{i}.act", u, train)
+            x = eng.linear(f"b{i}.fc2", u, blk.mlp.fc2, train, add=x)
+        # final norm on the class-token rows only (x[:, 0]); the other rows never reach the head
+        return eng.layernorm("norm", x, self.norm, train, rows=B, x_stride=T * D)
+
+    def run_backward(self, eng: HipEngine, g_emb: torch.Tensor, on_done=None):
+        sv = eng.saved["pe"]
+        B, T = sv["B"], sv["T"]
+        D = self.num_features
+        M = B * T
+        a = eng.arena
+        gx = eng.scratch("gx0", (M, D))
+        gx.zero_()
+        eng.layernorm_backward("norm", g_emb, gx, T * D)          # rows b*T (class tokens); everything else stays 0
+        if on_done is not None:
+            on_done(self.norm)
+        flip = 1
+        for i in range(len(self.blocks) - 1, -1, -1):
+            blk = self.blocks[i]
+            d_u = eng.linear_backward(f"b{i}.fc2", gx, "du")
+            d_a = eng.gelu_backward(f"b{i}.act", d_u, "da")
+            d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
+            gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
+            d_o = eng.linear_backward(f"b{i}.proj", gmid, "do")
+            d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv")
+            d_h = eng.linear_backward(f"b{i}.qkv", d_qkv, "dh")
+            gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid)
+            flip ^= 1
+            if on_done is not None:
+                on_done(blk)
+        # embedding: d_pos = sum_b gx[b], d_cls = sum_b gx[b, 0], d_tok = gx[:, 1:], then the patch projection
+        hip.colsum2d(eng.d, gx, a.grad_flat(self.pos_embed), B, T * D, T * D)
+        hip.colsum2d(eng.d, gx, a.grad_flat(self.cls_token), B, D, T * D)
+        npatch = T - 1
+        d_tok = eng.scratch("dtok", (B * npatch, D))
+        hip.vit_assemble(eng.d, True, d_tok, None, None, gx, B, T, D)
+        pr = self.patch_embed.proj
+        kp, K = sv["kp"], sv["K"]
+        if kp == K:
+            hip.conv_wgrad(eng.d, d_tok, sv["col"], a.grad_flat(pr.weight), N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1,
+                           Q=1, Cout=D, lddy=D)
+        else:
+            dwp = eng.ws.get("pe.dwpad", (D, kp), torch.float32)
+            dwp.zero_()
+            hip.conv_wgrad(eng.d, d_tok, sv["col"], dwp, N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D, lddy=D)
+            hip.add2d(dwp, a.grad_flat(pr.weight), D, K, kp, K)
+        hip.colsum2d(eng.d, d_tok, a.grad_flat(pr.bias), B * npatch, D, D)
+        if on_done is not None:
+            on_done(self.patch_embed)
+            on_done([self.cls_token, self.pos_embed])
+
+
+_VITS = {
+    "vit_base_patch16_224": dict(img=224, patch=16, dim=768, depth=12, heads=12),
+    "vit_small_patch16_224": dict(img=224, patch=16, dim=384, depth=12, heads=6),
+    "vit_large_patch16_224": dict(img=224, patch=16, dim=1024, depth=24, heads=16),
+    "vit_tiny_test": dict(img=64, patch=16, dim=128, depth=2, heads=2),   # reduced member for fast parity tests
+}
 
 
 def create_vit(name: str):
-    return None
+    cfg = _VITS.get(name)
+    return HipViT(**cfg) if cfg else None

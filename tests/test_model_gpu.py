@@ -40,7 +40,7 @@ def _relerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-@pytest.mark.parametrize("backbone", ["resnet_tiny_basic", "resnet_tiny_bottleneck", "resnet18"])
+@pytest.mark.parametrize("backbone", ["resnet_tiny_basic", "resnet_tiny_bottleneck", "resnet18", "vit_tiny_test"])
 def test_single_step_gradients_match_oracle_fp32(backbone):
     """Truth = the oracle evaluated in float64.  ReLU/max-pool decisions on near-zero pre-activations make the
     problem mildly ill-conditioned, so the HIP fp32 path is held to the same distance from the float64 truth as
@@ -160,6 +160,26 @@ def test_golden_trajectory_tiny_basic_single(golden):
 
 def test_golden_trajectory_tiny_bottleneck_multi(golden):
     _check_case(golden("g4_engine")["tiny_bottleneck_multi"], 1e-3)
+
+
+def test_golden_trajectory_tiny_vit_single(golden):
+    _check_case(golden("g4_engine")["tiny_vit_single"], 1e-3)
+
+
+def test_vit_base_forward_matches_oracle():
+    """Full-size timm-layout ViT-B/16 (197 tokens, 12 heads): eval-mode logits vs the CPU oracle, fp32 and bf16."""
+    cfg_model = dict(model="vit_base_patch16_224", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    oracle, model = _pair(cfg_model, [str(i) for i in range(10)])
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ref = oracle(x)
+        out = model(x.to(DEV))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out16 = model(x.to(DEV))
+    assert _relerr(out.cpu(), ref) < 1e-3 and out.argmax(-1).cpu().tolist() == ref.argmax(-1).tolist()
+    assert _relerr(out16.cpu(), ref) < 5e-2
 
 
 def test_golden_trajectory_config1_resnet18(golden):

@@ -344,3 +344,93 @@ def test_segment_sumsq():
     torch.cuda.synchronize()
     ref = torch.stack([(x[a:b] ** 2).sum() for a, b in ((0, 10), (10, 10), (10, 3000), (3000, 5000))])
     torch.testing.assert_close(out.cpu(), ref.cpu(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- transformer ops ----
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [128, 768])
+def test_layernorm_fwd_bwd(dtype, D):
+    torch.manual_seed(10)
+    rows = 37
+    x = rnd(torch.randn(rows, D) * 1.5 + 0.3, dtype).requires_grad_(True)
+    ln = torch.nn.LayerNorm(D, eps=1e-6)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_()
+    y = ln(x)
+    dy = rnd(torch.randn(rows, D), dtype)
+    add = rnd(torch.randn(rows, D), dtype)
+    y.backward(dy)
+    d = hip.dt(dtype)
+    xd = x.detach().to(DEV, dtype)
+    g, b = ln.weight.detach().to(DEV), ln.bias.detach().to(DEV)
+    yd = torch.empty(rows, D, device=DEV, dtype=dtype)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    hip.layernorm_fwd(d, xd, D, g, b, yd, D, mean, rstd, rows, D, 1e-6)
+    dx = torch.empty(rows, D, device=DEV, dtype=dtype)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    hip.layernorm_bwd(d, dy.to(DEV, dtype), D, xd, D, g, mean, rstd, add.to(DEV, dtype), dx, D, dg, db, rows, D)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **tol(dtype))
+    torch.testing.assert_close(dx.float().cpu(), x.grad + add, **tol(dtype, 4))
+    torch.testing.assert_close(dg.cpu(), ln.weight.grad, **tol(dtype, rows))
+    torch.testing.assert_close(db.cpu(), ln.bias.grad, **tol(dtype, rows))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gelu_fwd_bwd(dtype):
+    torch.manual_seed(11)
+    x = rnd(torch.randn(5000) * 2, dtype).requires_grad_(True)
+    y = torch.nn.functional.gelu(x)
+    dy = rnd(torch.randn(5000), dtype)
+    y.backward(dy)
+    xd = x.detach().to(DEV, dtype)
+    yd, dx = torch.empty_like(xd), torch.empty_like(xd)
+    hip.gelu(hip.dt(dtype), xd, None, yd, 5000)
+    hip.gelu(hip.dt(dtype), xd, dy.to(DEV, dtype), dx, 5000)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **tol(dtype))
+    torch.testing.assert_close(dx.float().cpu(), x.grad, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [17, 197])
+def test_attention_fwd_bwd(dtype, T):
+    """The engine's attention (batched MFMA GEMMs + softmax kernels) against torch's explicit softmax(QK^T/sqrt(d))V."""
+    from nkb_classification.hipnet import HipEngine
+    from nkb_classification.runtime import ParamArena
+    torch.manual_seed(12)
+    B, H, dh = 3, 2, 64
+    D = H * dh
+    qkv = rnd(torch.randn(B * T, 3 * D), dtype).requires_grad_(True)
+    q, k, v = (qkv.view(B, T, 3, H, dh).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    att = ((q * dh ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
+    o = (att @ v).transpose(1, 2).reshape(B * T, D)
+    do = rnd(torch.randn(B * T, D), dtype)
+    o.backward(do)
+    eng = HipEngine(ParamArena(), torch.device(DEV), dtype)
+    od = eng.attention("a", qkv.detach().to(DEV, dtype), B, T, H, True)
+    dq = eng.attention_backward("a", do.to(DEV, dtype), "dqkv")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(od.float().cpu(), o.detach(), **tol(dtype, dh))
+    t = tol(dtype, T)
+    torch.testing.assert_close(dq.float().cpu(), qkv.grad, **t)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum2d_and_assemble(dtype):
+    torch.manual_seed(13)
+    x = rnd(torch.randn(1000, 96), dtype)
+    out = torch.zeros(96, device=DEV)
+    hip.colsum2d(hip.dt(dtype), x.to(DEV, dtype), out, 1000, 96, 96)
+    B, Tn, D = 3, 5, 128
+    tok = rnd(torch.randn(B, Tn - 1, D), dtype)
+    cls, pos = torch.randn(D), torch.randn(Tn, D)
+    xx = torch.empty(B, Tn, D, device=DEV, dtype=dtype)
+    hip.vit_assemble(hip.dt(dtype), False, tok.to(DEV, dtype), cls.to(DEV), pos.to(DEV), xx, B, Tn, D)
+    back = torch.empty(B, Tn - 1, D, device=DEV, dtype=dtype)
+    hip.vit_assemble(hip.dt(dtype), True, back, None, None, xx, B, Tn, D)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu(), x.sum(0), **tol(dtype, 1000))
+    ref = torch.cat([cls.expand(B, 1, D), tok], 1) + pos
+    torch.testing.assert_close(xx.float().cpu(), rnd(ref, dtype), **tol(dtype))
+    torch.testing.assert_close(back.float().cpu(), xx[:, 1:].float().cpu(), rtol=0, atol=0)
