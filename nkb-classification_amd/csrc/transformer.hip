@@ -16,136 +16,178 @@ template <> struct V2<float> {
     __device__ static __forceinline__ void st(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
 };
 
-constexpr int LN_MAXP = 16;  // pairs per lane -> D <= 2048
+// VW-wide vector access (VW = 2: 4 B bf16 / 8 B fp32; VW = 4: 8 B bf16 / 16 B fp32)
+template <typename T, int VW> struct VecIO;
+template <typename T> struct VecIO<T, 2> {
+    __device__ static __forceinline__ void ld(const T* p, float* f) { V2<T>::ld(p, f[0], f[1]); }
+    __device__ static __forceinline__ void st(T* p, const float* f) { V2<T>::st(p, f[0], f[1]); }
+};
+template <> struct VecIO<bf16_t, 4> {
+    __device__ static __forceinline__ void ld(const bf16_t* p, float* f) {
+        const u32x2 u = *(const u32x2*)p;
+        f[0] = __uint_as_float(u[0] << 16); f[1] = __uint_as_float(u[0] & 0xffff0000u);
+        f[2] = __uint_as_float(u[1] << 16); f[3] = __uint_as_float(u[1] & 0xffff0000u);
+    }
+    __device__ static __forceinline__ void st(bf16_t* p, const float* f) { *(u32x2*)p = (u32x2){pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3])}; }
+};
+template <> struct VecIO<float, 4> {
+    __device__ static __forceinline__ void ld(const float* p, float* f) { const f32x4 v = *(const f32x4*)p; f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
+    __device__ static __forceinline__ void st(float* p, const float* f) { *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]}; }
+};
 
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm forward: y = (x - mean) * rstd * gamma + beta, biased variance, two-pass in registers (torch numerics).
-template <typename T>
+// One wave per row; D = 64 * VW * NP, every lane holds NP vectors of VW elements.
+template <typename T, int VW, int NP>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long long xs, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y, long long ys,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                            int D, float eps) {
+                                                            float eps) {
+    constexpr int D = 64 * VW * NP;
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    const int np = D / 128;  // pairs per lane
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
         const T* xr = x + (size_t)row * xs;
-        float v[2 * LN_MAXP];
+        float v[NP][VW];
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXP; ++k) {
-            if (k < np) { V2<T>::ld(xr + k * 128 + lane * 2, v[2 * k], v[2 * k + 1]); s += v[2 * k] + v[2 * k + 1]; }
+        for (int k = 0; k < NP; ++k) {
+            VecIO<T, VW>::ld(xr + (k * 64 + lane) * VW, v[k]);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) s += v[k][e];
         }
         const float mu = wave_sum(s) / (float)D;
         float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXP; ++k) {
-            if (k < np) { const float a = v[2 * k] - mu, b = v[2 * k + 1] - mu; q += a * a + b * b; }
-        }
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) { const float a = v[k][e] - mu; q += a * a; }
         const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
         T* yr = y + (size_t)row * ys;
 #pragma unroll
-        for (int k = 0; k < LN_MAXP; ++k) {
-            if (k < np) {
-                const int e = k * 128 + lane * 2;
-                V2<T>::st(yr + e, (v[2 * k] - mu) * rs * gamma[e] + beta[e], (v[2 * k + 1] - mu) * rs * gamma[e + 1] + beta[e + 1]);
-            }
+        for (int k = 0; k < NP; ++k) {
+            const int e0 = (k * 64 + lane) * VW;
+            float o[VW];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) o[e] = (v[k][e] - mu) * rs * gamma[e0 + e] + beta[e0 + e];
+            VecIO<T, VW>::st(yr + e0, o);
         }
         if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
     }
 }
 
 // LayerNorm backward: dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ add);  dgamma += sum dy*xhat, dbeta += sum dy
-template <typename T>
+template <typename T, int VW, int NP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, long long dys, const T* __restrict__ x,
                                                             long long xs, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const T* __restrict__ add, T* __restrict__ dx, long long dxs,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                            int D) {
-    __shared__ float red[4][2 * 64 * 2];  // per wave staging for the final reduction (reused per pair index)
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+    constexpr int D = 64 * VW * NP;
+    __shared__ float red[4][2][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
-    const int np = D / 128;
-    float ag[2 * LN_MAXP], ab[2 * LN_MAXP];
+    float ag[NP][VW], ab[NP][VW], gam[NP][VW];
 #pragma unroll
-    for (int k = 0; k < 2 * LN_MAXP; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gam[k][e] = gamma[(k * 64 + lane) * VW + e]; }
     for (int row = blockIdx.x * wpb + wave; row < rows; row += gridDim.x * wpb) {
         const T* xr = x + (size_t)row * xs;
         const T* gr = dy + (size_t)row * dys;
         const float mu = mean[row], rs = rstd[row];
-        float xh[2 * LN_MAXP], g[2 * LN_MAXP];
+        float xh[NP][VW], g[NP][VW];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXP; ++k) {
-            if (k < np) {
-                const int e = k * 128 + lane * 2;
-                float a, b, ga, gb;
-                V2<T>::ld(xr + e, a, b);
-                V2<T>::ld(gr + e, ga, gb);
-                xh[2 * k] = (a - mu) * rs; xh[2 * k + 1] = (b - mu) * rs;
-                ag[2 * k] += ga * xh[2 * k]; ag[2 * k + 1] += gb * xh[2 * k + 1];
-                ab[2 * k] += ga; ab[2 * k + 1] += gb;
-                g[2 * k] = ga * gamma[e]; g[2 * k + 1] = gb * gamma[e + 1];
-                c1 += g[2 * k] + g[2 * k + 1];
-                c2 += g[2 * k] * xh[2 * k] + g[2 * k + 1] * xh[2 * k + 1];
+        for (int k = 0; k < NP; ++k) {
+            VecIO<T, VW>::ld(xr + (k * 64 + lane) * VW, xh[k]);
+            VecIO<T, VW>::ld(gr + (k * 64 + lane) * VW, g[k]);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                xh[k][e] = (xh[k][e] - mu) * rs;
+                ag[k][e] += g[k][e] * xh[k][e];
+                ab[k][e] += g[k][e];
+                g[k][e] *= gam[k][e];
+                c1 += g[k][e];
+                c2 += g[k][e] * xh[k][e];
             }
         }
         c1 = wave_sum(c1) / (float)D;
         c2 = wave_sum(c2) / (float)D;
         T* or_ = dx + (size_t)row * dxs;
 #pragma unroll
-        for (int k = 0; k < LN_MAXP; ++k) {
-            if (k < np) {
-                const int e = k * 128 + lane * 2;
-                float o0 = rs * (g[2 * k] - c1 - xh[2 * k] * c2), o1 = rs * (g[2 * k + 1] - c1 - xh[2 * k + 1] * c2);
-                if (add) { float a0, a1; V2<T>::ld(add + (size_t)row * dxs + e, a0, a1); o0 += a0; o1 += a1; }
-                V2<T>::st(or_ + e, o0, o1);
+        for (int k = 0; k < NP; ++k) {
+            const int e0 = (k * 64 + lane) * VW;
+            float o[VW], a[VW];
+            if (add) VecIO<T, VW>::ld(add + (size_t)row * dxs + e0, a);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                o[e] = rs * (g[k][e] - c1 - xh[k][e] * c2);
+                if (add) o[e] += a[e];
             }
+            VecIO<T, VW>::st(or_ + e0, o);
         }
     }
     // block reduction of the per-lane column sums, then one atomic per column per block
 #pragma unroll
-    for (int k = 0; k < LN_MAXP; ++k) {
-        if (k < np) {
-            __syncthreads();
-            red[wave][lane * 2] = ag[2 * k]; red[wave][lane * 2 + 1] = ag[2 * k + 1];
-            red[wave][128 + lane * 2] = ab[2 * k]; red[wave][128 + lane * 2 + 1] = ab[2 * k + 1];
-            __syncthreads();
-            if (wave == 0) {
-                const int e = k * 128 + lane * 2;
-                float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
-                for (int w = 0; w < wpb; ++w) {
-                    s0 += red[w][lane * 2]; s1 += red[w][lane * 2 + 1];
-                    t0 += red[w][128 + lane * 2]; t1 += red[w][128 + lane * 2 + 1];
-                }
-                atomicAdd(dgamma + e, s0); atomicAdd(dgamma + e + 1, s1);
-                atomicAdd(dbeta + e, t0); atomicAdd(dbeta + e + 1, t1);
+    for (int k = 0; k < NP; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { red[wave][0][lane * VW + e] = ag[k][e]; red[wave][1][lane * VW + e] = ab[k][e]; }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                float s0 = 0.f, t0 = 0.f;
+                for (int w = 0; w < wpb; ++w) { s0 += red[w][0][lane * VW + e]; t0 += red[w][1][lane * VW + e]; }
+                atomicAdd(dgamma + (k * 64 + lane) * VW + e, s0);
+                atomicAdd(dbeta + (k * 64 + lane) * VW + e, t0);
             }
         }
     }
+}
+
+template <typename T, int VW, int NP>
+static void ln_launch(int backward, int grid, hipStream_t stream, const void* in, long long in_stride, const void* x,
+                      long long x_stride, const float* gamma, const float* beta, float* mean, float* rstd, const void* add,
+                      void* out, long long out_stride, float* dgamma, float* dbeta, int rows, float eps) {
+    if (!backward)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps);
+    else
+        hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows);
+}
+template <typename T, int VW>
+static int ln_dispatch(int np, int backward, int grid, hipStream_t stream, const void* in, long long is, const void* x, long long xs,
+                       const float* g, const float* b, float* mean, float* rstd, const void* add, void* out, long long os,
+                       float* dg, float* db, int rows, float eps) {
+#define LN_CASE(N) case N: ln_launch<T, VW, N>(backward, grid, stream, in, is, x, xs, g, b, mean, rstd, add, out, os, dg, db, rows, eps); return 0;
+    switch (np) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
+#undef LN_CASE
+    return 1;
 }
 
 extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
                              const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
                              long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps,
                              hipStream_t stream) {
-    if (D % 128 != 0 || D > 128 * LN_MAXP) { nkb_set_error("layernorm: D=%d must be a multiple of 128 and <= %d", D, 128 * LN_MAXP); return 1; }
+    const int vw = (D % 256 == 0) ? 4 : 2;
+    const int np = D / (64 * vw);
+    if (D % 128 != 0 || np < 1 || np > 8 || in_stride % vw || x_stride % vw || out_stride % vw) {
+        nkb_set_error("layernorm: D=%d must be a multiple of 128 (<= 2048) with vector-aligned strides", D);
+        return 1;
+    }
     NkbProfScope prof(NKB_K_LN, stream, 0);
     int grid = (rows + 3) / 4;
-    if (!backward) {
-        if (grid > 256 * 16) grid = 256 * 16;
-        if (dtype == NKB_DT_BF16)
-            hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, in_stride, gamma, beta, (bf16_t*)out, out_stride, mean, rstd, rows, D, eps);
-        else
-            hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)in, in_stride, gamma, beta, (float*)out, out_stride, mean, rstd, rows, D, eps);
-    } else {
-        if (grid > 1024) grid = 1024;  // bounds the atomics: grid * D * 2
-        if (dtype == NKB_DT_BF16)
-            hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, in_stride, (const bf16_t*)x, x_stride, mean, rstd, gamma, (const bf16_t*)add, (bf16_t*)out, out_stride, dgamma, dbeta, rows, D);
-        else
-            hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)in, in_stride, (const float*)x, x_stride, mean, rstd, gamma, (const float*)add, (float*)out, out_stride, dgamma, dbeta, rows, D);
-    }
+    if (!backward) { if (grid > 256 * 16) grid = 256 * 16; }
+    else if (grid > 1024) grid = 1024;   // bounds the atomics: grid * D * 2
+    int rc;
+    if (dtype == NKB_DT_BF16)
+        rc = vw == 4 ? ln_dispatch<bf16_t, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps)
+                     : ln_dispatch<bf16_t, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps);
+    else
+        rc = vw == 4 ? ln_dispatch<float, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps)
+                     : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps);
+    if (rc) { nkb_set_error("layernorm: unsupported D=%d", D); return 1; }
     return nkb_check_launch("layernorm");
 }
 

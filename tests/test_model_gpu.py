@@ -239,3 +239,64 @@ def test_train_py_end_to_end(tmp_path):
     assert len(lines) == 3 and "\t" in lines[0]
     sd = torch.load(exp / "weights" / "last.pth", map_location="cpu")
     assert "emb_model.layer4.1.bn2.running_var" in sd and "classifier.1.weight" in sd
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves CUDA tensors through the host
+    try:
+        from nkb_classification.parallel import GradReducer
+        cfg_model = dict(model="resnet_tiny_bottleneck", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                         classifier_initialization="kaiming_normal_", task="single")
+        torch.manual_seed(0)
+        model = get_model(cfg_model, ["a", "b", "c"], DEV)
+        with torch.no_grad():                       # non-trivial BN affine parameters so every path carries signal
+            g0 = torch.Generator().manual_seed(3)
+            for p in model.parameters():
+                if p.dim() == 1:
+                    p.copy_((torch.rand(p.shape, generator=g0) * 0.5 + 0.5).to(p.device))
+        crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+        opt = get_optimizer(model, dict(type="sgd", lr=0.1))
+        g = torch.Generator().manual_seed(100 + rank)
+        x, y = torch.randn(4, 3, 64, 64, generator=g).to(DEV), torch.randint(0, 3, (4,), generator=g).to(DEV)
+        model.train()
+        # local gradients first (no reducer attached)
+        crit(model(x), y).backward()
+        torch.cuda.synchronize()
+        local = model.arena.flat_grad.clone()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        expect_sum = sum(gathered)
+        params_before = model.arena.flat_param.clone()
+        # same step through the reducer: ranges are all-reduced while backward runs, the optimizer applies 1/world
+        opt.zero_grad()
+        red = GradReducer(model, opt)
+        crit(model(x), y).backward()
+        opt.step()
+        torch.cuda.synchronize()
+        got_sum = model.arena.flat_grad
+        ok_grad = torch.allclose(got_sum, expect_sum, rtol=1e-4, atol=1e-6)
+        ok_step = torch.allclose(model.arena.flat_param, params_before - 0.1 * expect_sum / world, rtol=1e-4, atol=1e-6)
+        q.put((rank, bool(ok_grad), bool(ok_step), opt.grad_scale))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_on_one_gpu():
+    """world_size 2 with both ranks on cuda:0 (gloo transport): the HIP model's backward hooks + GradReducer + fused
+    optimizer reproduce 'average of the per-rank gradients, then SGD' exactly."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True, True, 0.5), (1, True, True, 0.5)]
