@@ -44,7 +44,8 @@ int nkb_version(void);
 int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add, const float* bias,
                   float* stats, int N, int H, int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int ldadd,
                   int R, int S, int stride, int pad, int relu, int out_f32, nkb_stream_t stream);
-int nkb_conv_gemm_stat_tiles(int M, int Cout);
+int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout);
+void nkb_set_ring(int mode); /* 0: register-staged kernel only; 1: persistent LDS-DMA ring kernel where eligible */
 
 /* Weight gradient: dw[co][r][s][ci] += sum_{n,p,q} dy[n,p,q,co] * x[n, p*stride+r-pad, q*stride+s-pad, ci] (fp32 atomics) */
 int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int ldx, int P,
@@ -103,6 +104,9 @@ int nkb_head_transpose(int dtype, const void* in, int ld_in, long long sio, long
                        int T, int dh, int ldt, nkb_stream_t stream);
 int nkb_vit_assemble(int dtype, int backward, void* tok, const float* cls, const float* pos, void* x, int B, int Tn, int D,
                      nkb_stream_t stream);
+/* out = keep ? in/(1-p) : 0 (+ add); forward draws keep from a hash of (seed, index) and stores it in mask */
+int nkb_dropout(int dtype, int backward, const void* in, const void* add, void* out, unsigned char* mask, long long n,
+                float p, unsigned long long seed, nkb_stream_t stream);
 int nkb_colsum2d(int dtype, const void* x, float* out, long long rows, int C, long long ld, nkb_stream_t stream);
 
 /* Losses (kind 0: CrossEntropyLoss(weight) mean; kind 1: FocalLoss(alpha, gamma) mean over un-ignored rows).

@@ -12,27 +12,7 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------
-struct ConvParams {
-    const void* x;      // [N][H][W][ldx]   source activations (fwd: input, dgrad: dY)
-    const void* w;      // [Cout][R][S][Cin] (K-contiguous rows), same dtype as x
-    void* y;            // [M][ldy]          M = N*P*Q destination pixels
-    const void* add;    // optional [M][ldadd] tensor added in the epilogue (same dtype as y unless out_f32)
-    const float* bias;  // optional [Cout]
-    float* stats;       // optional per-row-tile partial sums: [tilesM][2][Cout]
-    int M;              // destination pixels
-    int H, W, Cin, ldx; // source geometry
-    int P, Q, Cout, ldy, ldadd;
-    int R, S, stride, pad;
-    int mode;           // 0: src = dst*stride + r - pad ; 1 (dgrad): src = (dst + pad - r)/stride when divisible
-    int relu;           // clamp at 0 in the epilogue
-    int out_f32;        // write fp32 regardless of the compute dtype
-    int tilesM, tilesN;
-    FastDiv divPQ, divQ;
-    // batched GEMM (attention): blockIdx.y = zo*inner + zi; element offsets zo*s?o + zi*s?i on x / w / y
-    int ldw;            // row stride of w in elements (R*S*Cin unless batched)
-    int inner;
-    long long sxo, sxi, swo, swi, syo, syi;
-};
+#include "conv_params.h"
 
 template <typename T> struct MmaTraits;
 template <> struct MmaTraits<bf16_t> { static constexpr int KSTEPS = 2; };  // 2 x (16x16x32) per 128-byte k-tile
@@ -72,58 +52,68 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int KT = p.R * p.S * cpk;
 
     // ---- per-thread staging coordinates -------------------------------------------------
+    // Every row this thread stages keeps ONE 32-bit byte offset for the whole kernel plus a bitmask of the filter
+    // taps that fall inside the image; per k-tile the address is `row offset + wave-uniform tap offset` and invalid
+    // taps / rows are redirected to an out-of-range offset, which a raw buffer load returns as zeros.  (The first
+    // version recomputed 64-bit addresses and bounds per k-tile: 185 VALU instructions per k-tile per wave, 4x the
+    // MFMA issue time — rocprofv3 SQ_INSTS_VALU, profiles/r01.)
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    constexpr int ESZ = (int)sizeof(T);
     const int cc = tid & 7;
     const int srow = tid >> 3;
-    int hb[NPR], wb[NPR], nb[NPR];
+    const int sh = p.stride >> 1;                       // stride in {1,2}
+    int xoff[NPR];
+    unsigned hmask[NPR], wmask[NPR];                    // bit r / bit s set: filter row r / column s lands inside the image
 #pragma unroll
     for (int j = 0; j < NPR; ++j) {
         const int m = m0 + srow + 32 * j;
+        xoff[j] = 0; hmask[j] = 0u; wmask[j] = 0u;
         if (m < p.M) {
             const unsigned n = fdiv((unsigned)m, p.divPQ);
             const unsigned rem = (unsigned)m - n * p.divPQ.d;
-            const unsigned pp = fdiv(rem, p.divQ);
-            const unsigned qq = rem - pp * p.divQ.d;
-            if (p.mode == 0) { hb[j] = (int)pp * p.stride - p.pad; wb[j] = (int)qq * p.stride - p.pad; }
-            else             { hb[j] = (int)pp + p.pad;            wb[j] = (int)qq + p.pad; }
-            nb[j] = (int)n * p.H * p.W;
-        } else {
-            hb[j] = -(1 << 28); wb[j] = 0; nb[j] = 0;
+            const int pp = (int)fdiv(rem, p.divQ);
+            const int qq = (int)rem - pp * (int)p.divQ.d;
+            int hb, wb;
+            if (p.mode == 0) { hb = pp * p.stride - p.pad; wb = qq * p.stride - p.pad; }
+            else             { hb = pp + p.pad;            wb = qq + p.pad; }
+            const int h0 = p.mode == 0 ? hb : (hb >> sh), w0 = p.mode == 0 ? wb : (wb >> sh);
+            xoff[j] = (((int)n * p.H + h0) * p.W + w0) * p.ldx * ESZ + cc * 16;
+            for (int rr = 0; rr < p.R; ++rr) {
+                const int t = p.mode == 0 ? hb + rr : hb - rr;
+                const bool ok = p.mode == 0 ? (unsigned)t < (unsigned)p.H
+                                            : (t >= 0 && (t & (p.stride - 1)) == 0 && (t >> sh) < p.H);
+                if (ok) hmask[j] |= 1u << rr;
+            }
+            for (int ss = 0; ss < p.S; ++ss) {
+                const int t = p.mode == 0 ? wb + ss : wb - ss;
+                const bool ok = p.mode == 0 ? (unsigned)t < (unsigned)p.W
+                                            : (t >= 0 && (t & (p.stride - 1)) == 0 && (t >> sh) < p.W);
+                if (ok) wmask[j] |= 1u << ss;
+            }
         }
     }
-    int wofs[NWR];
+    unsigned woff[NWR];
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
         const int co = c0 + srow + 32 * i;
-        wofs[i] = (co < p.Cout) ? co * p.ldw + cc * EPC : -1;
+        woff[i] = (co < p.Cout) ? (unsigned)(co * p.ldw * ESZ + cc * 16) : OOB;
     }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, OOB, 0x00020000);
 
     u32x4 sw[NWR], sx[NPR];
     int r = 0, s = 0, ck = 0;  // filter tap and channel-tile of the NEXT k-tile to load
 
     auto load_tile = [&](int kt) {
+        // wave-uniform byte offsets of this k-tile
+        const int tapoff = (p.mode == 0 ? (r * p.W + s) : -((r >> sh) * p.W + (s >> sh))) * p.ldx * ESZ + ck * 128;
 #pragma unroll
-        for (int i = 0; i < NWR; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (wofs[i] >= 0) v = *(const u32x4*)(Wt + (size_t)wofs[i] + (size_t)kt * KTE);
-            sw[i] = v;
-        }
-        const int cbase = ck * KTE + cc * EPC;
+        for (int i = 0; i < NWR; ++i)
+            sw[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)woff[i], kt * 128, 0);
 #pragma unroll
         for (int j = 0; j < NPR; ++j) {
-            int hi, wi;
-            bool ok;
-            if (p.mode == 0) {
-                hi = hb[j] + r; wi = wb[j] + s;
-                ok = true;
-            } else {
-                const int th = hb[j] - r, tw = wb[j] - s;
-                ok = (th >= 0) && (tw >= 0) && (((th | tw) & (p.stride - 1)) == 0);
-                hi = th >> (p.stride >> 1); wi = tw >> (p.stride >> 1);  // stride in {1,2}
-            }
-            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *(const u32x4*)(X + ((size_t)(nb[j] + hi * p.W + wi)) * p.ldx + cbase);
-            sx[j] = v;
+            const unsigned o = ((hmask[j] >> r) & (wmask[j] >> s) & 1u) ? (unsigned)(xoff[j] + tapoff) : OOB;
+            sx[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
         }
         if (++ck == cpk) { ck = 0; if (++s == p.S) { s = 0; ++r; } }
     };
@@ -517,6 +507,11 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
         return 1;
     }
     if (stride != 1 && stride != 2) { nkb_set_error("conv_gemm: stride %d unsupported", stride); return 1; }
+    if (R > 32 || S > 32) { nkb_set_error("conv_gemm: %dx%d filter exceeds the 32-tap-per-axis validity masks", R, S); return 1; }
+    if ((long long)N * H * W * ldx * esz >= 0xFFFFFF00ll || (long long)Cout * R * S * Cin * esz >= 0xFFFFFF00ll) {
+        nkb_set_error("conv_gemm: operand exceeds the 4 GiB buffer-addressing range");
+        return 1;
+    }
     if ((long long)N * H * W * ldx >= (1ll << 31) || (long long)N * P * Q * ldy >= (1ll << 31) ||
         (long long)Cout * R * S * Cin >= (1ll << 31)) {
         nkb_set_error("conv_gemm: tensor exceeds 2^31 elements");
@@ -531,6 +526,7 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     const double flops = 2.0 * p.M * (double)Cout * R * S * Cin;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops);
+    if (nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
     const bool narrow = Cout <= 64;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
@@ -563,7 +559,11 @@ extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y
 }
 
 // number of row tiles the stats buffer must hold for a given launch: [tilesM][2][Cout] floats
-extern "C" int nkb_conv_gemm_stat_tiles(int M, int Cout) { return (M + (Cout <= 64 ? 256 : 128) - 1) / (Cout <= 64 ? 256 : 128); }
+// (for the plain conv call: ldy == Cout, no residual, compute-dtype output)
+extern "C" int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout) {
+    if (nkb_conv_ring_eligible(dtype, Cout, Cout, 0, false, 0, M)) return nkb_conv_ring_stat_tiles(M, Cout);
+    return (M + (Cout <= 64 ? 256 : 128) - 1) / (Cout <= 64 ? 256 : 128);
+}
 
 extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                               int ldx, int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad,

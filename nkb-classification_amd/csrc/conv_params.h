@@ -1,0 +1,31 @@
+// Parameter block shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_ring.hip).
+#pragma once
+#include "common.h"
+
+struct ConvParams {
+    const void* x;      // [N][H][W][ldx]   source activations (fwd: input, dgrad: dY)
+    const void* w;      // [Cout][R][S][Cin] (K-contiguous rows), same dtype as x
+    void* y;            // [M][ldy]          M = N*P*Q destination pixels
+    const void* add;    // optional [M][ldadd] tensor added in the epilogue (same dtype as y unless out_f32)
+    const float* bias;  // optional [Cout]
+    float* stats;       // optional per-row-tile partial sums: [tilesM][2][Cout]
+    int M;              // destination pixels
+    int H, W, Cin, ldx; // source geometry
+    int P, Q, Cout, ldy, ldadd;
+    int R, S, stride, pad;
+    int mode;           // 0: src = dst*stride + r - pad ; 1 (dgrad): src = (dst + pad - r)/stride when divisible
+    int relu;           // clamp at 0 in the epilogue
+    int out_f32;        // write fp32 regardless of the compute dtype
+    int tilesM, tilesN;
+    FastDiv divPQ, divQ;
+    // batched GEMM (attention): blockIdx.y = zo*inner + zi; element offsets zo*s?o + zi*s?i on x / w / y
+    int ldw;            // row stride of w in elements (R*S*Cin unless batched)
+    int inner;
+    long long sxo, sxi, swo, swi, syo, syi;
+};
+
+
+// persistent LDS-DMA ring variant (conv_ring.hip); returns -1 when the problem is outside its envelope
+int nkb_launch_conv_ring(ConvParams& p, hipStream_t stream);
+int nkb_conv_ring_stat_tiles(int M, int Cout);
+bool nkb_conv_ring_eligible(int dtype, int Cout, int ldy, int ldadd, bool has_add, int out_f32, int M);

@@ -344,3 +344,43 @@ extern "C" int nkb_colsum2d(int dtype, const void* x, float* out, long long rows
     else hipLaunchKernelGGL(colsum2d_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, out, rows, C, ld, rpb);
     return nkb_check_launch("colsum2d");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Dropout with a counter-based generator (stateless hash of (seed, element index)): forward writes the keep mask,
+// backward re-applies it.  out = keep ? in / (1-p) : 0  (+ add).  Not bit-compatible with torch's Philox stream.
+__device__ __forceinline__ unsigned mix32(unsigned h) {
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ in, const T* __restrict__ add, T* __restrict__ out,
+                               unsigned char* __restrict__ mask, size_t n, float p, unsigned seed_lo, unsigned seed_hi,
+                               int backward) {
+    const float scale = 1.f / (1.f - p);
+    const unsigned thresh = (unsigned)((double)p * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)p * 4294967296.0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned char keep;
+        if (!backward) {
+            const unsigned r = mix32(mix32((unsigned)i ^ seed_lo) + (unsigned)(i >> 32) * 0x9e3779b9u + seed_hi);
+            keep = r >= thresh;
+            mask[i] = keep;
+        } else {
+            keep = mask[i];
+        }
+        float v = keep ? DT<T>::ld(in + i) * scale : 0.f;
+        if (add) v += DT<T>::ld(add + i);
+        DT<T>::st(out + i, v);
+    }
+}
+extern "C" int nkb_dropout(int dtype, int backward, const void* in, const void* add, void* out, unsigned char* mask,
+                           long long n, float p, unsigned long long seed, hipStream_t stream) {
+    if (!(p >= 0.f && p < 1.f)) { nkb_set_error("dropout: p=%f outside [0,1)", p); return 1; }
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    size_t g = ((size_t)n + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    const unsigned lo = (unsigned)seed, hi = (unsigned)(seed >> 32);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)in, (const bf16_t*)add, (bf16_t*)out, mask, (size_t)n, p, lo, hi, backward);
+    else hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)in, (const float*)add, (float*)out, mask, (size_t)n, p, lo, hi, backward);
+    return nkb_check_launch("dropout");
+}

@@ -140,6 +140,7 @@ class HipResNet(_ParamOnly):
         blocks = list(self.blocks())
         for bi in range(len(blocks) - 1, -1, -1):
             name, blk = blocks[bi]
+            eng.begin_block(bi)
             n = len(blk.stages())
             # last stage: ReLU(bn(conv) + shortcut); the masked incoming gradient also feeds the shortcut
             gc = eng.bn_backward(f"{name}.{n - 1}", g, "t0", write_masked=True)
@@ -152,8 +153,10 @@ class HipResNet(_ParamOnly):
                 add = eng.conv_backward(f"{name}.ds", gcd, "t6")
             g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add)
             flip ^= 1
+            eng.end_block(bi)
             if on_done is not None and name.endswith(".0"):
                 on_done(getattr(self, name.split(".")[0]))
+        eng.begin_block(-1)
         g = eng.maxpool_backward("pool", g, "mp")
         gc = eng.bn_backward("stem", g, "t0")
         eng.conv_backward("stem", gc, None)

@@ -23,7 +23,8 @@ _SIGS = {
     "nkb_version": (i32, []),
     "nkb_last_error": (C.c_char_p, []),
     "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp]),
-    "nkb_conv_gemm_stat_tiles": (i32, [i32, i32]),
+    "nkb_conv_gemm_stat_tiles": (i32, [i32, i32, i32]),
+    "nkb_set_ring": (None, [i32]),
     "nkb_conv_wgrad": (i32, [i32, vp, vp, vp] + [i32] * 13 + [vp]),
     "nkb_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
@@ -44,6 +45,7 @@ _SIGS = {
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
     "nkb_head_transpose": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, i32, i32, i32, vp]),
     "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "nkb_dropout": (i32, [i32, i32, vp, vp, vp, vp, i64, f32, C.c_ulonglong, vp]),
     "nkb_colsum2d": (i32, [i32, vp, vp, i64, i32, i64, vp]),
     "nkb_loss_forward": (i32, [i32, vp, i32, vp, i32, i32, vp, f32, i64, vp, i32, vp, vp, vp, vp]),
     "nkb_loss_row_state_bytes": (sz, [i32]),
@@ -118,8 +120,8 @@ def conv_gemm(dtype, mode, x, w, y, *, N, H, W, Cin, ldx, P, Q, Cout, ldy, R=1, 
                                P, Q, Cout, ldy, ldadd, R, S, stride, pad, int(relu), int(out_f32), stream()), "conv_gemm")
 
 
-def stat_tiles(M, Cout):
-    return load().nkb_conv_gemm_stat_tiles(M, Cout)
+def stat_tiles(dtype, M, Cout):
+    return load().nkb_conv_gemm_stat_tiles(dtype, M, Cout)
 
 
 def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0):
@@ -267,3 +269,7 @@ def vit_assemble(dtype, backward, tok, cls, pos, x, B, Tn, D):
 
 def colsum2d(dtype, x, out, rows, C_, ld):
     check(load().nkb_colsum2d(dtype, ptr(x), ptr(out), rows, C_, ld, stream()), "colsum2d")
+
+
+def dropout(dtype, backward, src, add, out, mask, n, p, seed=0):
+    check(load().nkb_dropout(dtype, int(backward), ptr(src), ptr(add), ptr(out), ptr(mask), n, p, seed, stream()), "dropout")

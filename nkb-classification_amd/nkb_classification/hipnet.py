@@ -7,6 +7,7 @@ Nothing here computes: every method only sizes buffers and enqueues libnkbhip ke
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -35,6 +36,12 @@ class HipEngine:
         self._stems: List[nn.Module] = []
         self._heads = None
         self._bn_scratch_off = 0
+        # weight gradients run on a side HIP stream next to the dgrad -> BN-backward chain of the main stream (both are
+        # latency-bound at ~20 % MFMA busy, so they overlap almost additively); see begin_block()/on_side()
+        self.overlap_wgrad = os.environ.get("NKB_WGRAD_STREAM", "1") != "0"
+        self._side: Optional[torch.cuda.Stream] = None
+        self._side_done: Dict[int, torch.cuda.Event] = {}
+        self._suffix = ""
 
     # ------------------------------------------------------------------ weights ----
     def register(self, convs, stems, head_weights, head_biases):
@@ -102,7 +109,7 @@ class HipEngine:
             geom = dict(N=N, H=H, W=W, Cin=ci, ldx=ci, P=P, Q=Q, Cout=co, ldy=co, R=R, S=S, stride=st, pad=pad)
         rows = N * P * Q
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
-        tiles = hip.stat_tiles(rows, co)
+        tiles = hip.stat_tiles(self.d, rows, co)
         stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
         hip.conv_gemm(self.d, 0, x, self.w_fwd(w), c, stats=stats, **geom)
         sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
@@ -133,12 +140,28 @@ class HipEngine:
         self.saved[key] = dict(in_shape=(N, H, W, C))
         return y
 
-    def head(self, emb: torch.Tensor, train: bool) -> torch.Tensor:
-        """Fused classifier heads: logits[B][sum C_t] (fp32) = emb @ W_all^T + b_all."""
+    def head(self, emb: torch.Tensor, train: bool, drop_p: float = 0.0) -> torch.Tensor:
+        """Fused classifier heads: logits[B][sum C_t] (fp32) = emb @ W_all^T + b_all.
+        With classifier dropout active (train, p > 0) every head draws its own mask (model.py:104-108 gives each head
+        its own nn.Dropout), so the heads run as separate GEMMs on separately dropped copies of the embedding."""
         hw, hb = self._heads
         ctot = sum(w.shape[0] for w in hw)
         B, E = emb.shape
         a = self.arena
+        if train and drop_p > 0:
+            logits = torch.empty(B, ctot, device=self.device, dtype=torch.float32)
+            dropped, masks, lo_c = [], [], 0
+            for t, w in enumerate(hw):
+                d_emb = self.ws.get(f"head.drop{t}", (B, E), self.T)
+                mask = self.ws.get(f"head.mask{t}", (B, E), torch.uint8)
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                hip.dropout(self.d, False, emb, None, d_emb, mask, B * E, drop_p, seed)
+                n_t = w.shape[0]
+                hip.conv_gemm(self.d, 0, d_emb, self.w_fwd(w), logits[:, lo_c:], N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1,
+                              Cout=n_t, ldy=ctot, bias=a.param_flat(hb[t]), out_f32=True)
+                dropped.append(d_emb); masks.append(mask); lo_c += n_t
+            self.saved["head"] = dict(emb=emb, ctot=ctot, dropped=dropped, masks=masks, drop_p=drop_p)
+            return logits
         lo = a.offset_of(hw[0])
         wall = (a.shadow if self.T == torch.bfloat16 else a.flat_param)[lo:lo + ctot * E]
         bo = a.offset_of(hb[0])
@@ -152,7 +175,42 @@ class HipEngine:
 
     # ------------------------------------------------------------------ backward ops ----
     def scratch(self, slot: str, shape) -> torch.Tensor:
-        return self.ws.get("grad.%s.%s" % (slot, "x".join(str(int(v)) for v in shape)), shape, self.T)
+        return self.ws.get("grad.%s%s.%s" % (slot, self._suffix, "x".join(str(int(v)) for v in shape)), shape, self.T)
+
+    # ---- side stream for weight gradients ---------------------------------------------------------------------
+    def on_side(self, fn):
+        """Enqueue fn's kernels on the side stream, ordered after everything enqueued so far on the main stream."""
+        if not self.overlap_wgrad:
+            fn()
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            fn()
+
+    def begin_block(self, index: int):
+        """Scratch gradient buffers alternate between two sets by block parity; before a set is reused the main
+        stream waits for the side-stream weight gradients that still read it (issued two blocks earlier)."""
+        self._suffix = ".p%d" % (index & 1)
+        ev = self._side_done.pop(index + 2, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def end_block(self, index: int):
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self._side_done[index] = ev
+
+    def wait_side(self):
+        """Main stream waits for every outstanding weight gradient (before the optimizer / the gradient exchange)."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._side_done.clear()
+        self._suffix = ""
 
     def head_backward(self, glogits: torch.Tensor, need_demb: bool) -> Optional[torch.Tensor]:
         sv = self.saved["head"]
@@ -161,6 +219,8 @@ class HipEngine:
         B, E = emb.shape
         cp = self.kpad(ctot)
         a = self.arena
+        if "dropped" in sv:
+            return self._head_backward_dropout(glogits, need_demb)
         dl = self.ws.get("head.dl", (B, cp), self.T)
         if not glogits.is_contiguous():
             glogits = glogits.contiguous()
@@ -175,6 +235,36 @@ class HipEngine:
         g = self.ws.get("head.demb", (B, E), self.T)
         hip.conv_gemm(self.d, 0, dl, self._wd["head"], g, N=B, H=1, W=1, Cin=cp, ldx=cp, P=1, Q=1, Cout=E, ldy=E)
         return g
+
+    def _head_backward_dropout(self, glogits: torch.Tensor, need_demb: bool) -> Optional[torch.Tensor]:
+        sv = self.saved["head"]
+        hw, hb = self._heads
+        emb, ctot, p = sv["emb"], sv["ctot"], sv["drop_p"]
+        B, E = emb.shape
+        a = self.arena
+        if not glogits.is_contiguous():
+            glogits = glogits.contiguous()
+        g_total = self.ws.get("head.demb", (B, E), self.T) if need_demb else None
+        lo_c = 0
+        wd_all = self._wd.get("head")            # [E][cp] transposed, all heads
+        cp = self.kpad(ctot)
+        for t, w in enumerate(hw):
+            n_t = w.shape[0]
+            cpt = self.kpad(n_t)
+            dl = self.ws.get(f"head.dl{t}", (B, cpt), self.T)
+            hip.pad_cast(self.d, glogits[:, lo_c:], dl, B, n_t, ctot, cpt)
+            hip.conv_wgrad(self.d, dl, sv["dropped"][t], a.grad_flat(w), N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1, Cout=n_t,
+                           lddy=cpt)
+            hip.colsum(self.d, dl, a.grad_flat(hb[t]), B, n_t, cpt)
+            if need_demb:
+                wt = self.ws.get(f"head.wt{t}", (E, cpt), self.T)
+                hip.wprep(self.d, a.param_flat(w), wt, n_t, 1, E, cpt, 1)
+                gt = self.ws.get(f"head.demb{t}", (B, E), self.T)
+                hip.conv_gemm(self.d, 0, dl, wt, gt, N=B, H=1, W=1, Cin=cpt, ldx=cpt, P=1, Q=1, Cout=E, ldy=E)
+                # through the head's own dropout mask, accumulated over heads
+                hip.dropout(self.d, True, gt, g_total if t > 0 else None, g_total, sv["masks"][t], B * E, p, 0)
+            lo_c += n_t
+        return g_total
 
     def avgpool_backward(self, key: str, g: torch.Tensor, slot: str) -> torch.Tensor:
         N, H, W, C = self.saved[key]["in_shape"]
@@ -218,13 +308,17 @@ class HipEngine:
             co = geom["Cout"]
             K = w.shape[1] * w.shape[2] * w.shape[3]
             dwp = self.ws.get(key + ".dwpad", (co, kp), torch.float32)
-            dwp.zero_()
-            hip.conv_wgrad(self.d, g_c, sv["x"], dwp, N=geom["N"], H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, lddy=co)
-            hip.add2d(dwp, a.grad_flat(w), co, K, kp, K)
+
+            def stem_wgrad():
+                dwp.zero_()
+                hip.conv_wgrad(self.d, g_c, sv["x"], dwp, N=geom["N"], H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, lddy=co)
+                hip.add2d(dwp, a.grad_flat(w), co, K, kp, K)
+            self.on_side(stem_wgrad)
             return None
-        hip.conv_wgrad(self.d, g_c, sv["x"], a.grad_flat(w), N=geom["N"], H=geom["H"], W=geom["W"], Cin=geom["Cin"],
-                       ldx=geom["ldx"], P=geom["P"], Q=geom["Q"], Cout=geom["Cout"], lddy=geom["Cout"], R=geom["R"],
-                       S=geom["S"], stride=geom["stride"], pad=geom["pad"])
+        self.on_side(lambda: hip.conv_wgrad(
+            self.d, g_c, sv["x"], a.grad_flat(w), N=geom["N"], H=geom["H"], W=geom["W"], Cin=geom["Cin"], ldx=geom["ldx"],
+            P=geom["P"], Q=geom["Q"], Cout=geom["Cout"], lddy=geom["Cout"], R=geom["R"], S=geom["S"],
+            stride=geom["stride"], pad=geom["pad"]))
         if slot is None:
             return None
         N, H, W, ci = geom["N"], geom["H"], geom["W"], geom["Cin"]
@@ -253,9 +347,12 @@ class HipEngine:
         M, K = x.shape
         N = lin.weight.shape[0]
         a = self.arena
-        hip.conv_wgrad(self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N)
-        if lin.bias is not None:
-            hip.colsum2d(self.d, g, a.grad_flat(lin.bias), M, N, N)
+
+        def wgrad():
+            hip.conv_wgrad(self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N)
+            if lin.bias is not None:
+                hip.colsum2d(self.d, g, a.grad_flat(lin.bias), M, N, N)
+        self.on_side(wgrad)
         if slot is None:
             return None
         dx = self.scratch(slot, (M, K))

@@ -150,7 +150,7 @@ class _HipClassifier(nn.Module):
         emb = self.emb_model.run_forward(eng, img, train)
         if train and self._nbt_flat is not None:
             self._nbt_flat.add_(1)
-        return eng.head(emb, train)
+        return eng.head(emb, train, self._classifier_dropout_p() if train else 0.0)
 
     def _backward_impl(self, glogits: torch.Tensor):
         eng = self._active
@@ -169,18 +169,18 @@ class _HipClassifier(nn.Module):
             on_done = None
             if hook is not None:
                 def on_done(module):
+                    eng.wait_side()      # the side-stream weight gradients of this range must be complete
                     rng = arena.range_of(list(module.parameters()) if isinstance(module, nn.Module) else list(module))
                     if rng is not None:
                         hook(*rng)
             self.emb_model.run_backward(eng, g_emb, on_done)
+        eng.wait_side()
         arena.publish_grads(wanted)
 
     def _logits(self, x: torch.Tensor) -> torch.Tensor:
         hip.require_device(x, "model.forward")
         if x.dim() != 4 or x.dtype != torch.float32:
             raise RuntimeError(f"expected a float32 NCHW image batch, got {tuple(x.shape)} {x.dtype}")
-        if self.training and self._classifier_dropout_p() > 0:
-            raise NotImplementedError("classifier_dropout > 0 is not implemented by the HIP engine yet; set it to 0")
         x = x.contiguous()
         self._active = self._engine(x.device, self._compute_dtype())
         self._fwd_token += 1

@@ -127,6 +127,7 @@ class HipViT(_ParamOnly):
         flip = 1
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
+            eng.begin_block(i)
             d_u = eng.linear_backward(f"b{i}.fc2", gx, "du")
             d_a = eng.gelu_backward(f"b{i}.act", d_u, "da")
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
@@ -136,8 +137,10 @@ class HipViT(_ParamOnly):
             d_h = eng.linear_backward(f"b{i}.qkv", d_qkv, "dh")
             gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid)
             flip ^= 1
+            eng.end_block(i)
             if on_done is not None:
                 on_done(blk)
+        eng.begin_block(-1)
         # embedding: d_pos = sum_b gx[b], d_cls = sum_b gx[b, 0], d_tok = gx[:, 1:], then the patch projection
         hip.colsum2d(eng.d, gx, a.grad_flat(self.pos_embed), B, T * D, T * D)
         hip.colsum2d(eng.d, gx, a.grad_flat(self.cls_token), B, D, T * D)

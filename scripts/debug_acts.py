@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, "."); sys.path.insert(0, "nkb-classification_amd")
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "nkb-classification_amd"))
 from nkb_classification.model import get_model
 from nkb_classification.losses import get_loss
 from oracle.torch_models import OracleClassifier

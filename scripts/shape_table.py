@@ -1,6 +1,6 @@
 """Per-shape MFMA efficiency of the conv kernels on one ResNet-50 bf16 train step (HIP-event profiler)."""
 import sys, collections, torch
-sys.path.insert(0, "."); sys.path.insert(0, "nkb-classification_amd")
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "nkb-classification_amd"))
 import bench
 from nkb_classification import hip
 args = bench.parse()

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_header_symbols():
     assert sorted(hip.exported_symbols()) == declared, "ctypes binding table and header disagree"
     assert lib.nkb_version() >= 100
     assert lib.nkb_last_error() is not None
-    assert lib.nkb_conv_gemm_stat_tiles(802816, 64) == 3136 and lib.nkb_conv_gemm_stat_tiles(12544, 2048) == 98
+    assert lib.nkb_conv_gemm_stat_tiles(1, 802816, 64) == 3136 and lib.nkb_conv_gemm_stat_tiles(0, 12544, 2048) == 98
     assert lib.nkb_kernel_name(0) == b"conv_igemm_fwd"
 
 

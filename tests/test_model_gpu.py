@@ -300,3 +300,38 @@ def test_data_parallel_two_ranks_on_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True, True, 0.5), (1, True, True, 0.5)]
+
+
+def test_classifier_dropout_train_path():
+    """classifier_dropout > 0 (reference sample configs use 0.1): per-head masks, 1/(1-p) scaling, consistent backward."""
+    from nkb_classification import hip
+    cfg_model = dict(model="resnet_tiny_basic", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.4,
+                     classifier_initialization="kaiming_normal_", task="multi")
+    classes = {"a": ["x", "y"], "b": ["p", "q", "r"]}
+    torch.manual_seed(1)
+    model = get_model(cfg_model, classes, DEV)
+    crit = get_loss(dict(task="multi", type="CrossEntropyLoss"), DEV)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(16, 3, 64, 64, generator=g).to(DEV)
+    y = {"a": torch.randint(0, 2, (16,), generator=g), "b": torch.randint(0, 3, (16,), generator=g)}
+    model.train()
+    out = model(x)
+    loss = crit(out, y)
+    loss["loss"].backward()
+    torch.cuda.synchronize()
+    sv = model._active.saved["head"]
+    emb = sv["emb"].float()
+    for t, (name, head) in enumerate(model.classifier.items()):
+        mask = sv["masks"][t].float()
+        assert 0.45 < mask.mean().item() < 0.75                          # keep rate ~ 1 - p = 0.6
+        dropped = sv["dropped"][t].float()
+        torch.testing.assert_close(dropped, emb * mask / 0.6, rtol=1e-5, atol=1e-6)
+        ref_logits = dropped @ head[1].weight.detach().t() + head[1].bias.detach()
+        torch.testing.assert_close(out[name].detach(), ref_logits, rtol=1e-4, atol=1e-5)
+        assert head[1].weight.grad is not None and torch.isfinite(head[1].weight.grad).all()
+    assert not torch.equal(sv["masks"][0], sv["masks"][1])                # every head draws its own mask
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.emb_model.parameters())
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(x), model(x)
+    assert torch.equal(e1["a"], e2["a"])                                  # eval: dropout is the identity

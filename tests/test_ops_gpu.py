@@ -30,7 +30,11 @@ def rnd(t, dtype):
 
 
 CONV_CASES = [
-    # N, H, Cin, Cout, k, stride, pad
+    # N, H, Cin, Cout, k, stride, pad   (the large-M cases take the persistent LDS-DMA ring kernel in bf16)
+    (8, 28, 128, 128, 3, 1, 1),
+    (6, 28, 64, 256, 1, 1, 0),
+    (5, 28, 256, 136, 3, 2, 1),
+    (3, 30, 64, 192, 3, 1, 1),
     (2, 14, 64, 64, 3, 1, 1),
     (2, 14, 64, 128, 3, 2, 1),
     (3, 7, 128, 256, 1, 1, 0),
@@ -55,7 +59,7 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     xd = nhwc(x.detach()).to(DEV, dtype)
     wd = nhwc(w.detach()).to(DEV, dtype)                      # [Cout][R][S][Cin]
     yd = torch.empty(N, P, P, Cout, device=DEV, dtype=dtype)
-    tiles = hip.stat_tiles(N * P * P, Cout)
+    tiles = hip.stat_tiles(d, N * P * P, Cout)
     stats = torch.zeros(tiles, 2, Cout, device=DEV)
     hip.conv_gemm(d, 0, xd, wd, yd, N=N, H=H, W=H, Cin=Cin, ldx=Cin, P=P, Q=P, Cout=Cout, ldy=Cout, R=k, S=k,
                   stride=st, pad=pad, stats=stats)
