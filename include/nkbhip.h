@@ -47,9 +47,10 @@ int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, co
 int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout);
 void nkb_set_ring(int mode); /* 0: register-staged kernel only; 1: persistent LDS-DMA ring kernel where eligible */
 
-/* Weight gradient: dw[co][r][s][ci] += sum_{n,p,q} dy[n,p,q,co] * x[n, p*stride+r-pad, q*stride+s-pad, ci] (fp32 atomics) */
-int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int ldx, int P,
-                   int Q, int Cout, int lddy, int R, int S, int stride, int pad, nkb_stream_t stream);
+/* Weight gradient: dw[co][r][s][ci] += sum_{n,p,q} dy[n,p,q,co] * x[n, p*stride+r-pad, q*stride+s-pad, ci] (fp32 atomics);
+ * optional bias gradient dbias[co] += sum_{n,p,q} dy[n,p,q,co] from the same pass over dy. */
+int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin, int ldx,
+                   int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad, nkb_stream_t stream);
 
 /* BatchNorm2d (torch semantics: biased var to normalise, unbiased var into running_var, momentum blend). */
 int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma, const float* beta,

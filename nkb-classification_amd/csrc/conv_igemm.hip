@@ -334,6 +334,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const bool direct = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
 
     u32x4 sa[4], sb[4];
+    const bool do_bias = p.dbias != nullptr && tile_n == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -356,6 +358,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 }
             }
             sa[i] = va; sb[i] = vb;
+            if (do_bias) {   // column sums of dY (bias gradient) ride along on the tile_n == 0 workgroups
+                if constexpr (sizeof(T) == 2) {
+                    float f[8];
+                    unpack8(va, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsum[e] += __uint_as_float(va[e]);
+                }
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -441,6 +454,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         __syncthreads();
     }
     if (nstage == 0) return;
+
+    if (do_bias) {   // fold the 16 row-groups that share a column chunk, one atomic per column per workgroup
+        float* red = (float*)smem;             // [16 srow][16 cc][8]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(srow * 16 + cc) * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 16 * EPC) {
+            const int c = tid / EPC, e = tid % EPC;
+            float t = 0.f;
+            for (int rr = 0; rr < 16; ++rr) t += red[(rr * 16 + c) * 8 + e];
+            const int col = c0 + c * EPC + e;
+            if (col < p.Cout) atomicAdd(p.dbias + col, t);
+        }
+        __syncthreads();
+    }
 
     // epilogue: stage the fp32 tile [cout][n] in LDS, then row-contiguous float atomics (256 B per wave-instruction)
     constexpr int EROW = TW * 4 + 16;
@@ -565,8 +593,8 @@ extern "C" int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout) {
     return (M + (Cout <= 64 ? 256 : 128) - 1) / (Cout <= 64 ? 256 : 128);
 }
 
-extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
-                              int ldx, int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad,
+extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
+                              int Cin, int ldx, int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad,
                               hipStream_t stream) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
     const int epc = 16 / esz;
@@ -581,7 +609,7 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
         return 1;
     }
     WgradParams p;
-    p.dy = dy; p.x = x; p.dw = dw; p.dbias = nullptr;
+    p.dy = dy; p.x = x; p.dw = dw; p.dbias = dbias;
     p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.lddy = lddy;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.Ntot = R * S * Cin;
     const int TW = 256 / esz;

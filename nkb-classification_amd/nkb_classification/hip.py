@@ -25,7 +25,7 @@ _SIGS = {
     "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp]),
     "nkb_conv_gemm_stat_tiles": (i32, [i32, i32, i32]),
     "nkb_set_ring": (None, [i32]),
-    "nkb_conv_wgrad": (i32, [i32, vp, vp, vp] + [i32] * 13 + [vp]),
+    "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp]),
     "nkb_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
@@ -124,8 +124,8 @@ def stat_tiles(dtype, M, Cout):
     return load().nkb_conv_gemm_stat_tiles(dtype, M, Cout)
 
 
-def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0):
-    check(load().nkb_conv_wgrad(dtype, ptr(dy), ptr(x), ptr(dw), N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad,
+def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0, dbias=None):
+    check(load().nkb_conv_wgrad(dtype, ptr(dy), ptr(x), ptr(dw), ptr(dbias), N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad,
                                 stream()), "conv_wgrad")
 
 

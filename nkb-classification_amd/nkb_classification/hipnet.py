@@ -348,11 +348,9 @@ class HipEngine:
         N = lin.weight.shape[0]
         a = self.arena
 
-        def wgrad():
-            hip.conv_wgrad(self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N)
-            if lin.bias is not None:
-                hip.colsum2d(self.d, g, a.grad_flat(lin.bias), M, N, N)
-        self.on_side(wgrad)
+        self.on_side(lambda: hip.conv_wgrad(
+            self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+            dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
         if slot is None:
             return None
         dx = self.scratch(slot, (M, K))

@@ -151,13 +151,13 @@ class HipViT(_ParamOnly):
         kp, K = sv["kp"], sv["K"]
         if kp == K:
             hip.conv_wgrad(eng.d, d_tok, sv["col"], a.grad_flat(pr.weight), N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1,
-                           Q=1, Cout=D, lddy=D)
+                           Q=1, Cout=D, lddy=D, dbias=a.grad_flat(pr.bias))
         else:
             dwp = eng.ws.get("pe.dwpad", (D, kp), torch.float32)
             dwp.zero_()
             hip.conv_wgrad(eng.d, d_tok, sv["col"], dwp, N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D, lddy=D)
             hip.add2d(dwp, a.grad_flat(pr.weight), D, K, kp, K)
-        hip.colsum2d(eng.d, d_tok, a.grad_flat(pr.bias), B * npatch, D, D)
+            hip.colsum2d(eng.d, d_tok, a.grad_flat(pr.bias), B * npatch, D, D)
         if on_done is not None:
             on_done(self.patch_embed)
             on_done([self.cls_token, self.pos_embed])

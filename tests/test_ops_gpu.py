@@ -84,9 +84,11 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     # wgrad (fp32 accumulate with atomics into a zeroed buffer)
     dyd = nhwc(dy).to(DEV, dtype)
     dwd = torch.zeros(Cout, k, k, Cin, device=DEV)
+    dbd = torch.zeros(Cout, device=DEV)
     hip.conv_wgrad(d, dyd, xd, dwd, N=N, H=H, W=H, Cin=Cin, ldx=Cin, P=P, Q=P, Cout=Cout, lddy=Cout, R=k, S=k,
-                   stride=st, pad=pad)
+                   stride=st, pad=pad, dbias=dbd)
     torch.cuda.synchronize()
+    torch.testing.assert_close(dbd.cpu(), dy.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * math.sqrt(N * P * P))
     t = tol(torch.float32, N * P * P)
     if dtype == torch.bfloat16:
         t = dict(rtol=1e-3, atol=1e-3 * math.sqrt(N * P * P))
