@@ -135,13 +135,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int arow0 = wc * (TC / 2) + frow;
     const int brow0 = TC + wp * (TP / 2) + frow;
 
+    // One LDS stage + one register stage: LDS per workgroup drops to ~33 KB, so 3 workgroups (VGPR-limited) share a CU
+    // instead of 2 and 1.5x the operand bytes are in flight; the price is a second barrier per k-tile.
     load_tile(0);
     store_tile(0);
     __syncthreads();
 
+    constexpr bool DBUF = (TC == 64);   // the 64x256 tile is VGPR-limited to 2 workgroups per CU: keep two LDS stages there
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
         if (kt + 1 < KT) load_tile(kt + 1);
+        const int buf = DBUF ? (kt & 1) : 0;
         const unsigned char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < MmaTraits<T>::KSTEPS; ++ks) {
@@ -169,22 +172,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < KT) store_tile(buf ^ 1);
-        __syncthreads();
+        if constexpr (DBUF) {
+            if (kt + 1 < KT) store_tile(buf ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();                               // every wave is done reading the stage
+            if (kt + 1 < KT) { store_tile(0); __syncthreads(); }
+        }
     }
 
-    // ---- epilogue: accumulators -> LDS [pixel][cout] fp32 -> coalesced global stores ------
-    // (the trailing __syncthreads of the k-loop guarantees nobody still reads the staging buffers)
-#pragma unroll
-    for (int i = 0; i < MC; ++i)
-#pragma unroll
-        for (int j = 0; j < MP; ++j) {
-            const int pix = wp * (TP / 2) + 16 * j + frow;
-            const int co = wc * (TC / 2) + 16 * i + fgrp * 4;
-            *(f32x4*)(smem + pix * EROW + co * 4) = acc[i][j];
-        }
-    __syncthreads();
-
+    // ---- epilogue: accumulators -> LDS [pixel][cout] fp32 -> coalesced global stores, one pixel half at a time ------
+    // (the trailing __syncthreads of the k-loop guarantees nobody still reads the staging buffer)
     constexpr int CPR = TC / 8;        // 8-channel groups per tile row
     constexpr int RPP = 256 / CPR;     // rows per pass
     const int eg = tid % CPR, er = tid / CPR;
@@ -197,8 +195,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int e = 0; e < 8; ++e) bv[e] = (p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
 
-    for (int row = er; row < TP; row += RPP) {
-        const int m = m0 + row;
+  for (int half = 0; half < 2; ++half) {
+    if (wp == half) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+#pragma unroll
+            for (int j = 0; j < MP; ++j) {
+                const int pix = 16 * j + frow;
+                const int cow = wc * (TC / 2) + 16 * i + fgrp * 4;
+                *(f32x4*)(smem + pix * EROW + cow * 4) = acc[i][j];
+            }
+    }
+    __syncthreads();
+    for (int row = er; row < TP / 2; row += RPP) {
+        const int m = m0 + half * (TP / 2) + row;
         if (m >= p.M) break;
         float v[8];
         {
@@ -250,6 +260,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
     }
+    __syncthreads();
+  }
 
     if (p.stats) {  // deterministic per-tile partial sums (reduced later by bn_finalize)
         __syncthreads();
@@ -510,8 +522,8 @@ template <typename T, int TC, int TP>
 static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
     p.tilesM = (p.M + TP - 1) / TP;
     p.tilesN = (p.Cout + TC - 1) / TC;
-    constexpr int stage = 2 * (TC + TP) * 128;
-    constexpr int epi = TP * (TC * 4 + 16);
+    constexpr int stage = (TC + TP) * 128 * (TC == 64 ? 2 : 1);
+    constexpr int epi = (TP / 2) * (TC * 4 + 16);
     constexpr int lds = stage > epi ? stage : epi;
     static bool attr_set = false;
     if (!attr_set) {
