@@ -178,6 +178,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0          # time to ENQUEUE the steps (host side only)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -232,6 +233,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
