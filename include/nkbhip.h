@@ -43,7 +43,9 @@ int nkb_version(void);
  * Cin must be a multiple of 64 (bf16) / 32 (fp32); stride in {1,2}. */
 int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add, const float* bias,
                   float* stats, int N, int H, int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int ldadd,
-                  int R, int S, int stride, int pad, int relu, int out_f32, nkb_stream_t stream);
+                  int R, int S, int stride, int pad, int relu, int out_f32, int add_h, int add_w, nkb_stream_t stream);
+/* add_h/add_w > 0: `add` is an [N][add_h][add_w] tensor living on the even (h, w) positions of the output grid (the
+ * gradient of a stride-2 1x1 shortcut conv, folded in without materialising its zero-dilated form). */
 int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout);
 void nkb_set_ring(int mode); /* 0: register-staged kernel only; 1: persistent LDS-DMA ring kernel where eligible */
 

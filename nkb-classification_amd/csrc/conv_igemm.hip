@@ -217,18 +217,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
         }
-        if (p.add) {
+        bool do_add = p.add != nullptr;
+        size_t am = (size_t)m;                 // row of the add tensor
+        if (do_add && p.add_h > 0) {           // add lives on the stride-2 sub-grid: only even (h, w) receive it
+            const unsigned n = fdiv((unsigned)m, p.divPQ);
+            const unsigned rem = (unsigned)m - n * p.divPQ.d;
+            const unsigned hh = fdiv(rem, p.divQ);
+            const unsigned ww = rem - hh * p.divQ.d;
+            do_add = ((hh | ww) & 1u) == 0u;
+            am = ((size_t)n * p.add_h + (hh >> 1)) * p.add_w + (ww >> 1);
+        }
+        if (do_add) {
             if (p.out_f32 || sizeof(T) == 4) {
-                const float* a = (const float*)p.add + (size_t)m * p.ldadd + co;
+                const float* a = (const float*)p.add + am * p.ldadd + co;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (co + e < p.Cout) v[e] += a[e];
             } else if (vec_ok) {
                 float fa[8];
-                unpack8(*(const u32x4*)((const bf16_t*)p.add + (size_t)m * p.ldadd + co), fa);
+                unpack8(*(const u32x4*)((const bf16_t*)p.add + am * p.ldadd + co), fa);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += fa[e];
             } else {
-                const bf16_t* a = (const bf16_t*)p.add + (size_t)m * p.ldadd + co;
+                const bf16_t* a = (const bf16_t*)p.add + am * p.ldadd + co;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (co + e < p.Cout) v[e] += bf2f(a[e]);
             }
@@ -538,7 +548,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
 extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add,
                              const float* bias, float* stats, int N, int H, int W, int Cin, int ldx, int P, int Q,
                              int Cout, int ldy, int ldadd, int R, int S, int stride, int pad, int relu, int out_f32,
-                             hipStream_t stream) {
+                             int add_h, int add_w, hipStream_t stream) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
     const int kte = 128 / esz;
     if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_gemm: bad dtype %d", dtype); return 1; }
@@ -564,9 +574,10 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     p.out_f32 = out_f32;
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = add_h; p.add_w = add_w;
     const double flops = 2.0 * p.M * (double)Cout * R * S * Cin;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops);
-    if (nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
+    if (add_h == 0 && nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
     const bool narrow = Cout <= 64;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
@@ -590,6 +601,7 @@ extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y
     p.M = M; p.H = M; p.W = 1; p.Cin = K; p.ldx = ldx; p.P = M; p.Q = 1; p.Cout = N; p.ldy = ldy; p.ldadd = 0;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 0; p.relu = 0; p.out_f32 = out_f32;
     p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
+    p.add_h = 0; p.add_w = 0;
     p.ldw = ldw; p.inner = inner; p.sxo = sxo; p.sxi = sxi; p.swo = swo; p.swi = swi; p.syo = syo; p.syi = syi;
     NkbProfScope prof(NKB_K_ATTN, stream, 2.0 * M * (double)N * K * outer * inner);
     const bool narrow = N <= 64;
@@ -628,7 +640,8 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     p.tilesC = (Cout + TW - 1) / TW;
     p.tilesN = (p.Ntot + TW - 1) / TW;
     const int tiles = p.tilesC * p.tilesN;
-    int splits = (1024 + tiles - 1) / tiles;
+    static const int target_wgs = [] { const char* e = getenv("NKB_WGRAD_WGS"); return e ? atoi(e) : 384; }();   // swept: fewer splits = fewer float atomics
+    int splits = (target_wgs + tiles - 1) / tiles;
     const int max_splits = (p.M + 255) / 256;  // at least 4 pipeline stages per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -19,6 +19,7 @@ struct ConvParams {
     int tilesM, tilesN;
     FastDiv divPQ, divQ;
     // batched GEMM (attention): blockIdx.y = zo*inner + zi; element offsets zo*s?o + zi*s?i on x / w / y
+    int add_h, add_w;   // > 0: `add` is [N][add_h][add_w][ldadd] on the stride-2 sub-grid of the output (zero elsewhere)
     int ldw;            // row stride of w in elements (R*S*Cin unless batched)
     int inner;
     long long sxo, sxi, swo, swi, syo, syi;

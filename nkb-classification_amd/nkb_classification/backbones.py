@@ -147,11 +147,15 @@ class HipResNet(_ParamOnly):
             for k in range(n - 1, 0, -1):
                 ga = eng.conv_backward(f"{name}.{k}", gc, f"a{k}")
                 gc = eng.bn_backward(f"{name}.{k - 1}", ga, f"c{k}")
-            add = g
+            add, add_hw = g, (0, 0)
             if blk.downsample is not None:
                 gcd = eng.bn_backward(f"{name}.ds", g, "t5")
-                add = eng.conv_backward(f"{name}.ds", gcd, "t6")
-            g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add)
+                dconv = blk.downsample[0]
+                sub = dconv.stride[0] == 2 and dconv.kernel_size[0] == 1 and dconv.padding[0] == 0
+                add = eng.conv_backward(f"{name}.ds", gcd, "t6", subgrid=sub)
+                if sub:
+                    add_hw = (add.shape[1], add.shape[2])
+            g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add, add_hw=add_hw)
             flip ^= 1
             eng.end_block(bi)
             if on_done is not None and name.endswith(".0"):

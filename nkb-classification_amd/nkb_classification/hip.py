@@ -22,7 +22,7 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 _SIGS = {
     "nkb_version": (i32, []),
     "nkb_last_error": (C.c_char_p, []),
-    "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp]),
+    "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 18 + [vp]),
     "nkb_conv_gemm_stat_tiles": (i32, [i32, i32, i32]),
     "nkb_set_ring": (None, [i32]),
     "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp]),
@@ -115,9 +115,10 @@ def require_device(t: torch.Tensor, what: str):
 
 # ------------------------------------------------------------------ thin typed wrappers ----
 def conv_gemm(dtype, mode, x, w, y, *, N, H, W, Cin, ldx, P, Q, Cout, ldy, R=1, S=1, stride=1, pad=0, add=None,
-              ldadd=0, bias=None, stats=None, relu=False, out_f32=False):
+              ldadd=0, bias=None, stats=None, relu=False, out_f32=False, add_hw=(0, 0)):
     check(load().nkb_conv_gemm(dtype, mode, ptr(x), ptr(w), ptr(y), ptr(add), ptr(bias), ptr(stats), N, H, W, Cin, ldx,
-                               P, Q, Cout, ldy, ldadd, R, S, stride, pad, int(relu), int(out_f32), stream()), "conv_gemm")
+                               P, Q, Cout, ldy, ldadd, R, S, stride, pad, int(relu), int(out_f32), add_hw[0], add_hw[1],
+                               stream()), "conv_gemm")
 
 
 def stat_tiles(dtype, M, Cout):

@@ -297,7 +297,8 @@ class HipEngine:
                         work, fscale=sv["scale"] if from_x else None, fshift=sv["shift"] if from_x else None)
         return gc
 
-    def conv_backward(self, key: str, g_c: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None):
+    def conv_backward(self, key: str, g_c: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None,
+                      add_hw=(0, 0), subgrid: bool = False):
         """Weight gradient into the arena; input gradient (optionally + add) when slot is given."""
         sv = self.saved[key]
         geom, conv = sv["geom"], sv["conv"]
@@ -322,10 +323,17 @@ class HipEngine:
         if slot is None:
             return None
         N, H, W, ci = geom["N"], geom["H"], geom["W"], geom["Cin"]
+        if subgrid:
+            # 1x1 stride-2 shortcut: its input gradient is non-zero only on the even (h, w) grid, so it is computed as a
+            # plain GEMM on the output grid [N,P,Q] and later folded in by the consumer's epilogue (add_hw)
+            dx = self.scratch(slot, (N, geom["P"], geom["Q"], ci))
+            hip.conv_gemm(self.d, 0, g_c, self._wd[id(w)], dx, N=N * geom["P"] * geom["Q"], H=1, W=1, Cin=geom["Cout"],
+                          ldx=geom["Cout"], P=1, Q=1, Cout=ci, ldy=ci)
+            return dx
         dx = self.scratch(slot, (N, H, W, ci))
         hip.conv_gemm(self.d, 1, g_c, self._wd[id(w)], dx, N=N, H=geom["P"], W=geom["Q"], Cin=geom["Cout"],
                       ldx=geom["Cout"], P=H, Q=W, Cout=ci, ldy=ci, R=geom["R"], S=geom["S"], stride=geom["stride"],
-                      pad=geom["pad"], add=add, ldadd=ci if add is not None else 0)
+                      pad=geom["pad"], add=add, ldadd=ci if add is not None else 0, add_hw=add_hw)
         return dx
 
     # ------------------------------------------------------------------ transformer ops ----
