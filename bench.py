@@ -131,16 +131,22 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("NKB_FORCE_REDUCER") == "1"     # rehearse the RCCL path with a single rank
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from nkb_classification import hip
     from nkb_classification.logging import softmax_argmax
     model, opt, crit = build(args, device)
     reducer = None
-    if world > 1:
+    if world > 1 or force_dist:
         from nkb_classification.parallel import GradReducer
         reducer = GradReducer(model, opt)
+        if force_dist:
+            reducer.world = 2        # take the multi-rank code path (bucketing, side stream, async work handles)
+            opt.grad_scale = 1.0
 
     g = torch.Generator().manual_seed(1234 + rank)
     img = torch.randn(args.batch, 3, 224, 224, generator=g).to(device)
@@ -251,7 +257,7 @@ def main():
                                    sorted(prof.items(), key=lambda kv: -kv[1]["ms"])} if prof else None,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

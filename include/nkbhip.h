@@ -103,6 +103,12 @@ int nkb_gelu(int dtype, const void* x, const void* dy, void* out, long long n, n
 /* softmax over fp32 score rows (forward: p = softmax(scale*s); backward: ds = scale*p*(dp - sum dp*p)), zero padded to ldp */
 int nkb_attn_softmax(int dtype, int backward, const float* s, int lds, const void* p_in, void* out, int ldp,
                      long long rows, int cols, float scale, nkb_stream_t stream);
+/* Fused attention (bf16, head dim 64, T <= 256): O = softmax(QK^T*scale)V with per-row log-sum-exp; the backward half
+ * recomputes P from Q, K, LSE and writes P and dS = P o (dP - rowsum(P o dP)) * scale as [B*H][T][ldp] bf16. */
+int nkb_attn_forward(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int dh, float scale,
+                     nkb_stream_t stream);
+int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout, const float* lse, void* P, void* dS, int ldp, int B,
+                         int T, int H, int dh, float scale, nkb_stream_t stream);
 int nkb_head_transpose(int dtype, const void* in, int ld_in, long long sio, long long sii, int outer, int inner, void* out,
                        int T, int dh, int ldt, nkb_stream_t stream);
 int nkb_vit_assemble(int dtype, int backward, void* tok, const float* cls, const float* pos, void* x, int B, int Tn, int D,

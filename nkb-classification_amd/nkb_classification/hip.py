@@ -43,6 +43,8 @@ _SIGS = {
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
+    "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "nkb_attn_backward_ds": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "nkb_head_transpose": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, i32, i32, i32, vp]),
     "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_dropout": (i32, [i32, i32, vp, vp, vp, vp, i64, f32, C.c_ulonglong, vp]),
@@ -274,3 +276,12 @@ def colsum2d(dtype, x, out, rows, C_, ld):
 
 def dropout(dtype, backward, src, add, out, mask, n, p, seed=0):
     check(load().nkb_dropout(dtype, int(backward), ptr(src), ptr(add), ptr(out), ptr(mask), n, p, seed, stream()), "dropout")
+
+
+def attn_forward(dtype, qkv, out, lse, B, T, H, dh, scale):
+    check(load().nkb_attn_forward(dtype, ptr(qkv), ptr(out), ptr(lse), B, T, H, dh, scale, stream()), "attn_forward")
+
+
+def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale):
+    check(load().nkb_attn_backward_ds(dtype, ptr(qkv), ptr(dout), ptr(lse), ptr(P), ptr(dS), ldp, B, T, H, dh, scale,
+                                      stream()), "attn_backward_ds")

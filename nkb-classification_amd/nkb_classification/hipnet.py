@@ -39,6 +39,7 @@ class HipEngine:
         # weight gradients run on a side HIP stream next to the dgrad -> BN-backward chain of the main stream (both are
         # latency-bound at ~20 % MFMA busy, so they overlap almost additively); see begin_block()/on_side()
         self.overlap_wgrad = os.environ.get("NKB_WGRAD_STREAM", "1") != "0"
+        self.fused_attention = os.environ.get("NKB_FUSED_ATTN", "1") != "0"
         self._side: Optional[torch.cuda.Stream] = None
         self._side_done: Dict[int, torch.cuda.Event] = {}
         self._suffix = ""
@@ -408,6 +409,14 @@ class HipEngine:
         D = qkv.shape[1] // 3
         dh = D // H
         Tp = _round_up(T, self.kte)
+        if self.fused_attention and self.T == torch.bfloat16 and dh == 64 and T <= 256:
+            # fused kernel: scores and probabilities never reach HBM; only the per-row log-sum-exp is kept
+            o = self.ws.get(key + ".o", (B * T, D), self.T)
+            lse = self.ws.get(key + ".lse", (B * H, T), torch.float32)
+            hip.attn_forward(self.d, qkv, o, lse, B, T, H, dh, dh ** -0.5)
+            if train:
+                self.saved[key] = dict(qkv=qkv, lse=lse, B=B, T=T, H=H, fused=True)
+            return o
         S = self.ws.get("attn.S", (B * H, T, Tp), torch.float32)
         P = self.ws.get(key + ".P", (B * H, T, Tp), self.T)
         Vt = self.ws.get("attn.Vt", (B * H, dh, Tp), self.T)
@@ -425,21 +434,29 @@ class HipEngine:
 
     def attention_backward(self, key: str, d_o: torch.Tensor, slot: str) -> torch.Tensor:
         sv = self.saved[key]
-        qkv, P, B, T, H = sv["qkv"], sv["P"], sv["B"], sv["T"], sv["H"]
+        qkv, B, T, H = sv["qkv"], sv["B"], sv["T"], sv["H"]
         D = qkv.shape[1] // 3
         dh = D // H
-        Tp = P.shape[2]
+        Tp = _round_up(T, self.kte)
         dqkv = self.scratch(slot, qkv.shape)
-        dP = self.ws.get("attn.S", (B * H, T, Tp), torch.float32)
-        dS = self.ws.get("attn.dS", (B * H, T, Tp), self.T)
         Kt = self.ws.get("attn.Vt", (B * H, dh, Tp), self.T)
         q, k, v = qkv, qkv[:, D:], qkv[:, 2 * D:]
         sq, sp, so = (T * 3 * D, dh), (H * T * Tp, T * Tp), (T * D, dh)
-        # dV = P^T dO
-        hip.gemm_tn_batched(self.d, P, d_o, dqkv[:, 2 * D:], T, T, dh, Tp, D, 3 * D, B, H, sp, so, sq)
-        # dP = dO V^T ; dS = softmax'(P, dP)
-        hip.gemm_batched(self.d, d_o, v, dP, T, T, dh, D, 3 * D, Tp, B, H, so, sq, sp, out_f32=True)
-        hip.attn_softmax(self.d, True, dP, Tp, P, dS, Tp, B * H * T, T, dh ** -0.5)
+        if sv.get("fused"):
+            # P and dS are recomputed in one pass (pad columns beyond roundup(T,16) stay zero from allocation)
+            P = self.ws.get("attn.Pbwd", (B * H, T, Tp), self.T, zero=True)
+            dS = self.ws.get("attn.dS", (B * H, T, Tp), self.T, zero=True)
+            hip.attn_backward_ds(self.d, qkv, d_o, sv["lse"], P, dS, Tp, B, T, H, dh, dh ** -0.5)
+            hip.gemm_tn_batched(self.d, P, d_o, dqkv[:, 2 * D:], T, T, dh, Tp, D, 3 * D, B, H, sp, so, sq)
+        else:
+            P = sv["P"]
+            dP = self.ws.get("attn.S", (B * H, T, Tp), torch.float32)
+            dS = self.ws.get("attn.dS", (B * H, T, Tp), self.T)
+            # dV = P^T dO
+            hip.gemm_tn_batched(self.d, P, d_o, dqkv[:, 2 * D:], T, T, dh, Tp, D, 3 * D, B, H, sp, so, sq)
+            # dP = dO V^T ; dS = softmax'(P, dP)
+            hip.gemm_batched(self.d, d_o, v, dP, T, T, dh, D, 3 * D, Tp, B, H, so, sq, sp, out_f32=True)
+            hip.attn_softmax(self.d, True, dP, Tp, P, dS, Tp, B * H * T, T, dh ** -0.5)
         # dQ = dS K ; dK = dS^T Q
         hip.head_transpose(self.d, k, 3 * D, T * 3 * D, dh, B, H, Kt, T, dh, Tp)
         hip.gemm_batched(self.d, dS, Kt, dqkv, T, dh, Tp, Tp, Tp, 3 * D, B, H, sp, (H * dh * Tp, dh * Tp), sq)

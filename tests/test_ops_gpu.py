@@ -413,13 +413,16 @@ def test_attention_fwd_bwd(dtype, T):
     o = (att @ v).transpose(1, 2).reshape(B * T, D)
     do = rnd(torch.randn(B * T, D), dtype)
     o.backward(do)
-    eng = HipEngine(ParamArena(), torch.device(DEV), dtype)
-    od = eng.attention("a", qkv.detach().to(DEV, dtype), B, T, H, True)
-    dq = eng.attention_backward("a", do.to(DEV, dtype), "dqkv")
-    torch.cuda.synchronize()
-    torch.testing.assert_close(od.float().cpu(), o.detach(), **tol(dtype, dh))
-    t = tol(dtype, T)
-    torch.testing.assert_close(dq.float().cpu(), qkv.grad, **t)
+    for fused in ((True, False) if dtype == torch.bfloat16 else (False,)):
+        eng = HipEngine(ParamArena(), torch.device(DEV), dtype)
+        eng.fused_attention = fused       # bf16: fused kernels (scores stay on chip) and the materialised reference path
+        od = eng.attention("a", qkv.detach().to(DEV, dtype), B, T, H, True)
+        assert eng.saved["a"].get("fused", False) == fused
+        dq = eng.attention_backward("a", do.to(DEV, dtype), "dqkv")
+        torch.cuda.synchronize()
+        torch.testing.assert_close(od.float().cpu(), o.detach(), **tol(dtype, dh))
+        t = tol(dtype, T)
+        torch.testing.assert_close(dq.float().cpu(), qkv.grad, **t)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
