@@ -93,6 +93,9 @@ int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y, int M, in
 int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int M, int Na, int Nb, int lda, int ldb,
                         int ldo, int outer, int inner, long long sao, long long sai, long long sbo, long long sbi,
                         long long soo, long long soi, nkb_stream_t stream);
+/* Linear layer with fused exact-erf GELU epilogue. act 1: y2 = xW^T+b, y = gelu(y2). act 2: y = (xW^T) * gelu'(aux). */
+int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y, void* y2,
+                    int M, int K, int N, nkb_stream_t stream);
 /* LayerNorm over the last dim (biased variance). backward=0: in = x -> out = y, writes mean/rstd.
  * backward=1: in = dy, x = saved input -> out = dx (+ add), dgamma/dbeta accumulated with atomics. Strides in elements. */
 int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,

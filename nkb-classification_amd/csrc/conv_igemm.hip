@@ -247,6 +247,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        if (p.act == 1) {          // GELU forward: keep the pre-activation in y2 (for backward), store gelu(v) in y
+            T* o2 = (T*)p.y2 + (size_t)m * p.ldy + co;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pre = DT<T>::rnd(v[e]);
+                if (co + e < p.Cout) DT<T>::st(o2 + e, pre);
+                v[e] = pre * 0.5f * (1.f + erff(pre * 0.70710678118654752f));
+            }
+        } else if (p.act == 2) {   // GELU backward: v = dL/d(gelu out) -> multiply by gelu'(pre-activation read from aux)
+            const T* ax = (const T*)p.aux + (size_t)m * p.ldy + co;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = (co + e < p.Cout) ? DT<T>::ld(ax + e) : 0.f;
+                v[e] *= 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * expf(-0.5f * a * a);
+            }
+        }
         if (p.out_f32 || sizeof(T) == 4) {
             float* o = (float*)p.y + yoff + (size_t)m * p.ldy + co;
             if (vec_ok) {
@@ -574,11 +590,39 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     p.out_f32 = out_f32;
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
-    p.add_h = add_h; p.add_w = add_w;
+    p.add_h = add_h; p.add_w = add_w; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
     const double flops = 2.0 * p.M * (double)Cout * R * S * Cin;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops);
     if (add_h == 0 && nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
     const bool narrow = Cout <= 64;
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
+    return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+}
+
+// Linear layer with a fused exact-erf GELU epilogue (timm ViT MLP):
+//   act 1: pre = x W^T + b -> y2 = pre, y = gelu(pre)        (fc1 forward)
+//   act 2: y = (x W^T) * gelu'(aux)                           (fc2 data-gradient, aux = fc1's pre-activation)
+extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y,
+                               void* y2, int M, int K, int N, hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int kte = 128 / esz;
+    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (act != 1 && act != 2) || K % kte != 0 || N % 8 != 0) {
+        nkb_set_error("linear_gelu: unsupported dtype/act/shape (K=%d N=%d)", K, N);
+        return 1;
+    }
+    if ((long long)M * K * esz >= 0xFFFFFF00ll || (long long)N * K * esz >= 0xFFFFFF00ll || (long long)M * N >= (1ll << 31)) {
+        nkb_set_error("linear_gelu: operand exceeds the 4 GiB buffer-addressing range");
+        return 1;
+    }
+    ConvParams p;
+    p.x = x; p.w = w; p.y = y; p.add = nullptr; p.bias = bias; p.stats = nullptr;
+    p.M = M; p.H = M; p.W = 1; p.Cin = K; p.ldx = K; p.P = M; p.Q = 1; p.Cout = N; p.ldy = N; p.ldadd = 0;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 0; p.relu = 0; p.out_f32 = 0;
+    p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
+    p.add_h = 0; p.add_w = 0; p.act = act; p.aux = aux; p.y2 = y2;
+    p.ldw = K; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    NkbProfScope prof(act == 1 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
+    const bool narrow = N <= 64;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
 }
@@ -601,7 +645,7 @@ extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y
     p.M = M; p.H = M; p.W = 1; p.Cin = K; p.ldx = ldx; p.P = M; p.Q = 1; p.Cout = N; p.ldy = ldy; p.ldadd = 0;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 0; p.relu = 0; p.out_f32 = out_f32;
     p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
-    p.add_h = 0; p.add_w = 0;
+    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
     p.ldw = ldw; p.inner = inner; p.sxo = sxo; p.sxi = sxi; p.swo = swo; p.swi = swi; p.syo = syo; p.syi = syi;
     NkbProfScope prof(NKB_K_ATTN, stream, 2.0 * M * (double)N * K * outer * inner);
     const bool narrow = N <= 64;

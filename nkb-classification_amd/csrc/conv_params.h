@@ -20,6 +20,9 @@ struct ConvParams {
     FastDiv divPQ, divQ;
     // batched GEMM (attention): blockIdx.y = zo*inner + zi; element offsets zo*s?o + zi*s?i on x / w / y
     int add_h, add_w;   // > 0: `add` is [N][add_h][add_w][ldadd] on the stride-2 sub-grid of the output (zero elsewhere)
+    int act;            // 0 none, 1 GELU forward (pre-activation also stored to y2), 2 multiply by gelu'(aux)
+    const void* aux;    // [M][ldy] pre-activation for act 2
+    void* y2;           // [M][ldy] pre-activation output for act 1
     int ldw;            // row stride of w in elements (R*S*Cin unless batched)
     int inner;
     long long sxo, sxi, swo, swi, syo, syi;

@@ -40,6 +40,7 @@ _SIGS = {
     "nkb_pad_cast": (i32, [i32, vp, vp, i32, i32, i32, i32, f32, vp]),
     "nkb_gemm_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [i32, vp]),
     "nkb_gemm_tn_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [vp]),
+    "nkb_linear_gelu": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
@@ -285,3 +286,8 @@ def attn_forward(dtype, qkv, out, lse, B, T, H, dh, scale):
 def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale):
     check(load().nkb_attn_backward_ds(dtype, ptr(qkv), ptr(dout), ptr(lse), ptr(P), ptr(dS), ldp, B, T, H, dh, scale,
                                       stream()), "attn_backward_ds")
+
+
+def linear_gelu(dtype, act, x, w, bias, aux, y, y2, M, K, N):
+    check(load().nkb_linear_gelu(dtype, act, ptr(x), ptr(w), ptr(bias), ptr(aux), ptr(y), ptr(y2), M, K, N, stream()),
+          "linear_gelu")

@@ -367,6 +367,32 @@ class HipEngine:
                       add=add, ldadd=K if add is not None else 0)
         return dx
 
+    def linear_gelu(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool) -> torch.Tensor:
+        """u = gelu(x @ W^T + b) with the GELU in the GEMM epilogue; the pre-activation is kept for backward."""
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        pre = self.ws.get(key + ".pre", (M, N), self.T)
+        u = self.ws.get(key + ".y", (M, N), self.T)
+        hip.linear_gelu(self.d, 1, x, self.w_fwd(lin.weight), self.arena.param_flat(lin.bias), None, u, pre, M, K, N)
+        if train:
+            self.saved[key] = dict(x=x, lin=lin, pre=pre)
+        return u
+
+    def linear_backward_through_gelu(self, key_next: str, key_act: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        """For u = gelu(pre), y = u @ W2^T + b2: weight/bias gradient of W2 (side stream) and d_pre = (g @ W2) * gelu'(pre)
+        in one GEMM epilogue (the separate GELU-backward pass and the d_u tensor disappear)."""
+        sv = self.saved[key_next]
+        x, lin = sv["x"], sv["lin"]          # x = u (gelu output), lin = fc2
+        M, K = x.shape                      # K = hidden width
+        N = lin.weight.shape[0]
+        a = self.arena
+        self.on_side(lambda: hip.conv_wgrad(
+            self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+            dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
+        d_pre = self.scratch(slot, (M, K))
+        hip.linear_gelu(self.d, 2, g, self._wd[id(lin.weight)], None, self.saved[key_act]["pre"], d_pre, None, M, N, K)
+        return d_pre
+
     def layernorm(self, key: str, x: torch.Tensor, ln: nn.LayerNorm, train: bool, rows: Optional[int] = None,
                   x_stride: Optional[int] = None) -> torch.Tensor:
         D = ln.weight.shape[0]

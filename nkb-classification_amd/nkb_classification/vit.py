@@ -7,12 +7,16 @@ bias, exact-erf GELU, pre-norm residual blocks, x[:, 0] of the final norm as the
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
 from . import hip
 from .backbones import _ParamOnly
 from .hipnet import HipEngine
+
+_FUSED_GELU = os.environ.get("NKB_FUSED_GELU", "0") != "0"   # measured: erf in the GEMM epilogue costs more than the pass it saves (66.3 vs 65.9 ms)
 
 
 class _PatchEmbed(_ParamOnly):
@@ -107,8 +111,10 @@ class HipViT(_ParamOnly):
             o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train)
             x = eng.linear(f"b{i}.proj", o, blk.attn.proj, train, add=x)
             h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train)
-            u = eng.linear(f"b{i}.fc1", h, blk.mlp.fc1, train)
-            u = eng.gelu(f"b{i}.act", u, train)
+            if _FUSED_GELU:
+                u = eng.linear_gelu(f"b{i}.fc1", h, blk.mlp.fc1, train)        # GELU fused into the fc1 epilogue
+            else:
+                u = eng.gelu(f"b{i}.act", eng.linear(f"b{i}.fc1", h, blk.mlp.fc1, train), train)
             x = eng.linear(f"b{i}.fc2", u, blk.mlp.fc2, train, add=x)
         # final norm on the class-token rows only (x[:, 0]); the other rows never reach the head
         return eng.layernorm("norm", x, self.norm, train, rows=B, x_stride=T * D)
@@ -128,8 +134,10 @@ class HipViT(_ParamOnly):
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
             eng.begin_block(i)
-            d_u = eng.linear_backward(f"b{i}.fc2", gx, "du")
-            d_a = eng.gelu_backward(f"b{i}.act", d_u, "da")
+            if _FUSED_GELU:   # gelu' fused into the fc2 data-gradient epilogue
+                d_a = eng.linear_backward_through_gelu(f"b{i}.fc2", f"b{i}.fc1", gx, "da")
+            else:
+                d_a = eng.gelu_backward(f"b{i}.act", eng.linear_backward(f"b{i}.fc2", gx, "du"), "da")
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
             gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
             d_o = eng.linear_backward(f"b{i}.proj", gmid, "do")
