@@ -59,23 +59,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int nkb = (T + 15) / 16, TK = nkb * 16;
     const int nks = (T + 31) / 32;                 // 32-key steps of the P*V product
-    const int VROW = nks * 64 + 16;                // bytes per V^T row (+16 pad: conflict-free ds_read_b64)
     unsigned char* Ks = smem;
-    unsigned char* Vt = smem + TK * 128;
+    unsigned char* Vs = smem + TK * 128;           // V rows [key][dh] in the same swizzled image, zero beyond T
     const long long rs = 3ll * D;
     const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
     load_rows(Ks, base + D, rs, T, TK);
-    // V^T image: Vt[dh][key] (bf16), zero beyond T
-    for (int c = threadIdx.x; c < nks * 32 * 8; c += blockDim.x) {
-        const int key = c >> 3, ch = c & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (key < T) v = *(const u32x4*)(base + 2 * D + (size_t)key * rs + ch * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            *(bf16_t*)(Vt + (ch * 8 + 2 * e) * VROW + key * 2) = (bf16_t)(v[e] & 0xffffu);
-            *(bf16_t*)(Vt + (ch * 8 + 2 * e + 1) * VROW + key * 2) = (bf16_t)(v[e] >> 16);
-        }
-    }
+    load_rows(Vs, base + 2 * D, rs, T, nks * 32);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
@@ -122,9 +111,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 const u32x4 pb = {pk[2 * t][0], pk[2 * t][1], pk[2 * t + 1][0], pk[2 * t + 1][1]};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const unsigned char* vrow = Vt + (16 * i + fr) * VROW + (32 * t + 4 * g) * 2;
-                    const u32x2 lo = *(const u32x2*)vrow;
-                    const u32x2 hi = *(const u32x2*)(vrow + 32);
+                    // V^T fragment straight from the row-major V image with the transposing LDS read: the 16-lane group
+                    // g fetches keys 32t + 4g + {0..3} (then +16) x dh 16i..16i+15, lane fr receives column dh = 16i + fr
+                    const int vr = 32 * t + 4 * g + (fr >> 2), pc = fr & 3;
+                    const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(Vs + kswz(vr, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
+                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(Vs + kswz(vr + 16, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
+                    const u32x2 lo = __builtin_bit_cast(u32x2, lo4), hi = __builtin_bit_cast(u32x2, hi4);
                     const u32x4 va = {lo[0], lo[1], hi[0], hi[1]};
                     o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pb), o[i], 0, 0, 0);
                 }
@@ -200,7 +194,7 @@ extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* ls
         return 1;
     }
     const int nkb = (T + 15) / 16, nks = (T + 31) / 32;
-    const int lds = nkb * 16 * 128 + DH * (nks * 64 + 16);
+    const int lds = nkb * 16 * 128 + nks * 32 * 128;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024); attr = true; }
     NkbProfScope prof(NKB_K_ATTN, stream, 4.0 * B * H * (double)T * T * DH);
