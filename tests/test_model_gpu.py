@@ -335,3 +335,56 @@ def test_classifier_dropout_train_path():
     with torch.no_grad():
         e1, e2 = model(x), model(x)
     assert torch.equal(e1["a"], e2["a"])                                  # eval: dropout is the identity
+
+
+def test_grad_scaler_enabled_matches_unscaled_step():
+    """cfg.enable_gradient_scaler=True (the reference's default): torch's GradScaler scales the loss, un-scales the arena
+    gradient views in place and steps the fused optimizer; the update equals the un-scaled one."""
+    cfg_model = dict(model="resnet_tiny_basic", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(8, 3, 64, 64, generator=g).to(DEV), torch.randint(0, 3, (8,), generator=g).to(DEV)
+    results = []
+    for enabled in (False, True):
+        torch.manual_seed(0)
+        model = get_model(cfg_model, ["a", "b", "c"], DEV)
+        opt = get_optimizer(model, dict(type="adam", lr=1e-3))
+        crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+        scaler = torch.amp.GradScaler("cuda", enabled=enabled, init_scale=1024.0)
+        model.train()
+        for _ in range(3):
+            opt.zero_grad()
+            loss = crit(model(x), y)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        torch.cuda.synchronize()
+        results.append(model.arena.flat_param.clone())
+    assert torch.isfinite(results[1]).all()
+    torch.testing.assert_close(results[1], results[0], rtol=2e-4, atol=2e-5)   # Adam normalises tiny gradients: 1-ulp scale/unscale differences move them
+
+
+def test_multitask_bench_shape_runs_bf16():
+    """BASELINE config 4 shape on one GPU: ResNet-50, 4 heads (2, 3, 5, 14 classes), focal loss gamma=1, bf16."""
+    cfg_model = dict(model="resnet50", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="multi")
+    classes = {"a": list("ab"), "b": list("abc"), "c": list("abcde"), "d": list("abcdefghijklmn")}
+    torch.manual_seed(0)
+    model = get_model(cfg_model, classes, DEV)
+    opt = get_optimizer(model, dict(type="nadam", lr=1e-4, weight_decay=0.01))
+    crit = get_loss(dict(task="multi", type="FocalLoss", gamma=1), DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 3, 224, 224, generator=g).to(DEV)
+    y = {t: torch.randint(0, len(c), (32,), generator=g) for t, c in classes.items()}
+    model.train()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(x)
+            loss = crit(out, y)
+        loss["loss"].backward()
+        opt.step()
+        losses.append(loss["loss"].item())
+    assert [tuple(out[t].shape) for t in classes] == [(32, 2), (32, 3), (32, 5), (32, 14)]
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0] * 1.5
