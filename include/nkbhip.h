@@ -100,7 +100,9 @@ int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const floa
  * backward=1: in = dy, x = saved input -> out = dx (+ add), dgamma/dbeta accumulated with atomics. Strides in elements. */
 int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
                   const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
-                  long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps, nkb_stream_t stream);
+                  long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps, float* workspace,
+                  nkb_stream_t stream);
+size_t nkb_layernorm_workspace_floats(int D); /* backward: optional scratch for the deterministic dgamma/dbeta reduction */
 /* exact-erf GELU: dy == NULL -> out = gelu(x); else out = dy * gelu'(x) */
 int nkb_gelu(int dtype, const void* x, const void* dy, void* out, long long n, nkb_stream_t stream);
 /* softmax over fp32 score rows (forward: p = softmax(scale*s); backward: ds = scale*p*(dp - sum dp*p)), zero padded to ldp */

@@ -287,22 +287,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         k2[e] = -a * is * sdyx;
         k3[e] = -a * sdy + a * is * sdyx * mu;
     }
-    for (unsigned r = r0; r < rows; r += rs) {
-        const size_t o = (size_t)r * C + cg * N;
-        float g[N], xv[N], ya[N], out[N];
-        Chunk<T>::load(dy + o, g);
-        Chunk<T>::load(x + o, xv);
-        if (yact) Chunk<T>::load(yact + o, ya);
+    for (unsigned r = r0; r < rows; r += 2 * rs) {     // two rows per trip: twice the loads in flight per thread
+        const bool two = r + rs < rows;
+        const size_t o0 = (size_t)r * C + cg * N;
+        const size_t o1 = two ? (size_t)(r + rs) * C + cg * N : o0;
+        float g0[N], x0[N], y0[N], g1[N], x1[N], y1[N], out0[N], out1[N];
+        Chunk<T>::load(dy + o0, g0);
+        Chunk<T>::load(x + o0, x0);
+        Chunk<T>::load(dy + o1, g1);
+        Chunk<T>::load(x + o1, x1);
+        if (yact) { Chunk<T>::load(yact + o0, y0); Chunk<T>::load(yact + o1, y1); }
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            float gg = g[e];
-            if (yact && !(ya[e] > 0.f)) gg = 0.f;
-            if (fscale && !(DT<T>::rnd(xv[e] * fs[e] + fb[e]) > 0.f)) gg = 0.f;
-            g[e] = gg;
-            out[e] = k1[e] * gg + (k2[e] * xv[e] + k3[e]);
+            float a = g0[e], b = g1[e];
+            if (yact) { if (!(y0[e] > 0.f)) a = 0.f; if (!(y1[e] > 0.f)) b = 0.f; }
+            if (fscale) {
+                if (!(DT<T>::rnd(x0[e] * fs[e] + fb[e]) > 0.f)) a = 0.f;
+                if (!(DT<T>::rnd(x1[e] * fs[e] + fb[e]) > 0.f)) b = 0.f;
+            }
+            g0[e] = a; g1[e] = b;
+            out0[e] = k1[e] * a + (k2[e] * x0[e] + k3[e]);
+            out1[e] = k1[e] * b + (k2[e] * x1[e] + k3[e]);
         }
-        Chunk<T>::store(dx + o, out);
-        if (dy_masked) Chunk<T>::store(dy_masked + o, g);
+        Chunk<T>::store(dx + o0, out0);
+        if (dy_masked) Chunk<T>::store(dy_masked + o0, g0);
+        if (two) {
+            Chunk<T>::store(dx + o1, out1);
+            if (dy_masked) Chunk<T>::store(dy_masked + o1, g1);
+        }
     }
 }
 

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             long long xs, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const T* __restrict__ add, T* __restrict__ dx, long long dxs,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                                            float* __restrict__ part) {
     constexpr int D = 64 * VW * NP;
     __shared__ float red[4][2][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -140,36 +141,60 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             for (int e = 0; e < VW; ++e) {
                 float s0 = 0.f, t0 = 0.f;
                 for (int w = 0; w < wpb; ++w) { s0 += red[w][0][lane * VW + e]; t0 += red[w][1][lane * VW + e]; }
-                atomicAdd(dgamma + (k * 64 + lane) * VW + e, s0);
-                atomicAdd(dbeta + (k * 64 + lane) * VW + e, t0);
+                const int col = (k * 64 + lane) * VW + e;
+                if (part) {   // deterministic two-stage reduction: per-block partials, summed by ln_param_grad_kernel
+                    part[((size_t)blockIdx.x * 2) * D + col] = s0;
+                    part[((size_t)blockIdx.x * 2 + 1) * D + col] = t0;
+                } else {      // same-address float atomics: fine for a few hundred blocks, serialises beyond that
+                    atomicAdd(dgamma + col, s0);
+                    atomicAdd(dbeta + col, t0);
+                }
             }
         }
     }
 }
 
+__global__ void ln_param_grad_kernel(const float* __restrict__ part, int blocks, int D, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+    __shared__ float red[2][16][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float a = 0.f, b = 0.f;
+    if (c < D)
+        for (int t = py; t < blocks; t += 16) { a += part[((size_t)t * 2) * D + c]; b += part[((size_t)t * 2 + 1) * D + c]; }
+    red[0][py][cx] = a; red[1][py][cx] = b;
+    __syncthreads();
+    if (py != 0 || c >= D) return;
+    a = 0.f; b = 0.f;
+    for (int k = 0; k < 16; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
+    dgamma[c] += a; dbeta[c] += b;
+}
+
 template <typename T, int VW, int NP>
 static void ln_launch(int backward, int grid, hipStream_t stream, const void* in, long long in_stride, const void* x,
                       long long x_stride, const float* gamma, const float* beta, float* mean, float* rstd, const void* add,
-                      void* out, long long out_stride, float* dgamma, float* dbeta, int rows, float eps) {
+                      void* out, long long out_stride, float* dgamma, float* dbeta, int rows, float eps, float* part) {
     if (!backward)
         hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps);
     else
-        hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows);
+        hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part);
 }
 template <typename T, int VW>
 static int ln_dispatch(int np, int backward, int grid, hipStream_t stream, const void* in, long long is, const void* x, long long xs,
                        const float* g, const float* b, float* mean, float* rstd, const void* add, void* out, long long os,
-                       float* dg, float* db, int rows, float eps) {
-#define LN_CASE(N) case N: ln_launch<T, VW, N>(backward, grid, stream, in, is, x, xs, g, b, mean, rstd, add, out, os, dg, db, rows, eps); return 0;
+                       float* dg, float* db, int rows, float eps, float* part) {
+#define LN_CASE(N) case N: ln_launch<T, VW, N>(backward, grid, stream, in, is, x, xs, g, b, mean, rstd, add, out, os, dg, db, rows, eps, part); return 0;
     switch (np) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
 #undef LN_CASE
     return 1;
 }
 
+extern "C" size_t nkb_layernorm_workspace_floats(int D) { return (size_t)2048 * 2 * D; }
+
 extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
                              const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
                              long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps,
-                             hipStream_t stream) {
+                             float* workspace, hipStream_t stream) {
     const int vw = (D % 256 == 0) ? 4 : 2;
     const int np = D / (64 * vw);
     if (D % 128 != 0 || np < 1 || np > 8 || in_stride % vw || x_stride % vw || out_stride % vw) {
@@ -179,43 +204,59 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
     NkbProfScope prof(NKB_K_LN, stream, 0);
     int grid = (rows + 3) / 4;
     if (!backward) { if (grid > 256 * 16) grid = 256 * 16; }
-    else if (grid > 1024) grid = 1024;   // bounds the atomics: grid * D * 2
+    else if (workspace) { if (grid > 1024) grid = 1024; }   // partials [grid][2][D] in the workspace
+    else if (grid > 512) grid = 512;                         // atomics path: keep same-address contention low
     int rc;
     if (dtype == NKB_DT_BF16)
-        rc = vw == 4 ? ln_dispatch<bf16_t, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps)
-                     : ln_dispatch<bf16_t, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps);
+        rc = vw == 4 ? ln_dispatch<bf16_t, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace)
+                     : ln_dispatch<bf16_t, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace);
     else
-        rc = vw == 4 ? ln_dispatch<float, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps)
-                     : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps);
+        rc = vw == 4 ? ln_dispatch<float, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace)
+                     : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace);
     if (rc) { nkb_set_error("layernorm: unsupported D=%d", D); return 1; }
+    if (backward && workspace)
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, workspace, grid, D, dgamma, dbeta);
     return nkb_check_launch("layernorm");
 }
 
 // ---------------------------------------------------------------------------------------------------
 // GELU (exact erf form, timm's nn.GELU()): forward y = gelu(x); backward dx = dy * gelu'(x)
+template <typename T> struct V16;      // 16-byte vectors: 8 bf16 / 4 fp32
+template <> struct V16<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void ld(const bf16_t* p, float* f) { unpack8(*(const u32x4*)p, f); }
+    __device__ static __forceinline__ void st(bf16_t* p, const float* f) { *(u32x4*)p = pack8(f); }
+};
+template <> struct V16<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void ld(const float* p, float* f) { const f32x4 v = *(const f32x4*)p; f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
+    __device__ static __forceinline__ void st(float* p, const float* f) { *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]}; }
+};
+
 template <typename T>
-__global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, size_t n2) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        float a, b;
-        V2<T>::ld(x + 2 * i, a, b);
-        const float ca = 0.5f * (1.f + erff(a * 0.70710678118654752f)), cb = 0.5f * (1.f + erff(b * 0.70710678118654752f));
-        if (!dy) {
-            V2<T>::st(out + 2 * i, a * ca, b * cb);
-        } else {
-            float ga, gb;
-            V2<T>::ld(dy + 2 * i, ga, gb);
-            const float pa = 0.3989422804014327f * expf(-0.5f * a * a), pb = 0.3989422804014327f * expf(-0.5f * b * b);
-            V2<T>::st(out + 2 * i, ga * (ca + a * pa), gb * (cb + b * pb));
+__global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, size_t nvec) {
+    constexpr int N = V16<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        float a[N], g[N], o[N];
+        V16<T>::ld(x + i * N, a);
+        if (dy) V16<T>::ld(dy + i * N, g);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float c = 0.5f * (1.f + erff(a[e] * 0.70710678118654752f));
+            o[e] = dy ? g[e] * (c + a[e] * 0.3989422804014327f * expf(-0.5f * a[e] * a[e])) : a[e] * c;
         }
+        V16<T>::st(out + i * N, o);
     }
 }
 extern "C" int nkb_gelu(int dtype, const void* x, const void* dy, void* out, long long n, hipStream_t stream) {
-    if (n % 2) { nkb_set_error("gelu: odd element count"); return 1; }
+    const int N = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (n % N) { nkb_set_error("gelu: element count %lld not a multiple of %d", n, N); return 1; }
     NkbProfScope prof(NKB_K_GELU, stream, 0);
-    size_t n2 = (size_t)n / 2, g = (n2 + 255) / 256;
+    size_t nvec = (size_t)n / N, g = (nvec + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
-    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(gelu_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, n2);
-    else hipLaunchKernelGGL(gelu_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)x, (const float*)dy, (float*)out, n2);
+    if (g < 1) g = 1;
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(gelu_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, nvec);
+    else hipLaunchKernelGGL(gelu_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)x, (const float*)dy, (float*)out, nvec);
     return nkb_check_launch("gelu");
 }
 

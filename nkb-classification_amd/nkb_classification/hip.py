@@ -41,7 +41,8 @@ _SIGS = {
     "nkb_gemm_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [i32, vp]),
     "nkb_gemm_tn_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [vp]),
     "nkb_linear_gelu": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp]),
+    "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp]),
+    "nkb_layernorm_workspace_floats": (sz, [i32]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
     "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
@@ -245,12 +246,18 @@ def gemm_tn_batched(dtype, a, b, out, M, Na, Nb, lda, ldb, ldo, outer, inner, sa
 
 def layernorm_fwd(dtype, x, x_stride, gamma, beta, y, y_stride, mean, rstd, rows, D, eps):
     check(load().nkb_layernorm(dtype, 0, ptr(x), x_stride, None, 0, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), None,
-                               ptr(y), y_stride, None, None, rows, D, eps, stream()), "layernorm_fwd")
+                               ptr(y), y_stride, None, None, rows, D, eps, None, stream()), "layernorm_fwd")
 
 
-def layernorm_bwd(dtype, dy, dy_stride, x, x_stride, gamma, mean, rstd, add, dx, dx_stride, dgamma, dbeta, rows, D):
+def layernorm_bwd(dtype, dy, dy_stride, x, x_stride, gamma, mean, rstd, add, dx, dx_stride, dgamma, dbeta, rows, D,
+                  workspace=None):
     check(load().nkb_layernorm(dtype, 1, ptr(dy), dy_stride, ptr(x), x_stride, ptr(gamma), None, ptr(mean), ptr(rstd),
-                               ptr(add), ptr(dx), dx_stride, ptr(dgamma), ptr(dbeta), rows, D, 0.0, stream()), "layernorm_bwd")
+                               ptr(add), ptr(dx), dx_stride, ptr(dgamma), ptr(dbeta), rows, D, 0.0, ptr(workspace),
+                               stream()), "layernorm_bwd")
+
+
+def layernorm_ws(D):
+    return load().nkb_layernorm_workspace_floats(D)
 
 
 def gelu(dtype, x, dy, out, n):

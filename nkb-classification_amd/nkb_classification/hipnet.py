@@ -413,8 +413,9 @@ class HipEngine:
         ln = sv["ln"]
         D = ln.weight.shape[0]
         a = self.arena
+        work = self.ws.at_least("ln.work", hip.layernorm_ws(D), torch.float32)
         hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
-                          out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), sv["rows"], D)
+                          out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), sv["rows"], D, workspace=work)
         return out
 
     def gelu(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:

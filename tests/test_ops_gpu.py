@@ -375,7 +375,15 @@ def test_layernorm_fwd_bwd(dtype, D):
     dx = torch.empty(rows, D, device=DEV, dtype=dtype)
     dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
     hip.layernorm_bwd(d, dy.to(DEV, dtype), D, xd, D, g, mean, rstd, add.to(DEV, dtype), dx, D, dg, db, rows, D)
+    # deterministic two-stage parameter-gradient reduction through a workspace
+    dg2, db2, dx2 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.empty_like(dx)
+    work = torch.empty(hip.layernorm_ws(D), device=DEV)
+    hip.layernorm_bwd(d, dy.to(DEV, dtype), D, xd, D, g, mean, rstd, add.to(DEV, dtype), dx2, D, dg2, db2, rows, D,
+                      workspace=work)
     torch.cuda.synchronize()
+    torch.testing.assert_close(dg2.cpu(), dg.cpu(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db2.cpu(), db.cpu(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(dx2, dx)
     torch.testing.assert_close(yd.float().cpu(), y.detach(), **tol(dtype))
     torch.testing.assert_close(dx.float().cpu(), x.grad + add, **tol(dtype, 4))
     torch.testing.assert_close(dg.cpu(), ln.weight.grad, **tol(dtype, rows))
@@ -385,7 +393,7 @@ def test_layernorm_fwd_bwd(dtype, D):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gelu_fwd_bwd(dtype):
     torch.manual_seed(11)
-    x = rnd(torch.randn(5000) * 2, dtype).requires_grad_(True)
+    x = rnd(torch.randn(5000) * 2, dtype).requires_grad_(True)  # 5000 = 625 x 8: whole 16-byte vectors
     y = torch.nn.functional.gelu(x)
     dy = rnd(torch.randn(5000), dtype)
     y.backward(dy)
