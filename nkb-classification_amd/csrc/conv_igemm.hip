@@ -334,7 +334,7 @@ __device__ __forceinline__ int lds_swz256(int row, int ch) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int TW = 256 / (int)sizeof(T);  // tile width in channels: 128 (bf16) / 64 (f32)
     constexpr int PK = 64;                    // pixels per pipeline stage
@@ -371,6 +371,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const bool dycol_ok = dycol < p.Cout;  // a chunk may run past Cout into the row padding (lddy >= roundup(Cout)); those rows are discarded
     const bool direct = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
 
+    constexpr unsigned WOOB = 0xFFFFFF00u;
+    const unsigned dy_row_bytes = (unsigned)p.lddy * sizeof(T), dy_col_bytes = (unsigned)dycol * sizeof(T);
+    const unsigned x_row_bytes = (unsigned)p.ldx * sizeof(T), x_col_bytes = (unsigned)tc * sizeof(T);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, WOOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, WOOB, 0x00020000);
     u32x4 sa[4], sb[4];
     // bias gradient (column sums of dY): every workgroup of a cout tile sees the same dY rows, so the tilesN workgroups
     // share the work by pipeline stage (stage % tilesN == tile_n) — a single "bias workgroup" per cout tile would run
@@ -383,12 +388,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mb + srow + 16 * i;
-            u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+            unsigned oa = WOOB, ob = WOOB;      // out-of-range offsets read back as zeros
             if (m < m_end) {
-                if (dycol_ok) va = *(const u32x4*)(DY + (size_t)m * p.lddy + dycol);
+                if (dycol_ok) oa = (unsigned)m * dy_row_bytes + dy_col_bytes;
                 if (ncol_ok) {
                     if (direct) {
-                        vb = *(const u32x4*)(X + (size_t)m * p.ldx + tc);
+                        ob = (unsigned)m * x_row_bytes + x_col_bytes;
                     } else {
                         const unsigned n = fdiv((unsigned)m, p.divPQ);
                         const unsigned rem = (unsigned)m - n * p.divPQ.d;
@@ -396,10 +401,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                         const unsigned qq = rem - pp * p.divQ.d;
                         const int hi = (int)pp * p.stride - p.pad + tr, wi = (int)qq * p.stride - p.pad + ts;
                         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                            vb = *(const u32x4*)(X + ((size_t)n * p.H * p.W + (size_t)hi * p.W + wi) * p.ldx + tc);
+                            ob = ((n * (unsigned)p.H + (unsigned)hi) * (unsigned)p.W + (unsigned)wi) * x_row_bytes + x_col_bytes;
                     }
                 }
             }
+            const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)oa, 0, 0);
+            const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rxx, (int)ob, 0, 0);
             sa[i] = va; sb[i] = vb;
             if (do_bias) {   // column sums of dY (bias gradient) ride along on the tile_n == 0 workgroups
                 if constexpr (sizeof(T) == 2) {
@@ -436,10 +443,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         store_tile(0);
     }
     __syncthreads();
+    // one LDS stage + one register stage (two barriers per stage): LDS per workgroup ~34 KB -> 3 workgroups per CU
     for (int st = 0; st < nstage; ++st) {
-        const int buf = st & 1;
         if (st + 1 < nstage) load_tile(m_begin + (st + 1) * PK);
-        const unsigned char* A = smem + buf * STAGE_BYTES;
+        const unsigned char* A = smem;
         const unsigned char* B = A + TILE_BYTES;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -493,8 +500,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (st + 1 < nstage) store_tile(buf ^ 1);
-        __syncthreads();
+        __syncthreads();                                      // every wave is done reading the stage
+        if (st + 1 < nstage) { store_tile(0); __syncthreads(); }
     }
     if (nstage == 0) return;
 
@@ -513,37 +520,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         __syncthreads();
     }
 
-    // epilogue: stage the fp32 tile [cout][n] in LDS, then row-contiguous float atomics (256 B per wave-instruction)
+    // epilogue, one half of the cout rows at a time (the half owned by waves wr == half): stage the fp32 tile
+    // [cout][n] in LDS, then row-contiguous float atomics (256 B per wave-instruction) or direct stores
     constexpr int EROW = TW * 4 + 16;
+    constexpr int HR = TW / 2;
+    T* out = p.out_t ? (T*)p.out_t + (zo * p.soo + zi * p.soi) : nullptr;
+    for (int half = 0; half < 2; ++half) {
+        if (wr == half) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+            for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int rbase = (wr * NB + i) * 16 + g * 4;
-            const int col = (wn * NB + j) * 16 + li;
+                for (int j = 0; j < NB; ++j) {
+                    const int rbase = i * 16 + g * 4;
+                    const int col = (wn * NB + j) * 16 + li;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) *(float*)(smem + (rbase + e) * EROW + col * 4) = acc[i][j][e];
+                    for (int e = 0; e < 4; ++e) *(float*)(smem + (rbase + e) * EROW + col * 4) = acc[i][j][e];
+                }
         }
-    __syncthreads();
-    if (p.out_t) {
-        T* out = (T*)p.out_t + (zo * p.soo + zi * p.soi);
-        for (int row = wave; row < TW; row += 4) {
-            const int co = c0 + row;
+        __syncthreads();
+        for (int row = wave; row < HR; row += 4) {
+            const int co = c0 + half * HR + row;
             if (co >= p.Cout) break;
             for (int col = lane; col < TW; col += 64) {
                 const int n = n0 + col;
-                if (n < p.Ntot) DT<T>::st(out + (size_t)co * p.ldo + n, *(const float*)(smem + row * EROW + col * 4));
+                if (n < p.Ntot) {
+                    const float v = *(const float*)(smem + row * EROW + col * 4);
+                    if (out) DT<T>::st(out + (size_t)co * p.ldo + n, v);
+                    else atomicAdd(p.dw + (size_t)co * p.Ntot + n, v);
+                }
             }
         }
-        return;
-    }
-    for (int row = wave; row < TW; row += 4) {
-        const int co = c0 + row;
-        if (co >= p.Cout) break;
-        for (int col = lane; col < TW; col += 64) {
-            const int n = n0 + col;
-            if (n < p.Ntot) atomicAdd(p.dw + (size_t)co * p.Ntot + n, *(const float*)(smem + row * EROW + col * 4));
-        }
+        __syncthreads();
     }
 }
 
@@ -701,10 +708,10 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.divCin = make_fastdiv((unsigned)Cin); p.divS = make_fastdiv((unsigned)S);
     p.out_t = nullptr; p.ldo = 0; p.inner = 1; p.sdo = p.sdi = p.sxo = p.sxi = p.soo = p.soi = 0;
-    const int lds = 2 * 2 * 64 * 256 > TW * (TW * 4 + 16) ? 2 * 2 * 64 * 256 : TW * (TW * 4 + 16);
+    const int lds = 2 * 64 * 256 > (TW / 2) * (TW * 4 + 16) ? 2 * 64 * 256 : (TW / 2) * (TW * 4 + 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (128 * 4 + 16));
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
@@ -737,10 +744,10 @@ extern "C" int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void
     p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
     p.divCin = make_fastdiv((unsigned)Nb); p.divS = make_fastdiv(1u);
     p.out_t = out; p.ldo = ldo; p.inner = inner; p.sdo = sao; p.sdi = sai; p.sxo = sbo; p.sxi = sbi; p.soo = soo; p.soi = soi;
-    const int lds = 2 * 2 * 64 * 256 > TW * (TW * 4 + 16) ? 2 * 2 * 64 * 256 : TW * (TW * 4 + 16);
+    const int lds = 2 * 64 * 256 > (TW / 2) * (TW * 4 + 16) ? 2 * 64 * 256 : (TW / 2) * (TW * 4 + 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (128 * 4 + 16));
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
