@@ -606,7 +606,8 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     const double flops = 2.0 * p.M * (double)Cout * R * S * Cin;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops);
     if (add_h == 0 && nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
-    const bool narrow = Cout <= 64;
+    static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
+    const bool narrow = Cout <= 64 && narrow_on;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
 }
@@ -670,7 +671,9 @@ extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y
 // (for the plain conv call: ldy == Cout, no residual, compute-dtype output)
 extern "C" int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout) {
     if (nkb_conv_ring_eligible(dtype, Cout, Cout, 0, false, 0, M)) return nkb_conv_ring_stat_tiles(M, Cout);
-    return (M + (Cout <= 64 ? 256 : 128) - 1) / (Cout <= 64 ? 256 : 128);
+    static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
+    const int tp = (Cout <= 64 && narrow_on) ? 256 : 128;
+    return (M + tp - 1) / tp;
 }
 
 extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
