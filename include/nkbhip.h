@@ -72,10 +72,37 @@ size_t nkb_bn_backward_workspace_floats(long long rows, int C);
 int nkb_maxpool3x3s2(int dtype, int backward, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C,
                      nkb_stream_t stream);
 int nkb_avgpool(int dtype, int backward, const void* in, void* out, int N, int HW, int C, nkb_stream_t stream);
+/* ResNet stem tail in one pass (timm resnet.py forward_features: bn1 -> act1 -> maxpool, reached from
+ * nkb_classification/model.py:84).  c is the raw conv1 output [N][H][W][C].
+ * backward=0: y_or_g (out) = maxpool3x3s2(relu(c*scale+shift)) [N][P][Q][C], idx = winning window slot.
+ * backward=1: y_or_g (in) is the pooled gradient; dc = gradient w.r.t. c through pool routing, ReLU mask and batch-norm
+ *             backward; dgamma/dbeta accumulate; workspace >= nkb_bn_relu_maxpool_workspace_floats floats. */
+int nkb_bn_relu_maxpool(int dtype, int backward, const void* c, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* gamma, void* y_or_g, unsigned char* idx,
+                        void* dc, float* dgamma, float* dbeta, float* workspace, size_t workspace_floats, int N, int H,
+                        int W, int C, nkb_stream_t stream);
+size_t nkb_bn_relu_maxpool_workspace_floats(int N, int H, int W, int C);
 
 /* NCHW fp32 image -> [N*P*Q][Kp] rows, k = (r*S+s)*Cin + c (stem conv / patch embedding as a GEMM). */
 int nkb_im2row(int dtype, const float* x, void* col, int N, int Cin, int H, int W, int R, int S, int stride, int pad,
                int Kp, nkb_stream_t stream);
+
+/* Packed ResNet stem: Conv2d(C<=4 -> Cout, 7x7, stride 2, pad 3) (timm resnet.py conv1, reached from
+ * nkb_classification/model.py:84) computed as an implicit GEMM straight from the channel-padded NHWC image instead of
+ * an im2row matrix.
+ *   nkb_stem_pack   NCHW fp32 image -> xp[N][H][Wp][4] in the compute dtype, Wp = W rounded up to even
+ *   nkb_stem_wprep  fp32 master [Cout][7][7][C] -> wp[Cout][nkb_stem_weight_cols(dtype)] in the compute dtype
+ *   nkb_stem_conv   y[N*P*Q][ldy] = conv(xp, wp), optional per-tile BN partial sums (as nkb_conv_gemm, mode 0)
+ *   nkb_stem_wgrad  dwp[Cout][224] (fp32, zeroed by the caller) += dY^T x window(xp)
+ *   nkb_stem_wfold  dw[Cout][7][7][C] += dwp (drops the padding columns) */
+int nkb_stem_pack(int dtype, const float* x, void* out, int N, int C, int H, int W, nkb_stream_t stream);
+int nkb_stem_wprep(int dtype, const float* w, void* wp, int Cout, int C, nkb_stream_t stream);
+int nkb_stem_weight_cols(int dtype);
+int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y, float* stats, int N, int H, int W, int Cout,
+                  int ldy, nkb_stream_t stream);
+int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N, int H, int W, int Cout, int lddy,
+                   nkb_stream_t stream);
+int nkb_stem_wfold(int dtype, const float* dwp, float* dw, int Cout, int C, nkb_stream_t stream);
 
 /* fp32 master filter [A][B][C] -> compute-dtype copy (mode 0: rows padded to ld; mode 1: transposed [C][B][ld]). */
 int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int ld, int mode, nkb_stream_t stream);

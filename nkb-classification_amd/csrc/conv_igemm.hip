@@ -74,9 +74,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             const int pp = (int)fdiv(rem, p.divQ);
             const int qq = (int)rem - pp * (int)p.divQ.d;
             int hb, wb;
-            if (p.mode == 0) { hb = pp * p.stride - p.pad; wb = qq * p.stride - p.pad; }
+            if (p.mode == 0) { hb = pp * p.stride - p.pad; wb = qq * p.stride_w - p.pad_w; }
             else             { hb = pp + p.pad;            wb = qq + p.pad; }
             const int h0 = p.mode == 0 ? hb : (hb >> sh), w0 = p.mode == 0 ? wb : (wb >> sh);
+            if (p.stem_cprw > 0) {
+                // packed stem: a k-tile is rpt filter rows x cprw chunks; this lane's chunk sits at filter row
+                // kt*rpt + rl, window chunk sc.  "R" counts k-tiles, S == 1, and p.W == rpt * (chunks per image row)
+                // so that the per-k-tile tap offset r*W*16 steps rpt image rows.
+                const int rpt = 8 / p.stem_cprw, rl = cc / p.stem_cprw, sc = cc - rl * p.stem_cprw;
+                const int Wc = p.W / rpt;
+                xoff[j] = (((int)n * p.H + h0 + rl) * Wc + w0 + sc) * 16;
+                if ((unsigned)(w0 + sc) < (unsigned)Wc) {
+                    wmask[j] = 1u;
+                    for (int rr = 0; rr < p.R; ++rr)
+                        if ((unsigned)(hb + rr * rpt + rl) < (unsigned)p.H) hmask[j] |= 1u << rr;
+                }
+                continue;
+            }
             xoff[j] = (((int)n * p.H + h0) * p.W + w0) * p.ldx * ESZ + cc * 16;
             for (int rr = 0; rr < p.R; ++rr) {
                 const int t = p.mode == 0 ? hb + rr : hb - rr;
@@ -319,6 +333,7 @@ struct WgradParams {
     int M, H, W, Cin, ldx;
     int P, Q, Cout, lddy;
     int R, S, stride, pad;
+    int stride_w, pad_w;   // horizontal stride / padding (== stride / pad except for the packed stem)
     int Ntot;         // R*S*Cin
     int tilesC, tilesN, splits, rows_per_split;
     FastDiv divPQ, divQ, divCin, divS;
@@ -399,7 +414,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
                         const unsigned rem = (unsigned)m - n * p.divPQ.d;
                         const unsigned pp = fdiv(rem, p.divQ);
                         const unsigned qq = rem - pp * p.divQ.d;
-                        const int hi = (int)pp * p.stride - p.pad + tr, wi = (int)qq * p.stride - p.pad + ts;
+                        const int hi = (int)pp * p.stride - p.pad + tr, wi = (int)qq * p.stride_w - p.pad_w + ts;
                         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
                             ob = ((n * (unsigned)p.H + (unsigned)hi) * (unsigned)p.W + (unsigned)wi) * x_row_bytes + x_col_bytes;
                     }
@@ -599,6 +614,7 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     p.x = x; p.w = w; p.y = y; p.add = add; p.bias = bias; p.stats = stats;
     p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.ldy = ldy;
     p.ldadd = ldadd; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.mode = mode; p.relu = relu;
+    p.stride_w = stride; p.pad_w = pad; p.stem_cprw = 0;
     p.out_f32 = out_f32;
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
@@ -631,6 +647,7 @@ extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w,
     p.x = x; p.w = w; p.y = y; p.add = nullptr; p.bias = bias; p.stats = nullptr;
     p.M = M; p.H = M; p.W = 1; p.Cin = K; p.ldx = K; p.P = M; p.Q = 1; p.Cout = N; p.ldy = N; p.ldadd = 0;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 0; p.relu = 0; p.out_f32 = 0;
+    p.stride_w = 1; p.pad_w = 0; p.stem_cprw = 0;
     p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
     p.add_h = 0; p.add_w = 0; p.act = act; p.aux = aux; p.y2 = y2;
     p.ldw = K; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
@@ -657,6 +674,7 @@ extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y
     p.x = x; p.w = w; p.y = y; p.add = nullptr; p.bias = nullptr; p.stats = nullptr;
     p.M = M; p.H = M; p.W = 1; p.Cin = K; p.ldx = ldx; p.P = M; p.Q = 1; p.Cout = N; p.ldy = ldy; p.ldadd = 0;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 0; p.relu = 0; p.out_f32 = out_f32;
+    p.stride_w = 1; p.pad_w = 0; p.stem_cprw = 0;
     p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
     p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
     p.ldw = ldw; p.inner = inner; p.sxo = sxo; p.sxi = sxi; p.swo = swo; p.swi = swi; p.syo = syo; p.syi = syi;
@@ -695,6 +713,7 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     p.dy = dy; p.x = x; p.dw = dw; p.dbias = dbias;
     p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.lddy = lddy;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.Ntot = R * S * Cin;
+    p.stride_w = stride; p.pad_w = pad;
     const int TW = 256 / esz;
     p.tilesC = (Cout + TW - 1) / TW;
     p.tilesN = (p.Ntot + TW - 1) / TW;
@@ -741,6 +760,7 @@ extern "C" int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void
     p.dy = a; p.x = b; p.dw = nullptr; p.dbias = nullptr;
     p.M = M; p.H = M; p.W = 1; p.Cin = Nb; p.ldx = ldb; p.P = M; p.Q = 1; p.Cout = Na; p.lddy = lda;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.Ntot = Nb;
+    p.stride_w = 1; p.pad_w = 0;
     const int TW = 256 / esz;
     p.tilesC = (Na + TW - 1) / TW; p.tilesN = (Nb + TW - 1) / TW;
     p.splits = 1; p.rows_per_split = (M + 63) / 64 * 64;
@@ -759,4 +779,91 @@ extern "C" int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
     return nkb_check_launch("gemm_tn_batched");
+}
+
+// ------------------------------------------------------------------------------------------
+// Packed stem: Conv2d(C<=4 -> Cout, 7x7, stride 2, pad 3) read straight from the channel-padded NHWC image
+// xp[N][H][W][4] (nkb_stem_pack) instead of a materialised im2row matrix (1 GB per ResNet-50 bs-256 step).
+// A 16-byte chunk holds ppc = EPC/4 pixels; the filter row window of an output pixel starts at chunk
+// q*stride_w - pad_w and spans cprw chunks (bf16: 4 chunks = pixels 2q-4 .. 2q+3, tap -1 has zero weight; fp32: 8
+// chunks = pixels 2q-3 .. 2q+4, tap 7 has zero weight).  The forward kernel packs rpt = 8/cprw filter rows into each
+// 128-byte k-tile; the weight gradient uses the plain (R=7, S=cprw, Cin=EPC) view of the same layout:
+//   column index = (r*cprw + sc)*EPC + j,  pixel offset in the window = sc*ppc + j/4,  channel = j%4.
+struct StemGeom { int epc, cprw, rpt, ktiles, stride_w, pad_w, Wc; };
+static StemGeom stem_geom(int dtype, int W) {
+    StemGeom g;
+    g.epc = dtype == NKB_DT_BF16 ? 8 : 4;
+    g.cprw = dtype == NKB_DT_BF16 ? 4 : 8;
+    g.rpt = 8 / g.cprw;
+    g.ktiles = (7 + g.rpt - 1) / g.rpt;
+    g.stride_w = dtype == NKB_DT_BF16 ? 1 : 2;
+    g.pad_w = dtype == NKB_DT_BF16 ? 2 : 3;
+    g.Wc = W * 4 / g.epc;
+    return g;
+}
+extern "C" int nkb_stem_weight_cols(int dtype) { StemGeom g = stem_geom(dtype, 0); return g.ktiles * 8 * g.epc; }
+
+extern "C" int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y, float* stats, int N, int H, int W,
+                             int Cout, int ldy, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("stem_conv: bad dtype %d", dtype); return 1; }
+    const int Wp = (W + 1) & ~1;    // nkb_stem_pack rounds the row up to an even number of pixels
+    if ((long long)N * H * Wp * 4 * (dtype == NKB_DT_BF16 ? 2 : 4) >= 0xFFFFFF00ll) {
+        nkb_set_error("stem_conv: image batch exceeds the 4 GiB buffer-addressing range");
+        return 1;
+    }
+    const StemGeom g = stem_geom(dtype, Wp);
+    const int P = (H + 6 - 7) / 2 + 1, Q = (W + 6 - 7) / 2 + 1;
+    ConvParams p;
+    p.x = xp; p.w = wp; p.y = y; p.add = nullptr; p.bias = nullptr; p.stats = stats;
+    p.M = N * P * Q; p.H = H; p.W = g.Wc * g.rpt; p.Cin = 8 * g.epc; p.ldx = g.epc; p.P = P; p.Q = Q; p.Cout = Cout;
+    p.ldy = ldy; p.ldadd = 0; p.R = g.ktiles; p.S = 1; p.stride = 2; p.pad = 3; p.mode = 0; p.relu = 0; p.out_f32 = 0;
+    p.stride_w = g.stride_w; p.pad_w = g.pad_w; p.stem_cprw = g.cprw;
+    p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
+    p.ldw = g.ktiles * 8 * g.epc; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
+    NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * p.M * (double)Cout * 147);
+    const bool narrow = Cout <= 64;
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
+    return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+}
+
+// dwp[Cout][7*cprw*EPC] (fp32, caller-zeroed) += dY^T * window(xp); fold into the parameter gradient with nkb_stem_wfold
+extern "C" int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N, int H, int W, int Cout, int lddy,
+                              hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("stem_wgrad: bad dtype %d", dtype); return 1; }
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const StemGeom g = stem_geom(dtype, (W + 1) & ~1);
+    if (lddy % g.epc || lddy < (Cout + g.epc - 1) / g.epc * g.epc) { nkb_set_error("stem_wgrad: bad lddy=%d", lddy); return 1; }
+    const int P = (H + 6 - 7) / 2 + 1, Q = (W + 6 - 7) / 2 + 1;
+    WgradParams p;
+    p.dy = dy; p.x = xp; p.dw = dwp; p.dbias = nullptr;
+    p.M = N * P * Q; p.H = H; p.W = g.Wc; p.Cin = g.epc; p.ldx = g.epc; p.P = P; p.Q = Q; p.Cout = Cout; p.lddy = lddy;
+    p.R = 7; p.S = g.cprw; p.stride = 2; p.pad = 3; p.stride_w = g.stride_w; p.pad_w = g.pad_w; p.Ntot = 7 * g.cprw * g.epc;
+    const int TW = 256 / esz;
+    p.tilesC = (Cout + TW - 1) / TW;
+    p.tilesN = (p.Ntot + TW - 1) / TW;
+    const int tiles = p.tilesC * p.tilesN;
+    int splits = (384 + tiles - 1) / tiles;
+    const int max_splits = (p.M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rps = (p.M + splits - 1) / splits;
+    rps = (rps + 63) / 64 * 64;
+    splits = (p.M + rps - 1) / rps;
+    p.splits = splits; p.rows_per_split = rps;
+    p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
+    p.divCin = make_fastdiv((unsigned)g.epc); p.divS = make_fastdiv((unsigned)g.cprw);
+    p.out_t = nullptr; p.ldo = 0; p.inner = 1; p.sdo = p.sdi = p.sxo = p.sxi = p.soo = p.soi = 0;
+    const int lds = 2 * 64 * 256 > (TW / 2) * (TW * 4 + 16) ? 2 * 64 * 256 : (TW / 2) * (TW * 4 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot);
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
+    return nkb_check_launch("stem_wgrad");
 }

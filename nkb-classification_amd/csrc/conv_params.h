@@ -23,6 +23,9 @@ struct ConvParams {
     int act;            // 0 none, 1 GELU forward (pre-activation also stored to y2), 2 multiply by gelu'(aux)
     const void* aux;    // [M][ldy] pre-activation for act 2
     void* y2;           // [M][ldy] pre-activation output for act 1
+    int stride_w, pad_w; // mode 0: horizontal stride / padding (== stride / pad except for the packed stem)
+    int stem_cprw;      // > 0: packed-stem addressing, 16-byte chunks per filter row inside one 128-byte k-tile (see
+                        //      nkb_stem_conv); x is [N][H][W/rpt][one chunk], W is passed pre-multiplied by rpt = 8/stem_cprw
     int ldw;            // row stride of w in elements (R*S*Cin unless batched)
     int inner;
     long long sxo, sxi, swo, swi, syo, syi;

@@ -1,6 +1,7 @@
 // HBM-bound kernels of the ResNet train step: BatchNorm (finalize / apply / backward), pooling,
 // stem im2row, weight re-layout.  All activations are NHWC, channel-contiguous, 16-byte vector I/O.
 #include "common.h"
+#include <stdlib.h>
 
 static inline unsigned grid_for(size_t work_items, int block = 256, unsigned cap = 256 * 16) {
     size_t g = (work_items + block - 1) / block;
@@ -23,6 +24,17 @@ template <> struct Chunk<float> {
     }
     __device__ static __forceinline__ void store(float* p, const float* f) { *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]}; }
 };
+
+// NC consecutive per-channel fp32 constants as 16-byte loads (a thread owns NC consecutive channels; one scalar load per
+// channel costs a whole wave-wide gather each and used to dominate the small BatchNorm launches)
+template <int NC>
+__device__ __forceinline__ void ldvec(const float* __restrict__ p, float* o) {
+#pragma unroll
+    for (int i = 0; i < NC / 4; ++i) {
+        const f32x4 v = *(const f32x4*)(p + 4 * i);
+        o[4 * i] = v[0]; o[4 * i + 1] = v[1]; o[4 * i + 2] = v[2]; o[4 * i + 3] = v[3];
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // bn_finalize: reduce the conv epilogue's per-tile partial sums -> batch mean / biased var,
@@ -119,7 +131,13 @@ extern "C" size_t nkb_bn_stats_floats(int tiles, int C) { return (size_t)tiles *
 // bn_apply: y = act(x*scale[c] + shift[c] (+ residual))
 // Thread t owns channel chunk (t % cpr) for the whole launch: scale/shift live in registers and the row loop has
 // no integer division.  Host guarantees (gridDim*blockDim) % cpr == 0.
-static inline unsigned grid_cols(size_t rows, int cpr, unsigned want_blocks = 256 * 8) {
+static inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+static inline unsigned grid_cols(size_t rows, int cpr, unsigned want_blocks = 0) {
+    static const unsigned dflt_blocks = (unsigned)env_int("NKB_BN_BLOCKS", 256 * 8);
+    if (!want_blocks) want_blocks = dflt_blocks;
     auto gcd = [](unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; };
     const unsigned g0 = (unsigned)cpr / gcd((unsigned)cpr, 256u);   // grid must be a multiple of this
     size_t need = (rows * (size_t)cpr + 255) / 256;
@@ -137,8 +155,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned cg = t % cpr, r0 = t / cpr, rs = (gridDim.x * blockDim.x) / cpr;
     float sc[N], sh[N];
-#pragma unroll
-    for (int e = 0; e < N; ++e) { sc[e] = scale[cg * N + e]; sh[e] = shift[cg * N + e]; }
+    ldvec<N>(scale + cg * N, sc);
+    ldvec<N>(shift + cg * N, sh);
     for (unsigned r = r0; r < rows; r += 2 * rs) {
         const size_t o0 = (size_t)r * C + cg * N;
         const bool two = r + rs < rows;
@@ -178,7 +196,7 @@ extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, 
 // ReLU mask of a BN+ReLU stage: from the stored activation (yact > 0, residual stages) or recomputed from the raw
 // conv output as x*scale+shift > 0 (same expression, same rounding as bn_apply), which saves one tensor read.
 // bn backward, pass 1: per-channel sum(dy') and sum(dy' * xhat), dy' = dy * mask.
-// Block b handles rows [b*rpb, (b+1)*rpb); thread t owns channel chunk t % (C/N) and walks rows with
+// Thread t owns channel chunk t % (C/N); the grid sweeps the rows front to back (see the loop) with
 // stride blockDim/(C/N); block partials go to part[b][2][C] (deterministic), reduced by pass 1b.
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
@@ -194,27 +212,34 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
 #pragma unroll
     for (int e = 0; e < N; ++e) { s1[e] = 0.f; s2[e] = 0.f; fs[e] = 0.f; fb[e] = 1.f; }
     if (rl < tpc) {
-#pragma unroll
-        for (int e = 0; e < N; ++e) { mu[e] = mean[cg * N + e]; is[e] = invstd[cg * N + e]; }
-        if (fscale) {
-#pragma unroll
-            for (int e = 0; e < N; ++e) { fs[e] = fscale[cg * N + e]; fb[e] = fshift[cg * N + e]; }
-        }
-        const long long r0 = (long long)blockIdx.x * rpb;
-        const long long r1 = min(rows, r0 + rpb);
-        for (long long r = r0 + rl; r < r1; r += tpc) {
+        ldvec<N>(mean + cg * N, mu);
+        ldvec<N>(invstd + cg * N, is);
+        if (fscale) { ldvec<N>(fscale + cg * N, fs); ldvec<N>(fshift + cg * N, fb); }
+        // the whole grid sweeps the tensor front to back (block b takes rows b*tpc + k*grid*tpc): neighbouring blocks
+        // read neighbouring DRAM pages, and the row -> thread assignment (hence the summation order) is fixed
+        const long long gs = (long long)gridDim.x * tpc;
+        for (long long r = (long long)blockIdx.x * tpc + rl; r < rows; r += 2 * gs) {
+            const bool two = r + gs < rows;
             const size_t off = (size_t)r * C + cg * N;
-            float g[N], xv[N], ya[N];
+            const size_t off1 = two ? off + (size_t)gs * C : off;
+            float g[N], xv[N], ya[N], g1[N], xv1[N], ya1[N];
             Chunk<T>::load(dy + off, g);
             Chunk<T>::load(x + off, xv);
-            if (yact) Chunk<T>::load(yact + off, ya);
+            Chunk<T>::load(dy + off1, g1);
+            Chunk<T>::load(x + off1, xv1);
+            if (yact) { Chunk<T>::load(yact + off, ya); Chunk<T>::load(yact + off1, ya1); }
 #pragma unroll
             for (int e = 0; e < N; ++e) {
-                float gg = g[e];
-                if (yact && !(ya[e] > 0.f)) gg = 0.f;
-                if (fscale && !(DT<T>::rnd(xv[e] * fs[e] + fb[e]) > 0.f)) gg = 0.f;
+                float gg = g[e], hh = two ? g1[e] : 0.f;
+                if (yact) { if (!(ya[e] > 0.f)) gg = 0.f; if (!(ya1[e] > 0.f)) hh = 0.f; }
+                if (fscale) {
+                    if (!(DT<T>::rnd(xv[e] * fs[e] + fb[e]) > 0.f)) gg = 0.f;
+                    if (!(DT<T>::rnd(xv1[e] * fs[e] + fb[e]) > 0.f)) hh = 0.f;
+                }
                 s1[e] += gg;
                 s2[e] += gg * (xv[e] - mu[e]) * is[e];
+                s1[e] += hh;
+                s2[e] += hh * (xv1[e] - mu[e]) * is[e];
             }
         }
     }
@@ -237,12 +262,23 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ sums) {
-    __shared__ double red[2][16][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    // block = 16 channels x 64 walkers over the block partials (C/16 workgroups; with 64 channels x 16 walkers a
+    // C=64 stage ran on 1 workgroup whose threads each chased 32 dependent-looking loads)
+    __shared__ double red[2][64][16];
+    const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int t = py; t < blocks; t += 16) {
+        int t = py;
+        for (; t + 192 < blocks; t += 256) {      // four independent pairs of loads in flight
+            const float a0 = part[((size_t)t * 2) * C + c], b0 = part[((size_t)t * 2 + 1) * C + c];
+            const float a1 = part[((size_t)(t + 64) * 2) * C + c], b1 = part[((size_t)(t + 64) * 2 + 1) * C + c];
+            const float a2 = part[((size_t)(t + 128) * 2) * C + c], b2 = part[((size_t)(t + 128) * 2 + 1) * C + c];
+            const float a3 = part[((size_t)(t + 192) * 2) * C + c], b3 = part[((size_t)(t + 192) * 2 + 1) * C + c];
+            a += (double)a0; a += (double)a1; a += (double)a2; a += (double)a3;
+            b += (double)b0; b += (double)b1; b += (double)b2; b += (double)b3;
+        }
+        for (; t < blocks; t += 64) {
             a += (double)part[((size_t)t * 2) * C + c];
             b += (double)part[((size_t)t * 2 + 1) * C + c];
         }
@@ -252,7 +288,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
     __syncthreads();
     if (py != 0 || c >= C) return;
     a = 0.0; b = 0.0;
-    for (int k = 0; k < 16; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
+    for (int k = 0; k < 64; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
     sums[c] = (float)a;       // sum dy
     sums[C + c] = (float)b;   // sum dy*xhat
     if (dbeta) dbeta[c] += (float)a;
@@ -274,15 +310,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned cg = t % cpr, r0 = t / cpr, rs = (gridDim.x * blockDim.x) / cpr;
     // dx = k1*dy' + k2*x + k3 with per-channel constants
-    float k1[N], k2[N], k3[N], fs[N], fb[N];
+    float k1[N], k2[N], k3[N], fs[N], fb[N], v_is[N], v_ga[N], v_mu[N], v_s1[N], v_s2[N];
+    ldvec<N>(invstd + cg * N, v_is);
+    ldvec<N>(mean + cg * N, v_mu);
+    ldvec<N>(sums + cg * N, v_s1);
+    ldvec<N>(sums + C + cg * N, v_s2);
+    if (gamma) ldvec<N>(gamma + cg * N, v_ga);
+    if (fscale) { ldvec<N>(fscale + cg * N, fs); ldvec<N>(fshift + cg * N, fb); }
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-        const int c = cg * N + e;
-        fs[e] = fscale ? fscale[c] : 0.f;
-        fb[e] = fscale ? fshift[c] : 1.f;
-        const float is = invstd[c], ga = gamma ? gamma[c] : 1.f, mu = mean[c];
+        if (!fscale) { fs[e] = 0.f; fb[e] = 1.f; }
+        const float is = v_is[e], ga = gamma ? v_ga[e] : 1.f, mu = v_mu[e];
         const float a = ga * is;
-        const float sdy = sums[c] * inv_count, sdyx = sums[C + c] * inv_count;
+        const float sdy = v_s1[e] * inv_count, sdyx = v_s2[e] * inv_count;
         k1[e] = a;
         k2[e] = -a * is * sdyx;
         k3[e] = -a * sdy + a * is * sdyx * mu;
@@ -330,11 +370,11 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
     int threads = 256;
     while (threads < cpr) threads *= 2;
     const int tpc = threads / cpr;
-    int blocks = (int)((rows + 63) / 64);
-    if (blocks > 512) blocks = 512;
-    if (blocks < 1) blocks = 1;
-    const int rpb = (int)((rows + blocks - 1) / blocks);
-    blocks = (int)((rows + rpb - 1) / rpb);
+    static const int max_blocks = env_int("NKB_BNR_BLOCKS", 512);
+    static const int min_rows = env_int("NKB_BNR_ROWS", 16);     // rows per thread below which blocks are not added
+    long long want = (rows + (long long)tpc * min_rows - 1) / ((long long)tpc * min_rows);
+    int blocks = (int)(want > max_blocks ? max_blocks : want < 1 ? 1 : want);
+    const int rpb = 0;
     const size_t need = (size_t)blocks * 2 * C + 2 * C;
     if (workspace_floats < need) { nkb_set_error("bn_backward: workspace %zu < %zu floats", workspace_floats, need); return 1; }
     float* part = workspace;
@@ -348,7 +388,7 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
         else
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(threads), lds, stream, (const float*)dy,
                                (const float*)x, (const float*)yact, fscale, fshift, mean, invstd, rows, C, rpb, part);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, part, blocks, C, dgamma,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, stream, part, blocks, C, dgamma,
                            dbeta, sums);
     }
     if (int rc = nkb_check_launch("bn_bwd_reduce")) return rc;
@@ -368,8 +408,8 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
 }
 
 extern "C" size_t nkb_bn_backward_workspace_floats(long long rows, int C) {
-    long long blocks = (rows + 63) / 64;
-    if (blocks > 512) blocks = 512;
+    long long blocks = (rows + 7) / 8;
+    if (blocks > 4096) blocks = 4096;   // upper bound of what nkb_bn_backward may use
     if (blocks < 1) blocks = 1;
     return (size_t)blocks * 2 * C + 2 * C;
 }
@@ -663,4 +703,329 @@ extern "C" int nkb_pad_cast(int dtype, const float* src, void* dst, int rows, in
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(pad_cast_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, src, (bf16_t*)dst, rows, C, ld_src, ld_dst, mul);
     else hipLaunchKernelGGL(pad_cast_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, (float*)dst, rows, C, ld_src, ld_dst, mul);
     return nkb_check_launch("pad_cast");
+}
+
+// ------------------------------------------------------------------------------------------
+// Stem tail fused: y = maxpool3x3s2(relu(c*scale + shift)) straight from the raw conv output, so the 112x112x64
+// activation (the largest tensor of a ResNet step) is never written or re-read.  Backward routes the pooled gradient
+// through the saved window slot, the recomputed ReLU mask and the BatchNorm backward in two passes.
+template <int NC> struct SlotWord;
+template <> struct SlotWord<8> {
+    unsigned long long w;
+    __device__ __forceinline__ void load(const unsigned char* p) { w = *(const unsigned long long*)p; }
+    __device__ __forceinline__ int get(int e) const { return (int)((w >> (8 * e)) & 0xff); }
+};
+template <> struct SlotWord<4> {
+    unsigned w;
+    __device__ __forceinline__ void load(const unsigned char* p) { w = *(const unsigned*)p; }
+    __device__ __forceinline__ int get(int e) const { return (int)((w >> (8 * e)) & 0xff); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ c, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, T* __restrict__ y,
+                                                                  unsigned char* __restrict__ idx, int N, int H, int W,
+                                                                  int C, int P, int Q) {
+    constexpr int NC = Chunk<T>::N;
+    const unsigned cpr = (unsigned)C / NC;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned cg = t % cpr, pstride = (gridDim.x * blockDim.x) / cpr;
+    const unsigned npix = (unsigned)N * P * Q;
+    float sc[NC], sh[NC];
+    ldvec<NC>(scale + cg * NC, sc);
+    ldvec<NC>(shift + cg * NC, sh);
+    for (unsigned pix = t / cpr; pix < npix; pix += pstride) {
+        const unsigned q = pix % (unsigned)Q, pn = pix / (unsigned)Q;
+        const unsigned pp = pn % (unsigned)P, n = pn / (unsigned)P;
+        float best[NC];
+        int bi[NC];
+#pragma unroll
+        for (int e = 0; e < NC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        bool first = true;
+        for (int r = 0; r < 3; ++r) {
+            const int h = 2 * (int)pp - 1 + r;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int w = 2 * (int)q - 1 + s;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float v[NC];
+                Chunk<T>::load(c + (((size_t)n * H + h) * W + w) * C + cg * NC, v);
+#pragma unroll
+                for (int e = 0; e < NC; ++e) {
+                    // the value bn_apply(relu) would have stored, then maxpool_fwd_kernel's comparison on it
+                    const float a = DT<T>::rnd(fmaxf(v[e] * sc[e] + sh[e], 0.f));
+                    if (first || a > best[e] || a != a) { best[e] = a; bi[e] = r * 3 + s; }
+                }
+                first = false;
+            }
+        }
+        const size_t o = (size_t)pix * C + cg * NC;
+        Chunk<T>::store(y + o, best);
+        unsigned long long word = 0;
+#pragma unroll
+        for (int e = 0; e < NC; ++e) word |= (unsigned long long)bi[e] << (8 * e);
+        if (NC == 8) *(unsigned long long*)(idx + o) = word;
+        else *(unsigned*)(idx + o) = (unsigned)word;
+    }
+}
+
+// backward pass 1 (pooled domain): per-channel sum(g') and sum(g' * xhat), g' = g where the selected activation > 0
+template <typename T>
+__global__ void bn_relu_maxpool_bwd_reduce_kernel(const T* __restrict__ g, const unsigned char* __restrict__ idx,
+                                                  const T* __restrict__ c, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, int N, int H, int W, int C, int P,
+                                                  int Q, int rpb, float* __restrict__ part) {
+    constexpr int NC = Chunk<T>::N;
+    extern __shared__ float red[];
+    const int cpr = C / NC;
+    const int tpc = blockDim.x / cpr;
+    const int cg = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float s1[NC], s2[NC];
+#pragma unroll
+    for (int e = 0; e < NC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const long long rows = (long long)N * P * Q;
+    if (rl < tpc) {
+        float sc[NC], sh[NC], mu[NC], is[NC];
+        ldvec<NC>(scale + cg * NC, sc);
+        ldvec<NC>(shift + cg * NC, sh);
+        ldvec<NC>(mean + cg * NC, mu);
+        ldvec<NC>(invstd + cg * NC, is);
+        for (long long r = (long long)blockIdx.x * tpc + rl; r < rows; r += (long long)gridDim.x * tpc) {
+            const unsigned ru = (unsigned)r;
+            const int q = (int)(ru % (unsigned)Q);
+            const unsigned pn = ru / (unsigned)Q;
+            const int pp = (int)(pn % (unsigned)P);
+            const int n = (int)(pn / (unsigned)P);
+            const size_t o = (size_t)r * C + cg * NC;
+            float gv[NC];
+            Chunk<T>::load(g + o, gv);
+            SlotWord<NC> sw;
+            sw.load(idx + o);
+            const T* cbase = c + (((size_t)n * H + (2 * pp - 1)) * W + (2 * q - 1)) * C + cg * NC;   // window origin
+#pragma unroll
+            for (int e = 0; e < NC; ++e) {
+                const int slot = sw.get(e);
+                const int dr = (slot * 11) >> 5;            // slot / 3 for slot in 0..8
+                const int ds = slot - 3 * dr;
+                const float x = DT<T>::ld(cbase + ((ptrdiff_t)dr * W + ds) * C + e);
+                if (DT<T>::rnd(x * sc[e] + sh[e]) > 0.f) { s1[e] += gv[e]; s2[e] += gv[e] * (x - mu[e]) * is[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NC; ++e) {
+            red[(0 * tpc + rl) * C + cg * NC + e] = s1[e];
+            red[(1 * tpc + rl) * C + cg * NC + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        const int which = i / C, ch = i % C;
+        float t = 0.f;
+        for (int k = 0; k < tpc; ++k) t += red[(which * tpc + k) * C + ch];
+        part[((size_t)blockIdx.x * 2 + which) * C + ch] = t;
+    }
+}
+
+// backward pass 2 (input domain): dc = gamma*invstd*(g' - sum_g/M - xhat*sum_gx/M), g' gathered from the <=4 windows.
+// The grid-stride is a multiple of C/NC, so a thread keeps its channel chunk and the per-channel constants stay in
+// registers (dc = k1*g' + k2*c + k3, as in bn_bwd_apply_kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_apply_kernel(
+    const T* __restrict__ g, const unsigned char* __restrict__ idx, const T* __restrict__ c,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ sums, float inv_count,
+    T* __restrict__ dc, int N, int H, int W, int C, int P, int Q) {
+    constexpr int NC = Chunk<T>::N;
+    const unsigned cpr = (unsigned)C / NC;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned cg = t % cpr, pstride = (gridDim.x * blockDim.x) / cpr;
+    const unsigned npix = (unsigned)N * H * W;
+    float k1[NC], k2[NC], k3[NC], fs[NC], fb[NC], v_is[NC], v_ga[NC], v_mu[NC], v_s1[NC], v_s2[NC];
+    ldvec<NC>(scale + cg * NC, fs);
+    ldvec<NC>(shift + cg * NC, fb);
+    ldvec<NC>(invstd + cg * NC, v_is);
+    ldvec<NC>(mean + cg * NC, v_mu);
+    ldvec<NC>(sums + cg * NC, v_s1);
+    ldvec<NC>(sums + C + cg * NC, v_s2);
+    if (gamma) ldvec<NC>(gamma + cg * NC, v_ga);
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+        const float is = v_is[e], ga = gamma ? v_ga[e] : 1.f, mu = v_mu[e];
+        const float a = ga * is;
+        const float sdy = v_s1[e] * inv_count, sdyx = v_s2[e] * inv_count;
+        k1[e] = a;
+        k2[e] = -a * is * sdyx;
+        k3[e] = -a * sdy + a * is * sdyx * mu;
+    }
+    for (unsigned pix = t / cpr; pix < npix; pix += pstride) {
+        const unsigned w = pix % (unsigned)W, hn = pix / (unsigned)W;
+        const unsigned h = hn % (unsigned)H, n = hn / (unsigned)H;
+        float acc[NC], xv[NC], out[NC];
+        const size_t ofs = (size_t)pix * C + cg * NC;
+        Chunk<T>::load(c + ofs, xv);
+#pragma unroll
+        for (int e = 0; e < NC; ++e) acc[e] = 0.f;
+        const int p0 = h >> 1, p1 = (h + 1) >> 1, q0 = w >> 1, q1 = (w + 1) >> 1;
+        for (int pp = p0; pp <= p1; ++pp) {
+            if (pp >= P) continue;
+            const int r = (int)h - (2 * pp - 1);
+            for (int q = q0; q <= q1; ++q) {
+                if (q >= Q) continue;
+                const int slot = r * 3 + ((int)w - (2 * q - 1));
+                const size_t o = ((((size_t)n * P + pp) * Q + q) * C) + cg * NC;
+                float gv[NC];
+                Chunk<T>::load(g + o, gv);
+                SlotWord<NC> sw;
+                sw.load(idx + o);
+#pragma unroll
+                for (int e = 0; e < NC; ++e) if (sw.get(e) == slot) acc[e] += gv[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NC; ++e) {
+            float gg = acc[e];
+            if (!(DT<T>::rnd(xv[e] * fs[e] + fb[e]) > 0.f)) gg = 0.f;
+            out[e] = k1[e] * gg + (k2[e] * xv[e] + k3[e]);
+        }
+        Chunk<T>::store(dc + ofs, out);
+    }
+}
+
+extern "C" int nkb_bn_relu_maxpool(int dtype, int backward, const void* c, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, const float* gamma, void* y_or_g,
+                                   unsigned char* idx, void* dc, float* dgamma, float* dbeta, float* workspace,
+                                   size_t workspace_floats, int N, int H, int W, int C, hipStream_t stream) {
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const int n = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (C % n || C / n > 256) { nkb_set_error("bn_relu_maxpool: unsupported C=%d", C); return 1; }
+    if ((long long)N * H * W >= (1ll << 31)) { nkb_set_error("bn_relu_maxpool: N*H*W too large"); return 1; }
+    if (!backward) {
+        NkbProfScope prof(NKB_K_MAXPOOL, stream, 0);
+        const unsigned grid = grid_cols((size_t)N * P * Q, C / n);
+        if (dtype == NKB_DT_BF16)
+            hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream,
+                               (const bf16_t*)c, scale, shift, (bf16_t*)y_or_g, idx, N, H, W, C, P, Q);
+        else
+            hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, stream,
+                               (const float*)c, scale, shift, (float*)y_or_g, idx, N, H, W, C, P, Q);
+        return nkb_check_launch("bn_relu_maxpool_fwd");
+    }
+    const long long rows = (long long)N * P * Q;
+    const int cpr = C / n;
+    const int tpc = 256 / cpr;
+    int blocks = (int)((rows + 63) / 64);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const int rpb = (int)((rows + blocks - 1) / blocks);
+    blocks = (int)((rows + rpb - 1) / rpb);
+    const size_t need = (size_t)blocks * 2 * C + 2 * C;
+    if (workspace_floats < need) { nkb_set_error("bn_relu_maxpool: workspace %zu < %zu floats", workspace_floats, need); return 1; }
+    float* part = workspace;
+    float* sums = workspace + (size_t)blocks * 2 * C;
+    const size_t lds = (size_t)2 * tpc * C * sizeof(float);
+    {
+        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0);
+        if (dtype == NKB_DT_BF16)
+            hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream,
+                               (const bf16_t*)y_or_g, idx, (const bf16_t*)c, scale, shift, mean, invstd, N, H, W, C, P, Q, rpb, part);
+        else
+            hipLaunchKernelGGL(bn_relu_maxpool_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), lds, stream,
+                               (const float*)y_or_g, idx, (const float*)c, scale, shift, mean, invstd, N, H, W, C, P, Q, rpb, part);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, stream, part, blocks, C, dgamma, dbeta, sums);
+    }
+    if (int rc = nkb_check_launch("bn_relu_maxpool_bwd_reduce")) return rc;
+    {
+        NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0);
+        const unsigned grid = grid_cols((size_t)N * H * W, cpr);
+        const float inv_count = 1.0f / (float)((long long)N * H * W);
+        if (dtype == NKB_DT_BF16)
+            hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream,
+                               (const bf16_t*)y_or_g, idx, (const bf16_t*)c, scale, shift, mean, invstd, gamma, sums, inv_count,
+                               (bf16_t*)dc, N, H, W, C, P, Q);
+        else
+            hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream,
+                               (const float*)y_or_g, idx, (const float*)c, scale, shift, mean, invstd, gamma, sums, inv_count,
+                               (float*)dc, N, H, W, C, P, Q);
+    }
+    return nkb_check_launch("bn_relu_maxpool_bwd_apply");
+}
+
+extern "C" size_t nkb_bn_relu_maxpool_workspace_floats(int N, int H, int W, int C) {
+    const long long P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    long long blocks = ((long long)N * P * Q + 63) / 64;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return (size_t)blocks * 2 * C + 2 * C;
+}
+
+// ------------------------------------------------------------------------------------------
+// Packed stem helpers (see nkb_stem_conv in conv_igemm.hip for the layout).
+// pack: NCHW fp32 image -> [N][H][Wp][4] in the compute dtype (Wp = W rounded up to even), channels >= C and the
+// extra column zero (a zero column on the right is what the convolution's own padding would have supplied).
+template <typename T>
+__global__ void stem_pack_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int H, int W, int Wp) {
+    const size_t total = (size_t)N * H * Wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % Wp);
+        const size_t nh = i / Wp;
+        const size_t n = nh / H, h = nh - n * H;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w < W)
+            for (int c = 0; c < C; ++c) v[c] = x[((n * C + c) * H + h) * W + w];
+        if constexpr (sizeof(T) == 2) {
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)(out + i * 4) = o;
+        } else {
+            *(f32x4*)(out + i * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+extern "C" int nkb_stem_pack(int dtype, const float* x, void* out, int N, int C, int H, int W, hipStream_t stream) {
+    if (C < 1 || C > 4) { nkb_set_error("stem_pack: C=%d outside 1..4", C); return 1; }
+    NkbProfScope prof(NKB_K_IM2COL, stream, 0);
+    const int Wp = (W + 1) & ~1;
+    const size_t total = (size_t)N * H * Wp;
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, x, (bf16_t*)out, N, C, H, W, Wp);
+    else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, x, (float*)out, N, C, H, W, Wp);
+    return nkb_check_launch("stem_pack");
+}
+
+// column (r, sc, j) of the packed stem weight <-> filter tap (r, s) / channel ch of the [Cout][7][7][C] master
+__device__ __forceinline__ bool stem_col_to_tap(int col, int epc, int cprw, int lead, int& r, int& s, int& ch) {
+    const int j = col % epc, sc = (col / epc) % cprw;
+    r = col / (epc * cprw);
+    s = sc * (epc / 4) + j / 4 - lead;
+    ch = j % 4;
+    return r < 7 && s >= 0 && s < 7;
+}
+// fold == 0: wp[co][cols] = cast(w[co][r][s][ch]) (zero where the column maps to no tap)
+// fold == 1: dw[co][r][s][ch] += dwp[co][col]      (dwp has `cols` columns)
+template <typename T>
+__global__ void stem_weight_kernel(const float* __restrict__ src, T* __restrict__ wp, float* __restrict__ dw, int Cout,
+                                   int C, int cols, int epc, int cprw, int lead, int fold) {
+    const int total = Cout * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i / cols, col = i - co * cols;
+        int r, s, ch;
+        const bool ok = stem_col_to_tap(col, epc, cprw, lead, r, s, ch) && ch < C;
+        const int widx = ((co * 7 + r) * 7 + s) * C + ch;    // master filters are [Cout][R][S][Cin]
+        if (fold) { if (ok) dw[widx] += src[i]; }
+        else DT<T>::st(wp + i, ok ? src[widx] : 0.f);
+    }
+}
+extern "C" int nkb_stem_wprep(int dtype, const float* w, void* wp, int Cout, int C, hipStream_t stream) {
+    const int epc = dtype == NKB_DT_BF16 ? 8 : 4, cprw = dtype == NKB_DT_BF16 ? 4 : 8, lead = dtype == NKB_DT_BF16 ? 1 : 0;
+    const int rpt = 8 / cprw, cols = (7 + rpt - 1) / rpt * 8 * epc;
+    NkbProfScope prof(NKB_K_WPREP, stream, 0);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(stem_weight_kernel<bf16_t>, dim3(grid_for((size_t)Cout * cols)), dim3(256), 0, stream, w, (bf16_t*)wp, nullptr, Cout, C, cols, epc, cprw, lead, 0);
+    else hipLaunchKernelGGL(stem_weight_kernel<float>, dim3(grid_for((size_t)Cout * cols)), dim3(256), 0, stream, w, (float*)wp, nullptr, Cout, C, cols, epc, cprw, lead, 0);
+    return nkb_check_launch("stem_wprep");
+}
+extern "C" int nkb_stem_wfold(int dtype, const float* dwp, float* dw, int Cout, int C, hipStream_t stream) {
+    const int epc = dtype == NKB_DT_BF16 ? 8 : 4, cprw = dtype == NKB_DT_BF16 ? 4 : 8, lead = dtype == NKB_DT_BF16 ? 1 : 0;
+    const int cols = 7 * cprw * epc;
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    hipLaunchKernelGGL(stem_weight_kernel<float>, dim3(grid_for((size_t)Cout * cols)), dim3(256), 0, stream, dwp, nullptr, dw, Cout, C, cols, epc, cprw, lead, 1);
+    return nkb_check_launch("stem_wfold");
 }

@@ -8,12 +8,16 @@ HipEngine through libnkbhip, never by torch.nn forward methods.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
 from torch import nn
 
 from .hipnet import HipEngine
+
+# bn1 -> relu -> maxpool of the stem as one kernel each way (0 = separate kernels, for A/B measurements)
+_FUSED_STEM_TAIL = os.environ.get("NKB_FUSED_STEM", "1") != "0"
 
 
 class _ParamOnly(nn.Module):
@@ -115,11 +119,18 @@ class HipResNet(_ParamOnly):
         conv = self.conv1
         R, st, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         P, Q = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
-        kp = eng.kpad(C * R * R)
-        col = eng.ws.get("stem.col", (N, P, Q, kp), eng.T)
-        hip.im2row(eng.d, img, col, N, C, H, W, R, R, st, pad, kp)
-        x = eng.conv_bn("stem", col, conv, self.bn1, True, None, train, col_input=True)
-        x = eng.maxpool("pool", x, train)
+        fused = _FUSED_STEM_TAIL
+        if eng.packed_stem(conv):
+            xp = eng.ws.get("stem.xp", (N, H, (W + 1) // 2 * 2, 4), eng.T)
+            hip.stem_pack(eng.d, img, xp, N, C, H, W)
+            x = eng.conv_bn("stem", xp, conv, self.bn1, True, None, train, pool=fused, stem_packed=(N, H, W))
+        else:
+            kp = eng.kpad(C * R * R)
+            col = eng.ws.get("stem.col", (N, P, Q, kp), eng.T)
+            hip.im2row(eng.d, img, col, N, C, H, W, R, R, st, pad, kp)
+            x = eng.conv_bn("stem", col, conv, self.bn1, True, None, train, col_input=True, pool=fused)
+        if not fused:
+            x = eng.maxpool("pool", x, train)
         for name, blk in self.blocks():
             inp = x
             stages = blk.stages()
@@ -161,8 +172,11 @@ class HipResNet(_ParamOnly):
             if on_done is not None and name.endswith(".0"):
                 on_done(getattr(self, name.split(".")[0]))
         eng.begin_block(-1)
-        g = eng.maxpool_backward("pool", g, "mp")
-        gc = eng.bn_backward("stem", g, "t0")
+        if eng.saved["stem"]["pool_idx"] is not None:
+            gc = eng.bn_pool_backward("stem", g, "t0")
+        else:
+            g = eng.maxpool_backward("pool", g, "mp")
+            gc = eng.bn_backward("stem", g, "t0")
         eng.conv_backward("stem", gc, None)
         if on_done is not None:
             on_done(self.conv1)

@@ -31,7 +31,15 @@ _SIGS = {
     "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
     "nkb_bn_stats_floats": (sz, [i32, i32]),
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
+    "nkb_stem_pack": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
+    "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
+    "nkb_stem_weight_cols": (i32, [i32]),
+    "nkb_stem_conv": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nkb_stem_wgrad": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nkb_stem_wfold": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_maxpool3x3s2": (i32, [i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "nkb_bn_relu_maxpool": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
+    "nkb_bn_relu_maxpool_workspace_floats": (sz, [i32, i32, i32, i32]),
     "nkb_avgpool": (i32, [i32, i32, vp, vp, i32, i32, i32, vp]),
     "nkb_im2row": (i32, [i32, vp, vp] + [i32] * 9 + [vp]),
     "nkb_wprep": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -160,12 +168,46 @@ def bn_backward_ws(rows, C_):
     return load().nkb_bn_backward_workspace_floats(rows, C_)
 
 
+def bn_relu_maxpool(dtype, backward, c, scale, shift, mean, invstd, gamma, y_or_g, idx, dc, dgamma, dbeta, work, N, H, W, C_):
+    check(load().nkb_bn_relu_maxpool(dtype, int(backward), ptr(c), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                     ptr(gamma), ptr(y_or_g), ptr(idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(work),
+                                     work.numel() if work is not None else 0, N, H, W, C_, stream()), "bn_relu_maxpool")
+
+
+def bn_relu_maxpool_ws(N, H, W, C_) -> int:
+    return int(load().nkb_bn_relu_maxpool_workspace_floats(N, H, W, C_))
+
+
 def maxpool(dtype, backward, src, dst, idx, N, H, W, C_):
     check(load().nkb_maxpool3x3s2(dtype, int(backward), ptr(src), ptr(dst), ptr(idx), N, H, W, C_, stream()), "maxpool")
 
 
 def avgpool(dtype, backward, src, dst, N, HW, C_):
     check(load().nkb_avgpool(dtype, int(backward), ptr(src), ptr(dst), N, HW, C_, stream()), "avgpool")
+
+
+def stem_pack(dtype, x, out, N, C_, H, W):
+    check(load().nkb_stem_pack(dtype, ptr(x), ptr(out), N, C_, H, W, stream()), "stem_pack")
+
+
+def stem_wprep(dtype, w, wp, Cout, C_):
+    check(load().nkb_stem_wprep(dtype, ptr(w), ptr(wp), Cout, C_, stream()), "stem_wprep")
+
+
+def stem_weight_cols(dtype) -> int:
+    return int(load().nkb_stem_weight_cols(dtype))
+
+
+def stem_conv(dtype, xp, wp, y, stats, N, H, W, Cout, ldy):
+    check(load().nkb_stem_conv(dtype, ptr(xp), ptr(wp), ptr(y), ptr(stats), N, H, W, Cout, ldy, stream()), "stem_conv")
+
+
+def stem_wgrad(dtype, dy, xp, dwp, N, H, W, Cout, lddy):
+    check(load().nkb_stem_wgrad(dtype, ptr(dy), ptr(xp), ptr(dwp), N, H, W, Cout, lddy, stream()), "stem_wgrad")
+
+
+def stem_wfold(dtype, dwp, dw, Cout, C_):
+    check(load().nkb_stem_wfold(dtype, ptr(dwp), ptr(dw), Cout, C_, stream()), "stem_wfold")
 
 
 def im2row(dtype, x, col, N, Cin, H, W, R, S, stride, pad, Kp):

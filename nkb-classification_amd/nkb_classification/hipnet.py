@@ -16,6 +16,8 @@ from torch import nn
 from . import hip
 from .runtime import ParamArena, Workspace, _round_up
 
+_PACKED_STEM = os.environ.get("NKB_PACKED_STEM", "1") != "0"
+
 
 class HipEngine:
     """One instance per (model, compute dtype).  dtype: torch.float32 (parity mode) or torch.bfloat16."""
@@ -62,6 +64,13 @@ class HipEngine:
             hip.wprep(self.d, a.flat_param, a.shadow, 1, 1, a.total, a.total, 0)
         for conv in self._stems:
             w = conv.weight
+            if self.packed_stem(conv):
+                buf = self._wpad.get(id(w))
+                if buf is None:
+                    buf = self._wpad[id(w)] = torch.empty(w.shape[0], hip.stem_weight_cols(self.d), device=self.device,
+                                                          dtype=self.T)
+                hip.stem_wprep(self.d, a.param_flat(w), buf, w.shape[0], w.shape[1])
+                continue
             K = w.shape[1] * w.shape[2] * w.shape[3]
             buf = self._wpad.get(id(w))
             if buf is None:
@@ -89,6 +98,13 @@ class HipEngine:
 
     _dgrad_ready = False
 
+    @staticmethod
+    def packed_stem(conv: nn.Conv2d) -> bool:
+        """ResNet conv1 (<=4 -> Cout channels, 7x7, stride 2, pad 3) runs as an implicit GEMM on the packed NHWC image
+        (nkb_stem_conv); any other stem goes through im2row.  NKB_PACKED_STEM=0 forces im2row (A/B measurements)."""
+        return (_PACKED_STEM and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+                and conv.in_channels <= 4 and conv.bias is None and conv.groups == 1)
+
     def w_fwd(self, w: torch.Tensor) -> torch.Tensor:
         if id(w) in self._wpad:
             return self._wpad[id(w)]
@@ -96,12 +112,21 @@ class HipEngine:
 
     # ------------------------------------------------------------------ forward ops ----
     def conv_bn(self, key: str, x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool,
-                res: Optional[torch.Tensor], train: bool, col_input: bool = False) -> torch.Tensor:
-        """y = act(bn(conv(x)) (+ res)).  x: [N,H,W,Cin] in the compute dtype (or the im2row matrix of the stem)."""
+                res: Optional[torch.Tensor], train: bool, col_input: bool = False, pool: bool = False,
+                stem_packed=None) -> torch.Tensor:
+        """y = act(bn(conv(x)) (+ res)).  x: [N,H,W,Cin] in the compute dtype (or the im2row matrix of the stem).
+        stem_packed=(N, H, W): x is the packed image of nkb_stem_pack and conv the 7x7/2 stem.
+        pool=True (stem): y = maxpool3x3s2(relu(bn(conv(x)))) in one pass over the raw conv output; the un-pooled
+        activation is never materialised."""
         w = conv.weight
         co, ci, R, S = w.shape
         st, pad = conv.stride[0], conv.padding[0]
-        if col_input:
+        packed = stem_packed
+        if packed:
+            N, H, W = stem_packed
+            P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            geom = dict(N=N, H=H, W=W, Cout=co, P=P, Q=Q)
+        elif col_input:
             N, P, Q, kp = x.shape
             geom = dict(N=N * P * Q, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, ldy=co, R=1, S=1, stride=1, pad=0)
         else:
@@ -112,16 +137,29 @@ class HipEngine:
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
         tiles = hip.stat_tiles(self.d, rows, co)
         stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
-        hip.conv_gemm(self.d, 0, x, self.w_fwd(w), c, stats=stats, **geom)
+        if packed:
+            hip.stem_conv(self.d, x, self.w_fwd(w), c, stats, N, H, W, co, co)
+        else:
+            hip.conv_gemm(self.d, 0, x, self.w_fwd(w), c, stats=stats, **geom)
         sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
         scale, shift, mean, invstd = sc[0], sc[1], sc[2], sc[3]
         hip.bn_finalize(stats, tiles, co, rows, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, train, scale, shift, mean, invstd)
-        y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
-        hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu)
+        if pool:
+            assert relu and res is None
+            P2, Q2 = (P - 1) // 2 + 1, (Q - 1) // 2 + 1
+            y = self.ws.get(key + ".y", (N, P2, Q2, co), self.T)
+            idx = self.ws.get(key + ".idx", (N, P2, Q2, co), torch.uint8)
+            hip.bn_relu_maxpool(self.d, False, c, scale, shift, mean, invstd, None, y, idx, None, None, None, None,
+                                N, P, Q, co)
+        else:
+            idx = None
+            y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
+            hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu)
         if train:
             self.saved[key] = dict(x=x, c=c, y=y, mean=mean, invstd=invstd, relu=relu, geom=geom, conv=conv, bn=bn,
-                                   rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None)
+                                   rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None,
+                                   pool_idx=idx, stem_packed=bool(packed))
         return y
 
     def maxpool(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:
@@ -298,6 +336,19 @@ class HipEngine:
                         work, fscale=sv["scale"] if from_x else None, fshift=sv["shift"] if from_x else None)
         return gc
 
+    def bn_pool_backward(self, key: str, g_p: torch.Tensor, slot: str) -> torch.Tensor:
+        """Backward of a pool=True stage: pooled gradient -> gradient w.r.t. the raw conv output (max-pool routing, ReLU
+        mask and BatchNorm backward fused; bn weight/bias gradients accumulate into the arena)."""
+        sv = self.saved[key]
+        bn = sv["bn"]
+        N, H, W, co = sv["c"].shape
+        a = self.arena
+        gc = self.scratch(slot, sv["c"].shape)
+        work = self.ws.at_least("bn.work", hip.bn_relu_maxpool_ws(N, H, W, co), torch.float32)
+        hip.bn_relu_maxpool(self.d, True, sv["c"], sv["scale"], sv["shift"], sv["mean"], sv["invstd"], bn.weight, g_p,
+                            sv["pool_idx"], gc, a.grad_flat(bn.weight), a.grad_flat(bn.bias), work, N, H, W, co)
+        return gc
+
     def conv_backward(self, key: str, g_c: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None,
                       add_hw=(0, 0), subgrid: bool = False):
         """Weight gradient into the arena; input gradient (optionally + add) when slot is given."""
@@ -305,6 +356,16 @@ class HipEngine:
         geom, conv = sv["geom"], sv["conv"]
         w = conv.weight
         a = self.arena
+        if sv["stem_packed"]:
+            co = geom["Cout"]
+            dwp = self.ws.get(key + ".dwpad", (co, 224), torch.float32)
+
+            def packed_wgrad():
+                dwp.zero_()
+                hip.stem_wgrad(self.d, g_c, sv["x"], dwp, geom["N"], geom["H"], geom["W"], co, co)
+                hip.stem_wfold(self.d, dwp, a.grad_flat(w), co, w.shape[1])
+            self.on_side(packed_wgrad)
+            return None
         if sv["col_input"]:
             kp = geom["Cin"]
             co = geom["Cout"]

@@ -240,6 +240,87 @@ def test_maxpool_fwd_bwd_and_ties(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_tail_fused_matches_unfused_kernels(dtype):
+    """bn -> relu -> maxpool in one pass (and its backward) == bn_apply + maxpool (+ maxpool_bwd + bn_backward),
+    which the tests above pin against torch; odd H exercises the clipped windows."""
+    torch.manual_seed(15)
+    N, H, W, C = 3, 13, 14, 64
+    d = hip.dt(dtype)
+    rows = N * H * W
+    c = torch.randn(N, H, W, C, device=DEV).to(dtype)
+    c[0, :4, :4, :] = 0.25                       # ties
+    gamma = (torch.rand(C, device=DEV) + 0.5)
+    cf = c.float().reshape(rows, C)
+    mean = cf.mean(0)
+    invstd = (cf.var(0, unbiased=False) + 1e-5).rsqrt()
+    scale = (gamma * invstd).contiguous()
+    shift = (0.1 - mean * scale).contiguous()
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    # unfused
+    a = torch.empty_like(c)
+    hip.bn_apply(d, c, None, a, scale, shift, rows, C, True)
+    y0 = torch.empty(N, P, Q, C, device=DEV, dtype=dtype)
+    i0 = torch.empty(N, P, Q, C, device=DEV, dtype=torch.uint8)
+    hip.maxpool(d, False, a, y0, i0, N, H, W, C)
+    g = torch.randn(N, P, Q, C, device=DEV).to(dtype)
+    ga = torch.empty_like(c)
+    hip.maxpool(d, True, g, ga, i0, N, H, W, C)
+    dg0, db0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dc0 = torch.empty_like(c)
+    work = torch.empty(hip.bn_backward_ws(rows, C), device=DEV)
+    hip.bn_backward(d, ga, c, None, mean, invstd, gamma, rows, C, dg0, db0, dc0, None, work, fscale=scale, fshift=shift)
+    # fused
+    y1 = torch.empty_like(y0)
+    i1 = torch.empty_like(i0)
+    hip.bn_relu_maxpool(d, False, c, scale, shift, mean, invstd, None, y1, i1, None, None, None, None, N, H, W, C)
+    dg1, db1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dc1 = torch.empty_like(c)
+    work1 = torch.empty(hip.bn_relu_maxpool_ws(N, H, W, C), device=DEV)
+    hip.bn_relu_maxpool(d, True, c, scale, shift, mean, invstd, gamma, g, i1, dc1, dg1, db1, work1, N, H, W, C)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(i0, i1)
+    # the unfused path rounds the un-pooled gradient to the storage dtype before reducing it, the fused one does not
+    st = dict(rtol=1e-5, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=0.1)
+    torch.testing.assert_close(db1, db0, **st)
+    torch.testing.assert_close(dg1, dg0, **st)
+    torch.testing.assert_close(dc1.float(), dc0.float(), **tol(dtype, 2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw", [(32, 32), (23, 29)])
+def test_packed_stem_conv_fwd_wgrad(dtype, hw):
+    """7x7/2 stem straight from the packed NHWC image (no im2row): forward and weight gradient vs torch, including an
+    odd width (the packer adds the zero column the convolution's padding would have supplied)."""
+    torch.manual_seed(16)
+    H, W = hw
+    N, C, Co = 3, 3, 64
+    d = hip.dt(dtype)
+    x = rnd(torch.randn(N, C, H, W), dtype)
+    w = (rnd(torch.randn(Co, C, 7, 7) * 0.1, dtype)).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 3)
+    P, Q = y.shape[2], y.shape[3]
+    dy = rnd(torch.randn_like(y), dtype)
+    y.backward(dy)
+    xp = torch.empty(N, H, (W + 1) // 2 * 2, 4, device=DEV, dtype=dtype)
+    hip.stem_pack(d, x.to(DEV), xp, N, C, H, W)
+    wp = torch.empty(Co, hip.stem_weight_cols(d), device=DEV, dtype=dtype)
+    hip.stem_wprep(d, w.detach().permute(0, 2, 3, 1).contiguous().to(DEV), wp, Co, C)   # [Cout][R][S][Cin] master
+    yd = torch.empty(N, P, Q, Co, device=DEV, dtype=dtype)
+    tiles = hip.stat_tiles(d, N * P * Q, Co)
+    stats = torch.zeros(hip.bn_stats_floats(tiles, Co), device=DEV)
+    hip.stem_conv(d, xp, wp, yd, stats, N, H, W, Co, Co)
+    dwp = torch.zeros(Co, 224, device=DEV)
+    hip.stem_wgrad(d, nhwc(dy).to(DEV, dtype), xp, dwp, N, H, W, Co, Co)
+    dw = torch.zeros(Co, 7, 7, C, device=DEV)
+    hip.stem_wfold(d, dwp, dw, Co, C)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(yd.float().cpu(), nhwc(y.detach()), **tol(dtype, 147))
+    st = stats[: tiles * 2 * Co].view(tiles, 2, Co).sum(0).cpu()
+    torch.testing.assert_close(st[0], y.detach().sum((0, 2, 3)), rtol=1e-3, atol=0.05 if dtype == torch.float32 else 0.5)
+    torch.testing.assert_close(dw.cpu().permute(0, 3, 1, 2), w.grad, **tol(dtype, N * P * Q))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_avgpool_fwd_bwd(dtype):
     torch.manual_seed(6)
     N, C, HW = 3, 512, 49
