@@ -65,6 +65,17 @@ int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, 
                     const float* fshift, const float* mean, const float* invstd, const float* gamma, long long rows,
                     int C, float* dgamma, float* dbeta, void* dx, void* dy_masked, float* workspace,
                     size_t workspace_floats, nkb_stream_t stream);
+/* Data gradient of a convolution whose input was relu(bn(c)) (engine.py:55-58 backward through timm's conv -> bn -> act
+ * chains): nkb_conv_gemm(mode 1) whose epilogue also applies the ReLU mask recomputed from (c, scale, shift), stores the
+ * masked gradient and leaves per-row-tile sums of g' and g'*(c-mean) in stats (nkb_conv_gemm_stat_tiles(dtype, N*P*Q,
+ * Cout) tiles, nkb_bn_stats_floats floats); nkb_bn_backward_from_stats then finishes that stage's BatchNorm backward
+ * without a reduction pass over g and c.  sums: 2*C floats of scratch. */
+int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,
+                      const float* shift, const float* mean, float* stats, int N, int H, int W, int Cin, int ldx, int P,
+                      int Q, int Cout, int ldy, int R, int S, int stride, int pad, nkb_stream_t stream);
+int nkb_bn_backward_from_stats(int dtype, const void* g, const void* x, float* stats, int tiles, const float* mean,
+                               const float* invstd, const float* gamma, long long rows, int C, float* dgamma,
+                               float* dbeta, void* dx, float* sums, nkb_stream_t stream);
 size_t nkb_bn_stats_floats(int tiles, int C); /* size of the `partials` buffer nkb_bn_finalize expects */
 size_t nkb_bn_backward_workspace_floats(long long rows, int C);
 

@@ -20,8 +20,8 @@ template <> struct MmaTraits<float> { static constexpr int KSTEPS = 8; };   // 8
 
 __device__ __forceinline__ int lds_swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <typename T, int TC, int TP>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+template <typename T, int TC, int TP, bool BNB = false>
+__global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int KTE = 128 / (int)sizeof(T);  // elements per k-tile row
     constexpr int NWR = TC / 32;               // weight rows staged per thread
@@ -206,10 +206,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
     float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bv[e] = (!BNB && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
+    // BNB: the stage's scale / shift / mean for this tile's channels live in LDS behind the epilogue tile (keeping them
+    // in registers next to the not-yet-stored accumulators cost a wave of occupancy)
+    constexpr int LDS_MAIN = ((TC + TP) * 128 * (TC == 64 ? 2 : 1)) > ((TP / 2) * EROW) ? ((TC + TP) * 128 * (TC == 64 ? 2 : 1))
+                                                                                       : ((TP / 2) * EROW);
+    float* bnl = (float*)(smem + LDS_MAIN);   // [3][TC]
+    if constexpr (BNB) {
+        if (tid < TC) {
+            const bool ok = c0 + tid < p.Cout;
+            bnl[tid] = ok ? p.bn_scale[c0 + tid] : 0.f;
+            bnl[TC + tid] = ok ? p.bn_shift[c0 + tid] : 0.f;
+            bnl[2 * TC + tid] = ok ? p.bn_mean[c0 + tid] : 0.f;
+        }
+    }
+
+    // BNB (bf16): the c rows of a half are requested before that half's accumulators go through LDS, so their latency
+    // hides behind the LDS round trip instead of stalling every row of the store loop
+    constexpr int RPH = (TP / 2) / RPP;                      // rows per thread per half
+    constexpr bool CPRE = BNB && sizeof(T) == 2;
+    u32x4 cpre[CPRE ? RPH : 1];
+    auto prefetch_c = [&](int half) {
+        if constexpr (CPRE) {
+#pragma unroll
+            for (int i = 0; i < RPH; ++i) {
+                const int m = m0 + half * (TP / 2) + er + RPP * i;
+                cpre[i] = (u32x4){0u, 0u, 0u, 0u};
+                if (m < p.M && co + 8 <= p.Cout) cpre[i] = *(const u32x4*)((const bf16_t*)p.aux + (size_t)m * p.ldy + co);
+            }
+        }
+    };
 
   for (int half = 0; half < 2; ++half) {
+    prefetch_c(half);
     if (wp == half) {
 #pragma unroll
         for (int i = 0; i < MC; ++i)
@@ -221,7 +251,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }
     }
     __syncthreads();
-    for (int row = er; row < TP / 2; row += RPP) {
+#pragma unroll
+    for (int ri = 0; ri < RPH; ++ri) {
+        const int row = er + RPP * ri;
         const int m = m0 + half * (TP / 2) + row;
         if (m >= p.M) break;
         float v[8];
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
         }
-        bool do_add = p.add != nullptr;
+        bool do_add = !BNB && p.add != nullptr;
         size_t am = (size_t)m;                 // row of the add tensor
         if (do_add && p.add_h > 0) {           // add lives on the stride-2 sub-grid: only even (h, w) receive it
             const unsigned n = fdiv((unsigned)m, p.divPQ);
@@ -257,11 +289,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 for (int e = 0; e < 8; ++e) if (co + e < p.Cout) v[e] += bf2f(a[e]);
             }
         }
-        if (p.relu) {
+        float cv[8];                           // BNB: raw conv output of the stage whose BN backward consumes v
+        if constexpr (BNB) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cv[e] = 0.f;
+            if (co + 8 <= p.Cout) {
+                if constexpr (sizeof(T) == 2) {
+                    unpack8(cpre[ri], cv);
+                } else {
+                    const float* ax = (const float*)p.aux + (size_t)m * p.ldy + co;
+                    const f32x4 lo = *(const f32x4*)ax, hi = *(const f32x4*)(ax + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { cv[e] = lo[e]; cv[4 + e] = hi[e]; }
+                }
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f32x4 sc4 = *(const f32x4*)(bnl + eg * 8 + 4 * h2), sh4 = *(const f32x4*)(bnl + TC + eg * 8 + 4 * h2),
+                            mu4 = *(const f32x4*)(bnl + 2 * TC + eg * 8 + 4 * h2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * h2 + e;
+                    if (!(DT<T>::rnd(cv[k] * sc4[e] + sh4[e]) > 0.f)) v[k] = 0.f;   // same expression / rounding as bn_apply
+                    cv[k] -= mu4[e];
+                }
+            }
+        }
+        if (!BNB && p.relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.act == 1) {          // GELU forward: keep the pre-activation in y2 (for backward), store gelu(v) in y
+        if (!BNB && p.act == 1) {          // GELU forward: keep the pre-activation in y2 (for backward), store gelu(v) in y
             T* o2 = (T*)p.y2 + (size_t)m * p.ldy + co;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -269,7 +327,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 if (co + e < p.Cout) DT<T>::st(o2 + e, pre);
                 v[e] = pre * 0.5f * (1.f + erff(pre * 0.70710678118654752f));
             }
-        } else if (p.act == 2) {   // GELU backward: v = dL/d(gelu out) -> multiply by gelu'(pre-activation read from aux)
+        } else if (!BNB && p.act == 2) {   // GELU backward: v = dL/d(gelu out) -> multiply by gelu'(pre-activation read from aux)
             const T* ax = (const T*)p.aux + (size_t)m * p.ldy + co;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -277,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 v[e] *= 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * expf(-0.5f * a * a);
             }
         }
-        if (p.out_f32 || sizeof(T) == 4) {
+        if ((!BNB && p.out_f32) || sizeof(T) == 4) {
             float* o = (float*)p.y + yoff + (size_t)m * p.ldy + co;
             if (vec_ok) {
                 *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
@@ -298,7 +356,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+        for (int e = 0; e < 8; ++e) {
+            ssum[e] += v[e];
+            if constexpr (BNB) ssq[e] += v[e] * cv[e];
+            else ssq[e] += v[e] * v[e];
+        }
     }
     __syncthreads();
   }
@@ -571,20 +633,20 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
 
 // ------------------------------------------------------------------------------------------
 // host launchers
-template <typename T, int TC, int TP>
+template <typename T, int TC, int TP, bool BNB = false>
 static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
     p.tilesM = (p.M + TP - 1) / TP;
     p.tilesN = (p.Cout + TC - 1) / TC;
     constexpr int stage = (TC + TP) * 128 * (TC == 64 ? 2 : 1);
     constexpr int epi = (TP / 2) * (TC * 4 + 16);
-    constexpr int lds = stage > epi ? stage : epi;
+    constexpr int lds = (stage > epi ? stage : epi) + (BNB ? 3 * TC * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TC, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TC, TP, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const unsigned grid = (unsigned)p.tilesM * (unsigned)p.tilesN;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, TC, TP>), dim3(grid, batch), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TC, TP, BNB>), dim3(grid, batch), dim3(256), lds, stream, p);
     return nkb_check_launch("conv_igemm");
 }
 
@@ -626,6 +688,45 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     const bool narrow = Cout <= 64 && narrow_on;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+}
+
+// Data gradient of a convolution whose input was relu(bn(c)): same contraction as nkb_conv_gemm(mode 1), but the epilogue
+// also applies that ReLU's mask (recomputed from c, scale, shift exactly as bn_apply evaluated it), stores the masked
+// gradient g' and leaves per-row-tile sums of g' and g'*(c-mean) in `stats` — the reduction pass of the BatchNorm
+// backward, without re-reading g and c (nkb_bn_backward_from_stats finishes the job).
+extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c,
+                                 const float* scale, const float* shift, const float* mean, float* stats, int N, int H,
+                                 int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int R, int S, int stride, int pad,
+                                 hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int kte = 128 / esz;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_dgrad_bn: bad dtype %d", dtype); return 1; }
+    if (Cin % kte != 0 || ldx % (16 / esz) != 0 || Cout % 8 != 0 || ldy % 8 != 0) {
+        nkb_set_error("conv_dgrad_bn: Cin=%d must be a multiple of %d, Cout=%d / ldy=%d of 8", Cin, kte, Cout, ldy);
+        return 1;
+    }
+    if (stride != 1 && stride != 2) { nkb_set_error("conv_dgrad_bn: stride %d unsupported", stride); return 1; }
+    if (R > 32 || S > 32) { nkb_set_error("conv_dgrad_bn: filter too large"); return 1; }
+    if ((long long)N * H * W * ldx * esz >= 0xFFFFFF00ll || (long long)Cout * R * S * Cin * esz >= 0xFFFFFF00ll ||
+        (long long)N * P * Q * ldy >= (1ll << 31)) {
+        nkb_set_error("conv_dgrad_bn: operand exceeds the addressing range");
+        return 1;
+    }
+    ConvParams p;
+    p.x = dy; p.w = w; p.y = g_masked; p.add = nullptr; p.bias = nullptr; p.stats = stats;
+    p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.ldy = ldy;
+    p.ldadd = 0; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.mode = 1; p.relu = 0;
+    p.stride_w = stride; p.pad_w = pad; p.stem_cprw = 0;
+    p.out_f32 = 0;
+    p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
+    p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = c; p.y2 = nullptr;
+    p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean;
+    NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * p.M * (double)Cout * R * S * Cin);
+    static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
+    const bool narrow = Cout <= 64 && narrow_on;
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, true>(p, stream) : launch_conv<bf16_t, 128, 128, true>(p, stream);
+    return narrow ? launch_conv<float, 64, 256, true>(p, stream) : launch_conv<float, 128, 128, true>(p, stream);
 }
 
 // Linear layer with a fused exact-erf GELU epilogue (timm ViT MLP):

@@ -26,6 +26,12 @@ struct ConvParams {
     int stride_w, pad_w; // mode 0: horizontal stride / padding (== stride / pad except for the packed stem)
     int stem_cprw;      // > 0: packed-stem addressing, 16-byte chunks per filter row inside one 128-byte k-tile (see
                         //      nkb_stem_conv); x is [N][H][W/rpt][one chunk], W is passed pre-multiplied by rpt = 8/stem_cprw
+    // BNB kernels (dgrad feeding a BN+ReLU stage's backward): aux = that stage's raw conv output c [M][ldy]; the epilogue
+    // zeroes the gradient where relu(c*bn_scale+bn_shift) was 0, stores it, and puts sum(g') / sum(g'*(c-bn_mean)) per
+    // row tile into `stats`
+    const float* bn_scale = nullptr;
+    const float* bn_shift = nullptr;
+    const float* bn_mean = nullptr;
     int ldw;            // row stride of w in elements (R*S*Cin unless batched)
     int inner;
     long long sxo, sxi, swo, swi, syo, syi;

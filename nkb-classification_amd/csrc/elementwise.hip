@@ -1029,3 +1029,66 @@ extern "C" int nkb_stem_wfold(int dtype, const float* dwp, float* dw, int Cout, 
     hipLaunchKernelGGL(stem_weight_kernel<float>, dim3(grid_for((size_t)Cout * cols)), dim3(256), 0, stream, dwp, nullptr, dw, Cout, C, cols, epc, cprw, lead, 1);
     return nkb_check_launch("stem_wfold");
 }
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm backward whose reduction pass already happened in the producing dgrad's epilogue (nkb_conv_dgrad_bn):
+// `stats` holds per-row-tile sum(g') and sum(g'*(c-mean)), g is the masked gradient g'.  Finalize (double accumulation,
+// fixed order) + the elementwise pass dx = gamma*invstd*(g' - sum_g/M - xhat*sum_gx/M).
+template <typename PT>
+__global__ void bn_bwd_finalize_tiles_kernel(const PT* __restrict__ partials, int tiles, int C,
+                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                             float* __restrict__ dbeta, float* __restrict__ sums) {
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int t = py; t < tiles; t += 16) {
+            a += (double)partials[((size_t)t * 2) * C + c];
+            b += (double)partials[((size_t)t * 2 + 1) * C + c];
+        }
+    }
+    red[0][py][cx] = a;
+    red[1][py][cx] = b;
+    __syncthreads();
+    if (py != 0 || c >= C) return;
+    a = 0.0; b = 0.0;
+    for (int k = 0; k < 16; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
+    const float sg = (float)a, sgx = (float)(b * (double)invstd[c]);
+    sums[c] = sg;
+    sums[C + c] = sgx;
+    if (dbeta) dbeta[c] += sg;
+    if (dgamma) dgamma[c] += sgx;
+}
+
+// `stats` must have the size nkb_bn_stats_floats(tiles, C) (room for the stage-A scratch); sums: 2*C floats of scratch.
+extern "C" int nkb_bn_backward_from_stats(int dtype, const void* g, const void* x, float* stats, int tiles,
+                                          const float* mean, const float* invstd, const float* gamma, long long rows,
+                                          int C, float* dgamma, float* dbeta, void* dx, float* sums, hipStream_t stream) {
+    const int n = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (C % n || rows >= (1ll << 31)) { nkb_set_error("bn_backward_from_stats: unsupported C=%d / rows", C); return 1; }
+    {
+        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0);
+        if (tiles > 128) {
+            double* dpart = (double*)(stats + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
+            hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, 16), dim3(1024), 0, stream, stats, tiles, C, dpart);
+            hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream,
+                               (const double*)dpart, 16, C, invstd, dgamma, dbeta, sums);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, stream,
+                               (const float*)stats, tiles, C, invstd, dgamma, dbeta, sums);
+        }
+    }
+    if (int rc = nkb_check_launch("bn_bwd_finalize_tiles")) return rc;
+    NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0);
+    const unsigned grid = grid_cols((size_t)rows, C / n);
+    if (dtype == NKB_DT_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)g, (const bf16_t*)x,
+                           (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, mean, invstd, gamma, sums,
+                           1.0f / (float)rows, (unsigned)rows, C, (bf16_t*)dx, (bf16_t*)nullptr);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)g, (const float*)x,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, mean, invstd, gamma, sums,
+                           1.0f / (float)rows, (unsigned)rows, C, (float*)dx, (float*)nullptr);
+    return nkb_check_launch("bn_bwd_apply");
+}

@@ -156,8 +156,13 @@ class HipResNet(_ParamOnly):
             # last stage: ReLU(bn(conv) + shortcut); the masked incoming gradient also feeds the shortcut
             gc = eng.bn_backward(f"{name}.{n - 1}", g, "t0", write_masked=True)
             for k in range(n - 1, 0, -1):
-                ga = eng.conv_backward(f"{name}.{k}", gc, f"a{k}")
-                gc = eng.bn_backward(f"{name}.{k - 1}", ga, f"c{k}")
+                prev = f"{name}.{k - 1}"
+                if eng.can_fuse_bn_backward(prev):
+                    ga, st = eng.conv_backward(f"{name}.{k}", gc, f"a{k}", fuse_bn=prev)
+                    gc = eng.bn_backward_fused(prev, ga, st, f"c{k}")
+                else:
+                    ga = eng.conv_backward(f"{name}.{k}", gc, f"a{k}")
+                    gc = eng.bn_backward(prev, ga, f"c{k}")
             add, add_hw = g, (0, 0)
             if blk.downsample is not None:
                 gcd = eng.bn_backward(f"{name}.ds", g, "t5")

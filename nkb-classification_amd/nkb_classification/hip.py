@@ -31,6 +31,8 @@ _SIGS = {
     "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
     "nkb_bn_stats_floats": (sz, [i32, i32]),
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
+    "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 13 + [vp]),
+    "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
     "nkb_stem_pack": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_stem_weight_cols": (i32, [i32]),
@@ -162,6 +164,19 @@ def bn_backward(dtype, dy, x, yact, mean, invstd, gamma, rows, C_, dgamma, dbeta
                                  ptr(gamma), rows, C_,
                                  ptr(dgamma), ptr(dbeta), ptr(dx), ptr(dy_masked), ptr(workspace), workspace.numel(),
                                  stream()), "bn_backward")
+
+
+def conv_dgrad_bn(dtype, dy, w, g_masked, c, scale, shift, mean, stats, *, N, H, W, Cin, ldx, P, Q, Cout, ldy, R, S,
+                  stride, pad):
+    check(load().nkb_conv_dgrad_bn(dtype, ptr(dy), ptr(w), ptr(g_masked), ptr(c), ptr(scale), ptr(shift), ptr(mean),
+                                   ptr(stats), N, H, W, Cin, ldx, P, Q, Cout, ldy, R, S, stride, pad, stream()),
+          "conv_dgrad_bn")
+
+
+def bn_backward_from_stats(dtype, g, x, stats, tiles, mean, invstd, gamma, rows, C_, dgamma, dbeta, dx, sums):
+    check(load().nkb_bn_backward_from_stats(dtype, ptr(g), ptr(x), ptr(stats), tiles, ptr(mean), ptr(invstd), ptr(gamma),
+                                            rows, C_, ptr(dgamma), ptr(dbeta), ptr(dx), ptr(sums), stream()),
+          "bn_backward_from_stats")
 
 
 def bn_backward_ws(rows, C_):

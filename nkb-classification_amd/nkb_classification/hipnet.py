@@ -17,6 +17,8 @@ from . import hip
 from .runtime import ParamArena, Workspace, _round_up
 
 _PACKED_STEM = os.environ.get("NKB_PACKED_STEM", "1") != "0"
+# reduction pass of an interior BN stage's backward folded into the epilogue of the dgrad that produces its input
+_FUSED_BN_BWD = os.environ.get("NKB_FUSED_BNBWD", "1") != "0"
 
 
 class HipEngine:
@@ -349,9 +351,29 @@ class HipEngine:
                             sv["pool_idx"], gc, a.grad_flat(bn.weight), a.grad_flat(bn.bias), work, N, H, W, co)
         return gc
 
+    def can_fuse_bn_backward(self, bn_key: str) -> bool:
+        sv = self.saved[bn_key]
+        return (_FUSED_BN_BWD and sv["relu"] and not sv["has_res"] and sv["pool_idx"] is None
+                and sv["c"].shape[-1] % 8 == 0)
+
+    def bn_backward_fused(self, key: str, g_masked: torch.Tensor, stats, slot: str) -> torch.Tensor:
+        """Second half of conv_backward(..., fuse_bn=key): g_masked is already ReLU-masked and `stats` = (buffer, tiles)
+        holds the per-tile sums, so only the finalize and the elementwise pass remain."""
+        sv = self.saved[key]
+        bn, rows = sv["bn"], sv["rows"]
+        co = sv["c"].shape[-1]
+        a = self.arena
+        gc = self.scratch(slot, sv["c"].shape)
+        sums = self.ws.at_least("bn.sums", 2 * co, torch.float32)
+        hip.bn_backward_from_stats(self.d, g_masked, sv["c"], stats[0], stats[1], sv["mean"], sv["invstd"], bn.weight, rows,
+                                   co, a.grad_flat(bn.weight), a.grad_flat(bn.bias), gc, sums)
+        return gc
+
     def conv_backward(self, key: str, g_c: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None,
-                      add_hw=(0, 0), subgrid: bool = False):
-        """Weight gradient into the arena; input gradient (optionally + add) when slot is given."""
+                      add_hw=(0, 0), subgrid: bool = False, fuse_bn: Optional[str] = None):
+        """Weight gradient into the arena; input gradient (optionally + add) when slot is given.
+        fuse_bn=<stage key>: the conv's input was that stage's relu(bn(c)); returns (masked gradient, stats) for
+        bn_backward_fused instead of the plain input gradient."""
         sv = self.saved[key]
         geom, conv = sv["geom"], sv["conv"]
         w = conv.weight
@@ -393,6 +415,15 @@ class HipEngine:
                           ldx=geom["Cout"], P=1, Q=1, Cout=ci, ldy=ci)
             return dx
         dx = self.scratch(slot, (N, H, W, ci))
+        if fuse_bn is not None:
+            assert add is None
+            svp = self.saved[fuse_bn]
+            tiles = hip.stat_tiles(self.d, N * H * W, ci)
+            stats = self.ws.get(fuse_bn + ".bstats", (hip.bn_stats_floats(tiles, ci),), torch.float32)
+            hip.conv_dgrad_bn(self.d, g_c, self._wd[id(w)], dx, svp["c"], svp["scale"], svp["shift"], svp["mean"], stats,
+                              N=N, H=geom["P"], W=geom["Q"], Cin=geom["Cout"], ldx=geom["Cout"], P=H, Q=W, Cout=ci, ldy=ci,
+                              R=geom["R"], S=geom["S"], stride=geom["stride"], pad=geom["pad"])
+            return dx, (stats, tiles)
         hip.conv_gemm(self.d, 1, g_c, self._wd[id(w)], dx, N=N, H=geom["P"], W=geom["Q"], Cin=geom["Cout"],
                       ldx=geom["Cout"], P=H, Q=W, Cout=ci, ldy=ci, R=geom["R"], S=geom["S"], stride=geom["stride"],
                       pad=geom["pad"], add=add, ldadd=ci if add is not None else 0, add_hw=add_hw)

@@ -321,6 +321,51 @@ def test_packed_stem_conv_fwd_wgrad(dtype, hw):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("geo", [(3, 1, 1, 64, 128), (1, 1, 0, 256, 64), (3, 2, 1, 128, 128)])
+def test_dgrad_with_fused_bn_backward_matches_unfused(dtype, geo):
+    """nkb_conv_dgrad_bn + nkb_bn_backward_from_stats == nkb_conv_gemm(mode 1) + nkb_bn_backward (both pinned against
+    torch above): same masked gradient, same dgamma/dbeta, same gradient w.r.t. the raw conv output."""
+    torch.manual_seed(17)
+    k, stride, pad, C, Co = geo          # the consumer conv maps C (the BN stage's channels) -> Co
+    N, H = 2, 12
+    P = (H + 2 * pad - k) // stride + 1
+    d = hip.dt(dtype)
+    rows = N * H * H
+    c = torch.randn(N, H, H, C, device=DEV).to(dtype)                 # raw output of the producing conv
+    dy = torch.randn(N, P, P, Co, device=DEV).to(dtype)               # gradient w.r.t. the consumer conv's output
+    wt = (torch.randn(C, k, k, Co, device=DEV) * 0.1).to(dtype)       # dgrad layout [Cin][R][S][Cout]
+    gamma = torch.rand(C, device=DEV) + 0.5
+    cf = c.float().reshape(rows, C)
+    mean = cf.mean(0).contiguous()
+    invstd = (cf.var(0, unbiased=False) + 1e-5).rsqrt().contiguous()
+    scale = (gamma * invstd).contiguous()
+    shift = (0.05 - mean * scale).contiguous()
+    geom = dict(N=N, H=P, W=P, Cin=Co, ldx=Co, P=H, Q=H, Cout=C, ldy=C, R=k, S=k, stride=stride, pad=pad)
+    # unfused
+    g0 = torch.empty(N, H, H, C, device=DEV, dtype=dtype)
+    hip.conv_gemm(d, 1, dy, wt, g0, **geom)
+    dg0, db0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dc0 = torch.empty_like(c)
+    work = torch.empty(hip.bn_backward_ws(rows, C), device=DEV)
+    hip.bn_backward(d, g0, c, None, mean, invstd, gamma, rows, C, dg0, db0, dc0, g0, work, fscale=scale, fshift=shift)
+    # fused
+    g1 = torch.empty_like(g0)
+    tiles = hip.stat_tiles(d, rows, C)
+    stats = torch.zeros(hip.bn_stats_floats(tiles, C), device=DEV)
+    hip.conv_dgrad_bn(d, dy, wt, g1, c, scale, shift, mean, stats, **geom)
+    dg1, db1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dc1 = torch.empty_like(c)
+    sums = torch.empty(2 * C, device=DEV)
+    hip.bn_backward_from_stats(d, g1, c, stats, tiles, mean, invstd, gamma, rows, C, dg1, db1, dc1, sums)
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1)                    # masked gradient (bn_backward wrote its mask back into g0)
+    st = dict(rtol=1e-4, atol=1e-3) if dtype == torch.float32 else dict(rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(db1, db0, **st)
+    torch.testing.assert_close(dg1, dg0, **st)
+    torch.testing.assert_close(dc1.float(), dc0.float(), **tol(dtype, 4))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_avgpool_fwd_bwd(dtype):
     torch.manual_seed(6)
     N, C, HW = 3, 512, 49
