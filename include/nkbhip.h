@@ -178,7 +178,7 @@ int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float*
 
 /* Per-launch HIP-event profiler (bench.py's roofline leg). */
 void nkb_prof_enable(int on);
-int nkb_prof_collect(double* ms, long long* launches, double* work, int slots);
+int nkb_prof_collect(double* ms, long long* launches, double* work, double* bytes, int slots);
 int nkb_prof_collect_raw(int* kernel_id, double* ms, double* work, int cap);
 const char* nkb_kernel_name(int kernel_id);
 

@@ -29,7 +29,7 @@ extern "C" const char* nkb_last_error() { return g_err; }
 extern "C" int nkb_version() { return 100; }
 
 // ---- profiler ---------------------------------------------------------------------------
-struct ProfRec { int kid; hipEvent_t a, b; double work; };
+struct ProfRec { int kid; hipEvent_t a, b; double work, bytes; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
@@ -42,11 +42,11 @@ static hipEvent_t get_event() {
     return e;
 }
 
-NkbProfScope::NkbProfScope(int kernel_id, hipStream_t s, double work) : slot(-1), stream(s) {
+NkbProfScope::NkbProfScope(int kernel_id, hipStream_t s, double work, double bytes) : slot(-1), stream(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
-    r.kid = kernel_id; r.work = work; r.a = get_event(); r.b = get_event();
+    r.kid = kernel_id; r.work = work; r.bytes = bytes; r.a = get_event(); r.b = get_event();
     hipEventRecord(r.a, s);
     slot = (int)g_prof.size();
     g_prof.push_back(r);
@@ -60,15 +60,15 @@ NkbProfScope::~NkbProfScope() {
 extern "C" void nkb_prof_enable(int on) { g_prof_on = on != 0; }
 
 // Synchronises the recorded events and returns, per kernel id (NKB_K_COUNT slots): total milliseconds,
-// number of launches and total algorithmic work (FLOPs where the launcher supplied them). Clears the log.
-extern "C" int nkb_prof_collect(double* ms, long long* launches, double* work, int slots) {
+// number of launches, total algorithmic FLOPs and total algorithmic bytes (where the launcher supplied them). Clears the log.
+extern "C" int nkb_prof_collect(double* ms, long long* launches, double* work, double* bytes, int slots) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int i = 0; i < slots; ++i) { ms[i] = 0; launches[i] = 0; work[i] = 0; }
+    for (int i = 0; i < slots; ++i) { ms[i] = 0; launches[i] = 0; work[i] = 0; bytes[i] = 0; }
     for (auto& r : g_prof) {
         hipEventSynchronize(r.b);
         float t = 0.f;
         hipEventElapsedTime(&t, r.a, r.b);
-        if (r.kid < slots) { ms[r.kid] += t; launches[r.kid] += 1; work[r.kid] += r.work; }
+        if (r.kid < slots) { ms[r.kid] += t; launches[r.kid] += 1; work[r.kid] += r.work; bytes[r.kid] += r.bytes; }
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }

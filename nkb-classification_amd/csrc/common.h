@@ -106,7 +106,7 @@ int nkb_check_launch(const char* what);
 struct NkbProfScope {
     int slot;
     hipStream_t stream;
-    NkbProfScope(int kernel_id, hipStream_t s, double work);
+    NkbProfScope(int kernel_id, hipStream_t s, double work, double bytes = 0.0);   // algorithmic FLOPs / bytes of the launch
     ~NkbProfScope();
 };
 enum NkbKernelId {

@@ -682,7 +682,10 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     p.add_h = add_h; p.add_w = add_w; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
     const double flops = 2.0 * p.M * (double)Cout * R * S * Cin;
-    NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops);
+    // algorithmic bytes: every operand element once (source image, filter, destination, residual operand)
+    const double bytes = ((double)N * H * W * Cin + (double)Cout * R * S * Cin) * esz +
+                         (double)p.M * Cout * (out_f32 ? 4 : esz) * (add ? 2 : 1);
+    NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops, bytes);
     if (add_h == 0 && nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
@@ -722,7 +725,8 @@ extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void*
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = c; p.y2 = nullptr;
     p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean;
-    NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * p.M * (double)Cout * R * S * Cin);
+    NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * p.M * (double)Cout * R * S * Cin,
+                      ((double)N * H * W * Cin + (double)Cout * R * S * Cin + 2.0 * p.M * Cout) * esz);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, true>(p, stream) : launch_conv<bf16_t, 128, 128, true>(p, stream);
@@ -838,7 +842,8 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
         hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot);
+    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot,
+                      ((double)N * H * W * Cin + (double)p.M * Cout) * esz + 2.0 * 4.0 * Cout * p.Ntot);
     dim3 grid((unsigned)tiles, (unsigned)splits);
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
@@ -922,7 +927,8 @@ extern "C" int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y,
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.ldw = g.ktiles * 8 * g.epc; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
-    NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * p.M * (double)Cout * 147);
+    NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * p.M * (double)Cout * 147,
+                      ((double)N * H * Wp * 4 + (double)p.M * Cout) * (dtype == NKB_DT_BF16 ? 2 : 4));
     const bool narrow = Cout <= 64;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);

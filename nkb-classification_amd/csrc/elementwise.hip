@@ -181,7 +181,7 @@ extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, 
                             long long rows, int C, int relu, hipStream_t stream) {
     const int n = dtype == NKB_DT_BF16 ? 8 : 4;
     if (C % n || rows >= (1ll << 31)) { nkb_set_error("bn_apply: C=%d not a multiple of %d (or too many rows)", C, n); return 1; }
-    NkbProfScope prof(NKB_K_BN_APPLY, stream, 0);
+    NkbProfScope prof(NKB_K_BN_APPLY, stream, 0, (double)rows * C * (dtype == NKB_DT_BF16 ? 2 : 4) * (res ? 3 : 2));
     const unsigned grid = grid_cols((size_t)rows, C / n);
     if (dtype == NKB_DT_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x,
@@ -380,8 +380,9 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
     float* part = workspace;
     float* sums = workspace + (size_t)blocks * 2 * C;
     const size_t lds = (size_t)2 * tpc * C * sizeof(float);
+    const double tensor_bytes = (double)rows * C * (dtype == NKB_DT_BF16 ? 2 : 4);
     {
-        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0);
+        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0, tensor_bytes * (yact ? 3 : 2));
         if (dtype == NKB_DT_BF16)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(threads), lds, stream, (const bf16_t*)dy,
                                (const bf16_t*)x, (const bf16_t*)yact, fscale, fshift, mean, invstd, rows, C, rpb, part);
@@ -393,7 +394,7 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
     }
     if (int rc = nkb_check_launch("bn_bwd_reduce")) return rc;
     if (dx) {
-        NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0);
+        NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0, tensor_bytes * ((yact ? 3 : 2) + 1 + (dy_masked ? 1 : 0)));
         const unsigned grid = grid_cols((size_t)rows, cpr);
         if (dtype == NKB_DT_BF16)
             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream,
@@ -1080,7 +1081,7 @@ extern "C" int nkb_bn_backward_from_stats(int dtype, const void* g, const void* 
         }
     }
     if (int rc = nkb_check_launch("bn_bwd_finalize_tiles")) return rc;
-    NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0);
+    NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0, (double)rows * C * (dtype == NKB_DT_BF16 ? 2 : 4) * 3);
     const unsigned grid = grid_cols((size_t)rows, C / n);
     if (dtype == NKB_DT_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)g, (const bf16_t*)x,

@@ -67,7 +67,7 @@ _SIGS = {
     "nkb_optim_step": (i32, [i32, vp, vp, vp, vp, vp, i64] + [f32] * 10 + [vp]),
     "nkb_segment_sumsq": (i32, [vp, vp, i32, vp, vp]),
     "nkb_prof_enable": (None, [i32]),
-    "nkb_prof_collect": (i32, [vp, vp, vp, i32]),
+    "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
     "nkb_prof_collect_raw": (i32, [vp, vp, vp, i32]),
     "nkb_kernel_name": (C.c_char_p, [i32]),
 }
@@ -273,11 +273,12 @@ def prof_collect():
     ms = (C.c_double * n)()
     cnt = (C.c_longlong * n)()
     work = (C.c_double * n)()
-    k = load().nkb_prof_collect(ms, cnt, work, n)
+    byts = (C.c_double * n)()
+    k = load().nkb_prof_collect(ms, cnt, work, byts, n)
     out = {}
     for i in range(k):
         if cnt[i]:
-            out[load().nkb_kernel_name(i).decode()] = dict(ms=ms[i], launches=cnt[i], work=work[i])
+            out[load().nkb_kernel_name(i).decode()] = dict(ms=ms[i], launches=cnt[i], work=work[i], bytes=byts[i])
     return out
 
 
