@@ -73,6 +73,15 @@ int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, 
 int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,
                       const float* shift, const float* mean, float* stats, int N, int H, int W, int Cin, int ldx, int P,
                       int Q, int Cout, int ldy, int R, int S, int stride, int pad, nkb_stream_t stream);
+/* One parity class (ph, pw) of the data gradient of a 3x3 / stride-2 / pad-1 convolution: output pixels (2h'+ph, 2w'+pw)
+ * as a stride-1 gather over dY with (1|2) x (1|2) taps; w_class = [C][Rc][Sc][K] from nkb_wprep modes 2..5 (= 2 + 2*ph + pw).
+ * The four classes together replace nkb_conv_gemm(mode 1, stride 2), which multiplies 3 taps out of 4 by zero.
+ * add: optional residual ([N][Hout][Wout][ldadd], or the sub-grid form of nkb_conv_gemm with add_h/add_w);
+ * c != NULL: fused BN-backward epilogue of nkb_conv_dgrad_bn, `stats` pointing at this class's own tile range. */
+int nkb_conv_dgrad_s2class(int dtype, const void* dy, const void* w_class, void* y, const void* add, const void* c,
+                           const float* scale, const float* shift, const float* mean, float* stats, int N, int Hdy,
+                           int Wdy, int K, int ldx, int Hout, int Wout, int C, int ldy, int ldadd, int ph, int pw,
+                           int add_h, int add_w, nkb_stream_t stream);
 int nkb_bn_backward_from_stats(int dtype, const void* g, const void* x, float* stats, int tiles, const float* mean,
                                const float* invstd, const float* gamma, long long rows, int C, float* dgamma,
                                float* dbeta, void* dx, float* sums, nkb_stream_t stream);
@@ -115,7 +124,8 @@ int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N,
                    nkb_stream_t stream);
 int nkb_stem_wfold(int dtype, const float* dwp, float* dw, int Cout, int C, nkb_stream_t stream);
 
-/* fp32 master filter [A][B][C] -> compute-dtype copy (mode 0: rows padded to ld; mode 1: transposed [C][B][ld]). */
+/* fp32 master filter [A][B][C] -> compute-dtype copy (mode 0: rows padded to ld; mode 1: transposed [C][B][ld];
+ * modes 2..5: transposed parity class 2*ph+pw of a 3x3 stride-2 filter, [C][Rc*Sc][ld], see nkb_conv_dgrad_s2class). */
 int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int ld, int mode, nkb_stream_t stream);
 int nkb_add2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, nkb_stream_t stream);
 int nkb_colsum(int dtype, const void* x, float* out, int rows, int C, int ld, nkb_stream_t stream);

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
             const int qq = (int)rem - pp * (int)p.divQ.d;
             int hb, wb;
             if (p.mode == 0) { hb = pp * p.stride - p.pad; wb = qq * p.stride_w - p.pad_w; }
-            else             { hb = pp + p.pad;            wb = qq + p.pad; }
+            else             { hb = pp + p.pad;            wb = qq + p.pad_w; }
             const int h0 = p.mode == 0 ? hb : (hb >> sh), w0 = p.mode == 0 ? wb : (wb >> sh);
             if (p.stem_cprw > 0) {
                 // packed stem: a k-tile is rpt filter rows x cprw chunks; this lane's chunk sits at filter row
@@ -233,7 +233,15 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
             for (int i = 0; i < RPH; ++i) {
                 const int m = m0 + half * (TP / 2) + er + RPP * i;
                 cpre[i] = (u32x4){0u, 0u, 0u, 0u};
-                if (m < p.M && co + 8 <= p.Cout) cpre[i] = *(const u32x4*)((const bf16_t*)p.aux + (size_t)m * p.ldy + co);
+                size_t crow = (size_t)m;
+                if (p.sub_h > 0) {
+                    const unsigned n = fdiv((unsigned)m, p.divPQ);
+                    const unsigned rem = (unsigned)m - n * p.divPQ.d;
+                    const unsigned hh = fdiv(rem, p.divQ);
+                    const unsigned ww = rem - hh * p.divQ.d;
+                    crow = ((size_t)n * p.sub_h + 2 * hh + p.sub_ph) * p.sub_w + 2 * ww + p.sub_pw;
+                }
+                if (m < p.M && co + 8 <= p.Cout) cpre[i] = *(const u32x4*)((const bf16_t*)p.aux + crow * p.ldy + co);
             }
         }
     };
@@ -263,9 +271,21 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
         }
+        size_t orow = (size_t)m;               // destination row (differs from m only for a parity-class launch)
+        if (p.sub_h > 0) {
+            const unsigned n = fdiv((unsigned)m, p.divPQ);
+            const unsigned rem = (unsigned)m - n * p.divPQ.d;
+            const unsigned hh = fdiv(rem, p.divQ);
+            const unsigned ww = rem - hh * p.divQ.d;
+            orow = ((size_t)n * p.sub_h + 2 * hh + p.sub_ph) * p.sub_w + 2 * ww + p.sub_pw;
+        }
         bool do_add = !BNB && p.add != nullptr;
-        size_t am = (size_t)m;                 // row of the add tensor
-        if (do_add && p.add_h > 0) {           // add lives on the stride-2 sub-grid: only even (h, w) receive it
+        size_t am = orow;                      // row of the add tensor
+        if (do_add && p.add_h > 0 && p.sub_h > 0) {
+            // sub-grid add on a parity-class launch: the even (h, w) grid IS class (0, 0), row for row
+            do_add = (p.sub_ph | p.sub_pw) == 0;
+            am = (size_t)m;
+        } else if (do_add && p.add_h > 0) {           // add lives on the stride-2 sub-grid: only even (h, w) receive it
             const unsigned n = fdiv((unsigned)m, p.divPQ);
             const unsigned rem = (unsigned)m - n * p.divPQ.d;
             const unsigned hh = fdiv(rem, p.divQ);
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
                 if constexpr (sizeof(T) == 2) {
                     unpack8(cpre[ri], cv);
                 } else {
-                    const float* ax = (const float*)p.aux + (size_t)m * p.ldy + co;
+                    const float* ax = (const float*)p.aux + orow * p.ldy + co;
                     const f32x4 lo = *(const f32x4*)ax, hi = *(const f32x4*)(ax + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { cv[e] = lo[e]; cv[4 + e] = hi[e]; }
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (!BNB && p.act == 1) {          // GELU forward: keep the pre-activation in y2 (for backward), store gelu(v) in y
-            T* o2 = (T*)p.y2 + (size_t)m * p.ldy + co;
+            T* o2 = (T*)p.y2 + orow * p.ldy + co;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float pre = DT<T>::rnd(v[e]);
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
                 v[e] = pre * 0.5f * (1.f + erff(pre * 0.70710678118654752f));
             }
         } else if (!BNB && p.act == 2) {   // GELU backward: v = dL/d(gelu out) -> multiply by gelu'(pre-activation read from aux)
-            const T* ax = (const T*)p.aux + (size_t)m * p.ldy + co;
+            const T* ax = (const T*)p.aux + orow * p.ldy + co;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float a = (co + e < p.Cout) ? DT<T>::ld(ax + e) : 0.f;
@@ -336,7 +356,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
             }
         }
         if ((!BNB && p.out_f32) || sizeof(T) == 4) {
-            float* o = (float*)p.y + yoff + (size_t)m * p.ldy + co;
+            float* o = (float*)p.y + yoff + orow * p.ldy + co;
             if (vec_ok) {
                 *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
                 *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -345,7 +365,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
                 for (int e = 0; e < 8; ++e) if (co + e < p.Cout) o[e] = v[e];
             }
         } else {
-            bf16_t* o = (bf16_t*)p.y + yoff + (size_t)m * p.ldy + co;
+            bf16_t* o = (bf16_t*)p.y + yoff + orow * p.ldy + co;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));  // statistics see the stored value
             if (vec_ok) {
@@ -731,6 +751,57 @@ extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void*
     const bool narrow = Cout <= 64 && narrow_on;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, true>(p, stream) : launch_conv<bf16_t, 128, 128, true>(p, stream);
     return narrow ? launch_conv<float, 64, 256, true>(p, stream) : launch_conv<float, 128, 128, true>(p, stream);
+}
+
+// One parity class of the data gradient of a 3x3 / stride-2 / pad-1 convolution.  Output pixels (h, w) with
+// (h%2, w%2) = (ph, pw) only receive the filter taps r = (ph+1)%2 + 2*ri, s = (pw+1)%2 + 2*si, so the class is a
+// stride-1 gather over the dY grid with Rc x Sc = (1 or 2) x (1 or 2) taps — 9 taps over the four classes instead of
+// the 36 the plain gather form multiplies (3 of 4 by zero).  w_class = [C][Rc][Sc][K] (nkb_wprep modes 2..5).
+// c != NULL selects the fused BN-backward epilogue of nkb_conv_dgrad_bn; `stats` then points at this class's tile range.
+extern "C" int nkb_conv_dgrad_s2class(int dtype, const void* dy, const void* w_class, void* y, const void* add,
+                                      const void* c, const float* scale, const float* shift, const float* mean,
+                                      float* stats, int N, int Hdy, int Wdy, int K, int ldx, int Hout, int Wout, int C,
+                                      int ldy, int ldadd, int ph, int pw, int add_h, int add_w, hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int kte = 128 / esz;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_dgrad_s2class: bad dtype %d", dtype); return 1; }
+    if (K % kte != 0 || ldx % (16 / esz) != 0 || (unsigned)ph > 1u || (unsigned)pw > 1u || (c && (C % 8 || ldy % 8))) {
+        nkb_set_error("conv_dgrad_s2class: unsupported K=%d ldx=%d C=%d ldy=%d class (%d,%d)", K, ldx, C, ldy, ph, pw);
+        return 1;
+    }
+    const int Pc = (Hout - ph + 1) / 2, Qc = (Wout - pw + 1) / 2;
+    const int Rc = ph ? 2 : 1, Sc = pw ? 2 : 1;
+    if (Pc <= 0 || Qc <= 0) return 0;
+    if ((long long)N * Hdy * Wdy * ldx * esz >= 0xFFFFFF00ll || (long long)N * Hout * Wout * ldy >= (1ll << 31)) {
+        nkb_set_error("conv_dgrad_s2class: operand exceeds the addressing range");
+        return 1;
+    }
+    if (add && add_h > 0 && (add_h != (Hout + 1) / 2 || add_w != (Wout + 1) / 2)) {
+        nkb_set_error("conv_dgrad_s2class: sub-grid add must be [N][ceil(H/2)][ceil(W/2)]");
+        return 1;
+    }
+    ConvParams p;
+    p.x = dy; p.w = w_class; p.y = y; p.add = c ? nullptr : add; p.bias = nullptr; p.stats = stats;
+    p.M = N * Pc * Qc; p.H = Hdy; p.W = Wdy; p.Cin = K; p.ldx = ldx; p.P = Pc; p.Q = Qc; p.Cout = C; p.ldy = ldy;
+    p.ldadd = ldadd; p.R = Rc; p.S = Sc; p.stride = 1; p.pad = ph; p.mode = 1; p.relu = 0;   // pad' = (ph+1-r0)/2 = ph
+    p.stride_w = 1; p.pad_w = pw; p.stem_cprw = 0;
+    p.out_f32 = 0;
+    p.divPQ = make_fastdiv((unsigned)(Pc * Qc)); p.divQ = make_fastdiv((unsigned)Qc);
+    p.ldw = Rc * Sc * K; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = add_h; p.add_w = add_w; p.act = 0; p.aux = c; p.y2 = nullptr;
+    p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean;
+    p.sub_h = Hout; p.sub_w = Wout; p.sub_ph = ph; p.sub_pw = pw;
+    const double flops = 2.0 * p.M * (double)C * Rc * Sc * K;
+    const double bytes = ((double)N * Hdy * Wdy * K / 4.0 + (double)C * Rc * Sc * K + (double)p.M * C * ((add || c) ? 2 : 1)) * esz;
+    NkbProfScope prof(NKB_K_CONV_DGRAD, stream, flops, bytes);
+    static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
+    const bool narrow = C <= 64 && narrow_on;
+    if (c) {
+        if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, true>(p, stream) : launch_conv<bf16_t, 128, 128, true>(p, stream);
+        return narrow ? launch_conv<float, 64, 256, true>(p, stream) : launch_conv<float, 128, 128, true>(p, stream);
+    }
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
+    return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
 }
 
 // Linear layer with a fused exact-erf GELU epilogue (timm ViT MLP):

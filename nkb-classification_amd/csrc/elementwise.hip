@@ -635,7 +635,7 @@ __global__ void wprep_kernel(const float* __restrict__ src, T* __restrict__ dst,
             const int k = (int)(i % ld), a = (int)(i / ld);
             DT<T>::st(dst + i, k < K ? src[(size_t)a * K + k] : 0.f);
         }
-    } else {
+    } else if (mode == 1) {
         const size_t total = (size_t)C * B * ld;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
             const int a = (int)(i % ld);
@@ -643,10 +643,25 @@ __global__ void wprep_kernel(const float* __restrict__ src, T* __restrict__ dst,
             const int c = (int)(i / ((size_t)ld * B));
             DT<T>::st(dst + i, a < A ? src[((size_t)a * B + b) * C + c] : 0.f);
         }
+    } else {
+        // modes 2..5: parity class (ph, pw) = ((mode-2)>>1, (mode-2)&1) of a 3x3 stride-2 filter in dgrad layout:
+        // dst[c][ri][si][a] = src[a][(r0+2ri)*3 + s0+2si][c], r0 = (ph+1)%2, s0 = (pw+1)%2   (B must be 9)
+        const int ph = (mode - 2) >> 1, pw = (mode - 2) & 1;
+        const int r0 = (ph + 1) & 1, s0 = (pw + 1) & 1, Rc = ph ? 2 : 1, Sc = pw ? 2 : 1;
+        const size_t total = (size_t)C * Rc * Sc * ld;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const int a = (int)(i % ld);
+            const int t = (int)((i / ld) % (Rc * Sc));
+            const int c = (int)(i / ((size_t)ld * Rc * Sc));
+            const int b = (r0 + 2 * (t / Sc)) * 3 + s0 + 2 * (t % Sc);
+            DT<T>::st(dst + i, a < A ? src[((size_t)a * B + b) * C + c] : 0.f);
+        }
     }
 }
 extern "C" int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int ld, int mode, hipStream_t stream) {
-    const size_t total = mode == 0 ? (size_t)A * ld : (size_t)C * B * ld;
+    if (mode < 0 || mode > 5 || (mode >= 2 && B != 9)) { nkb_set_error("wprep: bad mode %d (B=%d)", mode, B); return 1; }
+    const int ctaps = mode >= 2 ? (((mode - 2) >> 1) ? 2 : 1) * (((mode - 2) & 1) ? 2 : 1) : B;
+    const size_t total = mode == 0 ? (size_t)A * ld : (size_t)C * ctaps * ld;
     NkbProfScope prof(NKB_K_WPREP, stream, 0);
     if (dtype == NKB_DT_BF16)
         hipLaunchKernelGGL(wprep_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, src, (bf16_t*)dst, A, B, C, ld, mode);

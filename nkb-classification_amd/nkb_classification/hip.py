@@ -32,6 +32,7 @@ _SIGS = {
     "nkb_bn_stats_floats": (sz, [i32, i32]),
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
     "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 13 + [vp]),
+    "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
     "nkb_stem_pack": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
@@ -171,6 +172,13 @@ def conv_dgrad_bn(dtype, dy, w, g_masked, c, scale, shift, mean, stats, *, N, H,
     check(load().nkb_conv_dgrad_bn(dtype, ptr(dy), ptr(w), ptr(g_masked), ptr(c), ptr(scale), ptr(shift), ptr(mean),
                                    ptr(stats), N, H, W, Cin, ldx, P, Q, Cout, ldy, R, S, stride, pad, stream()),
           "conv_dgrad_bn")
+
+
+def conv_dgrad_s2class(dtype, dy, w_class, y, add, c, scale, shift, mean, stats, N, Hdy, Wdy, K, ldx, Hout, Wout, C_, ldy,
+                       ldadd, ph, pw, add_h=0, add_w=0):
+    check(load().nkb_conv_dgrad_s2class(dtype, ptr(dy), ptr(w_class), ptr(y), ptr(add), ptr(c), ptr(scale), ptr(shift),
+                                        ptr(mean), ptr(stats), N, Hdy, Wdy, K, ldx, Hout, Wout, C_, ldy, ldadd, ph, pw,
+                                        add_h, add_w, stream()), "conv_dgrad_s2class")
 
 
 def bn_backward_from_stats(dtype, g, x, stats, tiles, mean, invstd, gamma, rows, C_, dgamma, dbeta, dx, sums):

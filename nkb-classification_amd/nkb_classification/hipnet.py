@@ -19,6 +19,8 @@ from .runtime import ParamArena, Workspace, _round_up
 _PACKED_STEM = os.environ.get("NKB_PACKED_STEM", "1") != "0"
 # reduction pass of an interior BN stage's backward folded into the epilogue of the dgrad that produces its input
 _FUSED_BN_BWD = os.environ.get("NKB_FUSED_BNBWD", "1") != "0"
+# 3x3 stride-2 data gradients as four parity-class launches (9 taps instead of 36 multiplied, 27 of them by zero)
+_S2_CLASSES = os.environ.get("NKB_S2_CLASSES", "1") != "0"
 
 
 class HipEngine:
@@ -36,6 +38,7 @@ class HipEngine:
         self._wver = -1
         self._wd: Dict[int, torch.Tensor] = {}     # id(conv/linear weight) -> dgrad-layout shadow
         self._wpad: Dict[int, torch.Tensor] = {}   # id(stem weight) -> K-padded forward shadow
+        self._wd_cls: Dict[int, list] = {}         # id(3x3 stride-2 weight) -> four parity-class dgrad shadows
         self._convs: List[nn.Module] = []
         self._stems: List[nn.Module] = []
         self._heads = None
@@ -86,6 +89,13 @@ class HipEngine:
                 if buf is None:
                     buf = self._wd[id(w)] = torch.empty(ci, r, s, co, device=self.device, dtype=self.T)
                 hip.wprep(self.d, a.param_flat(w), buf, co, r * s, ci, co, 1)
+                if self.s2_classes(conv):
+                    cls = self._wd_cls.get(id(w))
+                    if cls is None:
+                        cls = self._wd_cls[id(w)] = [torch.empty(ci, (2 if k >> 1 else 1) * (2 if k & 1 else 1), co,
+                                                                 device=self.device, dtype=self.T) for k in range(4)]
+                    for k in range(4):
+                        hip.wprep(self.d, a.param_flat(w), cls[k], co, 9, ci, co, 2 + k)
             hw, _ = self._heads
             ctot = sum(w.shape[0] for w in hw)
             E = hw[0].shape[1]
@@ -99,6 +109,11 @@ class HipEngine:
         self._wver = a.version
 
     _dgrad_ready = False
+
+    @staticmethod
+    def s2_classes(conv) -> bool:
+        return (_S2_CLASSES and isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+                and conv.padding == (1, 1))
 
     @staticmethod
     def packed_stem(conv: nn.Conv2d) -> bool:
@@ -415,6 +430,25 @@ class HipEngine:
                           ldx=geom["Cout"], P=1, Q=1, Cout=ci, ldy=ci)
             return dx
         dx = self.scratch(slot, (N, H, W, ci))
+        if self.s2_classes(conv) and id(w) in self._wd_cls:
+            co, P, Q = geom["Cout"], geom["P"], geom["Q"]
+            svp = self.saved[fuse_bn] if fuse_bn is not None else None
+            shapes = [((H - (k >> 1) + 1) // 2, (W - (k & 1) + 1) // 2) for k in range(4)]
+            stats, tiles_of, total = None, [0] * 4, 0
+            if svp is not None:
+                assert add is None
+                tiles_of = [hip.stat_tiles(self.d, N * pc * qc, ci) if pc > 0 and qc > 0 else 0 for pc, qc in shapes]
+                total = sum(tiles_of)
+                stats = self.ws.get(fuse_bn + ".bstats", (hip.bn_stats_floats(total, ci),), torch.float32)
+            base = 0
+            for k in range(4):
+                st_k = stats[base * 2 * ci:] if stats is not None else None
+                hip.conv_dgrad_s2class(self.d, g_c, self._wd_cls[id(w)][k], dx, add, svp["c"] if svp else None,
+                                       svp["scale"] if svp else None, svp["shift"] if svp else None,
+                                       svp["mean"] if svp else None, st_k, N, P, Q, co, co, H, W, ci, ci,
+                                       ci if add is not None else 0, k >> 1, k & 1, add_hw[0], add_hw[1])
+                base += tiles_of[k]
+            return (dx, (stats, total)) if svp is not None else dx
         if fuse_bn is not None:
             assert add is None
             svp = self.saved[fuse_bn]

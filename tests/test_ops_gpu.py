@@ -366,6 +366,72 @@ def test_dgrad_with_fused_bn_backward_matches_unfused(dtype, geo):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H", [12, 13])
+@pytest.mark.parametrize("variant", ["plain", "add", "subadd", "bn"])
+def test_s2_dgrad_parity_classes_match_gather_form(dtype, H, variant):
+    """Four parity-class launches == nkb_conv_gemm(mode 1, stride 2) (pinned against torch above), with a residual
+    operand, with the sub-grid residual of a stride-2 shortcut, and with the fused BN-backward epilogue."""
+    torch.manual_seed(19)
+    N, C, K = 2, 128, 64 if dtype == torch.bfloat16 else 32      # conv: C -> K channels, 3x3 / 2 / pad 1
+    P = (H + 2 - 3) // 2 + 1
+    d = hip.dt(dtype)
+    dy = torch.randn(N, P, P, K, device=DEV).to(dtype)
+    w = (torch.randn(K, 3, 3, C, device=DEV) * 0.1)                # fp32 master [Cout][R][S][Cin]
+    wt = torch.empty(C, 9, K, device=DEV, dtype=dtype)
+    hip.wprep(d, w, wt, K, 9, C, K, 1)
+    wcls = [torch.empty(C, (2 if k >> 1 else 1) * (2 if k & 1 else 1), K, device=DEV, dtype=dtype) for k in range(4)]
+    for k in range(4):
+        hip.wprep(d, w, wcls[k], K, 9, C, K, 2 + k)
+    geom = dict(N=N, H=P, W=P, Cin=K, ldx=K, P=H, Q=H, Cout=C, ldy=C, R=3, S=3, stride=2, pad=1)
+    add, add_hw = None, (0, 0)
+    if variant == "add":
+        add = torch.randn(N, H, H, C, device=DEV).to(dtype)
+    elif variant == "subadd":
+        add_hw = ((H + 1) // 2, (H + 1) // 2)
+        add = torch.randn(N, add_hw[0], add_hw[1], C, device=DEV).to(dtype)
+    y0 = torch.empty(N, H, H, C, device=DEV, dtype=dtype)
+    y1 = torch.full_like(y0, float("nan"))
+    if variant != "bn":
+        hip.conv_gemm(d, 1, dy, wt, y0, add=add, ldadd=C if add is not None else 0, add_hw=add_hw, **geom)
+        for k in range(4):
+            hip.conv_dgrad_s2class(d, dy, wcls[k], y1, add, None, None, None, None, None, N, P, P, K, K, H, H, C, C,
+                                   C if add is not None else 0, k >> 1, k & 1, add_hw[0], add_hw[1])
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y1.float(), y0.float(), **tol(dtype, 9 * K))
+        return
+    rows = N * H * H
+    c = torch.randn(N, H, H, C, device=DEV).to(dtype)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    cf = c.float().reshape(rows, C)
+    mean = cf.mean(0).contiguous()
+    invstd = (cf.var(0, unbiased=False) + 1e-5).rsqrt().contiguous()
+    scale = (gamma * invstd).contiguous()
+    shift = (0.05 - mean * scale).contiguous()
+    tiles0 = hip.stat_tiles(d, rows, C)
+    st0 = torch.zeros(hip.bn_stats_floats(tiles0, C), device=DEV)
+    hip.conv_dgrad_bn(d, dy, wt, y0, c, scale, shift, mean, st0, **geom)
+    dg0, db0, dc0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.empty_like(c)
+    sums = torch.empty(2 * C, device=DEV)
+    hip.bn_backward_from_stats(d, y0, c, st0, tiles0, mean, invstd, gamma, rows, C, dg0, db0, dc0, sums)
+    shapes = [((H - (k >> 1) + 1) // 2, (H - (k & 1) + 1) // 2) for k in range(4)]
+    tiles_of = [hip.stat_tiles(d, N * a * b, C) for a, b in shapes]
+    st1 = torch.zeros(hip.bn_stats_floats(sum(tiles_of), C), device=DEV)
+    base = 0
+    for k in range(4):
+        hip.conv_dgrad_s2class(d, dy, wcls[k], y1, None, c, scale, shift, mean, st1[base * 2 * C:], N, P, P, K, K, H, H, C,
+                               C, 0, k >> 1, k & 1)
+        base += tiles_of[k]
+    dg1, db1, dc1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.empty_like(c)
+    hip.bn_backward_from_stats(d, y1, c, st1, sum(tiles_of), mean, invstd, gamma, rows, C, dg1, db1, dc1, sums)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y1.float(), y0.float(), **tol(dtype, 9 * K))
+    st = dict(rtol=1e-4, atol=1e-3) if dtype == torch.float32 else dict(rtol=2e-2, atol=0.3)
+    torch.testing.assert_close(db1, db0, **st)
+    torch.testing.assert_close(dg1, dg0, **st)
+    torch.testing.assert_close(dc1.float(), dc0.float(), **tol(dtype, 64))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_avgpool_fwd_bwd(dtype):
     torch.manual_seed(6)
     N, C, HW = 3, 512, 49
