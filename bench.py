@@ -40,6 +40,21 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(args, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
+    (profiles/r01d_pmc_traffic.json, produced by scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes).  A bench run cannot profile itself, so this is the measurement on file for the
+    default workload; any other workload reports null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_pmc_traffic.json")
+    if not (args.model == "resnet50" and args.batch == 256 and args.dtype == "bf16" and os.path.exists(path)):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def usable_cpus() -> int:
     """Host cores this process may really use: affinity mask, cgroup quota, and the GPU box's 16-core share."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -228,7 +243,7 @@ def main():
             peak_tf, peak_gbs = PEAK_TFLOPS[args.dtype], HBM_PEAK_GBS
             t_mfma, t_hbm = v["work"] / (peak_tf * 1e12), v.get("bytes", 0.0) / (peak_gbs * 1e9)
             total_ms = sum(x["ms"] for x in prof.values())
-            common = dict(traffic=None, kernel=name, launches_per_step=v["launches"] // nprof,
+            common = dict(traffic=pmc_traffic(args, name), kernel=name, launches_per_step=v["launches"] // nprof,
                           avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
                           share_of_gpu_time=round(v["ms"] / total_ms, 3),
                           gflop_per_launch=round(v["work"] / v["launches"] / 1e9, 3),

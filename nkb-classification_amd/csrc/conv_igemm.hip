@@ -442,9 +442,15 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wn = wave & 1;
-    const int tile_c = blockIdx.x % p.tilesC;
-    const int tile_n = blockIdx.x / p.tilesC;
-    const int split = blockIdx.y;
+    // 1-D grid of tiles x splits, XCD-aware: consecutive logical ids = the tiles of ONE pixel range (split) and land on
+    // one XCD, so a dY / X row that several tiles need is fetched into one L2 instead of eight
+    // (rocprofv3 FETCH_SIZE before: 443 MB per launch against 194 MB of operands)
+    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
+    const unsigned lid = gridDim.y == 1 && gridDim.z == 1 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tile = (int)(lid % ntile);
+    const int tile_c = tile % p.tilesC;
+    const int tile_n = tile / p.tilesC;
+    const int split = (int)(lid / ntile);
     const int c0 = tile_c * TW, n0 = tile_n * TW;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
@@ -915,7 +921,7 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     }
     NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot,
                       ((double)N * H * W * Cin + (double)p.M * Cout) * esz + 2.0 * 4.0 * Cout * p.Ntot);
-    dim3 grid((unsigned)tiles, (unsigned)splits);
+    dim3 grid((unsigned)tiles * (unsigned)splits);
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
     return nkb_check_launch("conv_wgrad");
@@ -1040,7 +1046,7 @@ extern "C" int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* 
         attr_set = true;
     }
     NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot);
-    dim3 grid((unsigned)tiles, (unsigned)splits);
+    dim3 grid((unsigned)tiles * (unsigned)splits);
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
     return nkb_check_launch("stem_wgrad");
