@@ -43,9 +43,12 @@ int nkb_version(void);
  * Cin must be a multiple of 64 (bf16) / 32 (fp32); stride in {1,2}. */
 int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add, const float* bias,
                   float* stats, int N, int H, int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int ldadd,
-                  int R, int S, int stride, int pad, int relu, int out_f32, int add_h, int add_w, nkb_stream_t stream);
+                  int R, int S, int stride, int pad, int relu, int out_f32, int add_h, int add_w,
+                  const unsigned char* add_bits, nkb_stream_t stream);
 /* add_h/add_w > 0: `add` is an [N][add_h][add_w] tensor living on the even (h, w) positions of the output grid (the
  * gradient of a stride-2 1x1 shortcut conv, folded in without materialising its zero-dilated form). */
+/* add_bits (optional): ReLU bit mask of the `add` operand as written by nkb_bn_apply(relu_bits): add[m][c] only counts
+ * where its bit is set (the gradient of a residual block's output, masked on the fly instead of in a separate pass). */
 int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout);
 void nkb_set_ring(int mode); /* 0: register-staged kernel only; 1: persistent LDS-DMA ring kernel where eligible */
 
@@ -58,10 +61,13 @@ int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* d
 int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
                     float* shift, float* save_mean, float* save_invstd, nkb_stream_t stream);
+/* relu_bits (optional out): one byte per 16-byte chunk of y (8 bf16 / 4 fp32 channels), bit e = y[chunk*n + e] > 0 */
 int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, const float* scale, const float* shift,
-                 long long rows, int C, int relu, nkb_stream_t stream);
-/* ReLU mask: from yact (> 0) when given, else recomputed as x*fscale+fshift > 0 when fscale is given, else none. */
-int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const float* fscale,
+                 long long rows, int C, int relu, unsigned char* relu_bits, nkb_stream_t stream);
+/* ReLU mask: from relu_bits when given, else yact (> 0), else recomputed as x*fscale+fshift > 0 when fscale is given,
+ * else none. */
+int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const unsigned char* relu_bits,
+                    const float* fscale,
                     const float* fshift, const float* mean, const float* invstd, const float* gamma, long long rows,
                     int C, float* dgamma, float* dbeta, void* dx, void* dy_masked, float* workspace,
                     size_t workspace_floats, nkb_stream_t stream);

@@ -294,19 +294,28 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
             am = ((size_t)n * p.add_h + (hh >> 1)) * p.add_w + (ww >> 1);
         }
         if (do_add) {
+            unsigned abits = 0xffu;
+            if (p.add_bits) {
+                if constexpr (sizeof(T) == 2) {
+                    abits = p.add_bits[am * (size_t)(p.ldadd >> 3) + (co >> 3)];
+                } else {
+                    const unsigned char* bp = p.add_bits + am * (size_t)(p.ldadd >> 2) + (co >> 2);
+                    abits = (unsigned)bp[0] | ((co + 4 < p.Cout ? (unsigned)bp[1] : 0u) << 4);
+                }
+            }
             if (p.out_f32 || sizeof(T) == 4) {
                 const float* a = (const float*)p.add + am * p.ldadd + co;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (co + e < p.Cout) v[e] += a[e];
+                for (int e = 0; e < 8; ++e) if (co + e < p.Cout && ((abits >> e) & 1u)) v[e] += a[e];
             } else if (vec_ok) {
                 float fa[8];
                 unpack8(*(const u32x4*)((const bf16_t*)p.add + am * p.ldadd + co), fa);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += fa[e];
+                for (int e = 0; e < 8; ++e) v[e] += ((abits >> e) & 1u) ? fa[e] : 0.f;
             } else {
                 const bf16_t* a = (const bf16_t*)p.add + am * p.ldadd + co;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (co + e < p.Cout) v[e] += bf2f(a[e]);
+                for (int e = 0; e < 8; ++e) if (co + e < p.Cout && ((abits >> e) & 1u)) v[e] += bf2f(a[e]);
             }
         }
         float cv[8];                           // BNB: raw conv output of the stage whose BN backward consumes v
@@ -679,7 +688,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
 extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add,
                              const float* bias, float* stats, int N, int H, int W, int Cin, int ldx, int P, int Q,
                              int Cout, int ldy, int ldadd, int R, int S, int stride, int pad, int relu, int out_f32,
-                             int add_h, int add_w, hipStream_t stream) {
+                             int add_h, int add_w, const unsigned char* add_bits, hipStream_t stream) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
     const int kte = 128 / esz;
     if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_gemm: bad dtype %d", dtype); return 1; }
@@ -707,6 +716,8 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     p.add_h = add_h; p.add_w = add_w; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
+    if (add_bits && (add == nullptr || add_h > 0 || ldadd % 8 != 0)) { nkb_set_error("conv_gemm: add_bits needs a full-grid add with ldadd %% 8 == 0"); return 1; }
+    p.add_bits = add_bits;
     const double flops = 2.0 * p.M * (double)Cout * R * S * Cin;
     // algorithmic bytes: every operand element once (source image, filter, destination, residual operand)
     const double bytes = ((double)N * H * W * Cin + (double)Cout * R * S * Cin) * esz +

@@ -35,6 +35,9 @@ struct ConvParams {
     // parity-class launch of a stride-2 dgrad: the M rows of this launch are the pixels (2h'+sub_ph, 2w'+sub_pw) of a
     // [N][sub_h][sub_w] destination (P, Q = the class sub-grid); 0 = off
     int sub_h = 0, sub_w = 0, sub_ph = 0, sub_pw = 0;
+    // optional ReLU bit mask of the `add` operand (bn_apply's relu_bits of the stage whose output gradient `add` is):
+    // add[m][c] only counts where bit (c % chunk) of add_bits[m][c / chunk] is set, chunk = 8 (bf16) / 4 (fp32) channels
+    const unsigned char* add_bits = nullptr;
     int ldw;            // row stride of w in elements (R*S*Cin unless batched)
     int inner;
     long long sxo, sxi, swo, swi, syo, syi;

@@ -149,7 +149,8 @@ static inline unsigned grid_cols(size_t rows, int cpr, unsigned want_blocks = 0)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ y, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, unsigned rows, int C, int relu) {
+                                                       const float* __restrict__ shift, unsigned rows, int C, int relu,
+                                                       unsigned char* __restrict__ bits) {
     constexpr int N = Chunk<T>::N;
     const unsigned cpr = (unsigned)C / N;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,21 +175,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         }
         Chunk<T>::store(y + o0, v0);
         if (two) Chunk<T>::store(y + o1, v1);
+        if (bits) {     // one byte per chunk: bit e = stored y[e] > 0 (the ReLU mask the backward pass needs, 16x smaller than y)
+            unsigned b0 = 0u, b1 = 0u;
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                b0 |= (DT<T>::rnd(v0[e]) > 0.f ? 1u : 0u) << e;
+                b1 |= (DT<T>::rnd(v1[e]) > 0.f ? 1u : 0u) << e;
+            }
+            bits[(size_t)r * cpr + cg] = (unsigned char)b0;
+            if (two) bits[(size_t)(r + rs) * cpr + cg] = (unsigned char)b1;
+        }
     }
 }
 
 extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, const float* scale, const float* shift,
-                            long long rows, int C, int relu, hipStream_t stream) {
+                            long long rows, int C, int relu, unsigned char* relu_bits, hipStream_t stream) {
     const int n = dtype == NKB_DT_BF16 ? 8 : 4;
     if (C % n || rows >= (1ll << 31)) { nkb_set_error("bn_apply: C=%d not a multiple of %d (or too many rows)", C, n); return 1; }
     NkbProfScope prof(NKB_K_BN_APPLY, stream, 0, (double)rows * C * (dtype == NKB_DT_BF16 ? 2 : 4) * (res ? 3 : 2));
     const unsigned grid = grid_cols((size_t)rows, C / n);
     if (dtype == NKB_DT_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x,
-                           (const bf16_t*)res, (bf16_t*)y, scale, shift, (unsigned)rows, C, relu);
+                           (const bf16_t*)res, (bf16_t*)y, scale, shift, (unsigned)rows, C, relu, relu_bits);
     else
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x,
-                           (const float*)res, (float*)y, scale, shift, (unsigned)rows, C, relu);
+                           (const float*)res, (float*)y, scale, shift, (unsigned)rows, C, relu, relu_bits);
     return nkb_check_launch("bn_apply");
 }
 
@@ -200,6 +211,7 @@ extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, 
 // stride blockDim/(C/N); block partials go to part[b][2][C] (deterministic), reduced by pass 1b.
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
+                                     const unsigned char* __restrict__ bits,
                                      const float* __restrict__ fscale, const float* __restrict__ fshift,
                                      const float* __restrict__ mean, const float* __restrict__ invstd, long long rows,
                                      int C, int rpb, float* __restrict__ part) {
@@ -228,9 +240,12 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
             Chunk<T>::load(dy + off1, g1);
             Chunk<T>::load(x + off1, xv1);
             if (yact) { Chunk<T>::load(yact + off, ya); Chunk<T>::load(yact + off1, ya1); }
+            unsigned m0 = 0xffu, m1 = 0xffu;
+            if (bits) { m0 = bits[(size_t)r * cpr + cg]; m1 = bits[(size_t)(two ? r + gs : r) * cpr + cg]; }
 #pragma unroll
             for (int e = 0; e < N; ++e) {
                 float gg = g[e], hh = two ? g1[e] : 0.f;
+                if (bits) { if (!((m0 >> e) & 1u)) gg = 0.f; if (!((m1 >> e) & 1u)) hh = 0.f; }
                 if (yact) { if (!(ya[e] > 0.f)) gg = 0.f; if (!(ya1[e] > 0.f)) hh = 0.f; }
                 if (fscale) {
                     if (!(DT<T>::rnd(xv[e] * fs[e] + fb[e]) > 0.f)) gg = 0.f;
@@ -298,7 +313,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 // pass 2: dx = gamma*invstd * (dy' - sum_dy/M - xhat*sum_dy_xhat/M); optionally writes dy' back (masked grad).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                           const T* __restrict__ yact, const float* __restrict__ fscale,
+                                                           const T* __restrict__ yact, const unsigned char* __restrict__ bits,
+                                                           const float* __restrict__ fscale,
                                                            const float* __restrict__ fshift, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
@@ -337,9 +353,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         Chunk<T>::load(dy + o1, g1);
         Chunk<T>::load(x + o1, x1);
         if (yact) { Chunk<T>::load(yact + o0, y0); Chunk<T>::load(yact + o1, y1); }
+        unsigned m0 = 0xffu, m1 = 0xffu;
+        if (bits) { m0 = bits[(size_t)r * cpr + cg]; m1 = bits[(size_t)(two ? r + rs : r) * cpr + cg]; }
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             float a = g0[e], b = g1[e];
+            if (bits) { if (!((m0 >> e) & 1u)) a = 0.f; if (!((m1 >> e) & 1u)) b = 0.f; }
             if (yact) { if (!(y0[e] > 0.f)) a = 0.f; if (!(y1[e] > 0.f)) b = 0.f; }
             if (fscale) {
                 if (!(DT<T>::rnd(x0[e] * fs[e] + fb[e]) > 0.f)) a = 0.f;
@@ -359,7 +378,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // eval-mode / frozen-stat backward is not needed: frozen backbones skip backward entirely.
-extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const float* fscale,
+extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const unsigned char* relu_bits,
+                               const float* fscale,
                                const float* fshift, const float* mean,
                                const float* invstd, const float* gamma, long long rows, int C, float* dgamma,
                                float* dbeta, void* dx, void* dy_masked, float* workspace, size_t workspace_floats,
@@ -382,27 +402,27 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
     const size_t lds = (size_t)2 * tpc * C * sizeof(float);
     const double tensor_bytes = (double)rows * C * (dtype == NKB_DT_BF16 ? 2 : 4);
     {
-        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0, tensor_bytes * (yact ? 3 : 2));
+        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0, tensor_bytes * (yact ? 3 : 2) + (relu_bits ? (double)rows * cpr : 0.0));
         if (dtype == NKB_DT_BF16)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(threads), lds, stream, (const bf16_t*)dy,
-                               (const bf16_t*)x, (const bf16_t*)yact, fscale, fshift, mean, invstd, rows, C, rpb, part);
+                               (const bf16_t*)x, (const bf16_t*)yact, relu_bits, fscale, fshift, mean, invstd, rows, C, rpb, part);
         else
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(threads), lds, stream, (const float*)dy,
-                               (const float*)x, (const float*)yact, fscale, fshift, mean, invstd, rows, C, rpb, part);
+                               (const float*)x, (const float*)yact, relu_bits, fscale, fshift, mean, invstd, rows, C, rpb, part);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, stream, part, blocks, C, dgamma,
                            dbeta, sums);
     }
     if (int rc = nkb_check_launch("bn_bwd_reduce")) return rc;
     if (dx) {
-        NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0, tensor_bytes * ((yact ? 3 : 2) + 1 + (dy_masked ? 1 : 0)));
+        NkbProfScope prof(NKB_K_BN_BWD_APPLY, stream, 0, tensor_bytes * ((yact ? 3 : 2) + 1 + (dy_masked ? 1 : 0)) + (relu_bits ? (double)rows * cpr : 0.0));
         const unsigned grid = grid_cols((size_t)rows, cpr);
         if (dtype == NKB_DT_BF16)
             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream,
-                               (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)yact, fscale, fshift, mean, invstd, gamma, sums,
+                               (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)yact, relu_bits, fscale, fshift, mean, invstd, gamma, sums,
                                1.0f / (float)rows, (unsigned)rows, C, (bf16_t*)dx, (bf16_t*)dy_masked);
         else
             hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream,
-                               (const float*)dy, (const float*)x, (const float*)yact, fscale, fshift, mean, invstd, gamma, sums,
+                               (const float*)dy, (const float*)x, (const float*)yact, relu_bits, fscale, fshift, mean, invstd, gamma, sums,
                                1.0f / (float)rows, (unsigned)rows, C, (float*)dx, (float*)dy_masked);
     }
     return nkb_check_launch("bn_bwd_apply");
@@ -1100,11 +1120,11 @@ extern "C" int nkb_bn_backward_from_stats(int dtype, const void* g, const void* 
     const unsigned grid = grid_cols((size_t)rows, C / n);
     if (dtype == NKB_DT_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)g, (const bf16_t*)x,
-                           (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, mean, invstd, gamma, sums,
+                           (const bf16_t*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, (const float*)nullptr, mean, invstd, gamma, sums,
                            1.0f / (float)rows, (unsigned)rows, C, (bf16_t*)dx, (bf16_t*)nullptr);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)g, (const float*)x,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, mean, invstd, gamma, sums,
+                           (const float*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, (const float*)nullptr, mean, invstd, gamma, sums,
                            1.0f / (float)rows, (unsigned)rows, C, (float*)dx, (float*)nullptr);
     return nkb_check_launch("bn_bwd_apply");
 }

@@ -154,7 +154,9 @@ class HipResNet(_ParamOnly):
             eng.begin_block(bi)
             n = len(blk.stages())
             # last stage: ReLU(bn(conv) + shortcut); the masked incoming gradient also feeds the shortcut
-            gc = eng.bn_backward(f"{name}.{n - 1}", g, "t0", write_masked=True)
+            last = f"{name}.{n - 1}"
+            gc = eng.bn_backward(last, g, "t0", write_masked=True)
+            bits = eng.saved[last].get("bits")       # set: g was NOT masked in place, consumers apply the bits
             for k in range(n - 1, 0, -1):
                 prev = f"{name}.{k - 1}"
                 if eng.can_fuse_bn_backward(prev):
@@ -163,15 +165,16 @@ class HipResNet(_ParamOnly):
                 else:
                     ga = eng.conv_backward(f"{name}.{k}", gc, f"a{k}")
                     gc = eng.bn_backward(prev, ga, f"c{k}")
-            add, add_hw = g, (0, 0)
+            add, add_hw, add_bits = g, (0, 0), bits
             if blk.downsample is not None:
-                gcd = eng.bn_backward(f"{name}.ds", g, "t5")
+                add_bits = None
+                gcd = eng.bn_backward(f"{name}.ds", g, "t5", g_bits=bits)
                 dconv = blk.downsample[0]
                 sub = dconv.stride[0] == 2 and dconv.kernel_size[0] == 1 and dconv.padding[0] == 0
                 add = eng.conv_backward(f"{name}.ds", gcd, "t6", subgrid=sub)
                 if sub:
                     add_hw = (add.shape[1], add.shape[2])
-            g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add, add_hw=add_hw)
+            g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add, add_hw=add_hw, add_bits=add_bits)
             flip ^= 1
             eng.end_block(bi)
             if on_done is not None and name.endswith(".0"):

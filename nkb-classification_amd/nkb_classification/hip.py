@@ -22,13 +22,13 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 _SIGS = {
     "nkb_version": (i32, []),
     "nkb_last_error": (C.c_char_p, []),
-    "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 18 + [vp]),
+    "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 18 + [vp, vp]),
     "nkb_conv_gemm_stat_tiles": (i32, [i32, i32, i32]),
     "nkb_set_ring": (None, [i32]),
     "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp]),
     "nkb_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
-    "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
-    "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
+    "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
     "nkb_bn_stats_floats": (sz, [i32, i32]),
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
     "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 13 + [vp]),
@@ -130,10 +130,10 @@ def require_device(t: torch.Tensor, what: str):
 
 # ------------------------------------------------------------------ thin typed wrappers ----
 def conv_gemm(dtype, mode, x, w, y, *, N, H, W, Cin, ldx, P, Q, Cout, ldy, R=1, S=1, stride=1, pad=0, add=None,
-              ldadd=0, bias=None, stats=None, relu=False, out_f32=False, add_hw=(0, 0)):
+              ldadd=0, bias=None, stats=None, relu=False, out_f32=False, add_hw=(0, 0), add_bits=None):
     check(load().nkb_conv_gemm(dtype, mode, ptr(x), ptr(w), ptr(y), ptr(add), ptr(bias), ptr(stats), N, H, W, Cin, ldx,
                                P, Q, Cout, ldy, ldadd, R, S, stride, pad, int(relu), int(out_f32), add_hw[0], add_hw[1],
-                               stream()), "conv_gemm")
+                               ptr(add_bits), stream()), "conv_gemm")
 
 
 def stat_tiles(dtype, M, Cout):
@@ -150,9 +150,9 @@ def bn_finalize(partials, tiles, C_, count, gamma, beta, rm, rv, momentum, eps, 
                                  int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream()), "bn_finalize")
 
 
-def bn_apply(dtype, x, res, y, scale, shift, rows, C_, relu):
-    check(load().nkb_bn_apply(dtype, ptr(x), ptr(res), ptr(y), ptr(scale), ptr(shift), rows, C_, int(relu), stream()),
-          "bn_apply")
+def bn_apply(dtype, x, res, y, scale, shift, rows, C_, relu, relu_bits=None):
+    check(load().nkb_bn_apply(dtype, ptr(x), ptr(res), ptr(y), ptr(scale), ptr(shift), rows, C_, int(relu),
+                              ptr(relu_bits), stream()), "bn_apply")
 
 
 def bn_stats_floats(tiles, C_):
@@ -160,8 +160,9 @@ def bn_stats_floats(tiles, C_):
 
 
 def bn_backward(dtype, dy, x, yact, mean, invstd, gamma, rows, C_, dgamma, dbeta, dx, dy_masked, workspace,
-                fscale=None, fshift=None):
-    check(load().nkb_bn_backward(dtype, ptr(dy), ptr(x), ptr(yact), ptr(fscale), ptr(fshift), ptr(mean), ptr(invstd),
+                fscale=None, fshift=None, relu_bits=None):
+    check(load().nkb_bn_backward(dtype, ptr(dy), ptr(x), ptr(yact), ptr(relu_bits), ptr(fscale), ptr(fshift), ptr(mean),
+                                 ptr(invstd),
                                  ptr(gamma), rows, C_,
                                  ptr(dgamma), ptr(dbeta), ptr(dx), ptr(dy_masked), ptr(workspace), workspace.numel(),
                                  stream()), "bn_backward")

@@ -21,6 +21,9 @@ _PACKED_STEM = os.environ.get("NKB_PACKED_STEM", "1") != "0"
 _FUSED_BN_BWD = os.environ.get("NKB_FUSED_BNBWD", "1") != "0"
 # 3x3 stride-2 data gradients as four parity-class launches (9 taps instead of 36 multiplied, 27 of them by zero)
 _S2_CLASSES = os.environ.get("NKB_S2_CLASSES", "1") != "0"
+# residual-closing stages keep a 1-bit/element ReLU mask; backward reads it instead of the activation and the masked
+# block-output gradient is never materialised (consumers apply the bits on the fly)
+_RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
 
 
 class HipEngine:
@@ -152,6 +155,7 @@ class HipEngine:
             geom = dict(N=N, H=H, W=W, Cin=ci, ldx=ci, P=P, Q=Q, Cout=co, ldy=co, R=R, S=S, stride=st, pad=pad)
         rows = N * P * Q
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
+        bits = None
         tiles = hip.stat_tiles(self.d, rows, co)
         stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
         if packed:
@@ -172,11 +176,15 @@ class HipEngine:
         else:
             idx = None
             y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
-            hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu)
+            # stages that close a residual block keep their ReLU mask as one bit per element for backward (the mask
+            # cannot be recomputed from c alone there); y itself is then only read by the next block's convolutions
+            if train and relu and res is not None and _RELU_BITS:
+                bits = self.ws.get(key + ".bits", (rows, co // (8 if self.T == torch.bfloat16 else 4)), torch.uint8)
+            hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu, bits)
         if train:
             self.saved[key] = dict(x=x, c=c, y=y, mean=mean, invstd=invstd, relu=relu, geom=geom, conv=conv, bn=bn,
                                    rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None,
-                                   pool_idx=idx, stem_packed=bool(packed))
+                                   pool_idx=idx, stem_packed=bool(packed), bits=bits)
         return y
 
     def maxpool(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:
@@ -335,10 +343,13 @@ class HipEngine:
         hip.maxpool(self.d, True, g, dx, sv["idx"], N, H, W, C)
         return dx
 
-    def bn_backward(self, key: str, g_y: torch.Tensor, slot: str, write_masked: bool = False) -> torch.Tensor:
+    def bn_backward(self, key: str, g_y: torch.Tensor, slot: str, write_masked: bool = False,
+                    g_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
         """g_y: gradient w.r.t. the stage output y.  Returns the gradient w.r.t. the raw conv output.
         With write_masked the ReLU-masked g_y is written back in place (it then is the gradient that flows
-        into the residual branch)."""
+        into the residual branch) — unless the stage kept a bit mask (saved["bits"]): then g_y stays as it is and every
+        consumer applies the bits itself.  g_bits: bit mask to apply to g_y on the way in (the shortcut's BN backward,
+        whose incoming gradient is the block-output gradient under the main branch's ReLU)."""
         sv = self.saved[key]
         bn, rows = sv["bn"], sv["rows"]
         co = sv["c"].shape[-1]
@@ -346,11 +357,15 @@ class HipEngine:
         gc = self.scratch(slot, sv["c"].shape)
         work = self.ws.at_least("bn.work", hip.bn_backward_ws(rows, co), torch.float32)
         # ReLU mask: stages without a residual recompute it from the raw conv output (one tensor read less)
-        from_y = sv["relu"] and sv["has_res"]
-        from_x = sv["relu"] and not sv["has_res"]
+        bits = sv.get("bits") if g_bits is None else g_bits
+        from_y = sv["relu"] and sv["has_res"] and bits is None
+        from_x = sv["relu"] and not sv["has_res"] and bits is None
+        # with a bit mask nothing needs to be written back: consumers of g_y apply the same bits themselves
+        masked_out = g_y if (write_masked and sv["relu"] and bits is None) else None
         hip.bn_backward(self.d, g_y, sv["c"], sv["y"] if from_y else None, sv["mean"], sv["invstd"], bn.weight, rows,
-                        co, a.grad_flat(bn.weight), a.grad_flat(bn.bias), gc, g_y if (write_masked and sv["relu"]) else None,
-                        work, fscale=sv["scale"] if from_x else None, fshift=sv["shift"] if from_x else None)
+                        co, a.grad_flat(bn.weight), a.grad_flat(bn.bias), gc, masked_out,
+                        work, fscale=sv["scale"] if from_x else None, fshift=sv["shift"] if from_x else None,
+                        relu_bits=bits)
         return gc
 
     def bn_pool_backward(self, key: str, g_p: torch.Tensor, slot: str) -> torch.Tensor:
@@ -385,7 +400,8 @@ class HipEngine:
         return gc
 
     def conv_backward(self, key: str, g_c: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None,
-                      add_hw=(0, 0), subgrid: bool = False, fuse_bn: Optional[str] = None):
+                      add_hw=(0, 0), subgrid: bool = False, fuse_bn: Optional[str] = None,
+                      add_bits: Optional[torch.Tensor] = None):
         """Weight gradient into the arena; input gradient (optionally + add) when slot is given.
         fuse_bn=<stage key>: the conv's input was that stage's relu(bn(c)); returns (masked gradient, stats) for
         bn_backward_fused instead of the plain input gradient."""
@@ -431,6 +447,7 @@ class HipEngine:
             return dx
         dx = self.scratch(slot, (N, H, W, ci))
         if self.s2_classes(conv) and id(w) in self._wd_cls:
+            assert add_bits is None      # a stride-2 conv never sits under an identity shortcut
             co, P, Q = geom["Cout"], geom["P"], geom["Q"]
             svp = self.saved[fuse_bn] if fuse_bn is not None else None
             shapes = [((H - (k >> 1) + 1) // 2, (W - (k & 1) + 1) // 2) for k in range(4)]
@@ -460,7 +477,7 @@ class HipEngine:
             return dx, (stats, tiles)
         hip.conv_gemm(self.d, 1, g_c, self._wd[id(w)], dx, N=N, H=geom["P"], W=geom["Q"], Cin=geom["Cout"],
                       ldx=geom["Cout"], P=H, Q=W, Cout=ci, ldy=ci, R=geom["R"], S=geom["S"], stride=geom["stride"],
-                      pad=geom["pad"], add=add, ldadd=ci if add is not None else 0, add_hw=add_hw)
+                      pad=geom["pad"], add=add, ldadd=ci if add is not None else 0, add_hw=add_hw, add_bits=add_bits)
         return dx
 
     # ------------------------------------------------------------------ transformer ops ----

@@ -30,9 +30,9 @@ def test_library_loads_and_exports_header_symbols():
 def test_argument_validation_without_gpu():
     """Entry points validate geometry on the host before any launch (error text through nkb_last_error)."""
     lib = hip.load()
-    rc = lib.nkb_conv_gemm(1, 0, None, None, None, None, None, None, 1, 8, 8, 48, 48, 8, 8, 64, 64, 0, 1, 1, 1, 0, 0, 0, 0, 0, None)
+    rc = lib.nkb_conv_gemm(1, 0, None, None, None, None, None, None, 1, 8, 8, 48, 48, 8, 8, 64, 64, 0, 1, 1, 1, 0, 0, 0, 0, 0, None, None)
     assert rc != 0 and b"Cin=48" in lib.nkb_last_error()
-    rc = lib.nkb_conv_gemm(1, 0, None, None, None, None, None, None, 1, 8, 8, 64, 64, 8, 8, 64, 64, 0, 3, 3, 3, 1, 0, 0, 0, 0, None)
+    rc = lib.nkb_conv_gemm(1, 0, None, None, None, None, None, None, 1, 8, 8, 64, 64, 8, 8, 64, 64, 0, 3, 3, 3, 1, 0, 0, 0, 0, None, None)
     assert rc != 0 and b"stride" in lib.nkb_last_error()
-    rc = lib.nkb_bn_apply(1, None, None, None, None, None, 10, 12, 0, None)
+    rc = lib.nkb_bn_apply(1, None, None, None, None, None, 10, 12, 0, None, None)
     assert rc != 0 and b"C=12" in lib.nkb_last_error()

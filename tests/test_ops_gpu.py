@@ -432,6 +432,49 @@ def test_s2_dgrad_parity_classes_match_gather_form(dtype, H, variant):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_relu_bit_mask_paths_match_activation_mask(dtype):
+    """bn_apply(relu_bits) -> bn_backward(relu_bits) == bn_backward(yact), and a conv epilogue that adds a gradient
+    under the bits == adding the pre-masked gradient."""
+    torch.manual_seed(20)
+    rows, C = 777, 128
+    N, H = 3, 7                       # rows of the conv check: N*H*H = 147
+    d = hip.dt(dtype)
+    c = torch.randn(rows, C, device=DEV).to(dtype)
+    res = torch.randn(rows, C, device=DEV).to(dtype)
+    scale = torch.rand(C, device=DEV) + 0.5
+    shift = torch.randn(C, device=DEV) * 0.1
+    y = torch.empty_like(c)
+    nb = C // (8 if dtype == torch.bfloat16 else 4)
+    bits = torch.zeros(rows, nb, device=DEV, dtype=torch.uint8)
+    hip.bn_apply(d, c, res, y, scale, shift, rows, C, True, bits)
+    g = torch.randn(rows, C, device=DEV).to(dtype)
+    mean = torch.zeros(C, device=DEV); invstd = torch.ones(C, device=DEV); gamma = torch.rand(C, device=DEV) + 0.5
+    work = torch.empty(hip.bn_backward_ws(rows, C), device=DEV)
+    dg0, db0, dx0, gm0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.empty_like(c), g.clone()
+    hip.bn_backward(d, gm0, c, y, mean, invstd, gamma, rows, C, dg0, db0, dx0, gm0, work)
+    dg1, db1, dx1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.empty_like(c)
+    hip.bn_backward(d, g, c, None, mean, invstd, gamma, rows, C, dg1, db1, dx1, None, work, relu_bits=bits)
+    torch.cuda.synchronize()
+    mask = (y.float() > 0)
+    assert torch.equal(gm0.float(), g.float() * mask)
+    torch.testing.assert_close(db1, db0, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(dg1, dg0, rtol=1e-5, atol=1e-4)
+    assert torch.equal(dx1, dx0)
+    # conv epilogue: y = x W^T + add under bits
+    M = N * H * H
+    Cin = 64 if dtype == torch.bfloat16 else 32
+    x = torch.randn(M, Cin, device=DEV).to(dtype)
+    w = (torch.randn(C, Cin, device=DEV) * 0.1).to(dtype)
+    add = g[:M].contiguous()
+    o0, o1 = torch.empty(M, C, device=DEV, dtype=dtype), torch.empty(M, C, device=DEV, dtype=dtype)
+    geom = dict(N=M, H=1, W=1, Cin=Cin, ldx=Cin, P=1, Q=1, Cout=C, ldy=C)
+    hip.conv_gemm(d, 0, x, w, o0, add=gm0[:M].contiguous(), ldadd=C, **geom)
+    hip.conv_gemm(d, 0, x, w, o1, add=add, ldadd=C, add_bits=bits[:M].contiguous(), **geom)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_avgpool_fwd_bwd(dtype):
     torch.manual_seed(6)
     N, C, HW = 3, 512, 49
