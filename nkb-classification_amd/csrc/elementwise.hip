@@ -646,47 +646,77 @@ extern "C" int nkb_im2row(int dtype, const float* x, void* col, int N, int Cin, 
 // Weight re-layout from the fp32 master [A][B][C] (= [Cout][R*S][Cin]):
 //   mode 0: dst[a][ldd] = cast(src[a][0..B*C))   (row copy with zero padding up to ldd)
 //   mode 1: dst[c][b][a .. lda) = cast(src[a][b][c])  (dgrad layout, [Cin][R*S][lda], zero padded beyond A)
+// element i of the destination of one re-layout job (see the mode list above)
 template <typename T>
-__global__ void wprep_kernel(const float* __restrict__ src, T* __restrict__ dst, int A, int B, int C, int ld, int mode) {
+__device__ __forceinline__ void wprep_elem(const float* __restrict__ src, T* __restrict__ dst, size_t i, int A, int B, int C,
+                                           int ld, int mode) {
     if (mode == 0) {
-        const size_t total = (size_t)A * ld;
         const int K = B * C;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-            const int k = (int)(i % ld), a = (int)(i / ld);
-            DT<T>::st(dst + i, k < K ? src[(size_t)a * K + k] : 0.f);
-        }
+        const int k = (int)(i % ld), a = (int)(i / ld);
+        DT<T>::st(dst + i, k < K ? src[(size_t)a * K + k] : 0.f);
     } else if (mode == 1) {
-        const size_t total = (size_t)C * B * ld;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-            const int a = (int)(i % ld);
-            const int b = (int)((i / ld) % B);
-            const int c = (int)(i / ((size_t)ld * B));
-            DT<T>::st(dst + i, a < A ? src[((size_t)a * B + b) * C + c] : 0.f);
-        }
+        const int a = (int)(i % ld);
+        const int b = (int)((i / ld) % B);
+        const int c = (int)(i / ((size_t)ld * B));
+        DT<T>::st(dst + i, a < A ? src[((size_t)a * B + b) * C + c] : 0.f);
     } else {
         // modes 2..5: parity class (ph, pw) = ((mode-2)>>1, (mode-2)&1) of a 3x3 stride-2 filter in dgrad layout:
         // dst[c][ri][si][a] = src[a][(r0+2ri)*3 + s0+2si][c], r0 = (ph+1)%2, s0 = (pw+1)%2   (B must be 9)
         const int ph = (mode - 2) >> 1, pw = (mode - 2) & 1;
         const int r0 = (ph + 1) & 1, s0 = (pw + 1) & 1, Rc = ph ? 2 : 1, Sc = pw ? 2 : 1;
-        const size_t total = (size_t)C * Rc * Sc * ld;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-            const int a = (int)(i % ld);
-            const int t = (int)((i / ld) % (Rc * Sc));
-            const int c = (int)(i / ((size_t)ld * Rc * Sc));
-            const int b = (r0 + 2 * (t / Sc)) * 3 + s0 + 2 * (t % Sc);
-            DT<T>::st(dst + i, a < A ? src[((size_t)a * B + b) * C + c] : 0.f);
-        }
+        const int a = (int)(i % ld);
+        const int t = (int)((i / ld) % (Rc * Sc));
+        const int c = (int)(i / ((size_t)ld * Rc * Sc));
+        const int bb = (r0 + 2 * (t / Sc)) * 3 + s0 + 2 * (t % Sc);
+        DT<T>::st(dst + i, a < A ? src[((size_t)a * B + bb) * C + c] : 0.f);
     }
+}
+static inline size_t wprep_total(int A, int B, int C, int ld, int mode) {
+    const int ctaps = mode >= 2 ? (((mode - 2) >> 1) ? 2 : 1) * (((mode - 2) & 1) ? 2 : 1) : B;
+    return mode == 0 ? (size_t)A * ld : (size_t)C * ctaps * ld;
+}
+template <typename T>
+__global__ void wprep_kernel(const float* __restrict__ src, T* __restrict__ dst, int A, int B, int C, int ld, int mode, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        wprep_elem<T>(src, dst, i, A, B, C, ld, mode);
+}
+// All re-layout jobs of a step in ONE launch (54 + 12 small launches otherwise).  jobs[j] = {src element offset from
+// `base`, dst pointer, A, B, C, ld, mode, first block}; every block covers NKB_WPREP_BLOCK_ELEMS destination elements.
+#define NKB_WPREP_BLOCK_ELEMS 4096
+template <typename T>
+__global__ void wprep_multi_kernel(const float* __restrict__ base, const long long* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                     // last job whose first block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid * 8 + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* jb = jobs + lo * 8;
+    const float* src = base + jb[0];
+    T* dst = (T*)jb[1];
+    const int A = (int)jb[2], B = (int)jb[3], C = (int)jb[4], ld = (int)jb[5], mode = (int)jb[6];
+    const int ctaps = mode >= 2 ? (((mode - 2) >> 1) ? 2 : 1) * (((mode - 2) & 1) ? 2 : 1) : B;
+    const size_t total = mode == 0 ? (size_t)A * ld : (size_t)C * ctaps * ld;
+    const size_t i0 = (size_t)(blockIdx.x - jb[7]) * NKB_WPREP_BLOCK_ELEMS;
+    const size_t i1 = i0 + NKB_WPREP_BLOCK_ELEMS < total ? i0 + NKB_WPREP_BLOCK_ELEMS : total;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) wprep_elem<T>(src, dst, i, A, B, C, ld, mode);
+}
+extern "C" int nkb_wprep_block_elems(void) { return NKB_WPREP_BLOCK_ELEMS; }
+extern "C" int nkb_wprep_multi(int dtype, const float* base, const long long* jobs, int njobs, int total_blocks,
+                               hipStream_t stream) {
+    if (njobs <= 0 || total_blocks <= 0) return 0;
+    NkbProfScope prof(NKB_K_WPREP, stream, 0);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(wprep_multi_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, stream, base, jobs, njobs);
+    else hipLaunchKernelGGL(wprep_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, base, jobs, njobs);
+    return nkb_check_launch("wprep_multi");
 }
 extern "C" int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int ld, int mode, hipStream_t stream) {
     if (mode < 0 || mode > 5 || (mode >= 2 && B != 9)) { nkb_set_error("wprep: bad mode %d (B=%d)", mode, B); return 1; }
-    const int ctaps = mode >= 2 ? (((mode - 2) >> 1) ? 2 : 1) * (((mode - 2) & 1) ? 2 : 1) : B;
-    const size_t total = mode == 0 ? (size_t)A * ld : (size_t)C * ctaps * ld;
+    const size_t total = wprep_total(A, B, C, ld, mode);
     NkbProfScope prof(NKB_K_WPREP, stream, 0);
     if (dtype == NKB_DT_BF16)
-        hipLaunchKernelGGL(wprep_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, src, (bf16_t*)dst, A, B, C, ld, mode);
+        hipLaunchKernelGGL(wprep_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, src, (bf16_t*)dst, A, B, C, ld, mode, total);
     else
-        hipLaunchKernelGGL(wprep_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, (float*)dst, A, B, C, ld, mode);
+        hipLaunchKernelGGL(wprep_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, (float*)dst, A, B, C, ld, mode, total);
     return nkb_check_launch("wprep");
 }
 

@@ -34,6 +34,8 @@ _SIGS = {
     "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 13 + [vp]),
     "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
+    "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp]),
+    "nkb_wprep_block_elems": (i32, []),
     "nkb_stem_pack": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_stem_weight_cols": (i32, [i32]),
@@ -236,6 +238,14 @@ def stem_wfold(dtype, dwp, dw, Cout, C_):
 
 def im2row(dtype, x, col, N, Cin, H, W, R, S, stride, pad, Kp):
     check(load().nkb_im2row(dtype, ptr(x), ptr(col), N, Cin, H, W, R, S, stride, pad, Kp, stream()), "im2row")
+
+
+def wprep_multi(dtype, base, jobs, njobs, total_blocks):
+    check(load().nkb_wprep_multi(dtype, ptr(base), ptr(jobs), njobs, total_blocks, stream()), "wprep_multi")
+
+
+def wprep_block_elems() -> int:
+    return int(load().nkb_wprep_block_elems())
 
 
 def wprep(dtype, src, dst, A, B, C_, ld, mode):

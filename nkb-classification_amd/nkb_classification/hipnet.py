@@ -85,33 +85,48 @@ class HipEngine:
                 buf = self._wpad[id(w)] = torch.empty(w.shape[0], self.kpad(K), device=self.device, dtype=self.T)
             hip.wprep(self.d, a.param_flat(w), buf, w.shape[0], 1, K, buf.shape[1], 0)
         if need_dgrad:
-            for conv in self._convs:
-                w = conv.weight
-                co, ci, r, s = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
-                buf = self._wd.get(id(w))
-                if buf is None:
-                    buf = self._wd[id(w)] = torch.empty(ci, r, s, co, device=self.device, dtype=self.T)
-                hip.wprep(self.d, a.param_flat(w), buf, co, r * s, ci, co, 1)
-                if self.s2_classes(conv):
-                    cls = self._wd_cls.get(id(w))
-                    if cls is None:
-                        cls = self._wd_cls[id(w)] = [torch.empty(ci, (2 if k >> 1 else 1) * (2 if k & 1 else 1), co,
-                                                                 device=self.device, dtype=self.T) for k in range(4)]
-                    for k in range(4):
-                        hip.wprep(self.d, a.param_flat(w), cls[k], co, 9, ci, co, 2 + k)
-            hw, _ = self._heads
-            ctot = sum(w.shape[0] for w in hw)
-            E = hw[0].shape[1]
-            cp = self.kpad(ctot)
-            buf = self._wd.get("head")
-            if buf is None:
-                buf = self._wd["head"] = torch.empty(E, cp, device=self.device, dtype=self.T)
-            lo = a.offset_of(hw[0])
-            hip.wprep(self.d, a.flat_param[lo:lo + ctot * E], buf, ctot, 1, E, cp, 1)
+            if self._wjobs is None:
+                self._wjobs = self._build_dgrad_jobs()
+            jobs, njobs, nblocks = self._wjobs
+            hip.wprep_multi(self.d, a.flat_param, jobs, njobs, nblocks)
         self._dgrad_ready = need_dgrad
         self._wver = a.version
 
     _dgrad_ready = False
+    _wjobs = None
+
+    def _build_dgrad_jobs(self):
+        """Job table of nkb_wprep_multi for every dgrad-layout shadow ([Cin][R][S][Cout], the four parity classes of the
+        3x3 stride-2 filters, the fused head); built once — parameter offsets and shadow buffers never move."""
+        a = self.arena
+        per_block = hip.wprep_block_elems()
+        rows, nblocks = [], 0
+
+        def add(src_off, dst, A, B, C, ld, mode):
+            nonlocal nblocks
+            taps = B if mode < 2 else (2 if (mode - 2) >> 1 else 1) * (2 if (mode - 2) & 1 else 1)
+            total = A * ld if mode == 0 else C * taps * ld
+            rows.append([src_off, dst.data_ptr(), A, B, C, ld, mode, nblocks])
+            nblocks += (total + per_block - 1) // per_block
+
+        for conv in self._convs:
+            w = conv.weight
+            co, ci, r, s = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+            buf = self._wd[id(w)] = torch.empty(ci, r, s, co, device=self.device, dtype=self.T)
+            add(a.offset_of(w), buf, co, r * s, ci, co, 1)
+            if self.s2_classes(conv):
+                cls = self._wd_cls[id(w)] = [torch.empty(ci, (2 if k >> 1 else 1) * (2 if k & 1 else 1), co,
+                                                         device=self.device, dtype=self.T) for k in range(4)]
+                for k in range(4):
+                    add(a.offset_of(w), cls[k], co, 9, ci, co, 2 + k)
+        hw, _ = self._heads
+        ctot = sum(w.shape[0] for w in hw)
+        E = hw[0].shape[1]
+        cp = self.kpad(ctot)
+        buf = self._wd["head"] = torch.empty(E, cp, device=self.device, dtype=self.T)
+        add(a.offset_of(hw[0]), buf, ctot, 1, E, cp, 1)
+        jobs = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        return jobs, len(rows), nblocks
 
     @staticmethod
     def s2_classes(conv) -> bool:
