@@ -196,11 +196,21 @@ def main():
             dist.barrier()
 
     sync()
+    if os.environ.get("NKB_BENCH_GC", "1") != "0":
+        # the interpreter's first full collection after model construction walks every module / tensor object (tens of
+        # ms of host time, once); take it now instead of inside the first timed step
+        import gc
+        gc.collect()
+        gc.freeze()
     log("warm-up done; timing")
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         loss = step()
+        step_marks.append(time.perf_counter())
     host_dt = time.perf_counter() - t0          # time to ENQUEUE the steps (host side only)
+    if os.environ.get("NKB_DEBUG_STEPS"):
+        log("enqueue ms per step: " + " ".join(f"{1e3 * (b - a):.1f}" for a, b in zip([t0] + step_marks[:-1], step_marks)))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
