@@ -77,8 +77,13 @@ int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, 
  * Cout) tiles, nkb_bn_stats_floats floats); nkb_bn_backward_from_stats then finishes that stage's BatchNorm backward
  * without a reduction pass over g and c.  sums: 2*C floats of scratch. */
 int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,
-                      const float* shift, const float* mean, float* stats, int N, int H, int W, int Cin, int ldx, int P,
-                      int Q, int Cout, int ldy, int R, int S, int stride, int pad, nkb_stream_t stream);
+                      const float* shift, const float* mean, float* stats, const unsigned char* relu_bits,
+                      const void* add, int ldadd, const unsigned char* add_bits, int add_h, int add_w, int N, int H,
+                      int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int R, int S, int stride, int pad,
+                      nkb_stream_t stream);
+/* relu_bits != NULL: the stage closes a residual block — its mask comes from nkb_bn_apply's bit array (scale/shift
+ * unused) and the residual operand `add` (optionally under add_bits, or on the sub-grid add_h x add_w) is still added
+ * before masking, so the block-output gradient is produced, masked and reduced in the one epilogue. */
 /* One parity class (ph, pw) of the data gradient of a 3x3 / stride-2 / pad-1 convolution: output pixels (2h'+ph, 2w'+pw)
  * as a stride-1 gather over dY with (1|2) x (1|2) taps; w_class = [C][Rc][Sc][K] from nkb_wprep modes 2..5 (= 2 + 2*ph + pw).
  * The four classes together replace nkb_conv_gemm(mode 1, stride 2), which multiplies 3 taps out of 4 by zero.

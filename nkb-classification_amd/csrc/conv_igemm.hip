@@ -20,7 +20,9 @@ template <> struct MmaTraits<float> { static constexpr int KSTEPS = 8; };   // 8
 
 __device__ __forceinline__ int lds_swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <typename T, int TC, int TP, bool BNB = false>
+// BNB: 0 plain epilogue; 1 fused BN-backward reduction with the ReLU mask recomputed from c (interior stages);
+//      2 the same for a stage that closes a residual block: mask from its bit array, residual operand still added
+template <typename T, int TC, int TP, int BNB = 0>
 __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int KTE = 128 / (int)sizeof(T);  // elements per k-tile row
@@ -216,8 +218,10 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
     if constexpr (BNB) {
         if (tid < TC) {
             const bool ok = c0 + tid < p.Cout;
-            bnl[tid] = ok ? p.bn_scale[c0 + tid] : 0.f;
-            bnl[TC + tid] = ok ? p.bn_shift[c0 + tid] : 0.f;
+            if constexpr (BNB == 1) {
+                bnl[tid] = ok ? p.bn_scale[c0 + tid] : 0.f;
+                bnl[TC + tid] = ok ? p.bn_shift[c0 + tid] : 0.f;
+            }
             bnl[2 * TC + tid] = ok ? p.bn_mean[c0 + tid] : 0.f;
         }
     }
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
             const unsigned ww = rem - hh * p.divQ.d;
             orow = ((size_t)n * p.sub_h + 2 * hh + p.sub_ph) * p.sub_w + 2 * ww + p.sub_pw;
         }
-        bool do_add = !BNB && p.add != nullptr;
+        bool do_add = BNB != 1 && p.add != nullptr;
         size_t am = orow;                      // row of the add tensor
         if (do_add && p.add_h > 0 && p.sub_h > 0) {
             // sub-grid add on a parity-class launch: the even (h, w) grid IS class (0, 0), row for row
@@ -332,15 +336,37 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
                     for (int e = 0; e < 4; ++e) { cv[e] = lo[e]; cv[4 + e] = hi[e]; }
                 }
             }
+            if constexpr (BNB == 2) {
+                unsigned ob = 0xffu;           // this stage's ReLU bits (bn_apply relu_bits), same chunking as add_bits
+                if (co + 8 <= p.Cout) {
+                    if constexpr (sizeof(T) == 2) {
+                        ob = p.bn_bits[orow * (size_t)(p.ldy >> 3) + (co >> 3)];
+                    } else {
+                        const unsigned char* bp = p.bn_bits + orow * (size_t)(p.ldy >> 2) + (co >> 2);
+                        ob = (unsigned)bp[0] | ((unsigned)bp[1] << 4);
+                    }
+                }
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const f32x4 sc4 = *(const f32x4*)(bnl + eg * 8 + 4 * h2), sh4 = *(const f32x4*)(bnl + TC + eg * 8 + 4 * h2),
-                            mu4 = *(const f32x4*)(bnl + 2 * TC + eg * 8 + 4 * h2);
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x4 mu4 = *(const f32x4*)(bnl + 2 * TC + eg * 8 + 4 * h2);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = 4 * h2 + e;
-                    if (!(DT<T>::rnd(cv[k] * sc4[e] + sh4[e]) > 0.f)) v[k] = 0.f;   // same expression / rounding as bn_apply
-                    cv[k] -= mu4[e];
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * h2 + e;
+                        if (!((ob >> k) & 1u)) v[k] = 0.f;
+                        cv[k] -= mu4[e];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x4 sc4 = *(const f32x4*)(bnl + eg * 8 + 4 * h2), sh4 = *(const f32x4*)(bnl + TC + eg * 8 + 4 * h2),
+                                mu4 = *(const f32x4*)(bnl + 2 * TC + eg * 8 + 4 * h2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * h2 + e;
+                        if (!(DT<T>::rnd(cv[k] * sc4[e] + sh4[e]) > 0.f)) v[k] = 0.f;   // same expression / rounding as bn_apply
+                        cv[k] -= mu4[e];
+                    }
                 }
             }
         }
@@ -668,7 +694,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
 
 // ------------------------------------------------------------------------------------------
 // host launchers
-template <typename T, int TC, int TP, bool BNB = false>
+template <typename T, int TC, int TP, int BNB = 0>
 static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
     p.tilesM = (p.M + TP - 1) / TP;
     p.tilesN = (p.Cout + TC - 1) / TC;
@@ -735,7 +761,9 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
 // gradient g' and leaves per-row-tile sums of g' and g'*(c-mean) in `stats` — the reduction pass of the BatchNorm
 // backward, without re-reading g and c (nkb_bn_backward_from_stats finishes the job).
 extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c,
-                                 const float* scale, const float* shift, const float* mean, float* stats, int N, int H,
+                                 const float* scale, const float* shift, const float* mean, float* stats,
+                                 const unsigned char* relu_bits, const void* add, int ldadd, const unsigned char* add_bits,
+                                 int add_h, int add_w, int N, int H,
                                  int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int R, int S, int stride, int pad,
                                  hipStream_t stream) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
@@ -753,21 +781,31 @@ extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void*
         return 1;
     }
     ConvParams p;
-    p.x = dy; p.w = w; p.y = g_masked; p.add = nullptr; p.bias = nullptr; p.stats = stats;
+    if (relu_bits == nullptr && (add != nullptr || scale == nullptr || shift == nullptr)) {
+        nkb_set_error("conv_dgrad_bn: the recomputed-mask form takes scale/shift and no residual operand");
+        return 1;
+    }
+    if (add && ((add_h == 0 && ldadd % 8 != 0) || (add_bits && add_h > 0))) { nkb_set_error("conv_dgrad_bn: bad add operand (ldadd=%d)", ldadd); return 1; }
+    p.x = dy; p.w = w; p.y = g_masked; p.add = add; p.bias = nullptr; p.stats = stats;
     p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.ldy = ldy;
-    p.ldadd = 0; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.mode = 1; p.relu = 0;
+    p.ldadd = ldadd; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.mode = 1; p.relu = 0;
     p.stride_w = stride; p.pad_w = pad; p.stem_cprw = 0;
     p.out_f32 = 0;
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
-    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = c; p.y2 = nullptr;
+    p.add_h = add_h; p.add_w = add_w; p.act = 0; p.aux = c; p.y2 = nullptr;
+    p.add_bits = add_bits; p.bn_bits = relu_bits;
     p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean;
     NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * p.M * (double)Cout * R * S * Cin,
-                      ((double)N * H * W * Cin + (double)Cout * R * S * Cin + 2.0 * p.M * Cout) * esz);
+                      ((double)N * H * W * Cin + (double)Cout * R * S * Cin + (add ? 3.0 : 2.0) * p.M * Cout) * esz);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, true>(p, stream) : launch_conv<bf16_t, 128, 128, true>(p, stream);
-    return narrow ? launch_conv<float, 64, 256, true>(p, stream) : launch_conv<float, 128, 128, true>(p, stream);
+    if (relu_bits) {
+        if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 2>(p, stream) : launch_conv<bf16_t, 128, 128, 2>(p, stream);
+        return narrow ? launch_conv<float, 64, 256, 2>(p, stream) : launch_conv<float, 128, 128, 2>(p, stream);
+    }
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
+    return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
 }
 
 // One parity class of the data gradient of a 3x3 / stride-2 / pad-1 convolution.  Output pixels (h, w) with
@@ -814,8 +852,8 @@ extern "C" int nkb_conv_dgrad_s2class(int dtype, const void* dy, const void* w_c
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = C <= 64 && narrow_on;
     if (c) {
-        if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, true>(p, stream) : launch_conv<bf16_t, 128, 128, true>(p, stream);
-        return narrow ? launch_conv<float, 64, 256, true>(p, stream) : launch_conv<float, 128, 128, true>(p, stream);
+        if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
+        return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
     }
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);

@@ -32,6 +32,7 @@ struct ConvParams {
     const float* bn_scale = nullptr;
     const float* bn_shift = nullptr;
     const float* bn_mean = nullptr;
+    const unsigned char* bn_bits = nullptr;   // BNB == 2: the stage's ReLU bit mask instead of scale / shift
     // parity-class launch of a stride-2 dgrad: the M rows of this launch are the pixels (2h'+sub_ph, 2w'+sub_pw) of a
     // [N][sub_h][sub_w] destination (P, Q = the class sub-grid); 0 = off
     int sub_h = 0, sub_w = 0, sub_ph = 0, sub_pw = 0;

@@ -149,14 +149,19 @@ class HipResNet(_ParamOnly):
         g = eng.avgpool_backward("gap", g_emb, "g0")
         flip = 1
         blocks = list(self.blocks())
+        g_stats = None        # set when g arrives already masked, with its BN reduction done by the producing dgrad
         for bi in range(len(blocks) - 1, -1, -1):
             name, blk = blocks[bi]
             eng.begin_block(bi)
             n = len(blk.stages())
             # last stage: ReLU(bn(conv) + shortcut); the masked incoming gradient also feeds the shortcut
             last = f"{name}.{n - 1}"
-            gc = eng.bn_backward(last, g, "t0", write_masked=True)
-            bits = eng.saved[last].get("bits")       # set: g was NOT masked in place, consumers apply the bits
+            if g_stats is not None:
+                gc = eng.bn_backward_fused(last, g, g_stats, "t0")
+                bits = None                              # g is masked already
+            else:
+                gc = eng.bn_backward(last, g, "t0", write_masked=True)
+                bits = eng.saved[last].get("bits")       # set: g was NOT masked in place, consumers apply the bits
             for k in range(n - 1, 0, -1):
                 prev = f"{name}.{k - 1}"
                 if eng.can_fuse_bn_backward(prev):
@@ -174,7 +179,17 @@ class HipResNet(_ParamOnly):
                 add = eng.conv_backward(f"{name}.ds", gcd, "t6", subgrid=sub)
                 if sub:
                     add_hw = (add.shape[1], add.shape[2])
-            g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add, add_hw=add_hw, add_bits=add_bits)
+            # the gradient leaving this block is the output gradient of the previous block's closing stage: let the
+            # epilogue that forms it also mask it and reduce it for that stage's BatchNorm backward
+            g_stats = None
+            if bi > 0:
+                pname, pblk = blocks[bi - 1]
+                plast = f"{pname}.{len(pblk.stages()) - 1}"
+                if eng.can_fuse_residual_bn_backward(plast, f"{name}.0"):
+                    g, g_stats = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add, add_hw=add_hw, add_bits=add_bits,
+                                                   fuse_bn=plast)
+            if g_stats is None:
+                g = eng.conv_backward(f"{name}.0", gc, f"g{flip}", add=add, add_hw=add_hw, add_bits=add_bits)
             flip ^= 1
             eng.end_block(bi)
             if on_done is not None and name.endswith(".0"):

@@ -31,7 +31,7 @@ _SIGS = {
     "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
     "nkb_bn_stats_floats": (sz, [i32, i32]),
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
-    "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp] + [i32] * 13 + [vp]),
+    "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32] + [i32] * 13 + [vp]),
     "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
     "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp]),
@@ -171,9 +171,10 @@ def bn_backward(dtype, dy, x, yact, mean, invstd, gamma, rows, C_, dgamma, dbeta
 
 
 def conv_dgrad_bn(dtype, dy, w, g_masked, c, scale, shift, mean, stats, *, N, H, W, Cin, ldx, P, Q, Cout, ldy, R, S,
-                  stride, pad):
+                  stride, pad, relu_bits=None, add=None, ldadd=0, add_bits=None, add_hw=(0, 0)):
     check(load().nkb_conv_dgrad_bn(dtype, ptr(dy), ptr(w), ptr(g_masked), ptr(c), ptr(scale), ptr(shift), ptr(mean),
-                                   ptr(stats), N, H, W, Cin, ldx, P, Q, Cout, ldy, R, S, stride, pad, stream()),
+                                   ptr(stats), ptr(relu_bits), ptr(add), ldadd, ptr(add_bits), add_hw[0], add_hw[1],
+                                   N, H, W, Cin, ldx, P, Q, Cout, ldy, R, S, stride, pad, stream()),
           "conv_dgrad_bn")
 
 

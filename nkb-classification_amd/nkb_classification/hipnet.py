@@ -21,6 +21,7 @@ _PACKED_STEM = os.environ.get("NKB_PACKED_STEM", "1") != "0"
 _FUSED_BN_BWD = os.environ.get("NKB_FUSED_BNBWD", "1") != "0"
 # 3x3 stride-2 data gradients as four parity-class launches (9 taps instead of 36 multiplied, 27 of them by zero)
 _S2_CLASSES = os.environ.get("NKB_S2_CLASSES", "1") != "0"
+_FUSED_RES_BN_BWD = os.environ.get("NKB_FUSED_RES_BNBWD", "1") != "0"
 # residual-closing stages keep a 1-bit/element ReLU mask; backward reads it instead of the activation and the masked
 # block-output gradient is never materialised (consumers apply the bits on the fly)
 _RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
@@ -401,6 +402,13 @@ class HipEngine:
         return (_FUSED_BN_BWD and sv["relu"] and not sv["has_res"] and sv["pool_idx"] is None
                 and sv["c"].shape[-1] % 8 == 0)
 
+    def can_fuse_residual_bn_backward(self, bn_key: str, consumer_key: str) -> bool:
+        """The stage `bn_key` closes a residual block (kept ReLU bits) and `consumer_key` is the first conv of the next
+        block, whose data gradient (+ shortcut gradient) IS the gradient of that stage's output."""
+        sv, cv = self.saved[bn_key], self.saved[consumer_key]
+        return (_FUSED_BN_BWD and _FUSED_RES_BN_BWD and sv.get("bits") is not None and sv["c"].shape[-1] % 8 == 0
+                and not self.s2_classes(cv["conv"]) and not cv["col_input"] and not cv["stem_packed"])
+
     def bn_backward_fused(self, key: str, g_masked: torch.Tensor, stats, slot: str) -> torch.Tensor:
         """Second half of conv_backward(..., fuse_bn=key): g_masked is already ReLU-masked and `stats` = (buffer, tiles)
         holds the per-tile sums, so only the finalize and the elementwise pass remain."""
@@ -482,13 +490,16 @@ class HipEngine:
                 base += tiles_of[k]
             return (dx, (stats, total)) if svp is not None else dx
         if fuse_bn is not None:
-            assert add is None
             svp = self.saved[fuse_bn]
+            residual = svp.get("bits") is not None       # the fused stage closes a residual block: mask = its bit array
+            assert add is None or residual
             tiles = hip.stat_tiles(self.d, N * H * W, ci)
             stats = self.ws.get(fuse_bn + ".bstats", (hip.bn_stats_floats(tiles, ci),), torch.float32)
             hip.conv_dgrad_bn(self.d, g_c, self._wd[id(w)], dx, svp["c"], svp["scale"], svp["shift"], svp["mean"], stats,
                               N=N, H=geom["P"], W=geom["Q"], Cin=geom["Cout"], ldx=geom["Cout"], P=H, Q=W, Cout=ci, ldy=ci,
-                              R=geom["R"], S=geom["S"], stride=geom["stride"], pad=geom["pad"])
+                              R=geom["R"], S=geom["S"], stride=geom["stride"], pad=geom["pad"],
+                              relu_bits=svp["bits"] if residual else None, add=add,
+                              ldadd=ci if add is not None else 0, add_bits=add_bits, add_hw=add_hw)
             return dx, (stats, tiles)
         hip.conv_gemm(self.d, 1, g_c, self._wd[id(w)], dx, N=N, H=geom["P"], W=geom["Q"], Cin=geom["Cout"],
                       ldx=geom["Cout"], P=H, Q=W, Cout=ci, ldy=ci, R=geom["R"], S=geom["S"], stride=geom["stride"],

@@ -475,6 +475,56 @@ def test_relu_bit_mask_paths_match_activation_mask(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("addkind", ["bits", "plain", "sub"])
+def test_dgrad_with_fused_residual_bn_backward(dtype, addkind):
+    """Closing stage of a residual block: dgrad + shortcut gradient, masked by the stage's ReLU bits and reduced in the
+    epilogue (nkb_conv_dgrad_bn with relu_bits) == conv_gemm(mode 1, add) followed by bn_backward(relu_bits)."""
+    torch.manual_seed(21)
+    N, H, C, K = 2, 10, 128, 64 if dtype == torch.bfloat16 else 32       # consumer conv: C -> K, 1x1
+    d = hip.dt(dtype)
+    rows = N * H * H
+    nb = C // (8 if dtype == torch.bfloat16 else 4)
+    c = torch.randn(N, H, H, C, device=DEV).to(dtype)
+    dy = torch.randn(N, H, H, K, device=DEV).to(dtype)
+    wt = (torch.randn(C, 1, 1, K, device=DEV) * 0.1).to(dtype)
+    bits = torch.randint(0, 256 if dtype == torch.bfloat16 else 16, (rows, nb), device=DEV, dtype=torch.uint8)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    cf = c.float().reshape(rows, C)
+    mean = cf.mean(0).contiguous()
+    invstd = (cf.var(0, unbiased=False) + 1e-5).rsqrt().contiguous()
+    add, add_bits, add_hw = None, None, (0, 0)
+    if addkind == "sub":
+        add_hw = (H // 2, H // 2)
+        add = torch.randn(N, add_hw[0], add_hw[1], C, device=DEV).to(dtype)
+    else:
+        add = torch.randn(N, H, H, C, device=DEV).to(dtype)
+        if addkind == "bits":
+            add_bits = torch.randint(0, 256 if dtype == torch.bfloat16 else 16, (rows, nb), device=DEV, dtype=torch.uint8)
+    geom = dict(N=N, H=H, W=H, Cin=K, ldx=K, P=H, Q=H, Cout=C, ldy=C, R=1, S=1, stride=1, pad=0)
+    g0 = torch.empty(N, H, H, C, device=DEV, dtype=dtype)
+    hip.conv_gemm(d, 1, dy, wt, g0, add=add, ldadd=C, add_hw=add_hw, add_bits=add_bits, **geom)
+    dg0, db0, dc0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.empty_like(c)
+    work = torch.empty(hip.bn_backward_ws(rows, C), device=DEV)
+    hip.bn_backward(d, g0, c, None, mean, invstd, gamma, rows, C, dg0, db0, dc0, None, work, relu_bits=bits)
+    g1 = torch.empty_like(g0)
+    tiles = hip.stat_tiles(d, rows, C)
+    stats = torch.zeros(hip.bn_stats_floats(tiles, C), device=DEV)
+    hip.conv_dgrad_bn(d, dy, wt, g1, c, None, None, mean, stats, relu_bits=bits, add=add, ldadd=C, add_bits=add_bits,
+                      add_hw=add_hw, **geom)
+    dg1, db1, dc1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.empty_like(c)
+    sums = torch.empty(2 * C, device=DEV)
+    hip.bn_backward_from_stats(d, g1, c, stats, tiles, mean, invstd, gamma, rows, C, dg1, db1, dc1, sums)
+    torch.cuda.synchronize()
+    shift_bits = 8 if dtype == torch.bfloat16 else 4
+    m = ((bits.unsqueeze(-1) >> torch.arange(shift_bits, device=DEV)) & 1).reshape(rows, C).bool().reshape(N, H, H, C)
+    assert torch.equal(g1.float(), g0.float() * m)
+    st = dict(rtol=1e-4, atol=1e-3) if dtype == torch.float32 else dict(rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(db1, db0, **st)
+    torch.testing.assert_close(dg1, dg0, **st)
+    torch.testing.assert_close(dc1.float(), dc0.float(), **tol(dtype, 4))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_avgpool_fwd_bwd(dtype):
     torch.manual_seed(6)
     N, C, HW = 3, 512, 49
