@@ -139,10 +139,11 @@ int nkb_stem_wfold(int dtype, const float* dwp, float* dw, int Cout, int C, nkb_
  * modes 2..5: transposed parity class 2*ph+pw of a 3x3 stride-2 filter, [C][Rc*Sc][ld], see nkb_conv_dgrad_s2class). */
 int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int ld, int mode, nkb_stream_t stream);
 /* All weight re-layouts of a step in one launch: jobs[j] = {src element offset from `base`, dst device pointer, A, B, C,
- * ld, mode (as nkb_wprep), index of the job's first block}, 8 x int64 per job on the device; every block covers
- * nkb_wprep_block_elems() destination elements, total_blocks = sum over jobs. */
+ * ld, mode (as nkb_wprep), index of the job's first block}, 8 x int64 per job on the device; a job occupies
+ * nkb_wprep_job_blocks(...) consecutive blocks, total_blocks = sum over jobs. */
 int nkb_wprep_multi(int dtype, const float* base, const long long* jobs, int njobs, int total_blocks, nkb_stream_t stream);
 int nkb_wprep_block_elems(void);
+long long nkb_wprep_job_blocks(int A, int B, int C, int ld, int mode); /* blocks a job occupies in nkb_wprep_multi */
 int nkb_add2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, nkb_stream_t stream);
 int nkb_colsum(int dtype, const void* x, float* out, int rows, int C, int ld, nkb_stream_t stream);
 int nkb_pad_cast(int dtype, const float* src, void* dst, int rows, int C, int ld_src, int ld_dst, float mul,

@@ -36,6 +36,7 @@ _SIGS = {
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
     "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_wprep_block_elems": (i32, []),
+    "nkb_wprep_job_blocks": (i64, [i32, i32, i32, i32, i32]),
     "nkb_stem_pack": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_stem_weight_cols": (i32, [i32]),
@@ -247,6 +248,10 @@ def wprep_multi(dtype, base, jobs, njobs, total_blocks):
 
 def wprep_block_elems() -> int:
     return int(load().nkb_wprep_block_elems())
+
+
+def wprep_job_blocks(A, B, C_, ld, mode) -> int:
+    return int(load().nkb_wprep_job_blocks(A, B, C_, ld, mode))
 
 
 def wprep(dtype, src, dst, A, B, C_, ld, mode):

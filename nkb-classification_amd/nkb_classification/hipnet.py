@@ -100,15 +100,12 @@ class HipEngine:
         """Job table of nkb_wprep_multi for every dgrad-layout shadow ([Cin][R][S][Cout], the four parity classes of the
         3x3 stride-2 filters, the fused head); built once — parameter offsets and shadow buffers never move."""
         a = self.arena
-        per_block = hip.wprep_block_elems()
         rows, nblocks = [], 0
 
         def add(src_off, dst, A, B, C, ld, mode):
             nonlocal nblocks
-            taps = B if mode < 2 else (2 if (mode - 2) >> 1 else 1) * (2 if (mode - 2) & 1 else 1)
-            total = A * ld if mode == 0 else C * taps * ld
             rows.append([src_off, dst.data_ptr(), A, B, C, ld, mode, nblocks])
-            nblocks += (total + per_block - 1) // per_block
+            nblocks += hip.wprep_job_blocks(A, B, C, ld, mode)
 
         for conv in self._convs:
             w = conv.weight

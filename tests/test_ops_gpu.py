@@ -525,6 +525,36 @@ def test_dgrad_with_fused_residual_bn_backward(dtype, addkind):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_wprep_multi_matches_single_jobs(dtype):
+    """One multi-job launch (tiled transposes through LDS) == the per-tensor nkb_wprep launches, including ragged
+    tiles, a zero-padded leading dimension and the four stride-2 parity classes."""
+    torch.manual_seed(22)
+    d = hip.dt(dtype)
+    shapes = [(64, 9, 128, 64, 1), (100, 1, 72, 104, 1), (48, 1, 40, 48, 0), (256, 9, 64, 256, 1)] + \
+             [(96, 9, 80, 96, 2 + k) for k in range(4)]
+    offs, total = [], 0
+    for A, B, C, ld, mode in shapes:
+        offs.append(total)
+        total += (A * B * C + 63) // 64 * 64
+    base = torch.randn(total, device=DEV)
+    rows, nblocks, outs, refs = [], 0, [], []
+    for (A, B, C, ld, mode), off in zip(shapes, offs):
+        taps = B if mode < 2 else (2 if (mode - 2) >> 1 else 1) * (2 if (mode - 2) & 1 else 1)
+        n_out = A * ld if mode == 0 else C * taps * ld
+        out = torch.full((n_out,), 7.0, device=DEV).to(dtype)
+        ref = torch.full((n_out,), 7.0, device=DEV).to(dtype)
+        hip.wprep(d, base[off:off + A * B * C], ref, A, B, C, ld, mode)
+        rows.append([off, out.data_ptr(), A, B, C, ld, mode, nblocks])
+        nblocks += hip.wprep_job_blocks(A, B, C, ld, mode)
+        outs.append(out); refs.append(ref)
+    jobs = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    hip.wprep_multi(d, base, jobs, len(rows), nblocks)
+    torch.cuda.synchronize()
+    for o, r, sh in zip(outs, refs, shapes):
+        assert torch.equal(o, r), sh
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_avgpool_fwd_bwd(dtype):
     torch.manual_seed(6)
     N, C, HW = 3, 512, 49
