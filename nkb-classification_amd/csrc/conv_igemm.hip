@@ -10,6 +10,7 @@
 // MFMA orientation: D[cout][pixel] = W[cout][k] * X[pixel][k]^T, so each lane ends up holding
 // 4 consecutive output channels of one pixel.
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 #include "conv_params.h"
@@ -22,6 +23,8 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) { return row * 128 + 
 
 // BNB: 0 plain epilogue; 1 fused BN-backward reduction with the ReLU mask recomputed from c (interior stages);
 //      2 the same for a stage that closes a residual block: mask from its bit array, residual operand still added
+//      3 plain bf16 epilogue only (bias / ReLU / per-tile statistics; no residual operand, activation epilogue, row
+//        remap or fp32 output): a lean row loop, selected by launch_conv when the launch qualifies
 template <typename T, int TC, int TP, int BNB = 0>
 __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
     constexpr int EPC = DT<T>::EPC;
@@ -208,14 +211,14 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
     float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (!BNB && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bv[e] = ((BNB == 0 || BNB == 3) && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
     // BNB: the stage's scale / shift / mean for this tile's channels live in LDS behind the epilogue tile (keeping them
     // in registers next to the not-yet-stored accumulators cost a wave of occupancy)
     constexpr int LDS_MAIN = ((TC + TP) * 128 * (TC == 64 ? 2 : 1)) > ((TP / 2) * EROW) ? ((TC + TP) * 128 * (TC == 64 ? 2 : 1))
                                                                                        : ((TP / 2) * EROW);
     float* bnl = (float*)(smem + LDS_MAIN);   // [3][TC]
-    if constexpr (BNB) {
+    if constexpr (BNB == 1 || BNB == 2) {
         if (tid < TC) {
             const bool ok = c0 + tid < p.Cout;
             if constexpr (BNB == 1) {
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
     // BNB (bf16): the c rows of a half are requested before that half's accumulators go through LDS, so their latency
     // hides behind the LDS round trip instead of stalling every row of the store loop
     constexpr int RPH = (TP / 2) / RPP;                      // rows per thread per half
-    constexpr bool CPRE = BNB && sizeof(T) == 2;
+    constexpr bool CPRE = (BNB == 1 || BNB == 2) && sizeof(T) == 2;
     u32x4 cpre[CPRE ? RPH : 1];
     auto prefetch_c = [&](int half) {
         if constexpr (CPRE) {
@@ -263,6 +266,45 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
             }
     }
     __syncthreads();
+    if constexpr (BNB == 3) {
+        // plain bf16 store path (no residual operand, activation epilogue, row remap or fp32 output): ~10 VALU
+        // instructions per row instead of ~70 — on the single-k-tile 1x1 shapes the general loop's address arithmetic
+        // and flag tests were ~45 % of the kernel's issue time (rocprofv3 SQ_INSTS_VALU: 881 per wave for 32 MFMAs)
+        const int mrow = m0 + half * (TP / 2) + er;
+        bf16_t* o = (bf16_t*)p.y + yoff + (size_t)mrow * p.ldy + co;
+        const size_t ostep = (size_t)RPP * p.ldy;
+        const unsigned char* lrow = smem + er * EROW + eg * 32;
+        auto rows = [&](auto HS, auto HB) {
+            constexpr bool hs = decltype(HS)::value, hb = decltype(HB)::value;
+#pragma unroll
+            for (int ri = 0; ri < RPH; ++ri) {
+                if (mrow + RPP * ri >= p.M) break;
+                const f32x4 lo = *(const f32x4*)(lrow + ri * RPP * EROW);
+                const f32x4 hi = *(const f32x4*)(lrow + ri * RPP * EROW + 16);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if constexpr (hb) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                const u32x4 pk = pack8(v);
+                *(u32x4*)(o + ri * ostep) = pk;
+                if constexpr (hs) {                    // statistics see the stored (rounded) value
+                    float r[8];
+                    unpack8(pk, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ssum[e] += r[e]; ssq[e] += r[e] * r[e]; }
+                }
+            }
+        };
+        if (co < p.Cout) {
+            if (p.stats) { if (p.bias) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+            else { if (p.bias) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+        }
+    } else
 #pragma unroll
     for (int ri = 0; ri < RPH; ++ri) {
         const int row = er + RPP * ri;
@@ -323,7 +365,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
             }
         }
         float cv[8];                           // BNB: raw conv output of the stage whose BN backward consumes v
-        if constexpr (BNB) {
+        if constexpr (BNB == 1 || BNB == 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) cv[e] = 0.f;
             if (co + 8 <= p.Cout) {
@@ -413,7 +455,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             ssum[e] += v[e];
-            if constexpr (BNB) ssq[e] += v[e] * cv[e];
+            if constexpr (BNB == 1 || BNB == 2) ssq[e] += v[e] * cv[e];
             else ssq[e] += v[e] * v[e];
         }
     }
@@ -700,7 +742,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
     p.tilesN = (p.Cout + TC - 1) / TC;
     constexpr int stage = (TC + TP) * 128 * (TC == 64 ? 2 : 1);
     constexpr int epi = (TP / 2) * (TC * 4 + 16);
-    constexpr int lds = (stage > epi ? stage : epi) + (BNB ? 3 * TC * 4 : 0);
+    constexpr int lds = (stage > epi ? stage : epi) + ((BNB == 1 || BNB == 2) ? 3 * TC * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TC, TP, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -709,6 +751,18 @@ static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
     const unsigned grid = (unsigned)p.tilesM * (unsigned)p.tilesN;
     hipLaunchKernelGGL((conv_igemm_kernel<T, TC, TP, BNB>), dim3(grid, batch), dim3(256), lds, stream, p);
     return nkb_check_launch("conv_igemm");
+}
+
+// picks the lean-epilogue instantiation (BNB = 3) when the launch has nothing but bias / ReLU / statistics to do
+template <typename T, int TC, int TP>
+static int launch_conv_auto(ConvParams& p, hipStream_t stream, int batch = 1) {
+    if constexpr (sizeof(T) == 2) {
+        static const int lean_on = [] { const char* e = getenv("NKB_LEAN_EPILOGUE"); return e ? atoi(e) : 1; }();
+        const bool plain = lean_on && p.add == nullptr && p.act == 0 && p.sub_h == 0 && !p.out_f32 && (p.Cout & 7) == 0 &&
+                           (p.ldy & 7) == 0;
+        if (plain) return launch_conv<T, TC, TP, 3>(p, stream, batch);
+    }
+    return launch_conv<T, TC, TP, 0>(p, stream, batch);
 }
 
 extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add,
@@ -752,8 +806,8 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     if (add_h == 0 && nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
-    return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream) : launch_conv_auto<bf16_t, 128, 128>(p, stream);
+    return narrow ? launch_conv_auto<float, 64, 256>(p, stream) : launch_conv_auto<float, 128, 128>(p, stream);
 }
 
 // Data gradient of a convolution whose input was relu(bn(c)): same contraction as nkb_conv_gemm(mode 1), but the epilogue
@@ -855,8 +909,8 @@ extern "C" int nkb_conv_dgrad_s2class(int dtype, const void* dy, const void* w_c
         if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
         return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
     }
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
-    return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream) : launch_conv_auto<bf16_t, 128, 128>(p, stream);
+    return narrow ? launch_conv_auto<float, 64, 256>(p, stream) : launch_conv_auto<float, 128, 128>(p, stream);
 }
 
 // Linear layer with a fused exact-erf GELU epilogue (timm ViT MLP):
@@ -884,8 +938,8 @@ extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w,
     p.ldw = K; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     NkbProfScope prof(act == 1 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
     const bool narrow = N <= 64;
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
-    return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream) : launch_conv_auto<bf16_t, 128, 128>(p, stream);
+    return narrow ? launch_conv_auto<float, 64, 256>(p, stream) : launch_conv_auto<float, 128, 128>(p, stream);
 }
 
 // Batched row-major GEMM  y[z][m][n] = sum_k x[z][m][k] * w[z][n][k]  (both operands K-contiguous rows with leading
@@ -912,8 +966,8 @@ extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y
     NkbProfScope prof(NKB_K_ATTN, stream, 2.0 * M * (double)N * K * outer * inner);
     const bool narrow = N <= 64;
     const int batch = outer * inner;
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream, batch) : launch_conv<bf16_t, 128, 128>(p, stream, batch);
-    return narrow ? launch_conv<float, 64, 256>(p, stream, batch) : launch_conv<float, 128, 128>(p, stream, batch);
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream, batch) : launch_conv_auto<bf16_t, 128, 128>(p, stream, batch);
+    return narrow ? launch_conv_auto<float, 64, 256>(p, stream, batch) : launch_conv_auto<float, 128, 128>(p, stream, batch);
 }
 
 // number of row tiles the stats buffer must hold for a given launch: [tilesM][2][Cout] floats
@@ -1056,8 +1110,8 @@ extern "C" int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y,
     NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * p.M * (double)Cout * 147,
                       ((double)N * H * Wp * 4 + (double)p.M * Cout) * (dtype == NKB_DT_BF16 ? 2 : 4));
     const bool narrow = Cout <= 64;
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256>(p, stream) : launch_conv<bf16_t, 128, 128>(p, stream);
-    return narrow ? launch_conv<float, 64, 256>(p, stream) : launch_conv<float, 128, 128>(p, stream);
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream) : launch_conv_auto<bf16_t, 128, 128>(p, stream);
+    return narrow ? launch_conv_auto<float, 64, 256>(p, stream) : launch_conv_auto<float, 128, 128>(p, stream);
 }
 
 // dwp[Cout][7*cprw*EPC] (fp32, caller-zeroed) += dY^T * window(xp); fold into the parameter gradient with nkb_stem_wfold
