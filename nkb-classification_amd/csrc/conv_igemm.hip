@@ -136,12 +136,13 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
         }
         if (++ck == cpk) { ck = 0; if (++s == p.S) { s = 0; ++r; } }
     };
+    const int st_off = lds_swz(srow, cc);               // (srow + 32*i) & 7 == srow & 7: rows 32 apart are 4096 B apart
     auto store_tile = [&](int buf) {
-        unsigned char* base = smem + buf * STAGE_BYTES;
+        unsigned char* base = smem + buf * STAGE_BYTES + st_off;
 #pragma unroll
-        for (int i = 0; i < NWR; ++i) *(u32x4*)(base + lds_swz(srow + 32 * i, cc)) = sw[i];
+        for (int i = 0; i < NWR; ++i) *(u32x4*)(base + 4096 * i) = sw[i];
 #pragma unroll
-        for (int j = 0; j < NPR; ++j) *(u32x4*)(base + lds_swz(TC + srow + 32 * j, cc)) = sx[j];
+        for (int j = 0; j < NPR; ++j) *(u32x4*)(base + TC * 128 + 4096 * j) = sx[j];
     };
 
     f32x4 acc[MC][MP];
@@ -153,6 +154,8 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
     const int frow = lane & 15, fgrp = lane >> 4;
     const int arow0 = wc * (TC / 2) + frow;
     const int brow0 = TC + wp * (TP / 2) + frow;
+    const int a_off0 = lds_swz(arow0, fgrp), a_off1 = lds_swz(arow0, 4 + fgrp);
+    const int b_off0 = lds_swz(brow0, fgrp), b_off1 = lds_swz(brow0, 4 + fgrp);
 
     // One LDS stage + one register stage: LDS per workgroup drops to ~33 KB, so 3 workgroups (VGPR-limited) share a CU
     // instead of 2 and 1.5x the operand bytes are in flight; the price is a second barrier per k-tile.
@@ -168,11 +171,15 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
 #pragma unroll
         for (int ks = 0; ks < MmaTraits<T>::KSTEPS; ++ks) {
             if constexpr (sizeof(T) == 2) {
+                // (row + 16*i) & 7 == row & 7, so a fragment address is one of two lane constants (k-step 0 / 1) plus
+                // the immediate 2048*i: no address arithmetic inside the k-loop
                 bf16x8 a[MC], b[MP];
+                const unsigned char* pa = base + (ks ? a_off1 : a_off0);
+                const unsigned char* pb = base + (ks ? b_off1 : b_off0);
 #pragma unroll
-                for (int i = 0; i < MC; ++i) a[i] = *(const bf16x8*)(base + lds_swz(arow0 + 16 * i, ks * 4 + fgrp));
+                for (int i = 0; i < MC; ++i) a[i] = *(const bf16x8*)(pa + 2048 * i);
 #pragma unroll
-                for (int j = 0; j < MP; ++j) b[j] = *(const bf16x8*)(base + lds_swz(brow0 + 16 * j, ks * 4 + fgrp));
+                for (int j = 0; j < MP; ++j) b[j] = *(const bf16x8*)(pb + 2048 * j);
 #pragma unroll
                 for (int i = 0; i < MC; ++i)
 #pragma unroll
