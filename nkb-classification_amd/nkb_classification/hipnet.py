@@ -597,12 +597,39 @@ class HipEngine:
         hip.gelu(self.d, x, g, dx, x.numel())
         return dx
 
-    def attention(self, key: str, qkv: torch.Tensor, B: int, T: int, H: int, train: bool) -> torch.Tensor:
-        """softmax(q k^T / sqrt(dh)) v over all (image, head) pairs; qkv: [B*T, 3*D] laid out [which][head][dh]."""
+    def dropout(self, key: str, x: torch.Tensor, p: float, train: bool, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """nn.Dropout(p) in train mode (+ add): y = keep * x / (1 - p) (+ add).  Identity (+ add) otherwise.  The keep mask
+        (one byte per element, counter-based generator seeded from torch's global generator) is kept for backward."""
+        if not (train and p > 0):
+            if add is None:
+                return x
+            y = self.ws.get(key + ".y", x.shape, self.T)
+            torch.add(x, add, out=y)
+            return y
+        y = self.ws.get(key + ".y", x.shape, x.dtype)
+        mask = self.ws.get(key + ".mask", x.shape, torch.uint8)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        hip.dropout(hip.dt(x.dtype), False, x, add, y, mask, x.numel(), p, seed)
+        self.saved[key] = dict(mask=mask, p=p)
+        return y
+
+    def dropout_backward(self, key: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        """Gradient through dropout(key); a pass-through when that dropout was inactive in the forward pass."""
+        sv = self.saved.get(key)
+        if sv is None:
+            return g
+        dx = self.ws.get("grad.%s%s.%s" % (slot, self._suffix, "x".join(str(int(v)) for v in g.shape)), g.shape, g.dtype)
+        hip.dropout(hip.dt(g.dtype), True, g, None, dx, sv["mask"], g.numel(), sv["p"], 0)
+        return dx
+
+    def attention(self, key: str, qkv: torch.Tensor, B: int, T: int, H: int, train: bool, drop_p: float = 0.0) -> torch.Tensor:
+        """softmax(q k^T / sqrt(dh)) v over all (image, head) pairs; qkv: [B*T, 3*D] laid out [which][head][dh].
+        drop_p: attention-probability dropout (timm Attention.attn_drop); active dropout takes the materialised path."""
         D = qkv.shape[1] // 3
         dh = D // H
         Tp = _round_up(T, self.kte)
-        if self.fused_attention and self.T == torch.bfloat16 and dh == 64 and T <= 256:
+        attn_drop = train and drop_p > 0
+        if self.fused_attention and self.T == torch.bfloat16 and dh == 64 and T <= 256 and not attn_drop:
             # fused kernel: scores and probabilities never reach HBM; only the per-row log-sum-exp is kept
             o = self.ws.get(key + ".o", (B * T, D), self.T)
             lse = self.ws.get(key + ".lse", (B * H, T), torch.float32)
@@ -618,11 +645,12 @@ class HipEngine:
         sq = (T * 3 * D, dh)
         hip.gemm_batched(self.d, q, k, S, T, T, dh, 3 * D, 3 * D, Tp, B, H, sq, sq, (H * T * Tp, T * Tp), out_f32=True)
         hip.attn_softmax(self.d, False, S, Tp, None, P, Tp, B * H * T, T, dh ** -0.5)
+        Pd = self.dropout(key + ".drop", P, drop_p, train) if attn_drop else P
         hip.head_transpose(self.d, v, 3 * D, T * 3 * D, dh, B, H, Vt, T, dh, Tp)
-        hip.gemm_batched(self.d, P, Vt, o, T, dh, Tp, Tp, Tp, D, B, H, (H * T * Tp, T * Tp), (H * dh * Tp, dh * Tp),
+        hip.gemm_batched(self.d, Pd, Vt, o, T, dh, Tp, Tp, Tp, D, B, H, (H * T * Tp, T * Tp), (H * dh * Tp, dh * Tp),
                          (T * D, dh))
         if train:
-            self.saved[key] = dict(qkv=qkv, P=P, B=B, T=T, H=H)
+            self.saved[key] = dict(qkv=qkv, P=P, Pd=Pd, B=B, T=T, H=H, drop=attn_drop)
         return o
 
     def attention_backward(self, key: str, d_o: torch.Tensor, slot: str) -> torch.Tensor:
@@ -645,10 +673,13 @@ class HipEngine:
             P = sv["P"]
             dP = self.ws.get("attn.S", (B * H, T, Tp), torch.float32)
             dS = self.ws.get("attn.dS", (B * H, T, Tp), self.T)
-            # dV = P^T dO
-            hip.gemm_tn_batched(self.d, P, d_o, dqkv[:, 2 * D:], T, T, dh, Tp, D, 3 * D, B, H, sp, so, sq)
-            # dP = dO V^T ; dS = softmax'(P, dP)
+            # dV = Pd^T dO   (Pd = dropped probabilities when attention dropout was active, else P itself)
+            hip.gemm_tn_batched(self.d, sv["Pd"], d_o, dqkv[:, 2 * D:], T, T, dh, Tp, D, 3 * D, B, H, sp, so, sq)
+            # dPd = dO V^T ; dP = dropout'(dPd) ; dS = softmax'(P, dP)
             hip.gemm_batched(self.d, d_o, v, dP, T, T, dh, D, 3 * D, Tp, B, H, so, sq, sp, out_f32=True)
+            if sv["drop"]:
+                dsv = self.saved[key + ".drop"]
+                hip.dropout(hip.dt(torch.float32), True, dP, None, dP, dsv["mask"], dP.numel(), dsv["p"], 0)
             hip.attn_softmax(self.d, True, dP, Tp, P, dS, Tp, B * H * T, T, dh ** -0.5)
         # dQ = dS K ; dK = dS^T Q
         hip.head_transpose(self.d, k, 3 * D, T * 3 * D, dh, B, H, Kt, T, dh, Tp)

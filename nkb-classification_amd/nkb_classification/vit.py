@@ -67,6 +67,7 @@ class HipViT(_ParamOnly):
         self.pos_drop = nn.Dropout(0.0)
         self.blocks = nn.Sequential(*[_Block(dim, heads, mlp_ratio) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.head_drop = nn.Dropout(0.0)
         nn.init.normal_(self.cls_token, std=1e-6)
         for m in self.modules():
             if isinstance(m, nn.Linear):
@@ -79,12 +80,12 @@ class HipViT(_ParamOnly):
     def stem_convs(self):
         return [self.patch_embed.proj]
 
-    def _check_dropout(self, train):
-        if train and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
-            raise NotImplementedError("backbone_dropout > 0 is not implemented by the HIP engine yet; set it to 0")
-
     def run_forward(self, eng: HipEngine, img: torch.Tensor, train: bool) -> torch.Tensor:
-        self._check_dropout(train)
+        """Dropout sites follow timm's VisionTransformer (every nn.Dropout the reference's set_dropout rewrites,
+        model.py:66-72): pos_drop after the position embedding, attn_drop on the attention probabilities, proj_drop and
+        mlp.drop2 before the residual additions, mlp.drop1 after the GELU, head_drop on the pooled embedding."""
+        for k in [k for k in eng.saved if k.endswith(".drop") or k.endswith("_drop")]:
+            del eng.saved[k]                                 # masks of a previous step must not leak into this backward
         B, C, Hh, Ww = img.shape
         if Hh != self.img or Ww != self.img:
             raise RuntimeError(f"this ViT expects {self.img}x{self.img} inputs (pos_embed is fixed), got {Hh}x{Ww}")
@@ -105,19 +106,29 @@ class HipViT(_ParamOnly):
         hip.vit_assemble(eng.d, False, tok, a.param_flat(self.cls_token), a.param_flat(self.pos_embed), x, B, T, D)
         if train:
             eng.saved["pe"] = dict(col=col, B=B, T=T, kp=kp, K=K)
+        x = eng.dropout("pos_drop", x, self.pos_drop.p, train)
         for i, blk in enumerate(self.blocks):
+            at, mlp = blk.attn, blk.mlp
             h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train)
-            qkv = eng.linear(f"b{i}.qkv", h, blk.attn.qkv, train)
-            o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train)
-            x = eng.linear(f"b{i}.proj", o, blk.attn.proj, train, add=x)
+            qkv = eng.linear(f"b{i}.qkv", h, at.qkv, train)
+            o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train, drop_p=at.attn_drop.p)
+            if train and at.proj_drop.p > 0:
+                x = eng.dropout(f"b{i}.proj_drop", eng.linear(f"b{i}.proj", o, at.proj, train), at.proj_drop.p, train, add=x)
+            else:
+                x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x)
             h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train)
             if _FUSED_GELU:
-                u = eng.linear_gelu(f"b{i}.fc1", h, blk.mlp.fc1, train)        # GELU fused into the fc1 epilogue
+                u = eng.linear_gelu(f"b{i}.fc1", h, mlp.fc1, train)        # GELU fused into the fc1 epilogue
             else:
-                u = eng.gelu(f"b{i}.act", eng.linear(f"b{i}.fc1", h, blk.mlp.fc1, train), train)
-            x = eng.linear(f"b{i}.fc2", u, blk.mlp.fc2, train, add=x)
+                u = eng.gelu(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train)
+            u = eng.dropout(f"b{i}.mlp_drop", u, mlp.drop1.p, train)
+            if train and mlp.drop2.p > 0:
+                x = eng.dropout(f"b{i}.mlp2_drop", eng.linear(f"b{i}.fc2", u, mlp.fc2, train), mlp.drop2.p, train, add=x)
+            else:
+                x = eng.linear(f"b{i}.fc2", u, mlp.fc2, train, add=x)
         # final norm on the class-token rows only (x[:, 0]); the other rows never reach the head
-        return eng.layernorm("norm", x, self.norm, train, rows=B, x_stride=T * D)
+        emb = eng.layernorm("norm", x, self.norm, train, rows=B, x_stride=T * D)
+        return eng.dropout("head_drop", emb, self.head_drop.p, train)
 
     def run_backward(self, eng: HipEngine, g_emb: torch.Tensor, on_done=None):
         sv = eng.saved["pe"]
@@ -127,6 +138,7 @@ class HipViT(_ParamOnly):
         a = eng.arena
         gx = eng.scratch("gx0", (M, D))
         gx.zero_()
+        g_emb = eng.dropout_backward("head_drop", g_emb, "gemb")
         eng.layernorm_backward("norm", g_emb, gx, T * D)          # rows b*T (class tokens); everything else stays 0
         if on_done is not None:
             on_done(self.norm)
@@ -134,13 +146,15 @@ class HipViT(_ParamOnly):
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
             eng.begin_block(i)
+            g2 = eng.dropout_backward(f"b{i}.mlp2_drop", gx, "g2")       # branch gradient; the residual path keeps gx
             if _FUSED_GELU:   # gelu' fused into the fc2 data-gradient epilogue
-                d_a = eng.linear_backward_through_gelu(f"b{i}.fc2", f"b{i}.fc1", gx, "da")
+                d_a = eng.linear_backward_through_gelu(f"b{i}.fc2", f"b{i}.fc1", g2, "da")
             else:
-                d_a = eng.gelu_backward(f"b{i}.act", eng.linear_backward(f"b{i}.fc2", gx, "du"), "da")
+                d_u = eng.dropout_backward(f"b{i}.mlp_drop", eng.linear_backward(f"b{i}.fc2", g2, "du"), "du2")
+                d_a = eng.gelu_backward(f"b{i}.act", d_u, "da")
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
             gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
-            d_o = eng.linear_backward(f"b{i}.proj", gmid, "do")
+            d_o = eng.linear_backward(f"b{i}.proj", eng.dropout_backward(f"b{i}.proj_drop", gmid, "g1"), "do")
             d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv")
             d_h = eng.linear_backward(f"b{i}.qkv", d_qkv, "dh")
             gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid)
@@ -149,6 +163,7 @@ class HipViT(_ParamOnly):
             if on_done is not None:
                 on_done(blk)
         eng.begin_block(-1)
+        gx = eng.dropout_backward("pos_drop", gx, "gpos")
         # embedding: d_pos = sum_b gx[b], d_cls = sum_b gx[b, 0], d_tok = gx[:, 1:], then the patch projection
         hip.colsum2d(eng.d, gx, a.grad_flat(self.pos_embed), B, T * D, T * D)
         hip.colsum2d(eng.d, gx, a.grad_flat(self.cls_token), B, D, T * D)

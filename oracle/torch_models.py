@@ -192,6 +192,7 @@ class VisionTransformer(nn.Module):
         self.pos_drop = nn.Dropout(0.0)
         self.blocks = nn.Sequential(*[Block(dim, heads, mlp_ratio) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.head_drop = nn.Dropout(0.0)      # timm forward_head: fc_norm -> head_drop -> head (Identity for num_classes=0)
         self.head = nn.Identity()
         nn.init.normal_(self.cls_token, std=1e-6)
         for m in self.modules():
@@ -204,7 +205,7 @@ class VisionTransformer(nn.Module):
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
         x = self.pos_drop(x + self.pos_embed)
         x = self.norm(self.blocks(x))
-        return self.head(x[:, 0])
+        return self.head(self.head_drop(x[:, 0]))
 
 
 _BACKBONES = {

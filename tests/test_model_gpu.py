@@ -302,6 +302,65 @@ def test_data_parallel_two_ranks_on_one_gpu():
     assert sorted(res) == [(0, True, True, 0.5), (1, True, True, 0.5)]
 
 
+def test_vit_backbone_dropout_matches_oracle_with_replayed_masks():
+    """backbone_dropout > 0 on a ViT (the reference's sample configs use 0.1; set_dropout rewrites every nn.Dropout of
+    timm's VisionTransformer): run the HIP model in train mode, then replay its keep masks inside the CPU oracle at the
+    same six kinds of sites — logits and every parameter gradient must agree (fp32)."""
+    cfg_model = dict(model="vit_tiny_test", pretrained=False, backbone_dropout=0.25, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    classes = ["a", "b", "c"]
+    oracle, model = _pair(cfg_model, classes, seed=3)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    y = torch.randint(0, 3, (4,), generator=g)
+    model.train(); oracle.train()
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    out = model(x.to(DEV))
+    crit(out, y.to(DEV)).backward()
+    torch.cuda.synchronize()
+    saved = model._active.saved
+    p = 0.25
+
+    class Replay(torch.nn.Module):
+        def __init__(self, mask):
+            super().__init__()
+            self.mask = mask.float().cpu()
+
+        def forward(self, t):
+            m = self.mask
+            if m.dim() == 3 and t.dim() == 4:                    # attention: [B*H, T, Tp] -> [B, H, T, T]
+                m = m[:, :, : t.shape[-1]].reshape(t.shape)
+            return t * m.reshape(t.shape) / (1 - p)
+
+    vit = oracle.emb_model
+    keys = ["pos_drop", "head_drop"]
+    vit.pos_drop = Replay(saved["pos_drop"]["mask"])
+    vit.head_drop = Replay(saved["head_drop"]["mask"])
+    for i, blk in enumerate(vit.blocks):
+        blk.attn.attn_drop = Replay(saved[f"b{i}.attn.drop"]["mask"])
+        blk.attn.proj_drop = Replay(saved[f"b{i}.proj_drop"]["mask"])
+        blk.mlp.drop1 = Replay(saved[f"b{i}.mlp_drop"]["mask"])
+        blk.mlp.drop2 = Replay(saved[f"b{i}.mlp2_drop"]["mask"])
+        keys += [f"b{i}.attn.drop", f"b{i}.proj_drop", f"b{i}.mlp_drop", f"b{i}.mlp2_drop"]
+    for k in keys:
+        keep = saved[k]["mask"].float().mean().item()
+        assert 0.6 < keep < 0.9, (k, keep)                        # keep rate ~ 0.75
+    ref = oracle(x)
+    torch.nn.functional.cross_entropy(ref, y).backward()
+    assert _relerr(out.detach().cpu(), ref.detach()) < 1e-3
+    po = dict(oracle.named_parameters())
+    num = den = 0.0
+    for name, prm in model.named_parameters():
+        assert prm.grad is not None, name
+        num += (prm.grad.detach().cpu().double() - po[name].grad.double()).pow(2).sum().item()
+        den += po[name].grad.double().pow(2).sum().item()
+    assert (num / den) ** 0.5 < 2e-3
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(x.to(DEV)), model(x.to(DEV))
+    assert torch.equal(e1, e2)                                    # eval: every dropout is the identity
+
+
 def test_classifier_dropout_train_path():
     """classifier_dropout > 0 (reference sample configs use 0.1): per-head masks, 1/(1-p) scaling, consistent backward."""
     from nkb_classification import hip
