@@ -5,8 +5,8 @@
 Same epoch driver as train.py:19-73: TrainLogger, GradScaler(enabled=cfg.enable_gradient_scaler), per-epoch
 backbone freeze policy, train_epoch / val_epoch, compute_metrics, best-by-validation-balanced-accuracy and last
 checkpoints under <experiment>/weights/.  Checkpoints are state dicts with timm-compatible keys
-(`best.pth`, `last.pth`); the reference additionally writes TorchScript archives of the torch module graph each
-epoch (train.py:66-73) — the HIP model has no torch module graph to script, see INTEGRATION.md.
+(`best.pth`, `last.pth`) plus the TorchScript archives `scripted_best.pt` / `scripted_last.pt` of train.py:66-73,
+scripted from a plain-torch module with the same architecture and weights (nkb_classification/scripted.py).
 Launch under `torch.distributed.run` to train data-parallel (one process per GPU, RCCL gradient all-reduce).
 """
 from __future__ import annotations
@@ -27,6 +27,7 @@ from nkb_classification.logging import TrainLogger, get_local_experiment  # noqa
 from nkb_classification.losses import get_loss  # noqa: E402
 from nkb_classification.metrics import compute_metrics  # noqa: E402
 from nkb_classification.model import get_model  # noqa: E402
+from nkb_classification.scripted import save_scripted  # noqa: E402
 from nkb_classification.utils import get_optimizer, get_scheduler, read_py_config  # noqa: E402
 
 
@@ -54,7 +55,9 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, come
         if epoch_val_acc is not None and epoch_val_acc > best_val_acc:
             best_val_acc = epoch_val_acc
             torch.save(model.state_dict(), Path(model_path, "best.pth"))
+            save_scripted(model, Path(model_path, "scripted_best.pt"))
         torch.save(model.state_dict(), Path(model_path, "last.pth"))
+        save_scripted(model, Path(model_path, "scripted_last.pt"))
 
 
 def main():

@@ -171,3 +171,32 @@ def test_read_py_config(tmp_path):
     exec(line, ns, ns)
     assert ns["cfg"].device == "cuda:0"
     assert utils.get_classes_configs(["a", "b"]) == ({"a": 0, "b": 1}, {0: "a", 1: "b"})
+
+
+@pytest.mark.parametrize("backbone,task", [("resnet_tiny_basic", "single"), ("resnet_tiny_bottleneck", "multi"),
+                                           ("vit_tiny_test", "single")])
+def test_scripted_export_matches_oracle(tmp_path, backbone, task):
+    """train.py:66-73 counterpart: the TorchScript archive written next to each checkpoint carries the trained weights
+    and the reference's forward contract (Tensor / dict of Tensors) — checked against the oracle on the same state."""
+    from nkb_classification.model import get_model
+    from nkb_classification.scripted import save_scripted
+    from oracle.torch_models import OracleClassifier
+    cfg_model = dict(model=backbone, pretrained=False, backbone_dropout=0.1, classifier_dropout=0.1,
+                     classifier_initialization="kaiming_normal_", task=task)
+    classes = ["a", "b", "c"] if task == "single" else {"t1": ["x", "y"], "t2": ["p", "q", "r"]}
+    torch.manual_seed(0)
+    oracle = OracleClassifier(cfg_model, classes).eval()
+    model = get_model(dict(cfg_model), classes, "cpu")
+    model.load_state_dict(oracle.state_dict())
+    path = tmp_path / "scripted_last.pt"
+    save_scripted(model, path)
+    loaded = torch.jit.load(str(path))
+    x = torch.randn(2, 3, 64, 64)
+    with torch.no_grad():
+        ref, out = oracle(x), loaded(x)
+    if task == "single":
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    else:
+        assert sorted(out) == sorted(ref)
+        for t in ref:
+            torch.testing.assert_close(out[t], ref[t], rtol=1e-5, atol=1e-5)

@@ -235,6 +235,7 @@ def test_train_py_end_to_end(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     exp = tmp_path / "exp"
     assert (exp / "weights" / "last.pth").exists() and (exp / "classes.json").exists()
+    assert (exp / "weights" / "scripted_last.pt").exists()          # train.py:66-73 TorchScript archive
     lines = (exp / "metrics.csv").read_text().strip().splitlines()
     assert len(lines) == 3 and "\t" in lines[0]
     sd = torch.load(exp / "weights" / "last.pth", map_location="cpu")
