@@ -300,10 +300,15 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
                 const u32x4 pk = pack8(v);
                 *(u32x4*)(o + ri * ostep) = pk;
                 if constexpr (hs) {                    // statistics see the stored (rounded) value
-                    float r[8];
-                    unpack8(pk, r);
+                    // two channels per instruction (v_pk_add_f32 / v_pk_mul_f32): same products and sums, half the issue slots
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { ssum[e] += r[e]; ssq[e] += r[e] * r[e]; }
+                    for (int e = 0; e < 4; ++e) {
+                        const nkb_f2 r2 = {__uint_as_float(pk[e] << 16), __uint_as_float(pk[e] & 0xffff0000u)};
+                        nkb_f2 s2 = {ssum[2 * e], ssum[2 * e + 1]}, q2 = {ssq[2 * e], ssq[2 * e + 1]};
+                        s2 += r2;
+                        q2 += r2 * r2;
+                        ssum[2 * e] = s2[0]; ssum[2 * e + 1] = s2[1]; ssq[2 * e] = q2[0]; ssq[2 * e + 1] = q2[1];
+                    }
                 }
             }
         };
