@@ -40,12 +40,19 @@ def _relerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-@pytest.mark.parametrize("backbone", ["resnet_tiny_basic", "resnet_tiny_bottleneck", "resnet18", "vit_tiny_test"])
+@pytest.mark.parametrize("backbone", ["resnet_tiny_basic", "resnet_tiny_bottleneck", "resnet18", "vit_tiny_test",
+                                      # odd sizes: clipped pooling windows, odd parity-class grids of the stride-2 data
+                                      # gradients, ceil-sized sub-grid shortcut gradients, the packed stem's pad column
+                                      "resnet_tiny_basic@54x3", "resnet_tiny_bottleneck@70x3", "resnet_tiny_bottleneck@45x2"])
 def test_single_step_gradients_match_oracle_fp32(backbone):
     """Truth = the oracle evaluated in float64.  ReLU/max-pool decisions on near-zero pre-activations make the
     problem mildly ill-conditioned, so the HIP fp32 path is held to the same distance from the float64 truth as
     torch's own CPU fp32 path instead of to a fixed distance from the fp32 CPU result (see the bounds below).
     Logits keep the 1e-3 / exact-argmax bar."""
+    shape = None
+    if "@" in backbone:
+        backbone, shape = backbone.split("@")
+        shape = tuple(int(v) for v in shape.split("x"))
     cfg_model = dict(model=backbone, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
                      classifier_initialization="kaiming_normal_", task="single")
     classes = ["a", "b", "c"]
@@ -60,8 +67,11 @@ def test_single_step_gradients_match_oracle_fp32(backbone):
     o64 = OracleClassifier(cfg_model, classes).double()
     o64.load_state_dict(o32.state_dict())
     hw = 64 if backbone != "resnet18" else 96
-    x = torch.randn(4, 3, hw, hw, generator=g)
-    y = torch.randint(0, 3, (4,), generator=g)
+    nb = 4
+    if shape is not None:
+        hw, nb = shape
+    x = torch.randn(nb, 3, hw, hw + (3 if shape is not None else 0), generator=g)      # odd cases are non-square too
+    y = torch.randint(0, 3, (nb,), generator=g)
     o32.train(); o64.train(); model.train()
     ref32 = o32(x)
     torch.nn.functional.cross_entropy(ref32, y).backward()
