@@ -22,6 +22,9 @@ _FUSED_BN_BWD = os.environ.get("NKB_FUSED_BNBWD", "1") != "0"
 # 3x3 stride-2 data gradients as four parity-class launches (9 taps instead of 36 multiplied, 27 of them by zero)
 _S2_CLASSES = os.environ.get("NKB_S2_CLASSES", "1") != "0"
 _FUSED_RES_BN_BWD = os.environ.get("NKB_FUSED_RES_BNBWD", "1") != "0"
+# stages with <= 64 channels use the 64x256 conv tile (2 workgroups per CU), whose fused epilogue costs more than the
+# separate reduction pass it replaces (A/B on ResNet-50: 23.75 vs 23.64 ms/step) -> fuse from 65 channels up
+_FUSE_MIN_C = int(os.environ.get("NKB_FUSE_MIN_C", "65"))
 # residual-closing stages keep a 1-bit/element ReLU mask; backward reads it instead of the activation and the masked
 # block-output gradient is never materialised (consumers apply the bits on the fly)
 _RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
@@ -397,7 +400,7 @@ class HipEngine:
     def can_fuse_bn_backward(self, bn_key: str) -> bool:
         sv = self.saved[bn_key]
         return (_FUSED_BN_BWD and sv["relu"] and not sv["has_res"] and sv["pool_idx"] is None
-                and sv["c"].shape[-1] % 8 == 0)
+                and sv["c"].shape[-1] % 8 == 0 and sv["c"].shape[-1] >= _FUSE_MIN_C)
 
     def can_fuse_residual_bn_backward(self, bn_key: str, consumer_key: str) -> bool:
         """The stage `bn_key` closes a residual block (kept ReLU bits) and `consumer_key` is the first conv of the next
