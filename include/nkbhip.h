@@ -62,8 +62,11 @@ int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, co
                     float* running_mean, float* running_var, float momentum, float eps, int training, float* scale,
                     float* shift, float* save_mean, float* save_invstd, nkb_stream_t stream);
 /* relu_bits (optional out): one byte per 16-byte chunk of y (8 bf16 / 4 fp32 channels), bit e = y[chunk*n + e] > 0 */
+/* res_scale/res_shift (optional): `res` is itself a raw conv output (the projection shortcut of a block's first unit);
+ * it enters as bn(res) = res*res_scale + res_shift without a separate pass that would write and re-read it */
 int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, const float* scale, const float* shift,
-                 long long rows, int C, int relu, unsigned char* relu_bits, nkb_stream_t stream);
+                 long long rows, int C, int relu, unsigned char* relu_bits, const float* res_scale,
+                 const float* res_shift, nkb_stream_t stream);
 /* ReLU mask: from relu_bits when given, else yact (> 0), else recomputed as x*fscale+fshift > 0 when fscale is given,
  * else none. */
 int nkb_bn_backward(int dtype, const void* dy, const void* x, const void* yact, const unsigned char* relu_bits,

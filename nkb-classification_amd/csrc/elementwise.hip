@@ -150,14 +150,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, unsigned rows, int C, int relu,
-                                                       unsigned char* __restrict__ bits) {
+                                                       unsigned char* __restrict__ bits,
+                                                       const float* __restrict__ res_scale,
+                                                       const float* __restrict__ res_shift) {
     constexpr int N = Chunk<T>::N;
     const unsigned cpr = (unsigned)C / N;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned cg = t % cpr, r0 = t / cpr, rs = (gridDim.x * blockDim.x) / cpr;
-    float sc[N], sh[N];
+    float sc[N], sh[N], rsc[N], rsh[N];
     ldvec<N>(scale + cg * N, sc);
     ldvec<N>(shift + cg * N, sh);
+    if (res_scale) { ldvec<N>(res_scale + cg * N, rsc); ldvec<N>(res_shift + cg * N, rsh); }
     for (unsigned r = r0; r < rows; r += 2 * rs) {
         const size_t o0 = (size_t)r * C + cg * N;
         const bool two = r + rs < rows;
@@ -166,6 +169,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         Chunk<T>::load(x + o0, v0);
         Chunk<T>::load(x + o1, v1);
         if (res) { Chunk<T>::load(res + o0, q0); Chunk<T>::load(res + o1, q1); }
+        if (res_scale) {     // the residual operand is itself a raw conv output (projection shortcut): normalise it on
+                             // the fly, rounded to the storage dtype exactly as a separate bn_apply pass would have left it
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                q0[e] = DT<T>::rnd(q0[e] * rsc[e] + rsh[e]);
+                q1[e] = DT<T>::rnd(q1[e] * rsc[e] + rsh[e]);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             float a = v0[e] * sc[e] + sh[e], b = v1[e] * sc[e] + sh[e];
@@ -189,17 +200,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, const float* scale, const float* shift,
-                            long long rows, int C, int relu, unsigned char* relu_bits, hipStream_t stream) {
+                            long long rows, int C, int relu, unsigned char* relu_bits, const float* res_scale,
+                            const float* res_shift, hipStream_t stream) {
     const int n = dtype == NKB_DT_BF16 ? 8 : 4;
     if (C % n || rows >= (1ll << 31)) { nkb_set_error("bn_apply: C=%d not a multiple of %d (or too many rows)", C, n); return 1; }
     NkbProfScope prof(NKB_K_BN_APPLY, stream, 0, (double)rows * C * (dtype == NKB_DT_BF16 ? 2 : 4) * (res ? 3 : 2));
     const unsigned grid = grid_cols((size_t)rows, C / n);
     if (dtype == NKB_DT_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x,
-                           (const bf16_t*)res, (bf16_t*)y, scale, shift, (unsigned)rows, C, relu, relu_bits);
+                           (const bf16_t*)res, (bf16_t*)y, scale, shift, (unsigned)rows, C, relu, relu_bits, res_scale, res_shift);
     else
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x,
-                           (const float*)res, (float*)y, scale, shift, (unsigned)rows, C, relu, relu_bits);
+                           (const float*)res, (float*)y, scale, shift, (unsigned)rows, C, relu, relu_bits, res_scale, res_shift);
     return nkb_check_launch("bn_apply");
 }
 

@@ -136,11 +136,14 @@ class HipResNet(_ParamOnly):
             stages = blk.stages()
             for k, (cv, bn) in enumerate(stages[:-1]):
                 x = eng.conv_bn(f"{name}.{k}", x, cv, bn, True, None, train)
-            short = inp
+            short, short_affine = inp, None
             if blk.downsample is not None:
-                short = eng.conv_bn(f"{name}.ds", inp, blk.downsample[0], blk.downsample[1], False, None, train)
+                # projection shortcut: its BatchNorm is applied inside the closing stage's pass (never materialised)
+                short, s_scale, s_shift = eng.conv_bn(f"{name}.ds", inp, blk.downsample[0], blk.downsample[1], False, None,
+                                                      train, defer_apply=True)
+                short_affine = (s_scale, s_shift)
             cv, bn = stages[-1]
-            x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train)
+            x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train, res_affine=short_affine)
         return eng.avgpool("gap", x)
 
     def run_backward(self, eng: HipEngine, g_emb: torch.Tensor, on_done=None):

@@ -27,7 +27,7 @@ _SIGS = {
     "nkb_set_ring": (None, [i32]),
     "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp]),
     "nkb_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
-    "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
+    "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp]),
     "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
     "nkb_bn_stats_floats": (sz, [i32, i32]),
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
@@ -153,9 +153,9 @@ def bn_finalize(partials, tiles, C_, count, gamma, beta, rm, rv, momentum, eps, 
                                  int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream()), "bn_finalize")
 
 
-def bn_apply(dtype, x, res, y, scale, shift, rows, C_, relu, relu_bits=None):
+def bn_apply(dtype, x, res, y, scale, shift, rows, C_, relu, relu_bits=None, res_scale=None, res_shift=None):
     check(load().nkb_bn_apply(dtype, ptr(x), ptr(res), ptr(y), ptr(scale), ptr(shift), rows, C_, int(relu),
-                              ptr(relu_bits), stream()), "bn_apply")
+                              ptr(relu_bits), ptr(res_scale), ptr(res_shift), stream()), "bn_apply")
 
 
 def bn_stats_floats(tiles, C_):

@@ -149,9 +149,11 @@ class HipEngine:
     # ------------------------------------------------------------------ forward ops ----
     def conv_bn(self, key: str, x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool,
                 res: Optional[torch.Tensor], train: bool, col_input: bool = False, pool: bool = False,
-                stem_packed=None) -> torch.Tensor:
+                stem_packed=None, defer_apply: bool = False, res_affine=None):
         """y = act(bn(conv(x)) (+ res)).  x: [N,H,W,Cin] in the compute dtype (or the im2row matrix of the stem).
         stem_packed=(N, H, W): x is the packed image of nkb_stem_pack and conv the 7x7/2 stem.
+        defer_apply=True: stop after the statistics and return (c, scale, shift) — for a projection shortcut, whose
+        normalisation the consuming stage applies on the fly (res=c, res_affine=(scale, shift)).
         pool=True (stem): y = maxpool3x3s2(relu(bn(conv(x)))) in one pass over the raw conv output; the un-pooled
         activation is never materialised."""
         w = conv.weight
@@ -182,6 +184,13 @@ class HipEngine:
         scale, shift, mean, invstd = sc[0], sc[1], sc[2], sc[3]
         hip.bn_finalize(stats, tiles, co, rows, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, train, scale, shift, mean, invstd)
+        if defer_apply:
+            assert not relu and res is None and not pool
+            if train:
+                self.saved[key] = dict(x=x, c=c, y=None, mean=mean, invstd=invstd, relu=False, geom=geom, conv=conv, bn=bn,
+                                       rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=False,
+                                       pool_idx=None, stem_packed=bool(packed), bits=None)
+            return c, scale, shift
         if pool:
             assert relu and res is None
             P2, Q2 = (P - 1) // 2 + 1, (Q - 1) // 2 + 1
@@ -196,7 +205,8 @@ class HipEngine:
             # cannot be recomputed from c alone there); y itself is then only read by the next block's convolutions
             if train and relu and res is not None and _RELU_BITS:
                 bits = self.ws.get(key + ".bits", (rows, co // (8 if self.T == torch.bfloat16 else 4)), torch.uint8)
-            hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu, bits)
+            hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu, bits,
+                         res_scale=res_affine[0] if res_affine else None, res_shift=res_affine[1] if res_affine else None)
         if train:
             self.saved[key] = dict(x=x, c=c, y=y, mean=mean, invstd=invstd, relu=relu, geom=geom, conv=conv, bn=bn,
                                    rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None,

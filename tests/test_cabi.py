@@ -34,5 +34,5 @@ def test_argument_validation_without_gpu():
     assert rc != 0 and b"Cin=48" in lib.nkb_last_error()
     rc = lib.nkb_conv_gemm(1, 0, None, None, None, None, None, None, 1, 8, 8, 64, 64, 8, 8, 64, 64, 0, 3, 3, 3, 1, 0, 0, 0, 0, None, None)
     assert rc != 0 and b"stride" in lib.nkb_last_error()
-    rc = lib.nkb_bn_apply(1, None, None, None, None, None, 10, 12, 0, None, None)
+    rc = lib.nkb_bn_apply(1, None, None, None, None, None, 10, 12, 0, None, None, None, None)
     assert rc != 0 and b"C=12" in lib.nkb_last_error()
