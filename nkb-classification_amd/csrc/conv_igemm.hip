@@ -1015,7 +1015,7 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     p.tilesC = (Cout + TW - 1) / TW;
     p.tilesN = (p.Ntot + TW - 1) / TW;
     const int tiles = p.tilesC * p.tilesN;
-    static const int target_wgs = [] { const char* e = getenv("NKB_WGRAD_WGS"); return e ? atoi(e) : 384; }();   // swept: fewer splits = fewer float atomics
+    static const int target_wgs = [] { const char* e = getenv("NKB_WGRAD_WGS"); return e ? atoi(e) : 256; }();   // swept (128..768) on ResNet-50 and ViT-B/16: fewer splits = fewer float atomics and less competition with the main stream
     int splits = (target_wgs + tiles - 1) / tiles;
     const int max_splits = (p.M + 255) / 256;  // at least 4 pipeline stages per split
     if (splits > max_splits) splits = max_splits;
@@ -1142,7 +1142,7 @@ extern "C" int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* 
     p.tilesC = (Cout + TW - 1) / TW;
     p.tilesN = (p.Ntot + TW - 1) / TW;
     const int tiles = p.tilesC * p.tilesN;
-    int splits = (384 + tiles - 1) / tiles;
+    int splits = (256 + tiles - 1) / tiles;
     const int max_splits = (p.M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
