@@ -18,6 +18,8 @@ from .hipnet import HipEngine
 
 # bn1 -> relu -> maxpool of the stem as one kernel each way (0 = separate kernels, for A/B measurements)
 _FUSED_STEM_TAIL = os.environ.get("NKB_FUSED_STEM", "1") != "0"
+# forward: projection-shortcut convolution on the side stream, next to the block's main branch
+_SIDE_SHORTCUT = os.environ.get("NKB_SIDE_SHORTCUT", "1") != "0"
 
 
 class _ParamOnly(nn.Module):
@@ -134,13 +136,25 @@ class HipResNet(_ParamOnly):
         for name, blk in self.blocks():
             inp = x
             stages = blk.stages()
-            for k, (cv, bn) in enumerate(stages[:-1]):
-                x = eng.conv_bn(f"{name}.{k}", x, cv, bn, True, None, train)
             short, short_affine = inp, None
             if blk.downsample is not None:
-                # projection shortcut: its BatchNorm is applied inside the closing stage's pass (never materialised)
-                short, s_scale, s_shift = eng.conv_bn(f"{name}.ds", inp, blk.downsample[0], blk.downsample[1], False, None,
-                                                      train, defer_apply=True)
+                # projection shortcut: its BatchNorm is applied inside the closing stage's pass (never materialised);
+                # the convolution itself only depends on the block input, so it runs on the side stream next to the
+                # main branch (the forward pass has nothing else to overlap)
+                box = {}
+
+                def shortcut(key=f"{name}.ds", src=inp, ds=blk.downsample):
+                    box["r"] = eng.conv_bn(key, src, ds[0], ds[1], False, None, train, defer_apply=True)
+                if _SIDE_SHORTCUT:
+                    eng.on_side(shortcut)
+                else:
+                    shortcut()
+            for k, (cv, bn) in enumerate(stages[:-1]):
+                x = eng.conv_bn(f"{name}.{k}", x, cv, bn, True, None, train)
+            if blk.downsample is not None:
+                if _SIDE_SHORTCUT:
+                    eng.join_side()
+                short, s_scale, s_shift = box["r"]
                 short_affine = (s_scale, s_shift)
             cv, bn = stages[-1]
             x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train, res_affine=short_affine)

@@ -281,6 +281,12 @@ class HipEngine:
         with torch.cuda.stream(self._side):
             fn()
 
+    def join_side(self):
+        """Main stream waits for everything enqueued on the side stream so far (forward-pass use; the backward pass
+        tracks its weight gradients per block with begin_block / end_block instead)."""
+        if self._side is not None and self.overlap_wgrad:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def begin_block(self, index: int):
         """Scratch gradient buffers alternate between two sets by block parity; before a set is reused the main
         stream waits for the side-stream weight gradients that still read it (issued two blocks earlier)."""
