@@ -26,7 +26,7 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) { return row * 128 + 
 //      3 plain bf16 epilogue only (bias / ReLU / per-tile statistics; no residual operand, activation epilogue, row
 //        remap or fp32 output): a lean row loop, selected by launch_conv when the launch qualifies
 template <typename T, int TC, int TP, int BNB = 0>
-__global__ __launch_bounds__(256, (BNB && TC == 128 && TP == 128) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int KTE = 128 / (int)sizeof(T);  // elements per k-tile row
     constexpr int NWR = TC / 32;               // weight rows staged per thread
@@ -768,13 +768,6 @@ static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
 // picks the lean-epilogue instantiation (BNB = 3) when the launch has nothing but bias / ReLU / statistics to do
 template <typename T, int TC, int TP>
 static int launch_conv_auto(ConvParams& p, hipStream_t stream, int batch = 1) {
-    if constexpr (sizeof(T) == 2 && TC == 128 && TP == 128) {
-        static const int tall = [] { const char* e = getenv("NKB_TALL"); return e ? atoi(e) : 0; }();   // experiment: 128x256 tile
-        if (tall && batch == 1 && p.M >= 256 * 512) {
-            const bool plain = p.add == nullptr && p.act == 0 && p.sub_h == 0 && !p.out_f32 && (p.Cout & 7) == 0 && (p.ldy & 7) == 0;
-            return plain ? launch_conv<T, 128, 256, 3>(p, stream, batch) : launch_conv<T, 128, 256, 0>(p, stream, batch);
-        }
-    }
     if constexpr (sizeof(T) == 2) {
         static const int lean_on = [] { const char* e = getenv("NKB_LEAN_EPILOGUE"); return e ? atoi(e) : 1; }();
         const bool plain = lean_on && p.add == nullptr && p.act == 0 && p.sub_h == 0 && !p.out_f32 && (p.Cout & 7) == 0 &&
