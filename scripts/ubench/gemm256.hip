@@ -258,6 +258,100 @@ __global__ __launch_bounds__(512, 1) void gemm256_ring_kernel(const bf16_t* __re
     }
 }
 
+// Variant 4: the vendor kernel's shape — 4 waves (one per SIMD), each 128 x 128 of the 256 x 256 tile (64 accumulator
+// tiles = 256 registers, AGPRs), two 64-deep LDS buffers filled by LDS-DMA, one barrier per k-tile.
+__global__ __launch_bounds__(256, 1) void gemm256_w4_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                            bf16_t* __restrict__ C, int M, int N, int K, int tilesN) {
+    constexpr int TB = 256 * 128;
+    constexpr int BUF = 2 * TB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wcn = wave & 1;     // wave: 128 W-rows x 128 X-rows
+    const unsigned nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = blockIdx.x & 7, o = blockIdx.x >> 3;
+    const unsigned lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    const int tile_n = lid % tilesN, tile_m = lid / tilesN;
+    const int n0 = tile_n * 256, m0 = tile_m * 256;
+    const int KT = K / 64;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int chunk = lslot ^ lrow;
+    // 32 pieces per operand and k-tile; wave w issues pieces w, w+4, ..., w+28
+    unsigned woff[8], xoff[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = (p * 4 + wave) * 8 + lrow;
+        int wn = n0 + row; if (wn >= N) wn = N - 1;
+        int xm = m0 + row; if (xm >= M) xm = M - 1;
+        woff[p] = (unsigned)wn * (unsigned)K + chunk * 8;
+        xoff[p] = (unsigned)xm * (unsigned)K + chunk * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + woff[p] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(base + (p * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + xoff[p] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(base + TB + (p * 4 + wave) * 1024), 16, 0, 0);
+    };
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int a_off0 = lds_swz(wr * 128 + frow, fgrp), a_off1 = lds_swz(wr * 128 + frow, 4 + fgrp);
+    const int b_off0 = TB + lds_swz(wcn * 128 + frow, fgrp), b_off1 = TB + lds_swz(wcn * 128 + frow, 4 + fgrp);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);
+        const unsigned char* base = smem + (kt & 1) * BUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned char* pa = base + (ks ? a_off1 : a_off0);
+            const unsigned char* pb = base + (ks ? b_off1 : b_off0);
+            bf16x8 a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8*)(pa + 2048 * i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16x8 b = *(const bf16x8*)(pb + 2048 * j);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // epilogue: four passes of 64 X-rows; pass p holds X-rows [64p, 64p+64) = wave column p>>1, j in [4*(p&1), +4)
+    constexpr int EROW = 256 * 4 + 16;
+    for (int pass = 0; pass < 4; ++pass) {
+        if (wcn == (pass >> 1)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    *(f32x4*)(smem + (16 * jj + frow) * EROW + (wr * 128 + 16 * i + fgrp * 4) * 4) = acc[i][4 * (pass & 1) + jj];
+        }
+        __syncthreads();
+        const int eg = tid & 31, er = tid >> 5;            // 32 chunks per row, 8 rows per trip
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = er + 8 * t;
+            const int m = m0 + pass * 64 + row, n = n0 + eg * 8;
+            if (m < M && n < N) {
+                const f32x4 lo = *(const f32x4*)(smem + row * EROW + eg * 32), hi = *(const f32x4*)(smem + row * EROW + eg * 32 + 16);
+                u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                *(u32x4*)(C + (size_t)m * N + n) = pk;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void ref_rows_kernel(const bf16_t* X, const bf16_t* W, float* out, int N, int K, const int* rows, int nrows) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, ri = blockIdx.y;
     if (n >= N || ri >= nrows) return;
@@ -284,11 +378,13 @@ int main(int argc, char** argv) {
     const int tilesM = (M + 255) / 256, tilesN = N / 256;
     const int lds = 2 * 2 * 256 * 128 > 64 * (256 * 4 + 16) ? 2 * 2 * 256 * 128 : 64 * (256 * 4 + 16);
     hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemm256_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute((const void*)gemm256_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute((const void*)gemm256_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int variant = argc > 4 ? atoi(argv[4]) : VARIANT;
     auto launch = [&]() {
         if (variant == 2) hipLaunchKernelGGL(gemm256_ring_kernel<false>, dim3(tilesM * tilesN), dim3(512), lds, 0, dx, dw, dc, M, N, K, tilesN);
+        else if (variant == 4) hipLaunchKernelGGL(gemm256_w4_kernel, dim3(tilesM * tilesN), dim3(256), lds, 0, dx, dw, dc, M, N, K, tilesN);
         else if (variant == 3) hipLaunchKernelGGL(gemm256_ring_kernel<true>, dim3(tilesM * tilesN), dim3(512), lds, 0, dx, dw, dc, M, N, K, tilesN);
         else hipLaunchKernelGGL(gemm256_kernel<1>, dim3(tilesM * tilesN), dim3(512), lds, 0, dx, dw, dc, M, N, K, tilesN);
     };
