@@ -1142,7 +1142,10 @@ extern "C" int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* 
     p.tilesC = (Cout + TW - 1) / TW;
     p.tilesN = (p.Ntot + TW - 1) / TW;
     const int tiles = p.tilesC * p.tilesN;
-    int splits = (256 + tiles - 1) / tiles;
+    // this is the last kernel of the backward pass (it needs the stem's BN-backward output) and runs alone on the GPU:
+    // three workgroups per CU instead of the one the shared-GPU split target would give (408 -> ~150 us of pure tail)
+    static const int stem_wgs = [] { const char* e = getenv("NKB_STEM_WGRAD_WGS"); return e ? atoi(e) : 768; }();
+    int splits = (stem_wgs + tiles - 1) / tiles;
     const int max_splits = (p.M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
