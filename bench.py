@@ -50,7 +50,11 @@ def pmc_traffic(args, kernel):
         return None
     try:
         with open(path) as f:
-            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
+            ks = json.load(f)["kernels"]
+        if kernel == "conv_igemm":      # launch-weighted mean over the forward and data-gradient launches
+            parts = [ks[k] for k in ("conv_igemm_fwd", "conv_igemm_dgrad")]
+            return round(sum(x["traffic_bytes_per_launch"] * x["launches"] for x in parts) / sum(x["launches"] for x in parts))
+        return ks[kernel]["traffic_bytes_per_launch"]
     except (KeyError, ValueError):
         return None
 
@@ -243,7 +247,13 @@ def main():
         for e, o in zip(engines, saved_overlap):
             e.overlap_wgrad = o
         prof = hip.prof_collect()
-        cand = {k: v for k, v in prof.items() if v["work"] > 0 or v.get("bytes", 0) > 0}
+        # forward and data-gradient launches are the same kernel (conv_igemm_kernel<...>); the profiler only tags them
+        # separately.  Rank kernels the way rocprofv3 --stats does, by kernel, so merge the two tags.
+        merged = dict(prof)
+        parts = [merged.pop(k) for k in ("conv_igemm_fwd", "conv_igemm_dgrad") if k in merged]
+        if parts:
+            merged["conv_igemm"] = {f: sum(x.get(f, 0) for x in parts) for f in ("ms", "launches", "work", "bytes")}
+        cand = {k: v for k, v in merged.items() if v["work"] > 0 or v.get("bytes", 0) > 0}
         if cand:
             # dominant kernel family by device time; its bound is whichever floor is higher for the launches it made:
             # algorithmic FLOPs / dense MFMA peak or algorithmic bytes / HBM peak (both from MI355X_MICROARCH.md)
