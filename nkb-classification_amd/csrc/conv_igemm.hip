@@ -15,6 +15,13 @@
 // ------------------------------------------------------------------------------------------
 #include "conv_params.h"
 
+// 64x256 tile (Cout <= 64) as ONE LDS stage with the pixel fragments streamed through a single register set: 164 VGPRs
+// -> 3 workgroups per CU like the 128x128 tile (was: two LDS stages, 188 VGPRs, 2 per CU).  ResNet-50 layer1 shapes
+// -12 %, step 22.5 -> 22.1 ms.  (0 restores the double-buffered form for A/B builds.)
+#ifndef NKB_NARROW3
+#define NKB_NARROW3 1
+#endif
+
 template <typename T> struct MmaTraits;
 template <> struct MmaTraits<bf16_t> { static constexpr int KSTEPS = 2; };  // 2 x (16x16x32) per 128-byte k-tile
 template <> struct MmaTraits<float> { static constexpr int KSTEPS = 8; };   // 8 x (16x16x4)
@@ -26,7 +33,7 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) { return row * 128 + 
 //      3 plain bf16 epilogue only (bias / ReLU / per-tile statistics; no residual operand, activation epilogue, row
 //        remap or fp32 output): a lean row loop, selected by launch_conv when the launch qualifies
 template <typename T, int TC, int TP, int BNB = 0>
-__global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 64)) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int KTE = 128 / (int)sizeof(T);  // elements per k-tile row
     constexpr int NWR = TC / 32;               // weight rows staged per thread
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
     store_tile(0);
     __syncthreads();
 
-    constexpr bool DBUF = (TC == 64);   // the 64x256 tile is VGPR-limited to 2 workgroups per CU: keep two LDS stages there
+    constexpr bool DBUF = (TC == 64) && !NKB_NARROW3;   // (the former two-stage form of the 64x256 tile)
     for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) load_tile(kt + 1);
         const int buf = DBUF ? (kt & 1) : 0;
@@ -178,6 +185,14 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
                 const unsigned char* pb = base + (ks ? b_off1 : b_off0);
 #pragma unroll
                 for (int i = 0; i < MC; ++i) a[i] = *(const bf16x8*)(pa + 2048 * i);
+                if constexpr (NKB_NARROW3 && MP >= 8) {
+#pragma unroll
+                    for (int j = 0; j < MP; ++j) {
+                        b[0] = *(const bf16x8*)(pb + 2048 * j);
+#pragma unroll
+                        for (int i = 0; i < MC; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[0], acc[i][j], 0, 0, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int j = 0; j < MP; ++j) b[j] = *(const bf16x8*)(pb + 2048 * j);
 #pragma unroll
@@ -185,6 +200,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
 #pragma unroll
                     for (int j = 0; j < MP; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
             } else {
                 float a[MC], b[MP];
 #pragma unroll
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(256, (BNB && TC == 128) ? 3 : 1) void conv_igemm_ke
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
     // BNB: the stage's scale / shift / mean for this tile's channels live in LDS behind the epilogue tile (keeping them
     // in registers next to the not-yet-stored accumulators cost a wave of occupancy)
-    constexpr int LDS_MAIN = ((TC + TP) * 128 * (TC == 64 ? 2 : 1)) > ((TP / 2) * EROW) ? ((TC + TP) * 128 * (TC == 64 ? 2 : 1))
+    constexpr int LDS_MAIN = ((TC + TP) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1)) > ((TP / 2) * EROW) ? ((TC + TP) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1))
                                                                                        : ((TP / 2) * EROW);
     float* bnl = (float*)(smem + LDS_MAIN);   // [3][TC]
     if constexpr (BNB == 1 || BNB == 2) {
@@ -752,7 +768,7 @@ template <typename T, int TC, int TP, int BNB = 0>
 static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
     p.tilesM = (p.M + TP - 1) / TP;
     p.tilesN = (p.Cout + TC - 1) / TC;
-    constexpr int stage = (TC + TP) * 128 * (TC == 64 ? 2 : 1);
+    constexpr int stage = (TC + TP) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1);
     constexpr int epi = (TP / 2) * (TC * 4 + 16);
     constexpr int lds = (stage > epi ? stage : epi) + ((BNB == 1 || BNB == 2) ? 3 * TC * 4 : 0);
     static bool attr_set = false;
