@@ -221,8 +221,10 @@ extern "C" int nkb_bn_apply(int dtype, const void* x, const void* res, void* y, 
 // bn backward, pass 1: per-channel sum(dy') and sum(dy' * xhat), dy' = dy * mask.
 // Thread t owns channel chunk t % (C/N); the grid sweeps the rows front to back (see the loop) with
 // stride blockDim/(C/N); block partials go to part[b][2][C] (deterministic), reduced by pass 1b.
-template <typename T>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
+// MAXT: launch bound (256 for every ResNet shape; without it hipcc assumes 1024 threads, caps the kernel at 128 VGPRs and
+// spills 40 registers inside the two-row loop)
+template <typename T, int MAXT>
+__global__ __launch_bounds__(MAXT) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
                                      const unsigned char* __restrict__ bits,
                                      const float* __restrict__ fscale, const float* __restrict__ fshift,
                                      const float* __restrict__ mean, const float* __restrict__ invstd, long long rows,
@@ -416,10 +418,17 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
     {
         NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0, tensor_bytes * (yact ? 3 : 2) + (relu_bits ? (double)rows * cpr : 0.0));
         if (dtype == NKB_DT_BF16)
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(threads), lds, stream, (const bf16_t*)dy,
-                               (const bf16_t*)x, (const bf16_t*)yact, relu_bits, fscale, fshift, mean, invstd, rows, C, rpb, part);
+            if (threads <= 256)
+                hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 256>), dim3(blocks), dim3(threads), lds, stream, (const bf16_t*)dy,
+                                   (const bf16_t*)x, (const bf16_t*)yact, relu_bits, fscale, fshift, mean, invstd, rows, C, rpb, part);
+            else
+                hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 1024>), dim3(blocks), dim3(threads), lds, stream, (const bf16_t*)dy,
+                                   (const bf16_t*)x, (const bf16_t*)yact, relu_bits, fscale, fshift, mean, invstd, rows, C, rpb, part);
+        else if (threads <= 256)
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 256>), dim3(blocks), dim3(threads), lds, stream, (const float*)dy,
+                               (const float*)x, (const float*)yact, relu_bits, fscale, fshift, mean, invstd, rows, C, rpb, part);
         else
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(threads), lds, stream, (const float*)dy,
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3(blocks), dim3(threads), lds, stream, (const float*)dy,
                                (const float*)x, (const float*)yact, relu_bits, fscale, fshift, mean, invstd, rows, C, rpb, part);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, stream, part, blocks, C, dgamma,
                            dbeta, sums);
