@@ -32,7 +32,11 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) { return row * 128 + 
 //      2 the same for a stage that closes a residual block: mask from its bit array, residual operand still added
 //      3 plain bf16 epilogue only (bias / ReLU / per-tile statistics; no residual operand, activation epilogue, row
 //        remap or fp32 output): a lean row loop, selected by launch_conv when the launch qualifies
-template <typename T, int TC, int TP, int BNB = 0>
+// HALO (bf16, 3x3 / stride 1 / pad 1, forward or data gradient): the three taps of one filter row share ONE staged
+//      activation tile of TP + 2 pixel rows (flattened pixels m0-1 .. m0+TP); tap s reads it shifted by s rows, and the
+//      lanes whose left / right neighbour lies in another image row get zeros.  Activation loads per channel chunk drop
+//      from 9 tiles to 3, and two k-tiles out of three only wait for the (L2-resident) weight tile.
+template <typename T, int TC, int TP, int BNB = 0, bool HALO = false>
 __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 64)) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int KTE = 128 / (int)sizeof(T);  // elements per k-tile row
@@ -40,7 +44,8 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     constexpr int NPR = TP / 32;               // pixel rows staged per thread
     constexpr int MC = TC / 32;                // 16-row blocks along cout per wave
     constexpr int MP = TP / 32;                // 16-col blocks along pixels per wave
-    constexpr int STAGE_BYTES = (TC + TP) * 128;
+    constexpr int NPX = HALO ? (TP + 2 + 31) / 32 : NPR;     // activation rows staged per thread (halo: TP + 2 rows)
+    constexpr int STAGE_BYTES = (TC + 32 * NPX) * 128;
     constexpr int EROW = TC * 4 + 16;          // epilogue tile row stride (fp32 + pad)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -74,12 +79,25 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     const int cc = tid & 7;
     const int srow = tid >> 3;
     const int sh = p.stride >> 1;                       // stride in {1,2}
-    int xoff[NPR];
-    unsigned hmask[NPR], wmask[NPR];                    // bit r / bit s set: filter row r / column s lands inside the image
+    int xoff[NPX];
+    unsigned hmask[NPX], wmask[NPX];                    // bit r / bit s set: filter row r / column s lands inside the image
+    const int hsign = p.mode == 0 ? 1 : -1;             // halo: source row of filter row r = own row + hsign * (r - 1)
 #pragma unroll
-    for (int j = 0; j < NPR; ++j) {
-        const int m = m0 + srow + 32 * j;
+    for (int j = 0; j < NPX; ++j) {
+        const int m = HALO ? m0 - 1 + srow + 32 * j : m0 + srow + 32 * j;
         xoff[j] = 0; hmask[j] = 0u; wmask[j] = 0u;
+        if constexpr (HALO) {
+            if (m >= 0 && m < p.M && srow + 32 * j < TP + 2) {
+                const unsigned n = fdiv((unsigned)m, p.divPQ);
+                const unsigned rem = (unsigned)m - n * p.divPQ.d;
+                const int pp = (int)fdiv(rem, p.divQ);
+                const int qq = (int)rem - pp * (int)p.divQ.d;
+                xoff[j] = (((int)n * p.H + pp) * p.W + qq) * p.ldx * ESZ + cc * 16;     // the pixel itself
+                for (int rr = 0; rr < 3; ++rr)
+                    if ((unsigned)(pp + hsign * (rr - 1)) < (unsigned)p.H) hmask[j] |= 1u << rr;
+            }
+            continue;
+        }
         if (m < p.M) {
             const unsigned n = fdiv((unsigned)m, p.divPQ);
             const unsigned rem = (unsigned)m - n * p.divPQ.d;
@@ -127,17 +145,37 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, OOB, 0x00020000);
 
-    u32x4 sw[NWR], sx[NPR];
+    u32x4 sw[NWR], sx[NPX];
     int r = 0, s = 0, ck = 0;  // filter tap and channel-tile of the NEXT k-tile to load
+    bool x_loaded = true;      // halo: the k-tile just loaded brought a new activation tile (s == 0)
 
     auto load_tile = [&](int kt) {
+        if constexpr (HALO) {
+            // k-tile order: filter row r, channel chunk ck, column s (fastest); the weight row is [r][s][cin]
+            const int ktw = (r * 3 + s) * cpk + ck;
+#pragma unroll
+            for (int i = 0; i < NWR; ++i)
+                sw[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)woff[i], ktw * 128, 0);
+            x_loaded = (s == 0);
+            if (x_loaded) {
+                const int rowoff = hsign * (r - 1) * p.W * p.ldx * ESZ + ck * 128;
+#pragma unroll
+                for (int j = 0; j < NPX; ++j) {
+                    if (32 * j + 32 > TP + 2 && srow + 32 * j >= TP + 2) continue;    // only 2 rows of the last group exist
+                    const unsigned o = ((hmask[j] >> r) & 1u) ? (unsigned)(xoff[j] + rowoff) : OOB;
+                    sx[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
+                }
+            }
+            if (++s == 3) { s = 0; if (++ck == cpk) { ck = 0; ++r; } }
+            return;
+        }
         // wave-uniform byte offsets of this k-tile
         const int tapoff = (p.mode == 0 ? (r * p.W + s) : -((r >> sh) * p.W + (s >> sh))) * p.ldx * ESZ + ck * 128;
 #pragma unroll
         for (int i = 0; i < NWR; ++i)
             sw[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)woff[i], kt * 128, 0);
 #pragma unroll
-        for (int j = 0; j < NPR; ++j) {
+        for (int j = 0; j < NPX; ++j) {
             const unsigned o = ((hmask[j] >> r) & (wmask[j] >> s) & 1u) ? (unsigned)(xoff[j] + tapoff) : OOB;
             sx[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
         }
@@ -148,8 +186,13 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
         unsigned char* base = smem + buf * STAGE_BYTES + st_off;
 #pragma unroll
         for (int i = 0; i < NWR; ++i) *(u32x4*)(base + 4096 * i) = sw[i];
+        if (!HALO || x_loaded) {
 #pragma unroll
-        for (int j = 0; j < NPR; ++j) *(u32x4*)(base + TC * 128 + 4096 * j) = sx[j];
+            for (int j = 0; j < NPX; ++j) {
+                if (HALO && 32 * j + 32 > TP + 2 && srow + 32 * j >= TP + 2) continue;
+                *(u32x4*)(base + TC * 128 + 4096 * j) = sx[j];
+            }
+        }
     };
 
     f32x4 acc[MC][MP];
@@ -164,6 +207,19 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     const int a_off0 = lds_swz(arow0, fgrp), a_off1 = lds_swz(arow0, 4 + fgrp);
     const int b_off0 = lds_swz(brow0, fgrp), b_off1 = lds_swz(brow0, 4 + fgrp);
 
+    // halo: which of this lane's MP pixels have a left / right neighbour in the same image row (bit j)
+    unsigned lnb = 0u, rnb = 0u;
+    int cs = 0;                                          // column tap of the k-tile being computed
+    if constexpr (HALO) {
+#pragma unroll
+        for (int j = 0; j < MP; ++j) {
+            const unsigned m = (unsigned)(m0 + wp * (TP / 2) + 16 * j + frow);
+            const unsigned w = m - fdiv(m, p.divQ) * p.divQ.d;
+            if (w > 0u) lnb |= 1u << j;
+            if (w + 1u < (unsigned)p.W) rnb |= 1u << j;
+        }
+    }
+
     // One LDS stage + one register stage: LDS per workgroup drops to ~33 KB, so 3 workgroups (VGPR-limited) share a CU
     // instead of 2 and 1.5x the operand bytes are in flight; the price is a second barrier per k-tile.
     load_tile(0);
@@ -171,6 +227,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     __syncthreads();
 
     constexpr bool DBUF = (TC == 64) && !NKB_NARROW3;   // (the former two-stage form of the 64x256 tile)
+    static_assert(!(HALO && DBUF), "the shared activation tile lives in the single LDS stage");
     for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) load_tile(kt + 1);
         const int buf = DBUF ? (kt & 1) : 0;
@@ -185,6 +242,21 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 const unsigned char* pb = base + (ks ? b_off1 : b_off0);
 #pragma unroll
                 for (int i = 0; i < MC; ++i) a[i] = *(const bf16x8*)(pa + 2048 * i);
+                if constexpr (HALO) {
+                    // staged row 0 is pixel m0 - 1: forward tap s reads pixel p + s - 1 = row p + s, the data gradient
+                    // reads p + 1 - s = row p + 2 - s; shift 0 needs a left neighbour, shift 2 a right one
+                    const int shift = p.mode == 0 ? cs : 2 - cs;
+                    const unsigned keep = shift == 0 ? lnb : (shift == 2 ? rnb : 0xffffffffu);
+                    const int brow = brow0 + shift;
+                    const int bsw = ((ks * 4 + fgrp) ^ (brow & 7)) << 4;     // (brow + 16*j) & 7 == brow & 7
+#pragma unroll
+                    for (int j = 0; j < MP; ++j) {
+                        bf16x8 bj = *(const bf16x8*)(base + (brow + 16 * j) * 128 + bsw);
+                        if (!((keep >> j) & 1u)) bj = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int i = 0; i < MC; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bj, acc[i][j], 0, 0, 0);
+                    }
+                } else
                 if constexpr (NKB_NARROW3 && MP >= 8) {
 #pragma unroll
                     for (int j = 0; j < MP; ++j) {
@@ -214,6 +286,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
+        if constexpr (HALO) { if (++cs == 3) cs = 0; }
         if constexpr (DBUF) {
             if (kt + 1 < KT) store_tile(buf ^ 1);
             __syncthreads();
@@ -238,7 +311,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
     // BNB: the stage's scale / shift / mean for this tile's channels live in LDS behind the epilogue tile (keeping them
     // in registers next to the not-yet-stored accumulators cost a wave of occupancy)
-    constexpr int LDS_MAIN = ((TC + TP) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1)) > ((TP / 2) * EROW) ? ((TC + TP) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1))
+    constexpr int LDS_MAIN = (STAGE_BYTES * ((TC == 64 && !NKB_NARROW3) ? 2 : 1)) > ((TP / 2) * EROW) ? (STAGE_BYTES * ((TC == 64 && !NKB_NARROW3) ? 2 : 1))
                                                                                        : ((TP / 2) * EROW);
     float* bnl = (float*)(smem + LDS_MAIN);   // [3][TC]
     if constexpr (BNB == 1 || BNB == 2) {
@@ -764,21 +837,35 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
 
 // ------------------------------------------------------------------------------------------
 // host launchers
-template <typename T, int TC, int TP, int BNB = 0>
-static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
+template <typename T, int TC, int TP, int BNB, bool HALO>
+static int launch_conv_impl(ConvParams& p, hipStream_t stream, int batch) {
     p.tilesM = (p.M + TP - 1) / TP;
     p.tilesN = (p.Cout + TC - 1) / TC;
-    constexpr int stage = (TC + TP) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1);
+    constexpr int xrows = HALO ? 32 * ((TP + 2 + 31) / 32) : TP;
+    constexpr int stage = (TC + xrows) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1);
     constexpr int epi = (TP / 2) * (TC * 4 + 16);
     constexpr int lds = (stage > epi ? stage : epi) + ((BNB == 1 || BNB == 2) ? 3 * TC * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TC, TP, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TC, TP, BNB, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const unsigned grid = (unsigned)p.tilesM * (unsigned)p.tilesN;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, TC, TP, BNB>), dim3(grid, batch), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TC, TP, BNB, HALO>), dim3(grid, batch), dim3(256), lds, stream, p);
     return nkb_check_launch("conv_igemm");
+}
+
+template <typename T, int TC, int TP, int BNB = 0>
+static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
+    if constexpr (sizeof(T) == 2 && (NKB_NARROW3 || TC != 64)) {
+        // 3x3 / stride 1 / pad 1 (forward and data gradient): the filter-row-sharing form, 3 activation tiles per
+        // channel chunk instead of 9
+        static const int halo_on = [] { const char* e = getenv("NKB_HALO"); return e ? atoi(e) : 1; }();
+        if (halo_on && p.R == 3 && p.S == 3 && p.stride == 1 && p.stride_w == 1 && p.pad == 1 && p.pad_w == 1 &&
+            p.stem_cprw == 0 && p.sub_h == 0 && p.H == p.P && p.W == p.Q)
+            return launch_conv_impl<T, TC, TP, BNB, true>(p, stream, batch);
+    }
+    return launch_conv_impl<T, TC, TP, BNB, false>(p, stream, batch);
 }
 
 // picks the lean-epilogue instantiation (BNB = 3) when the launch has nothing but bias / ReLU / statistics to do
