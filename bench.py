@@ -31,7 +31,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 # algorithmic FLOPs per image of one train step (fwd + dgrad + wgrad MACs x2), SURVEY.md §8(d)
-TRAIN_GFLOP_PER_IMG = {"resnet18": 10.645, "resnet50": 24.287, "vit_base_patch16_224": 105.147}
+TRAIN_GFLOP_PER_IMG = {"resnet18": 10.645, "resnet50": 24.287, "vit_base_patch16_224": 105.147,
+                       "unicom ViT-L/14": 485.4}   # SURVEY.md §8(d) algorithmic FLOPs (fwd + dgrad + wgrad)
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                          # HBM3E, MI355X_MICROARCH.md
 

@@ -184,8 +184,16 @@ int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout, const flo
                          int T, int H, int dh, float scale, nkb_stream_t stream);
 int nkb_head_transpose(int dtype, const void* in, int ld_in, long long sio, long long sii, int outer, int inner, void* out,
                        int T, int dh, int ldt, nkb_stream_t stream);
+/* token assembly: forward x[b][t] = (t == 0 ? cls : tok[b][t-1]) + pos[t]; cls == NULL (unicom layout, no class token):
+ * x[b][t] = tok[b][t] + pos[t].  backward (class-token layout only): tok := x[:, 1:]. */
 int nkb_vit_assemble(int dtype, int backward, void* tok, const float* cls, const float* pos, void* x, int B, int Tn, int D,
                      nkb_stream_t stream);
+/* ReLU6 (unicom Mlp.act, reached through unicom.load at model.py:77-79): dy == NULL -> out = min(max(x,0),6);
+ * else out = dy where 0 < x < 6, 0 elsewhere */
+int nkb_relu6(int dtype, const void* x, const void* dy, void* out, long long n, nkb_stream_t stream);
+/* stochastic depth (unicom Block.drop_path): out[r][i] = x[r][i] * scale[r] (+ add[r][i]); also its own backward */
+int nkb_scale_rows(int dtype, const void* x, const void* add, void* out, const float* scale, int rows, long long inner,
+                   nkb_stream_t stream);
 /* out = keep ? in/(1-p) : 0 (+ add); forward draws keep from a hash of (seed, index) and stores it in mask */
 int nkb_dropout(int dtype, int backward, const void* in, const void* add, void* out, unsigned char* mask, long long n,
                 float p, unsigned long long seed, nkb_stream_t stream);

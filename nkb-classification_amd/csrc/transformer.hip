@@ -261,6 +261,66 @@ extern "C" int nkb_gelu(int dtype, const void* x, const void* dy, void* out, lon
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ReLU6 (the MLP activation of the unicom transformer blocks): forward y = min(max(x, 0), 6); backward dx = dy where
+// 0 < x < 6 (strict on both ends, torch's hardtanh_backward) and 0 elsewhere.
+template <typename T>
+__global__ void relu6_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, size_t nvec) {
+    constexpr int N = V16<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        float a[N], g[N], o[N];
+        V16<T>::ld(x + i * N, a);
+        if (dy) V16<T>::ld(dy + i * N, g);
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = dy ? ((a[e] > 0.f && a[e] < 6.f) ? g[e] : 0.f) : fminf(fmaxf(a[e], 0.f), 6.f);
+        V16<T>::st(out + i * N, o);
+    }
+}
+extern "C" int nkb_relu6(int dtype, const void* x, const void* dy, void* out, long long n, hipStream_t stream) {
+    const int N = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("relu6: bad dtype %d", dtype); return 1; }
+    if (n % N) { nkb_set_error("relu6: element count %lld not a multiple of %d", n, N); return 1; }
+    NkbProfScope prof(NKB_K_GELU, stream, 0);
+    size_t nvec = (size_t)n / N, g = (nvec + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(relu6_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, nvec);
+    else hipLaunchKernelGGL(relu6_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)x, (const float*)dy, (float*)out, nvec);
+    return nkb_check_launch("relu6");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-sample scaling (stochastic depth / DropPath): out[b][i] = x[b][i] * scale[b] (+ add[b][i]); scale[b] is 0 for a
+// dropped sample and 1 / keep_prob for a kept one.  The same kernel is its own backward (dx = dy * scale[b]).
+template <typename T>
+__global__ void scale_rows_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ out,
+                                  const float* __restrict__ scale, size_t nvec, size_t vec_per_row) {
+    constexpr int N = V16<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const float sc = scale[i / vec_per_row];
+        float a[N], r[N], o[N];
+        V16<T>::ld(x + i * N, a);
+        if (add) V16<T>::ld(add + i * N, r);
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = add ? a[e] * sc + r[e] : a[e] * sc;
+        V16<T>::st(out + i * N, o);
+    }
+}
+extern "C" int nkb_scale_rows(int dtype, const void* x, const void* add, void* out, const float* scale, int rows,
+                              long long inner, hipStream_t stream) {
+    const int N = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("scale_rows: bad dtype %d", dtype); return 1; }
+    if (inner % N || rows < 0) { nkb_set_error("scale_rows: inner=%lld must be a multiple of %d", inner, N); return 1; }
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    const size_t vpr = (size_t)inner / N, nvec = vpr * (size_t)rows;
+    if (nvec == 0) return 0;
+    size_t g = (nvec + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)add, (bf16_t*)out, scale, nvec, vpr);
+    else hipLaunchKernelGGL(scale_rows_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)x, (const float*)add, (float*)out, scale, nvec, vpr);
+    return nkb_check_launch("scale_rows");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Attention softmax on materialised fp32 score rows s[rows][lds] (first `cols` valid):
 //   forward  p = softmax(scale * s)             -> p[rows][ldp] in the compute dtype, zero beyond cols
 //   backward ds = scale * p * (dp - sum_j dp_j p_j) -> same layout
@@ -341,7 +401,9 @@ __global__ void vit_assemble_kernel(const T* __restrict__ tok, const float* __re
         const int d = (int)(i % D);
         if (!backward) {
             const int t = (int)((i / D) % Tn), b = (int)(i / ((size_t)D * Tn));
-            const float v = t == 0 ? cls[d] : DT<T>::ld(tok + ((size_t)b * (Tn - 1) + (t - 1)) * D + d);
+            // cls == NULL: no class token (unicom layout), all Tn rows are patch tokens
+            const float v = cls == nullptr ? DT<T>::ld(tok + i)
+                                           : (t == 0 ? cls[d] : DT<T>::ld(tok + ((size_t)b * (Tn - 1) + (t - 1)) * D + d));
             DT<T>::st(x + i, v + pos[(size_t)t * D + d]);
         } else {  // x := grad of tokens [B][Tn][D] (input), tok := d_tok [B][Tn-1][D] (output)
             const int p = (int)((i / D) % (Tn - 1)), b = (int)(i / ((size_t)D * (Tn - 1)));

@@ -58,6 +58,8 @@ _SIGS = {
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp]),
     "nkb_layernorm_workspace_floats": (sz, [i32]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
+    "nkb_relu6": (i32, [i32, vp, vp, vp, i64, vp]),
+    "nkb_scale_rows": (i32, [i32, vp, vp, vp, vp, i32, i64, vp]),
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
     "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "nkb_attn_backward_ds": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
@@ -345,6 +347,14 @@ def layernorm_ws(D):
 
 def gelu(dtype, x, dy, out, n):
     check(load().nkb_gelu(dtype, ptr(x), ptr(dy), ptr(out), n, stream()), "gelu")
+
+
+def relu6(dtype, x, dy, out, n):
+    check(load().nkb_relu6(dtype, ptr(x), ptr(dy), ptr(out), n, stream()), "relu6")
+
+
+def scale_rows(dtype, x, add, out, scale, rows, inner):
+    check(load().nkb_scale_rows(dtype, ptr(x), ptr(add), ptr(out), ptr(scale), rows, inner, stream()), "scale_rows")
 
 
 def attn_softmax(dtype, backward, s, lds, p_in, out, ldp, rows, cols, scale):

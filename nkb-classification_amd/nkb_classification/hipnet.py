@@ -157,8 +157,13 @@ class HipEngine:
         pool=True (stem): y = maxpool3x3s2(relu(bn(conv(x)))) in one pass over the raw conv output; the un-pooled
         activation is never materialised."""
         w = conv.weight
-        co, ci, R, S = w.shape
-        st, pad = conv.stride[0], conv.padding[0]
+        if w.dim() == 2:
+            # Linear -> BatchNorm1d (the unicom `feature` head): a 1x1 convolution over a [N,1,1,K] activation
+            (co, ci), R, S, st, pad = w.shape, 1, 1, 1, 0
+            x = x.view(x.shape[0], 1, 1, x.shape[-1])
+        else:
+            co, ci, R, S = w.shape
+            st, pad = conv.stride[0], conv.padding[0]
         packed = stem_packed
         if packed:
             N, H, W = stem_packed
@@ -614,6 +619,43 @@ class HipEngine:
         x = self.saved[key]["x"]
         dx = self.scratch(slot, x.shape)
         hip.gelu(self.d, x, g, dx, x.numel())
+        return dx
+
+    def relu6(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:
+        y = self.ws.get(key + ".y", x.shape, self.T)
+        hip.relu6(self.d, x, None, y, x.numel())
+        if train:
+            self.saved[key] = dict(x=x)
+        return y
+
+    def relu6_backward(self, key: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        x = self.saved[key]["x"]
+        dx = self.scratch(slot, x.shape)
+        hip.relu6(self.d, x, g, dx, x.numel())
+        return dx
+
+    def drop_path(self, key: str, x: torch.Tensor, p: float, train: bool, samples: int, add: torch.Tensor) -> torch.Tensor:
+        """Stochastic depth on a residual branch: y = add + x * keep[b] / (1 - p), one Bernoulli(1 - p) draw per sample
+        (timm-style DropPath as used by the unicom blocks).  Only called when active (train and p > 0)."""
+        assert train and p > 0
+        ones = self.ws.get("droppath.ones", (samples,), torch.float32)
+        ones.fill_(1.0)
+        scale = self.ws.get(key + ".scale", (samples,), torch.float32)
+        mask = self.ws.get(key + ".mask", (samples,), torch.uint8)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        hip.dropout(hip.F32, False, ones, None, scale, mask, samples, p, seed)       # scale[b] = keep / (1 - p)
+        y = self.ws.get(key + ".y", x.shape, self.T)
+        hip.scale_rows(self.d, x, add, y, scale, samples, x.numel() // samples)
+        self.saved[key] = dict(scale=scale, samples=samples)
+        return y
+
+    def drop_path_backward(self, key: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        """Branch gradient through drop_path(key); a pass-through when it was inactive in the forward pass."""
+        sv = self.saved.get(key)
+        if sv is None:
+            return g
+        dx = self.scratch(slot, g.shape)
+        hip.scale_rows(self.d, g, None, dx, sv["scale"], sv["samples"], g.numel() // sv["samples"])
         return dx
 
     def dropout(self, key: str, x: torch.Tensor, p: float, train: bool, add: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -60,8 +60,10 @@ class _HipClassifier(nn.Module):
     def get_emb_model(cfg_model: dict):
         name = cfg_model["model"]
         if name.lower().startswith("unicom"):
-            raise NotImplementedError("unicom backbones are not available offline (model.py:77-79 loads them "
-                                      "from the unicom package's weight hub)")
+            # model.py:77-79: `unicom.load(name.split()[1])[0]`, embedding width = feature[-2].out_features
+            from . import unicom
+            emb_model = unicom.load(name.split()[1])
+            return emb_model, emb_model.feature[-2].out_features
         emb_model = create_backbone(name, pretrained=cfg_model.get("pretrained", False))
         return emb_model, emb_model.num_features
 
@@ -104,7 +106,7 @@ class _HipClassifier(nn.Module):
         blocks.append([h.bias for h in heads])
         self.arena.pack(blocks, device)
         # one int64 word per BatchNorm for num_batches_tracked, bumped by a single add per step
-        bns = [m for m in self.emb_model.modules() if isinstance(m, nn.BatchNorm2d)]
+        bns = [m for m in self.emb_model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
         if bns:
             flat = torch.stack([m.num_batches_tracked.to(device).reshape(()) for m in bns]).contiguous()
             for i, m in enumerate(bns):

@@ -140,6 +140,61 @@ class _ViT(nn.Module):
         return self.norm(self.blocks(x))[:, 0]
 
 
+class _UnicomAttention(nn.Module):
+    def __init__(self, dim: int, heads: int):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, T, D = x.shape
+        qkv = self.qkv(x).reshape(B, T, 3, self.num_heads, D // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        att = (q @ k.transpose(-2, -1)) * (float(D // self.num_heads) ** -0.5)
+        y = (att.softmax(dim=-1) @ v).transpose(1, 2).reshape(B, T, D)
+        return self.proj(y)
+
+
+class _UnicomMlp(nn.Module):
+    def __init__(self, dim: int, hidden: int):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.fc2(torch.nn.functional.relu6(self.fc1(x)))
+
+
+class _UnicomBlock(nn.Module):
+    def __init__(self, dim: int, heads: int):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = _UnicomAttention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _UnicomMlp(dim, dim * 4)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:      # stochastic depth is the identity at inference
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class _UnicomViT(nn.Module):
+    def __init__(self, img: int, patch: int, dim: int, emb: int, depth: int, heads: int):
+        super().__init__()
+        self.patch_embed = _PatchEmbed(patch, dim)
+        T = (img // patch) ** 2
+        self.pos_embed = nn.Parameter(torch.zeros(1, T, dim))
+        self.blocks = nn.Sequential(*[_UnicomBlock(dim, heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim)
+        self.feature = nn.Sequential(nn.Linear(dim * T, dim, bias=False), nn.BatchNorm1d(dim, eps=2e-5),
+                                     nn.Linear(dim, emb, bias=False), nn.BatchNorm1d(emb, eps=2e-5))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.norm(self.blocks(self.patch_embed(x) + self.pos_embed))
+        return self.feature(x.reshape(x.shape[0], -1))
+
+
 class _SingleHead(nn.Module):
     def __init__(self, emb_model: nn.Module, emb: int, n: int):
         super().__init__()
@@ -165,6 +220,9 @@ class _MultiHead(nn.Module):
 
 
 def _backbone_like(hip_backbone) -> nn.Module:
+    if getattr(hip_backbone, "family", "") == "unicom":
+        return _UnicomViT(hip_backbone.img, hip_backbone.patch, hip_backbone.dim, hip_backbone.num_features,
+                          len(hip_backbone.blocks), hip_backbone.heads)
     if getattr(hip_backbone, "family", "") == "vit":
         return _ViT(hip_backbone.img, hip_backbone.patch, hip_backbone.num_features, len(hip_backbone.blocks), hip_backbone.heads)
     layers = [len(getattr(hip_backbone, f"layer{i}")) for i in (1, 2, 3, 4)]

@@ -8,7 +8,7 @@ classifier wrappers (model.py:17-159).  timm itself is NOT vendored under
 unpinned), so the topology below is restated from timm's published
 ``resnet.py`` / ``vision_transformer.py`` and pinned by computed invariants
 (parameter counts 11.177 M / 23.508 M / 85.80 M, feature widths 512/2048/768,
-state-dict key names) in tests/test_oracle_models.py.
+state-dict key names) in tests/test_oracle_golden.py.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  The product package never does.
@@ -208,6 +208,133 @@ class VisionTransformer(nn.Module):
         return self.head(self.head_drop(x[:, 0]))
 
 
+# --------------------------------------------------------------------------
+# unicom VisionTransformer (model.py:77-79: unicom.load(name.split()[1])[0]).
+# PARITY UNPINNED: deepglint/unicom is an un-pinned git dependency
+# (pyproject.toml:81), absent from /root/reference and not installed; this
+# restates its published vision_transformer.py as recorded in SURVEY.md §8 A9
+# (no class token, bias-free qkv, fp32 softmax, ReLU6 MLP, DropPath,
+# LayerNorm eps 1e-5, `feature` = Linear -> BN1d(2e-5) -> Linear -> BN1d(2e-5)).
+# Pinned only by computed invariants (572.33 M parameters for ViT-L/14, the
+# 768-wide feature[-2], key names) in tests/test_oracle_golden.py.
+# --------------------------------------------------------------------------
+def _at_least_f32(t: torch.Tensor) -> torch.Tensor:
+    """The package's `.float()` islands (softmax, final norm): fp32 under autocast, a no-op for the float64 truth runs."""
+    return t if t.dtype == torch.float64 else t.float()
+
+
+class UnicomAttention(nn.Module):
+    def __init__(self, dim: int, heads: int):
+        super().__init__()
+        self.num_heads = heads
+        self.scale = (dim // heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, T, D = x.shape
+        qkv = self.qkv(x).reshape(B, T, 3, self.num_heads, D // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        att = ((_at_least_f32(q) @ _at_least_f32(k).transpose(-2, -1)) * self.scale).softmax(dim=-1)   # fp32 island
+        x = (att @ _at_least_f32(v)).to(x.dtype).transpose(1, 2).reshape(B, T, D)
+        return self.proj(x)
+
+
+class UnicomMlp(nn.Module):
+    def __init__(self, dim: int, hidden: int):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.ReLU6()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth; `forced_keep` ([B] of 0/1) replays a recorded draw in the parity tests."""
+
+    def __init__(self, drop_prob: float):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self.forced_keep = None
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep_prob = 1.0 - self.drop_prob
+        shape = (x.shape[0],) + (1,) * (x.dim() - 1)
+        keep = (self.forced_keep.to(x.dtype).reshape(shape) if self.forced_keep is not None
+                else torch.bernoulli(torch.full(shape, keep_prob, dtype=x.dtype)))
+        return x * keep / keep_prob
+
+
+class UnicomBlock(nn.Module):
+    def __init__(self, dim: int, heads: int, mlp_ratio: int, drop_path: float):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = UnicomAttention(dim, heads)
+        self.drop_path = DropPath(drop_path) if drop_path > 0 else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = UnicomMlp(dim, dim * mlp_ratio)
+
+    def forward(self, x):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class UnicomPatchEmbedding(nn.Module):
+    def __init__(self, img: int, patch: int, in_chans: int, dim: int):
+        super().__init__()
+        self.num_patches = (img // patch) ** 2
+        self.proj = nn.Conv2d(in_chans, dim, patch, patch)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class UnicomViT(nn.Module):
+    def __init__(self, input_size=224, patch_size=32, dim=768, embedding_size=768, depth=12, num_heads=12,
+                 drop_path_rate=0.1, mlp_ratio=4):
+        super().__init__()
+        self.dim = dim
+        self.patch_embed = UnicomPatchEmbedding(input_size, patch_size, 3, dim)
+        T = self.patch_embed.num_patches
+        self.pos_embed = nn.Parameter(torch.zeros(1, T, dim))
+        self.blocks = nn.ModuleList([UnicomBlock(dim, num_heads, mlp_ratio, drop_path_rate) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim)
+        self.feature = nn.Sequential(
+            nn.Linear(dim * T, dim, bias=False),
+            nn.BatchNorm1d(dim, eps=2e-5),
+            nn.Linear(dim, embedding_size, bias=False),
+            nn.BatchNorm1d(embedding_size, eps=2e-5),
+        )
+        self.num_features = embedding_size
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        B = x.shape[0]
+        x = self.patch_embed(x) + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x)
+        x = self.norm(_at_least_f32(x))
+        return self.feature(x.reshape(B, -1))
+
+
+_UNICOM = {
+    "vit-b/32": dict(input_size=224, patch_size=32, dim=768, embedding_size=512, depth=12, num_heads=12),
+    "vit-b/16": dict(input_size=224, patch_size=16, dim=768, embedding_size=768, depth=12, num_heads=12),
+    "vit-l/14": dict(input_size=224, patch_size=14, dim=1024, embedding_size=768, depth=24, num_heads=16),
+    "vit-l/14@336px": dict(input_size=336, patch_size=14, dim=1024, embedding_size=768, depth=24, num_heads=16),
+    "vit-tiny-test": dict(input_size=56, patch_size=14, dim=128, embedding_size=64, depth=2, num_heads=2),
+}
+
+
 _BACKBONES = {
     "resnet18": lambda: ResNet(BasicBlock, (2, 2, 2, 2)),
     "resnet34": lambda: ResNet(BasicBlock, (3, 4, 6, 3)),
@@ -223,6 +350,8 @@ _BACKBONES = {
 
 def create_backbone(name: str) -> nn.Module:
     """Stand-in for ``timm.create_model(name, pretrained=False, num_classes=0)``."""
+    if name.lower().startswith("unicom"):        # model.py:77-79
+        return UnicomViT(**_UNICOM[name.split()[1].lower()])
     if name not in _BACKBONES:
         raise NotImplementedError(f"oracle has no restatement of backbone {name!r}")
     return _BACKBONES[name]()
@@ -259,6 +388,7 @@ class OracleClassifier(nn.Module):
     def __init__(self, cfg_model: dict, classes: Union[List, Dict[str, List]]):
         super().__init__()
         self.emb_model = create_backbone(cfg_model["model"])
+        # model.py:79 reads feature[-2].out_features for unicom, model.py:83 num_features for timm: both are this
         self.emb_size = self.emb_model.num_features
         _set_dropout(self.emb_model, cfg_model.get("backbone_dropout", 0.0))
         pd = cfg_model.get("classifier_dropout", 0.0)

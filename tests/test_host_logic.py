@@ -174,7 +174,7 @@ def test_read_py_config(tmp_path):
 
 
 @pytest.mark.parametrize("backbone,task", [("resnet_tiny_basic", "single"), ("resnet_tiny_bottleneck", "multi"),
-                                           ("vit_tiny_test", "single")])
+                                           ("vit_tiny_test", "single"), ("unicom ViT-tiny-test", "single")])
 def test_scripted_export_matches_oracle(tmp_path, backbone, task):
     """train.py:66-73 counterpart: the TorchScript archive written next to each checkpoint carries the trained weights
     and the reference's forward contract (Tensor / dict of Tensors) — checked against the oracle on the same state."""
@@ -191,7 +191,8 @@ def test_scripted_export_matches_oracle(tmp_path, backbone, task):
     path = tmp_path / "scripted_last.pt"
     save_scripted(model, path)
     loaded = torch.jit.load(str(path))
-    x = torch.randn(2, 3, 64, 64)
+    hw = 56 if backbone.startswith("unicom") else 64
+    x = torch.randn(2, 3, hw, hw)
     with torch.no_grad():
         ref, out = oracle(x), loaded(x)
     if task == "single":
@@ -200,3 +201,20 @@ def test_scripted_export_matches_oracle(tmp_path, backbone, task):
         assert sorted(out) == sorted(ref)
         for t in ref:
             torch.testing.assert_close(out[t], ref[t], rtol=1e-5, atol=1e-5)
+
+
+def test_unicom_family_matches_reference_call_site():
+    """model.py:75-79: `unicom.load(name.split()[1])[0]`, emb_size = feature[-2].out_features; key names and shapes of the
+    product containers equal the oracle restatement's (so unicom checkpoints load into either)."""
+    from nkb_classification.model import SingletaskClassifier
+    from nkb_classification import unicom
+    from oracle.torch_models import create_backbone
+    with torch.device("meta"):
+        prod, orc = unicom.load("ViT-L/14"), create_backbone("unicom ViT-L/14")
+    ps, os_ = prod.state_dict(), orc.state_dict()
+    assert list(ps) == list(os_) and all(ps[k].shape == os_[k].shape for k in ps)
+    assert sum(p.numel() for p in prod.parameters()) == 572_328_448
+    emb_model, emb_size = SingletaskClassifier.get_emb_model(dict(model="unicom ViT-tiny-test", pretrained=False))
+    assert emb_size == emb_model.feature[-2].out_features == 64
+    with pytest.raises(RuntimeError, match="not found"):
+        unicom.load("ViT-H/14")

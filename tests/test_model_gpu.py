@@ -41,6 +41,7 @@ def _relerr(a, b):
 
 
 @pytest.mark.parametrize("backbone", ["resnet_tiny_basic", "resnet_tiny_bottleneck", "resnet18", "vit_tiny_test",
+                                      "unicom ViT-tiny-test",     # model.py:77-79 family (stochastic depth switched off here)
                                       # odd sizes: clipped pooling windows, odd parity-class grids of the stride-2 data
                                       # gradients, ceil-sized sub-grid shortcut gradients, the packed stem's pad column
                                       "resnet_tiny_basic@54x3", "resnet_tiny_bottleneck@70x3", "resnet_tiny_bottleneck@45x2"])
@@ -68,6 +69,11 @@ def test_single_step_gradients_match_oracle_fp32(backbone):
     o64.load_state_dict(o32.state_dict())
     hw = 64 if backbone != "resnet18" else 96
     nb = 4
+    if backbone.startswith("unicom"):
+        hw = 56                                    # 16 tokens of 14x14 pixels; pos_embed fixes the input size
+        for net in (o32, o64, model):
+            for blk in net.emb_model.blocks:
+                blk.drop_path.drop_prob = 0.0      # the draw is replayed in test_unicom_drop_path_matches_oracle
     if shape is not None:
         hw, nb = shape
     x = torch.randn(nb, 3, hw, hw + (3 if shape is not None else 0), generator=g)      # odd cases are non-square too
@@ -370,6 +376,51 @@ def test_vit_backbone_dropout_matches_oracle_with_replayed_masks():
     with torch.no_grad():
         e1, e2 = model(x.to(DEV)), model(x.to(DEV))
     assert torch.equal(e1, e2)                                    # eval: every dropout is the identity
+
+
+def test_unicom_drop_path_matches_oracle():
+    """Stochastic depth of the unicom blocks (train mode, rate 0.1 per block): the HIP engine's per-sample keep draws
+    are replayed in the oracle's DropPath modules; logits and gradients must then agree."""
+    cfg_model = dict(model="unicom ViT-tiny-test", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    classes = ["a", "b", "c"]
+    oracle, model = _pair(cfg_model, classes, seed=3)
+    for net in (oracle, model):
+        for blk in net.emb_model.blocks:
+            blk.drop_path.drop_prob = 0.5          # make drops likely with 8 samples x 4 sites
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 3, 56, 56, generator=g)
+    y = torch.randint(0, 3, (8,), generator=g)
+    oracle.train(); model.train()
+    torch.manual_seed(21)
+    out = model(x.to(DEV))
+    eng = model._active
+    dropped = 0
+    for i, blk in enumerate(oracle.emb_model.blocks):
+        s1, s2 = eng.saved[f"b{i}.dp1"]["scale"].cpu(), eng.saved[f"b{i}.dp2"]["scale"].cpu()
+        assert set(s1.tolist()) <= {0.0, 2.0} and set(s2.tolist()) <= {0.0, 2.0}
+        dropped += int((s1 == 0).sum() + (s2 == 0).sum())
+        keeps = iter([(s1 > 0).float(), (s2 > 0).float()])
+        # the two drop_path calls of a block share one module: feed the recorded draws in call order
+        blk.drop_path.forward = (lambda mod, it: (lambda t: t * next(it).reshape(-1, 1, 1) / (1.0 - mod.drop_prob)))(blk.drop_path, keeps)
+    assert 0 < dropped < 32
+    ref = oracle(x)
+    torch.nn.functional.cross_entropy(ref, y).backward()
+    get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)(out, y.to(DEV)).backward()
+    torch.cuda.synchronize()
+    assert _relerr(out.detach().cpu(), ref.detach()) < 1e-3
+    ref_p = dict(oracle.named_parameters())
+    num = den = 0.0
+    for name, p in model.named_parameters():
+        num += (p.grad.cpu().double() - ref_p[name].grad.double()).pow(2).sum().item()
+        den += ref_p[name].grad.double().pow(2).sum().item()
+    assert (num / den) ** 0.5 < 3e-3, (num / den) ** 0.5
+    # eval mode: no stochastic depth, batch statistics replaced by the running ones
+    model.eval(); oracle.eval()
+    for blk in oracle.emb_model.blocks:
+        del blk.drop_path.forward
+    with torch.no_grad():
+        assert _relerr(model(x.to(DEV)).cpu(), oracle(x)) < 1e-3
 
 
 def test_classifier_dropout_train_path():

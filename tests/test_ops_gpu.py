@@ -722,6 +722,41 @@ def test_gelu_fwd_bwd(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_relu6_fwd_bwd(dtype):
+    torch.manual_seed(11)
+    x = rnd(torch.randn(5000) * 4, dtype)
+    x[:8] = torch.tensor([0.0, 6.0, -0.0, 5.96875, 6.03125, -1.0, 3.0, 7.0])     # the interval ends are exclusive in backward
+    x.requires_grad_(True)
+    y = torch.nn.functional.relu6(x)
+    dy = rnd(torch.randn(5000), dtype)
+    y.backward(dy)
+    xd = x.detach().to(DEV, dtype)
+    yd, dx = torch.empty_like(xd), torch.empty_like(xd)
+    hip.relu6(hip.dt(dtype), xd, None, yd, 5000)
+    hip.relu6(hip.dt(dtype), xd, dy.to(DEV, dtype), dx, 5000)
+    torch.cuda.synchronize()
+    assert torch.equal(yd.float().cpu(), y.detach())
+    assert torch.equal(dx.float().cpu(), x.grad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_scale_rows_drop_path(dtype):
+    torch.manual_seed(12)
+    B, inner = 5, 3 * 64
+    x, add = rnd(torch.randn(B, inner), dtype), rnd(torch.randn(B, inner), dtype)
+    scale = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9, 0.0, 2.0])
+    xd, ad, sd = x.to(DEV, dtype), add.to(DEV, dtype), scale.to(DEV)
+    out, out2 = torch.empty_like(xd), torch.empty_like(xd)
+    hip.scale_rows(hip.dt(dtype), xd, ad, out, sd, B, inner)
+    hip.scale_rows(hip.dt(dtype), xd, None, out2, sd, B, inner)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.float().cpu(), x * scale[:, None] + add, **tol(dtype))
+    torch.testing.assert_close(out2.float().cpu(), x * scale[:, None], **tol(dtype))
+    with pytest.raises(RuntimeError, match="scale_rows"):
+        hip.scale_rows(hip.dt(dtype), xd, None, out2, sd, B, inner - 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T", [17, 197])
 def test_attention_fwd_bwd(dtype, T):
     """The engine's attention (batched MFMA GEMMs + softmax kernels) against torch's explicit softmax(QK^T/sqrt(d))V."""

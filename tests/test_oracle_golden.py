@@ -170,6 +170,19 @@ def test_backbone_invariants():
     for k in ("cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.0.attn.qkv.bias", "blocks.11.mlp.fc2.weight",
               "norm.bias"):
         assert k in vk
+    # unicom family (model.py:77-79) — restated from SURVEY §8 A9, parity unpinned: 572.33 M parameters for ViT-L/14
+    # (268.4 M of them in feature.0), 768-wide feature[-2], 256 tokens, bias-free qkv
+    with torch.device("meta"):
+        uni = create_backbone("unicom ViT-L/14")
+    assert count_params(uni) == 572_328_448 and uni.feature[-2].out_features == 768 == uni.num_features
+    assert uni.feature[0].weight.shape == (1024, 256 * 1024) and uni.pos_embed.shape == (1, 256, 1024)
+    uk = set(uni.state_dict())
+    for k in ("pos_embed", "patch_embed.proj.bias", "blocks.23.attn.qkv.weight", "blocks.0.mlp.fc1.bias", "norm.weight",
+              "feature.0.weight", "feature.1.running_var", "feature.3.num_batches_tracked"):
+        assert k in uk
+    assert "blocks.0.attn.qkv.bias" not in uk and "cls_token" not in uk and "feature.0.bias" not in uk
+    with torch.no_grad():
+        assert create_backbone("unicom ViT-tiny-test").eval()(torch.zeros(2, 3, 56, 56)).shape == (2, 64)
     with torch.no_grad():
         assert r18.eval()(torch.zeros(1, 3, 64, 64)).shape == (1, 512)
         assert create_backbone("vit_tiny_test").eval()(torch.zeros(2, 3, 64, 64)).shape == (2, 128)
