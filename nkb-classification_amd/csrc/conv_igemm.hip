@@ -14,6 +14,7 @@
 
 // ------------------------------------------------------------------------------------------
 #include "conv_params.h"
+#include "wgrad256.h"
 
 // 64x256 tile (Cout <= 64) as ONE LDS stage with the pixel fragments streamed through a single register set: 164 VGPRs
 // -> 3 workgroups per CU like the 128x128 tile (was: two LDS stages, 188 VGPRs, 2 per CU).  ResNet-50 layer1 shapes
@@ -1108,6 +1109,13 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     if ((long long)N * H * W * ldx >= (1ll << 31) || (long long)N * P * Q * lddy >= (1ll << 31)) {
         nkb_set_error("conv_wgrad: tensor exceeds 2^31 elements");
         return 1;
+    }
+    if (nkb_wgrad256_eligible(dtype, N * P * Q, Cin, Cout, R, S, stride, pad)) {
+        // wide Linear layers: 256 x 256 tiles (wgrad256.hip)
+        const int M = N * P * Q;
+        NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * M * (double)Cout * Cin,
+                          ((double)M * Cin + (double)M * Cout) * esz + 2.0 * 4.0 * Cout * Cin);
+        return nkb_launch_wgrad256(dy, x, dw, dbias, M, Cin, ldx, Cout, lddy, stream);
     }
     WgradParams p;
     p.dy = dy; p.x = x; p.dw = dw; p.dbias = dbias;

@@ -1,0 +1,9 @@
+// 256 x 256-tile weight-gradient kernel for wide Linear layers (wgrad256.hip); used by nkb_conv_wgrad when eligible.
+#pragma once
+#include <hip/hip_runtime.h>
+
+bool nkb_wgrad256_eligible(int dtype, int M, int Cin, int Cout, int R, int S, int stride, int pad);
+// dw[Cout][Cin] += dy[M][lddy]^T x[M][ldx], dbias[Cout] += column sums of dy when given (bf16 operands, fp32 atomics);
+// returns nkb_check_launch's code
+int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, int M, int Cin, int ldx, int Cout, int lddy,
+                        hipStream_t stream);

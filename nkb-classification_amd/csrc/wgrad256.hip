@@ -1,0 +1,217 @@
+// Weight gradient of the wide Linear layers (ViT / unicom blocks): dW[cout][n] += sum_m dY[m][cout] * X[m][n] as a bf16
+// "TN" GEMM with a 256 x 256 output tile per workgroup and the token dimension m as the reduction.
+//
+// Why a second weight-gradient kernel: conv_wgrad_kernel (conv_igemm.hip) uses 128 x 128 tiles with 64 x 64 per wave; on
+// these shapes it sits at 0.35-0.5 PFLOP/s because every MFMA byte is matched by as many LDS bytes (rocprofv3,
+// profiles/r01i: 81 ms of the 118 ms unicom ViT-L/14 step).  Here a wave owns 128 x 64 of the tile (acc = 128 VGPRs), so
+// a 64-token stage feeds 64 MFMAs per wave from 24 KB of LDS reads, operands go HBM -> LDS directly
+// (global_load_lds_dwordx4, no staging registers) into two 64 KB buffers, and there is ONE barrier per stage.
+//
+// Layout of one stage in LDS: dY tile = 2 sub-tiles [64 tokens][128 channels] (256-B rows), X tile likewise; each sub-tile
+// uses the 16-byte-chunk swizzle of conv_wgrad_kernel (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))), applied on the
+// SOURCE address because the LDS-DMA destination is linear (wave base + lane * 16).  MFMA fragments come out of LDS with
+// the transposing read ds_read_b64_tr_b16 (both operands are token-major).
+#include "common.h"
+#include "wgrad256.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+
+__device__ __forceinline__ int swz256(int row, int ch) {
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+struct W256Params {
+    const bf16_t* dy;    // [M][lddy]
+    const bf16_t* x;     // [M][ldx]
+    float* dw;           // [Cout][Ntot] fp32, accumulated with atomics
+    float* dbias;        // optional [Cout]: column sums of dY, accumulated with atomics by the tile_n == 0 workgroups
+    int M, lddy, ldx, Ntot;
+    int tilesC, tilesN, splits, rows_per_split;
+};
+
+__global__ __launch_bounds__(512, 1) void wgrad256_kernel(const W256Params p) {
+    constexpr int SUB = 64 * 256;                 // one [64][128] sub-tile
+    constexpr int OPB = 2 * SUB;                  // one operand of one stage (256 channels)
+    constexpr int STG = 2 * OPB;                  // dY + X
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wn = wave & 3;      // wave tile: cout [128 wr, +128) x n [64 wn, +64)
+
+    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);       // consecutive ids (one token range) share an XCD's L2
+    const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
+    const int tile_c = tile % p.tilesC, tile_n = tile / p.tilesC;
+    const int c0 = tile_c * 256, n0 = tile_n * 256;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nstage = (m_end - m_begin) / 64;    // host guarantees whole stages
+    if (nstage <= 0) return;
+
+    // loader: one operand stage = 32 pieces of 1 KiB (4 token rows of one sub-tile); wave w moves pieces w, w+8, w+16, w+24
+    const int lrow = lane >> 4, lslot = lane & 15;
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave + 8 * q, sub = piece >> 4, rg = piece & 15;
+        const int row = rg * 4 + lrow;                                        // token row inside the stage
+        const int ch = lslot ^ (((row & 3) << 2) | ((row >> 2) & 3));         // source chunk that belongs in this LDS slot
+        asrc[q] = p.dy + (size_t)(m_begin + row) * p.lddy + c0 + sub * 128 + ch * 8;
+        bsrc[q] = p.x + (size_t)(m_begin + row) * p.ldx + n0 + sub * 128 + ch * 8;
+    }
+    const size_t astep = (size_t)64 * p.lddy, bstep = (size_t)64 * p.ldx;
+    auto issue = [&](int st, int buf) {
+        unsigned char* base = smem + buf * STG;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + st * astep),
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * q) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + st * bstep),
+                                             (__attribute__((address_space(3))) void*)(base + OPB + (wave + 8 * q) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing (as conv_wgrad_kernel): lane (g, q4, p4) reads 8 B of token row 32 kk + 8 g + q4 (+4), chunk
+    // 2 blk + (p4 >> 1), half p4 & 1.  Every offset below is loop-invariant (the compiler keeps them in registers).
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+    auto frag = [&](const unsigned char* tile, int row, int blk) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) bf16x4*)(tile + swz256(row, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) bf16x4*)(tile + swz256(row + 4, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    const int bblk0 = (wn & 1) * 4;
+    // bias gradient: the wn == 0 waves of the tile_n == 0 workgroups sum the dY fragments they load anyway (a lane holds
+    // 8 tokens of one channel per fragment); VALU work in the shadow of the MFMAs, no extra pass over dY
+    const bool do_bias = p.dbias != nullptr && tile_n == 0 && wn == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage) issue(st + 1, (st + 1) & 1);
+        const unsigned char* base = smem + (st & 1) * STG;
+        const unsigned char* A = base + wr * SUB;
+        const unsigned char* B = base + OPB + (wn >> 1) * SUB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int row = 32 * kk + 8 * g + q4;
+            bf16x8 a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = frag(A, row, i);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4 v = __builtin_bit_cast(u32x4, a[i]);
+                    float t = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t += __uint_as_float(v[e] << 16) + __uint_as_float(v[e] & 0xffff0000u);
+                    bsum[i] += t;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 b = frag(B, row, bblk0 + j);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next stage has landed
+        __syncthreads();                                        // ... and everyone is done with this one
+    }
+
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = bsum[i];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (lane < 16) atomicAdd(p.dbias + c0 + wr * 128 + 16 * i + lane, t);
+        }
+    }
+
+    // epilogue: four passes of 64 cout rows through LDS [64][256 f32 + pad], then row-contiguous float atomics
+    // (256 B per wave instruction)
+    constexpr int EROW = 256 * 4 + 16;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        if (wr == (pass >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = 4 * (pass & 1) + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rbase = 16 * ii + 4 * g, col = wn * 64 + 16 * j + li;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *(float*)(smem + (rbase + e) * EROW + col * 4) = acc[i][j][e];
+                }
+            }
+        }
+        __syncthreads();
+        for (int row = wave; row < 64; row += 8) {
+            float* dst = p.dw + (size_t)(c0 + pass * 64 + row) * p.Ntot + n0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(dst + lane + 64 * c, *(const float*)(smem + row * EROW + (lane + 64 * c) * 4));
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+static int wgrad256_target_wgs() {
+    static const int target = [] { const char* e = getenv("NKB_WGRAD256_WGS"); return e ? atoi(e) : 256; }();
+    return target;
+}
+
+// stages (64 tokens) per split for `tiles` output tiles: ~target workgroups in total
+static int wgrad256_stages_per_split(int M, int tiles, int* splits_out) {
+    int splits = (wgrad256_target_wgs() + tiles / 2) / tiles;
+    if (splits < 1) splits = 1;
+    const int stages = M / 64;
+    if (splits > stages) splits = stages;
+    const int sps = (stages + splits - 1) / splits;
+    if (splits_out) *splits_out = (stages + sps - 1) / sps;
+    return sps;
+}
+
+bool nkb_wgrad256_eligible(int dtype, int M, int Cin, int Cout, int R, int S, int stride, int pad) {
+    static const int on = [] { const char* e = getenv("NKB_WGRAD256"); return e ? atoi(e) : 1; }();
+    if (!(on && dtype == NKB_DT_BF16 && R == 1 && S == 1 && stride == 1 && pad == 0 && Cout % 256 == 0 && Cin % 256 == 0 &&
+          M % 64 == 0 && M >= 4096))
+        return false;
+    // a split must be long enough to amortise its 256 KB of float atomics (measured: 12 stages per split is slower than
+    // the 128 x 128 kernel, 28 is 20 % faster)
+    const int tiles = (Cout / 256) * (Cin / 256);
+    return tiles >= 6 && wgrad256_stages_per_split(M, tiles, nullptr) >= 24;
+}
+
+int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, int M, int Cin, int ldx, int Cout, int lddy,
+                        hipStream_t stream) {
+    W256Params p;
+    p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw; p.dbias = dbias;
+    p.M = M; p.lddy = lddy; p.ldx = ldx; p.Ntot = Cin;
+    p.tilesC = Cout / 256; p.tilesN = Cin / 256;
+    const int tiles = p.tilesC * p.tilesN;
+    const int sps = wgrad256_stages_per_split(M, tiles, &p.splits);
+    p.rows_per_split = sps * 64;
+    constexpr int lds = 2 * 4 * 64 * 256;                        // two stages of 64 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
+    return nkb_check_launch("wgrad256");
+}

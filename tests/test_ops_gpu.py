@@ -721,6 +721,28 @@ def test_gelu_fwd_bwd(dtype):
     torch.testing.assert_close(dx.float().cpu(), x.grad, **tol(dtype))
 
 
+@pytest.mark.parametrize("shape", [(8192, 512, 768, 0), (16384, 768, 512, 64), (4096 * 5 + 64 * 7, 1024, 1536, 0)])
+def test_linear_wgrad_256_tile_kernel(shape):
+    """Wide bf16 Linear weight gradients take the 256x256-tile kernel (wgrad256.hip): dW += dY^T X with fp32 atomics into a
+    pre-filled gradient, bias gradient alongside, operands with row padding; compared with the fp32 product of the same
+    bf16 operands and with the 128x128 kernel's result on a shape just outside the envelope."""
+    M, Cin, Cout, padc = shape
+    torch.manual_seed(31)
+    d = hip.BF16
+    x = torch.randn(M, Cin + padc).to(torch.bfloat16)
+    dy = torch.randn(M, Cout + padc).to(torch.bfloat16)
+    pre = torch.randn(Cout, Cin)
+    ref = pre + dy[:, :Cout].float().t() @ x[:, :Cin].float()
+    refb = dy[:, :Cout].float().sum(0)
+    dw, db = pre.to(DEV).clone(), torch.zeros(Cout, device=DEV)
+    hip.conv_wgrad(d, dy.to(DEV), x.to(DEV), dw, N=M, H=1, W=1, Cin=Cin, ldx=Cin + padc, P=1, Q=1, Cout=Cout,
+                   lddy=Cout + padc, R=1, S=1, stride=1, pad=0, dbias=db)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (dw.cpu() - ref).abs().max().item() < 2e-5 * scale * math.sqrt(M / 4096)      # fp32 accumulation order only
+    torch.testing.assert_close(db.cpu(), refb, rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_relu6_fwd_bwd(dtype):
     torch.manual_seed(11)
