@@ -82,6 +82,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--input", default="hbm", choices=["hbm", "host-uint8", "host-fp32"],
+                    help="hbm: batch resident in HBM (the headline value). host-uint8: pinned uint8 HWC batches through "
+                         "DeviceLoader (async H2D one batch ahead + on-GPU pad/flip/normalise). host-fp32: the reference's "
+                         "way, a blocking fp32 .to(device) per step (engine.py:40).  The host variants are PCIe-inclusive "
+                         "rates for DESIGN.md, never the headline.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -175,11 +180,28 @@ def main():
     amp = args.dtype == "bf16"
     model.train()
 
+    def host_batches(n):
+        """n batches in the chosen host format, cycling over two pinned buffers."""
+        if args.input == "host-uint8":
+            from nkb_classification.dataset import DeviceLoader
+            raws = [torch.randint(0, 256, (args.batch, 224, 224, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+            tg = tgt.cpu().pin_memory()
+            return iter(DeviceLoader([(raws[i & 1], None, tg) for i in range(n)], device, 224, hflip_p=0.5, seed=rank))
+        host = [torch.randn(args.batch, 3, 224, 224, generator=g).pin_memory() for _ in range(2)]
+        tg = tgt.cpu()
+        return iter([(host[i & 1], tg) for i in range(n)])
+
+    feed = None
+
     def step():
+        x, t = img, tgt
+        if feed is not None:
+            x, t = next(feed)
+            x, t = x.to(device), t.to(device)       # engine.py:40-41; a no-op for DeviceLoader batches
         opt.zero_grad()
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=amp):
-            preds = model(img)
-            loss = crit(preds, tgt)
+            preds = model(x)
+            loss = crit(preds, t)
         loss.backward()
         opt.step()
         softmax_argmax(preds)       # the logger's per-step by-products (device side, no host sync)
@@ -207,6 +229,10 @@ def main():
         import gc
         gc.collect()
         gc.freeze()
+    if args.input != "hbm":
+        feed = host_batches(args.steps + 2)
+        step(); step()                       # pipeline primed: the first copy is not hidden behind a step
+        sync()
     log("warm-up done; timing")
     t0 = time.perf_counter()
     step_marks = []
@@ -228,6 +254,7 @@ def main():
     final_loss = float(loss.item())
     log(f"timed region: {dt:.3f}s for {args.steps} steps")
 
+    feed = None
     roofline = None
     prof = {}
     if rank == 0 and not args.no_roofline:
@@ -301,7 +328,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic randn images resident in HBM, random-init weights",
+            "data": {"hbm": "synthetic randn images resident in HBM, random-init weights",
+                     "host-uint8": "synthetic uint8 HWC batches in pinned host memory -> async H2D + on-GPU normalise/flip "
+                                   "(PCIe-inclusive, not the headline), random-init weights",
+                     "host-fp32": "synthetic fp32 NCHW batches in pinned host memory, blocking .to(device) per step "
+                                  "(PCIe-inclusive, not the headline), random-init weights"}[args.input],
             "config": {"workload": f"{args.model} single-task train step, {args.classes} classes, bs={args.batch}/GPU, "
                                    f"{args.dtype} compute + fp32 master weights, NAdam, 3x224x224",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},

@@ -194,6 +194,13 @@ int nkb_relu6(int dtype, const void* x, const void* dy, void* out, long long n, 
 /* stochastic depth (unicom Block.drop_path): out[r][i] = x[r][i] * scale[r] (+ add[r][i]); also its own backward */
 int nkb_scale_rows(int dtype, const void* x, const void* add, void* out, const float* scale, int rows, long long inner,
                    nkb_stream_t stream);
+/* Input pipeline on the device (replaces the PadIfNeeded -> Horizontal/VerticalFlip -> Normalize -> ToTensorV2 tail of
+ * the albumentations stack, configs/singletask_config.py:162-219, and lets engine.py:40's H2D copy move uint8):
+ * src [B][Hs][Ws][3] uint8 (device), sizes [B][2] int32 (h, w of the valid top-left region; NULL = Hs x Ws),
+ * flags [B] uint8 (bit 0 horizontal, bit 1 vertical flip; NULL = none), out [B][3][Ho][Wo] fp32 (device);
+ * mean / stdev: 3 HOST floats each (fractions of 255 as in A.Normalize); fill: pad value in 0..255. */
+int nkb_image_prep(const unsigned char* src, const int* sizes, const unsigned char* flags, float* out, int B, int Hs, int Ws,
+                   int Ho, int Wo, const float* mean, const float* stdev, float fill, nkb_stream_t stream);
 /* out = keep ? in/(1-p) : 0 (+ add); forward draws keep from a hash of (seed, index) and stores it in mask */
 int nkb_dropout(int dtype, int backward, const void* in, const void* add, void* out, unsigned char* mask, long long n,
                 float p, unsigned long long seed, nkb_stream_t stream);

@@ -58,6 +58,7 @@ _SIGS = {
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp]),
     "nkb_layernorm_workspace_floats": (sz, [i32]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
+    "nkb_image_prep": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp]),
     "nkb_relu6": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_scale_rows": (i32, [i32, vp, vp, vp, vp, i32, i64, vp]),
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
@@ -347,6 +348,12 @@ def layernorm_ws(D):
 
 def gelu(dtype, x, dy, out, n):
     check(load().nkb_gelu(dtype, ptr(x), ptr(dy), ptr(out), n, stream()), "gelu")
+
+
+def image_prep(src, sizes, flags, out, B, Hs, Ws, Ho, Wo, mean, std, fill=0.0):
+    m, sd = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(load().nkb_image_prep(ptr(src), ptr(sizes), ptr(flags), ptr(out), B, Hs, Ws, Ho, Wo, C.cast(m, C.c_void_p),
+                                C.cast(sd, C.c_void_p), float(fill), stream()), "image_prep")
 
 
 def relu6(dtype, x, dy, out, n):

@@ -218,3 +218,64 @@ def test_unicom_family_matches_reference_call_site():
     assert emb_size == emb_model.feature[-2].out_features == 64
     with pytest.raises(RuntimeError, match="not found"):
         unicom.load("ViT-H/14")
+
+
+def test_samplers_match_reference_formulas():
+    """dataset.py:27-86 (weights 1 / count[label], multinomial with replacement from the global generator) and the
+    data-parallel split of SURVEY.md §8(e) (seed-shared permutation, rank r takes r::W)."""
+    from nkb_classification.dataset import ImbalancedDatasetSampler, ShardedSampler
+
+    class DS(torch.utils.data.Dataset):
+        labels = [0, 0, 0, 0, 0, 0, 0, 1, 1, 2]
+
+        def __len__(self):
+            return len(self.labels)
+
+        def get_labels(self):
+            return self.labels
+
+    s = ImbalancedDatasetSampler(DS())
+    assert len(s) == 10
+    torch.testing.assert_close(s.weights, torch.tensor([1 / 7] * 7 + [0.5, 0.5, 1.0], dtype=torch.float64))
+    torch.manual_seed(4)
+    drawn = list(s)
+    torch.manual_seed(4)
+    assert drawn == torch.multinomial(s.weights, 10, replacement=True).tolist()
+    sub = ImbalancedDatasetSampler(DS(), indices=[0, 7, 9], num_samples=50)
+    assert len(sub) == 50 and set(sub) <= {0, 7, 9} and sub.weights.tolist() == [1.0, 1.0, 1.0]
+    # per-rank streams (seed + rank), each drawing its share
+    r0, r1 = (ImbalancedDatasetSampler(DS(), seed=3, rank=r, world=2) for r in (0, 1))
+    assert len(r0) == len(r1) == 5 and list(r0) != list(r1)
+    shards = [ShardedSampler(10, r, 4, shuffle=True, seed=3) for r in range(4)]
+    got = [list(sh) for sh in shards]
+    assert all(len(g) == 3 for g in got) and set(sum(got, [])) == set(range(10))
+    perm = torch.randperm(10, generator=torch.Generator().manual_seed(3)).tolist()
+    assert got[1] == (perm + perm[:2])[1::4]
+    for sh in shards:
+        sh.set_epoch(1)
+    assert [list(sh) for sh in shards] != got
+    assert list(ShardedSampler(5, 1, 2, shuffle=False)) == [1, 3, 0]
+
+
+def test_get_dataset_sampling_options(tmp_path):
+    """get_dataset (dataset.py:541-629): weighted_sampling / shuffle / drop_last / world sharding reach the DataLoader."""
+    from PIL import Image
+    from nkb_classification.dataset import ImbalancedDatasetSampler, ShardedSampler, get_dataset
+    import numpy as np
+    for cls, n in (("a", 5), ("b", 2)):
+        (tmp_path / cls).mkdir()
+        for i in range(n):
+            Image.fromarray(np.full((12 + i, 20, 3), 40 * i, np.uint8)).save(tmp_path / cls / f"{i}.png")
+    base = dict(root=str(tmp_path), size=16, batch_size=2, num_workers=0)
+    ld = get_dataset(dict(base, weighted_sampling=True, drop_last=True))
+    assert isinstance(ld.sampler, ImbalancedDatasetSampler) and ld.drop_last and ld.dataset.classes == ["a", "b"]
+    assert ld.sampler.weights.tolist() == [0.2] * 5 + [0.5] * 2
+    ld = get_dataset(dict(base, shuffle=True, rank=1, world=2, seed=5))
+    assert isinstance(ld.sampler, ShardedSampler) and len(ld.sampler) == 4
+    x, y = next(iter(get_dataset(dict(base, shuffle=False))))
+    assert x.shape == (2, 3, 16, 16) and x.dtype == torch.float32 and y.tolist() == [0, 0]
+    # raw mode of the folder source (what DeviceLoader consumes): longest side scaled to `size`, top-left placement
+    from nkb_classification.dataset import FolderDataset
+    raw, hw, label = FolderDataset(str(tmp_path), size=16, raw=True)[0]
+    assert raw.dtype == torch.uint8 and raw.shape == (16, 16, 3) and hw.tolist() == [10, 16] and label == 0
+    assert raw[10:].abs().sum() == 0

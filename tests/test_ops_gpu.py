@@ -823,3 +823,79 @@ def test_colsum2d_and_assemble(dtype):
     ref = torch.cat([cls.expand(B, 1, D), tok], 1) + pos
     torch.testing.assert_close(xx.float().cpu(), rnd(ref, dtype), **tol(dtype))
     torch.testing.assert_close(back.float().cpu(), xx[:, 1:].float().cpu(), rtol=0, atol=0)
+
+
+def _ref_image_prep(img, Ho, Wo, flag, mean, std, fill):
+    """PadIfNeeded(centre, constant) -> HorizontalFlip / VerticalFlip -> Normalize(max_pixel_value=255) -> ToTensorV2, as the
+    albumentations stack of configs/singletask_config.py:162-219 computes them (float32 throughout)."""
+    import numpy as np
+    h, w, _ = img.shape
+    top, left = (Ho - h) // 2, (Wo - w) // 2
+    canvas = np.full((Ho, Wo, 3), fill, np.float32)
+    canvas[top:top + h, left:left + w] = img
+    if flag & 1:
+        canvas = canvas[:, ::-1]
+    if flag & 2:
+        canvas = canvas[::-1]
+    m = np.asarray(mean, np.float32) * np.float32(255.0)
+    r = np.float32(1.0) / (np.asarray(std, np.float32) * np.float32(255.0))
+    return ((canvas - m) * r).transpose(2, 0, 1)
+
+
+@pytest.mark.parametrize("out_hw", [(32, 32), (30, 37)])
+def test_image_prep_matches_albumentations_semantics(out_hw):
+    import numpy as np
+    Ho, Wo = out_hw
+    rng = np.random.default_rng(3)
+    B, Hs, Ws = 6, Ho - 2, Wo
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    sizes = [(Hs, Ws), (Hs - 5, Ws), (Hs, Ws - 9), (1, 1), (Hs - 3, Ws - 4), (7, Ws)]
+    flags = [0, 1, 2, 3, 3, 1]
+    src = rng.integers(0, 256, (B, Hs, Ws, 3), dtype=np.uint8)
+    out = torch.empty(B, 3, Ho, Wo, device=DEV)
+    hip.image_prep(torch.from_numpy(src).to(DEV), torch.tensor(sizes, dtype=torch.int32, device=DEV),
+                   torch.tensor(flags, dtype=torch.uint8, device=DEV), out, B, Hs, Ws, Ho, Wo, mean, std, fill=0.0)
+    torch.cuda.synchronize()
+    for b in range(B):
+        h, w = sizes[b]
+        ref = _ref_image_prep(src[b, :h, :w], Ho, Wo, flags[b], mean, std, 0.0)
+        torch.testing.assert_close(out[b].cpu(), torch.from_numpy(np.ascontiguousarray(ref)), rtol=1e-6, atol=1e-6)
+    # no sizes / flags: the whole source, centred, un-flipped; a non-zero fill
+    out2 = torch.empty(B, 3, Ho, Wo, device=DEV)
+    hip.image_prep(torch.from_numpy(src).to(DEV), None, None, out2, B, Hs, Ws, Ho, Wo, mean, std, fill=114.0)
+    torch.cuda.synchronize()
+    ref = _ref_image_prep(src[2], Ho, Wo, 0, mean, std, 114.0)
+    torch.testing.assert_close(out2[2].cpu(), torch.from_numpy(np.ascontiguousarray(ref)), rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError, match="image_prep"):
+        hip.image_prep(torch.from_numpy(src).to(DEV), None, None, out2, B, Hs, Ws, Hs - 1, Wo, mean, std)
+
+
+def test_device_loader_double_buffers_uint8_batches():
+    """DeviceLoader: uint8 host batches -> (float32 NCHW on the device, target), copies one batch ahead on its own stream;
+    every batch arrives, in order, equal to the host-side reference of the same pipeline tail."""
+    import numpy as np
+    from nkb_classification.dataset import DeviceLoader
+    rng = np.random.default_rng(5)
+    size, nb, B = 40, 5, 4
+    batches = []
+    for k in range(nb):
+        raw = torch.from_numpy(rng.integers(0, 256, (B, size, size, 3), dtype=np.uint8))
+        sizes = torch.tensor([[size - (k + i) % 7, size - (2 * k + i) % 5] for i in range(B)], dtype=torch.int32)
+        batches.append((raw, sizes, torch.arange(B) + 10 * k))
+    dl = DeviceLoader(batches, DEV, size, hflip_p=0.5, vflip_p=0.5, seed=9)
+    assert len(dl) == nb
+    gen = torch.Generator().manual_seed(9)             # the loader's flip draws, replayed
+    seen = 0
+    for k, (img, target) in enumerate(dl):
+        assert img.is_cuda and img.dtype == torch.float32 and img.shape == (B, 3, size, size)
+        assert target.is_cuda and target.tolist() == (torch.arange(B) + 10 * k).tolist()
+        u = torch.rand(B, 2, generator=gen)
+        raw, sizes, _ = batches[k]
+        for i in range(B):
+            flag = int(u[i, 0] < 0.5) | (int(u[i, 1] < 0.5) << 1)
+            h, w = sizes[i].tolist()
+            ref = _ref_image_prep(raw[i, :h, :w].numpy(), size, size, flag, dl.mean, dl.std, 0.0)
+            torch.testing.assert_close(img[i].cpu(), torch.from_numpy(np.ascontiguousarray(ref)), rtol=1e-6, atol=1e-6)
+        seen += 1
+    assert seen == nb
+    assert list(DeviceLoader([], DEV, size)) == []
