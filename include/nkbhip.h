@@ -194,6 +194,9 @@ int nkb_relu6(int dtype, const void* x, const void* dy, void* out, long long n, 
 /* stochastic depth (unicom Block.drop_path): out[r][i] = x[r][i] * scale[r] (+ add[r][i]); also its own backward */
 int nkb_scale_rows(int dtype, const void* x, const void* add, void* out, const float* scale, int rows, long long inner,
                    nkb_stream_t stream);
+/* Eval-mode BatchNorm folding (val_epoch, engine.py:88-117): dst[Cout][K] = w[Cout][K] * scale[Cout] in the compute dtype;
+ * the folded filter + bias = shift + the conv epilogue's residual add / ReLU replace conv -> bn -> act in eval mode. */
+int nkb_wfold(int dtype, const float* w, const float* scale, void* dst, int Cout, int K, nkb_stream_t stream);
 /* Input pipeline on the device (replaces the PadIfNeeded -> Horizontal/VerticalFlip -> Normalize -> ToTensorV2 tail of
  * the albumentations stack, configs/singletask_config.py:162-219, and lets engine.py:40's H2D copy move uint8):
  * src [B][Hs][Ws][3] uint8 (device), sizes [B][2] int32 (h, w of the valid top-left region; NULL = Hs x Ws),

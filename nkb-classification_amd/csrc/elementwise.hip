@@ -775,6 +775,24 @@ extern "C" int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, i
     return nkb_check_launch("wprep");
 }
 
+// Inference-time BatchNorm folding (engine.py:88-117 val_epoch runs the model in eval mode):
+// dst[co][k] = T(w[co][k] * scale[co]) with scale = gamma / sqrt(running_var + eps), so that
+// relu(bn(conv(x, w)) + res) = relu(conv(x, dst) + shift + res) comes out of ONE conv launch (bias / add / ReLU epilogue).
+template <typename T>
+__global__ void wfold_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ dst, int K, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        DT<T>::st(dst + i, w[i] * scale[i / K]);
+}
+extern "C" int nkb_wfold(int dtype, const float* w, const float* scale, void* dst, int Cout, int K, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("wfold: bad dtype %d", dtype); return 1; }
+    if (Cout <= 0 || K <= 0) return 0;
+    const size_t total = (size_t)Cout * K;
+    NkbProfScope prof(NKB_K_WPREP, stream, 0);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(wfold_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, w, scale, (bf16_t*)dst, K, total);
+    else hipLaunchKernelGGL(wfold_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, w, scale, (float*)dst, K, total);
+    return nkb_check_launch("wfold");
+}
+
 // strided 2-D fp32 copy-add: dst[r][0..cols) (ld_dst) += src[r][0..cols) (ld_src); used to fold the padded stem
 // weight gradient back into the parameter gradient.
 __global__ void add2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int ld_src, int ld_dst) {

@@ -155,7 +155,7 @@ class HipResNet(_ParamOnly):
                 if _SIDE_SHORTCUT:
                     eng.join_side()
                 short, s_scale, s_shift = box["r"]
-                short_affine = (s_scale, s_shift)
+                short_affine = (s_scale, s_shift) if s_scale is not None else None     # None: eval mode, already normalised
             cv, bn = stages[-1]
             x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train, res_affine=short_affine)
         return eng.avgpool("gap", x)

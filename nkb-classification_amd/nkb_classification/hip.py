@@ -58,6 +58,7 @@ _SIGS = {
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp]),
     "nkb_layernorm_workspace_floats": (sz, [i32]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
+    "nkb_wfold": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "nkb_image_prep": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp]),
     "nkb_relu6": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_scale_rows": (i32, [i32, vp, vp, vp, vp, i32, i64, vp]),
@@ -348,6 +349,10 @@ def layernorm_ws(D):
 
 def gelu(dtype, x, dy, out, n):
     check(load().nkb_gelu(dtype, ptr(x), ptr(dy), ptr(out), n, stream()), "gelu")
+
+
+def wfold(dtype, w, scale, dst, Cout, K):
+    check(load().nkb_wfold(dtype, ptr(w), ptr(scale), ptr(dst), Cout, K, stream()), "wfold")
 
 
 def image_prep(src, sizes, flags, out, B, Hs, Ws, Ho, Wo, mean, std, fill=0.0):

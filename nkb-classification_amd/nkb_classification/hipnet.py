@@ -28,6 +28,7 @@ _FUSE_MIN_C = int(os.environ.get("NKB_FUSE_MIN_C", "65"))
 # residual-closing stages keep a 1-bit/element ReLU mask; backward reads it instead of the activation and the masked
 # block-output gradient is never materialised (consumers apply the bits on the fly)
 _RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
+_EVAL_FOLD = os.environ.get("NKB_EVAL_FOLD", "1") != "0"     # eval mode: BatchNorm folded into the conv (one launch per stage)
 
 
 class HipEngine:
@@ -57,6 +58,8 @@ class HipEngine:
         self._side: Optional[torch.cuda.Stream] = None
         self._side_done: Dict[int, torch.cuda.Event] = {}
         self._suffix = ""
+        self._fold: Dict[str, tuple] = {}          # stage key -> (fold_key, folded filter, shift) for eval mode
+        self.fold_key = None                       # set by the owning classifier: (arena version, eval phase counter)
 
     # ------------------------------------------------------------------ weights ----
     def register(self, convs, stems, head_weights, head_biases):
@@ -177,6 +180,23 @@ class HipEngine:
             P, Q = (H + 2 * pad - R) // st + 1, (W + 2 * pad - S) // st + 1
             geom = dict(N=N, H=H, W=W, Cin=ci, ldx=ci, P=P, Q=Q, Cout=co, ldy=co, R=R, S=S, stride=st, pad=pad)
         rows = N * P * Q
+        if not train and _EVAL_FOLD and not packed and not col_input and not pool:
+            # eval fast path: filter * scale (running statistics) once per eval phase, then conv + shift (+ res) (+ ReLU)
+            # in one launch; nothing is saved and the raw conv output is never written
+            sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
+            ent = self._fold.get(key)
+            if ent is None or ent[0] != self.fold_key:
+                hip.bn_finalize(None, 0, co, rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1, bn.eps, False,
+                                sc[0], sc[1], sc[2], sc[3])
+                wf = ent[1] if ent is not None else torch.empty(co, R * S * ci, device=self.device, dtype=self.T)
+                shift = ent[2] if ent is not None else torch.empty(co, device=self.device, dtype=torch.float32)
+                hip.wfold(self.d, self.arena.param_flat(w), sc[0], wf, co, R * S * ci)
+                shift.copy_(sc[1])
+                ent = self._fold[key] = (self.fold_key, wf, shift)
+            y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
+            assert res_affine is None or res_affine[0] is None
+            hip.conv_gemm(self.d, 0, x, ent[1], y, bias=ent[2], relu=relu, add=res, ldadd=co if res is not None else 0, **geom)
+            return (y, None, None) if defer_apply else y
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
         bits = None
         tiles = hip.stat_tiles(self.d, rows, co)

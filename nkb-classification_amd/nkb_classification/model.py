@@ -144,11 +144,17 @@ class _HipClassifier(nn.Module):
     def _classifier_dropout_p(self) -> float:
         raise NotImplementedError
 
+    def train(self, mode: bool = True):
+        # every train()/eval() switch starts a new eval phase: folded eval-mode filters are rebuilt on first use
+        self._eval_phase = getattr(self, "_eval_phase", 0) + 1
+        return super().train(mode)
+
     def _forward_impl(self, img: torch.Tensor) -> torch.Tensor:
         eng = self._active
         train = self.training
         need_dgrad = train and any(p.requires_grad for p in self.emb_model.parameters())
         eng.refresh_weights(need_dgrad=need_dgrad)
+        eng.fold_key = (self.arena.version, getattr(self, "_eval_phase", 0))
         emb = self.emb_model.run_forward(eng, img, train)
         if train and self._nbt_flat is not None:
             self._nbt_flat.add_(1)

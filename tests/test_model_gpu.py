@@ -423,6 +423,51 @@ def test_unicom_drop_path_matches_oracle():
         assert _relerr(model(x.to(DEV)).cpu(), oracle(x)) < 1e-3
 
 
+@pytest.mark.parametrize("backbone", ["resnet_tiny_basic", "resnet_tiny_bottleneck"])
+def test_eval_mode_folded_batchnorm_tracks_training(backbone):
+    """Eval mode (val_epoch, engine.py:88-117) runs conv + folded BatchNorm + residual + ReLU as one launch per stage; the
+    folded filters must follow the weights and running statistics through train steps and state-dict loads."""
+    cfg_model = dict(model=backbone, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    classes = ["a", "b", "c"]
+    oracle, model = _pair(cfg_model, classes, seed=2)
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for n_, b_ in oracle.named_buffers():                      # non-trivial running statistics
+            if n_.endswith("running_mean"):
+                b_.copy_(torch.randn(b_.shape, generator=g) * 0.2)
+            elif n_.endswith("running_var"):
+                b_.copy_(torch.rand(b_.shape, generator=g) + 0.5)
+        for p in oracle.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.5)
+    model.load_state_dict(oracle.state_dict())
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    y = torch.randint(0, 3, (4,), generator=g)
+
+    def check():
+        oracle.eval(); model.eval()
+        with torch.no_grad():
+            ref, out = oracle(x), model(x.to(DEV)).cpu()
+        assert _relerr(out, ref) < 1e-3 and out.argmax(-1).tolist() == ref.argmax(-1).tolist()
+        return out
+
+    first = check()
+    # one SGD step on both sides: weights AND running statistics move; the next eval phase must see them
+    o_opt = torch.optim.SGD(oracle.parameters(), lr=0.05)
+    m_opt = get_optimizer(model, dict(type="sgd", lr=0.05))
+    oracle.train(); model.train()
+    torch.nn.functional.cross_entropy(oracle(x), y).backward(); o_opt.step()
+    get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)(model(x.to(DEV)), y.to(DEV)).backward(); m_opt.step()
+    second = check()
+    assert (second - first).abs().max() > 1e-4
+    # a state-dict load while in eval mode (model.py:170-172 checkpoint path)
+    model.load_state_dict(OracleClassifier(cfg_model, classes).state_dict())
+    oracle.load_state_dict(model.state_dict())
+    third = check()
+    assert (third - second).abs().max() > 1e-4
+
+
 def test_classifier_dropout_train_path():
     """classifier_dropout > 0 (reference sample configs use 0.1): per-head masks, 1/(1-p) scaling, consistent backward."""
     from nkb_classification import hip
