@@ -43,10 +43,10 @@ def log(*a):
 
 def pmc_traffic(args, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
-    (profiles/r01d_pmc_traffic.json, produced by scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as
+    (profiles/r01i_pmc_traffic.json, produced by scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as
     MI355X_MICROARCH.md prescribes).  A bench run cannot profile itself, so this is the measurement on file for the
     default workload; any other workload reports null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01i_pmc_traffic.json")
     if not (args.model == "resnet50" and args.batch == 256 and args.dtype == "bf16" and os.path.exists(path)):
         return None
     try:
