@@ -258,17 +258,21 @@ def test_train_py_end_to_end(tmp_path):
     assert "emb_model.layer4.1.bn2.running_var" in sd and "classifier.1.weight" in sd
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, backbone="resnet_tiny_bottleneck"):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves CUDA tensors through the host
     try:
         from nkb_classification.parallel import GradReducer
-        cfg_model = dict(model="resnet_tiny_bottleneck", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+        cfg_model = dict(model=backbone, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
                          classifier_initialization="kaiming_normal_", task="single")
         torch.manual_seed(0)
         model = get_model(cfg_model, ["a", "b", "c"], DEV)
+        hw = 56 if backbone.startswith("unicom") else 64
+        if backbone.startswith("unicom"):
+            for blk in model.emb_model.blocks:
+                blk.drop_path.drop_prob = 0.0       # the two backward passes below must see the same function
         with torch.no_grad():                       # non-trivial BN affine parameters so every path carries signal
             g0 = torch.Generator().manual_seed(3)
             for p in model.parameters():
@@ -277,7 +281,7 @@ def _ddp_worker(rank, world, port, q):
         crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
         opt = get_optimizer(model, dict(type="sgd", lr=0.1))
         g = torch.Generator().manual_seed(100 + rank)
-        x, y = torch.randn(4, 3, 64, 64, generator=g).to(DEV), torch.randint(0, 3, (4,), generator=g).to(DEV)
+        x, y = torch.randn(4, 3, hw, hw, generator=g).to(DEV), torch.randint(0, 3, (4,), generator=g).to(DEV)
         model.train()
         # local gradients first (no reducer attached)
         crit(model(x), y).backward()
@@ -301,15 +305,17 @@ def _ddp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_data_parallel_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("backbone", ["resnet_tiny_bottleneck", "vit_tiny_test", "unicom ViT-tiny-test"])
+def test_data_parallel_two_ranks_on_one_gpu(backbone):
     """world_size 2 with both ranks on cuda:0 (gloo transport): the HIP model's backward hooks + GradReducer + fused
-    optimizer reproduce 'average of the per-rank gradients, then SGD' exactly."""
+    optimizer reproduce 'average of the per-rank gradients, then SGD' exactly — for every backbone family's
+    gradient-ready notification order."""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, backbone)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
