@@ -26,6 +26,11 @@ for p in (ROOT, ROOT / "nkb-classification_amd"):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The step uses three HIP streams (compute, weight gradients, gradient exchange) next to RCCL's own.  The runtime maps
+# streams onto 4 hardware queues by default, and once RCCL has taken its share the weight-gradient stream lands on the
+# compute stream's queue: everything serialises (measured, single-rank rehearsal of the exchange path: 26.8 ms/step with
+# 4 queues, 21.9 with 8; 21.6 without the exchange).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -326,6 +326,14 @@ class HipEngine:
             ev.record(self._side)
             self._side_done[index] = ev
 
+    def side_event(self):
+        """Event marking the current tail of the weight-gradient stream (None while that stream is unused)."""
+        if self._side is None or not self.overlap_wgrad:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        return ev
+
     def wait_side(self):
         """Main stream waits for every outstanding weight gradient (before the optimizer / the gradient exchange)."""
         if self._side is not None:

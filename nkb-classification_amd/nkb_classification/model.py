@@ -172,15 +172,16 @@ class _HipClassifier(nn.Module):
         hook = self.grad_ready_hook
         if hook is not None:
             lo = arena.offset_of(heads[0].weight)
-            hook(lo, arena.total)
+            hook(lo, arena.total, side_event=eng.side_event())
         if bb_params:
             on_done = None
             if hook is not None:
                 def on_done(module):
-                    eng.wait_side()      # the side-stream weight gradients of this range must be complete
+                    # the range is final once the compute stream AND the weight-gradient stream reach this point; the
+                    # communication stream waits for both, the compute stream for neither
                     rng = arena.range_of(list(module.parameters()) if isinstance(module, nn.Module) else list(module))
                     if rng is not None:
-                        hook(*rng)
+                        hook(*rng, side_event=eng.side_event())
             self.emb_model.run_backward(eng, g_emb, on_done)
         eng.wait_side()
         arena.publish_grads(wanted)

@@ -17,7 +17,7 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes: int = 25 << 20):
         if not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.model = model
@@ -25,6 +25,8 @@ class GradReducer:
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._pending: List = []
+        self._ready: List[List[int]] = []          # finished, not yet sent arena intervals [lo, hi), merged and sorted
+        self._side_event = None
         self._stream: Optional[torch.cuda.Stream] = None
         model.grad_ready_hook = self.on_range_ready
         if optimizer is not None:
@@ -39,20 +41,55 @@ class GradReducer:
                 dist.broadcast(b, 0, group=self.group)
 
     # -- called by the model while backward is still running --------------------------------------------
-    def on_range_ready(self, lo: int, hi: int):
+    def on_range_ready(self, lo: int, hi: int, side_event=None):
+        """Gradients [lo, hi) of the flat arena are final once everything enqueued so far on the compute stream — and,
+        when given, `side_event` of the weight-gradient stream — has run.  Finished ranges are merged and exchanged in
+        buckets of at least `bucket_bytes` (a few large collectives instead of one per layer: RCCL ring time on xGMI is
+        per-link bound, and every call costs host time that the enqueue loop does not have to spare); the rest goes out
+        in wait().  The compute stream never waits here: only the communication stream does."""
         if self.world == 1 or hi <= lo:
+            return
+        if side_event is not None:
+            self._side_event = side_event
+        self._ready.append([lo, hi])
+        self._ready.sort()
+        merged = [self._ready[0]]
+        for a, b in self._ready[1:]:
+            if a <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], b)
+            else:
+                merged.append([a, b])
+        self._ready = merged
+        self._flush(final=False)
+
+    def _flush(self, final: bool):
+        keep = []
+        todo = []
+        for a, b in self._ready:
+            # send whole buckets from the tail of the interval (produced first); keep the remainder for later merging
+            while b - a >= self.bucket_elems:
+                todo.append((b - self.bucket_elems, b))
+                b -= self.bucket_elems
+            if b > a:
+                (todo if final else keep).append((a, b) if final else [a, b])
+        self._ready = keep
+        if not todo:
             return
         flat = self.model.arena.flat_grad
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
             ev = torch.cuda.Event()
-            ev.record()                       # gradients [lo, hi) are complete at this point of the compute stream
+            ev.record()                       # everything enqueued so far on the compute stream
             self._stream.wait_event(ev)
+            if self._side_event is not None:
+                self._stream.wait_event(self._side_event)
             with torch.cuda.stream(self._stream):
-                self._launch(flat, lo, hi)
+                for a, b in todo:
+                    self._launch(flat, a, b)
         else:
-            self._launch(flat, lo, hi)
+            for a, b in todo:
+                self._launch(flat, a, b)
 
     def _launch(self, flat, lo, hi):
         # walk from the tail: those gradients were produced first
@@ -63,7 +100,9 @@ class GradReducer:
             b = a
 
     def wait(self):
-        """Make the compute stream wait for every outstanding bucket (no host block on GPU)."""
+        """Send what is left, then make the compute stream wait for every outstanding bucket (no host block on GPU)."""
+        self._flush(final=True)
+        self._side_event = None
         for w in self._pending:
             w.wait()
         self._pending.clear()

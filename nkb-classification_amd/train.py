@@ -16,8 +16,11 @@ import os
 import sys
 from pathlib import Path
 
-import torch
-from tqdm import tqdm
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # before the HIP runtime starts: see nkb_classification/__init__.py
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+from tqdm import tqdm  # noqa: E402
 
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 
