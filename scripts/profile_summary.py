@@ -17,7 +17,7 @@ first = ends[-keep - 1] + 1 if len(ends) > keep else 0
 sel = rows[first:ends[-1] + 1]
 agg = collections.OrderedDict()
 for s, e, name in sel:
-    short = name.split("(")[0]
+    short = name.replace("(anonymous namespace)::", "").split("(")[0]
     a = agg.setdefault(short, [0, 0])
     a[0] += 1
     a[1] += e - s
