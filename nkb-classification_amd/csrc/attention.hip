@@ -19,32 +19,45 @@ constexpr int DH = 64;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-// cooperative load of one head's K (or V) rows into the swizzled 128-byte-row LDS image; rows >= T are zero
-__device__ __forceinline__ void load_rows(unsigned char* lds, const bf16_t* __restrict__ src, long long row_stride, int T,
-                                          int rows_padded) {
-    for (int c = threadIdx.x; c < rows_padded * 8; c += blockDim.x) {
-        const int row = c >> 3, ch = c & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < T) v = *(const u32x4*)(src + (size_t)row * row_stride + ch * 8);
-        *(u32x4*)(lds + kswz(row, ch)) = v;
+// cooperative load of one head's K and V rows into two swizzled 128-byte-row LDS images; rows >= T are zero.  All global
+// loads are issued before the first LDS store (one memory latency per workgroup; the rolled load->store loop paid one
+// per 256 chunks: 13 round trips for T = 197).
+__device__ __forceinline__ void load_kv(unsigned char* ks, unsigned char* vs, const bf16_t* __restrict__ ksrc,
+                                        const bf16_t* __restrict__ vsrc, long long row_stride, int T, int krows, int vrows) {
+    constexpr int IT = MAXKB * 16 * 8 / 256;        // 8 chunks of 16 B per row, 256 threads
+    u32x4 kv[IT], vv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int c = threadIdx.x + 256 * i, row = c >> 3, ch = c & 7;
+        kv[i] = (u32x4){0u, 0u, 0u, 0u};
+        vv[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (row < T) {
+            kv[i] = *(const u32x4*)(ksrc + (size_t)row * row_stride + ch * 8);
+            vv[i] = *(const u32x4*)(vsrc + (size_t)row * row_stride + ch * 8);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int c = threadIdx.x + 256 * i, row = c >> 3, ch = c & 7;
+        if (row < krows) *(u32x4*)(ks + kswz(row, ch)) = kv[i];
+        if (row < vrows) *(u32x4*)(vs + kswz(row, ch)) = vv[i];
     }
 }
 
-// S^T tile for 16 queries: acc[kb] = D[key 16kb + 4g + reg][query lane&15], A = rows image (K or V), B = global rows
-__device__ __forceinline__ void score_tile(const unsigned char* rows_img, const bf16_t* __restrict__ qrow, int nkb,
-                                           f32x4 (&acc)[MAXKB]) {
+// S^T tile for 16 queries: acc[kb] = D[key 16kb + 4g + reg][query lane&15], A = rows image (K or V), B = global rows.
+// NKB (16-key blocks per row) is a compile-time constant: with a runtime bound every unrolled block carried its own
+// predicate (148 spilled SGPRs) and the blocks beyond T were still walked.
+template <int NKB>
+__device__ __forceinline__ void score_tile(const unsigned char* rows_img, const bf16x8 q0, const bf16x8 q1, f32x4 (&acc)[NKB]) {
     const int lane = threadIdx.x & 63, fr = lane & 15, g = lane >> 4;
-    const bf16x8 q0 = *(const bf16x8*)(qrow + g * 8);
-    const bf16x8 q1 = *(const bf16x8*)(qrow + (4 + g) * 8);
+    const unsigned char* p0 = rows_img + kswz(fr, g);          // (16 kb + fr) & 7 == fr & 7: +2048 B per key block
+    const unsigned char* p1 = rows_img + kswz(fr, 4 + g);
 #pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb) {
-        acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (kb < nkb) {
-            const bf16x8 a0 = *(const bf16x8*)(rows_img + kswz(kb * 16 + fr, g));
-            const bf16x8 a1 = *(const bf16x8*)(rows_img + kswz(kb * 16 + fr, 4 + g));
-            acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, q0, acc[kb], 0, 0, 0);
-            acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, q1, acc[kb], 0, 0, 0);
-        }
+    for (int kb = 0; kb < NKB; ++kb) {
+        const bf16x8 a0 = *(const bf16x8*)(p0 + 2048 * kb);
+        const bf16x8 a1 = *(const bf16x8*)(p1 + 2048 * kb);
+        acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, q0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, q1, acc[kb], 0, 0, 0);
     }
 }
 
@@ -52,76 +65,77 @@ __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64)
 __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, int T, int H, float scale) {
+template <int NKB>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          float* __restrict__ lse, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TK = NKB * 16, NKS = (NKB + 1) / 2;   // 32-key steps of the P*V product
     const int D = H * DH;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const int nkb = (T + 15) / 16, TK = nkb * 16;
-    const int nks = (T + 31) / 32;                 // 32-key steps of the P*V product
     unsigned char* Ks = smem;
     unsigned char* Vs = smem + TK * 128;           // V rows [key][dh] in the same swizzled image, zero beyond T
     const long long rs = 3ll * D;
     const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
-    load_rows(Ks, base + D, rs, T, TK);
-    load_rows(Vs, base + 2 * D, rs, T, nks * 32);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    // this wave's first query rows are requested before the K / V staging so that their latency hides behind it
+    auto qrow = [&](int qb) { const int q = qb * 16 + fr; return base + (size_t)(q < T ? q : T - 1) * rs; };
+    bf16x8 q0 = *(const bf16x8*)(qrow(wave) + g * 8), q1 = *(const bf16x8*)(qrow(wave) + (4 + g) * 8);
+    load_kv(Ks, Vs, base + D, base + 2 * D, rs, T, TK, NKS * 32);
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    const float sl2 = scale * 1.4426950408889634f;   // exp(x) = exp2(x log2 e): the hardware exponential is base 2
     for (int qb = wave; qb * 16 < T; qb += 4) {
         const int q = qb * 16 + fr;
-        const int qc = q < T ? q : T - 1;
-        f32x4 acc[MAXKB];
-        score_tile(Ks, base + (size_t)qc * rs, nkb, acc);
+        f32x4 acc[NKB];
+        score_tile<NKB>(Ks, q0, q1, acc);
+        if ((qb + 4) * 16 < T) {                        // next block's queries: in flight during this block's softmax
+            q0 = *(const bf16x8*)(qrow(qb + 4) + g * 8);
+            q1 = *(const bf16x8*)(qrow(qb + 4) + (4 + g) * 8);
+        }
         float m = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < MAXKB; ++kb)
-            if (kb < nkb) {
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = kb * 16 + 4 * g + e;
-                    acc[kb][e] = key < T ? acc[kb][e] * scale : -INFINITY;
-                    m = fmaxf(m, acc[kb][e]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                acc[kb][e] *= sl2;
+                if (kb == NKB - 1 && kb * 16 + 4 * g + e >= T) acc[kb][e] = -INFINITY;      // only the last block can run past T
+                m = fmaxf(m, acc[kb][e]);
             }
         m = group_max(m);
         float sum = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < MAXKB; ++kb)
-            if (kb < nkb) {
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { acc[kb][e] = __expf(acc[kb][e] - m); sum += acc[kb][e]; }
-            }
+            for (int e = 0; e < 4; ++e) { acc[kb][e] = __builtin_amdgcn_exp2f(acc[kb][e] - m); sum += acc[kb][e]; }
         sum = group_sum(sum);
         const float inv = 1.f / sum;
-        if (g == 0 && q < T) lse[((size_t)b * H + h) * T + q] = m + __logf(sum);
+        if (g == 0 && q < T) lse[((size_t)b * H + h) * T + q] = m * 0.6931471805599453f + __logf(sum);
         // P -> packed bf16, two 16-key blocks per 32-key step
-        u32x2 pk[MAXKB];
+        u32x2 pk[2 * NKS];
 #pragma unroll
-        for (int kb = 0; kb < MAXKB; ++kb) {
+        for (int kb = 0; kb < 2 * NKS; ++kb) {
             pk[kb] = (u32x2){0u, 0u};
-            if (kb < nkb) pk[kb] = (u32x2){pack_bf2(acc[kb][0] * inv, acc[kb][1] * inv), pack_bf2(acc[kb][2] * inv, acc[kb][3] * inv)};
+            if (kb < NKB) pk[kb] = (u32x2){pack_bf2(acc[kb][0] * inv, acc[kb][1] * inv), pack_bf2(acc[kb][2] * inv, acc[kb][3] * inv)};
         }
         f32x4 o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // V^T fragments straight from the row-major V image with the transposing LDS read: the 16-lane group g fetches keys
+        // 32t + 4g + {0..3} (then +16) x dh 16i..16i+15, lane fr receives column dh = 16i + fr.  (32 t + c) & 7 == c & 7,
+        // so the swizzled offsets are lane constants per i and a step is +4096 B.
+        const int vr = 4 * g + (fr >> 2), pc = fr & 3;
 #pragma unroll
-        for (int t = 0; t < MAXKB / 2; ++t) {
-            if (t < nks) {
-                const u32x4 pb = {pk[2 * t][0], pk[2 * t][1], pk[2 * t + 1][0], pk[2 * t + 1][1]};
+        for (int t = 0; t < NKS; ++t) {
+            const u32x4 pb = {pk[2 * t][0], pk[2 * t][1], pk[2 * t + 1][0], pk[2 * t + 1][1]};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // V^T fragment straight from the row-major V image with the transposing LDS read: the 16-lane group
-                    // g fetches keys 32t + 4g + {0..3} (then +16) x dh 16i..16i+15, lane fr receives column dh = 16i + fr
-                    const int vr = 32 * t + 4 * g + (fr >> 2), pc = fr & 3;
-                    const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4*)(Vs + kswz(vr, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
-                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4*)(Vs + kswz(vr + 16, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
-                    const u32x2 lo = __builtin_bit_cast(u32x2, lo4), hi = __builtin_bit_cast(u32x2, hi4);
-                    const u32x4 va = {lo[0], lo[1], hi[0], hi[1]};
-                    o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pb), o[i], 0, 0, 0);
-                }
+            for (int i = 0; i < 4; ++i) {
+                const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4*)(Vs + 4096 * t + kswz(vr, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
+                const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4*)(Vs + 4096 * t + kswz(vr + 16, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
+                const u32x2 lo = __builtin_bit_cast(u32x2, lo4), hi = __builtin_bit_cast(u32x2, hi4);
+                const u32x4 va = {lo[0], lo[1], hi[0], hi[1]};
+                o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pb), o[i], 0, 0, 0);
             }
         }
         if (q < T) {
@@ -134,53 +148,68 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+template <int NKB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, bf16_t* __restrict__ P,
                                                           bf16_t* __restrict__ dS, int ldp, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int D = H * DH;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const int nkb = (T + 15) / 16, TK = nkb * 16;
+    constexpr int TK = NKB * 16;
     unsigned char* Ks = smem;
     unsigned char* Vs = smem + TK * 128;
     const long long rs = 3ll * D;
     const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
-    load_rows(Ks, base + D, rs, T, TK);
-    load_rows(Vs, base + 2 * D, rs, T, TK);
+    load_kv(Ks, Vs, base + D, base + 2 * D, rs, T, TK, TK);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    const float sl2 = scale * 1.4426950408889634f;
     for (int qb = wave; qb * 16 < T; qb += 4) {
         const int q = qb * 16 + fr;
         const int qc = q < T ? q : T - 1;
-        f32x4 s[MAXKB], dp[MAXKB];
-        score_tile(Ks, base + (size_t)qc * rs, nkb, s);
-        score_tile(Vs, dout + ((size_t)b * T + qc) * D + h * DH, nkb, dp);
-        const float l = lse[((size_t)b * H + h) * T + qc];
+        const bf16_t* qr = base + (size_t)qc * rs;
+        const bf16_t* dr = dout + ((size_t)b * T + qc) * D + h * DH;
+        const bf16x8 q0 = *(const bf16x8*)(qr + g * 8), q1 = *(const bf16x8*)(qr + (4 + g) * 8);
+        const bf16x8 d0 = *(const bf16x8*)(dr + g * 8), d1 = *(const bf16x8*)(dr + (4 + g) * 8);
+        const float l2 = lse[((size_t)b * H + h) * T + qc] * 1.4426950408889634f;
+        f32x4 s[NKB], dp[NKB];
+        {   // both score tiles in one walk over the key blocks; the scheduling barrier keeps the fragment loads of later
+            // blocks from being hoisted above the MFMAs (that cost 88-160 spilled VGPRs next to the two accumulator sets)
+            const unsigned char* k0 = Ks + kswz(fr, g), *k1 = Ks + kswz(fr, 4 + g);
+            const unsigned char* v0 = Vs + kswz(fr, g), *v1 = Vs + kswz(fr, 4 + g);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const bf16x8 ka = *(const bf16x8*)(k0 + 2048 * kb), kc = *(const bf16x8*)(k1 + 2048 * kb);
+                const bf16x8 va = *(const bf16x8*)(v0 + 2048 * kb), vc = *(const bf16x8*)(v1 + 2048 * kb);
+                s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, q0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, d0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, q1, s[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc, d1, dp[kb], 0, 0, 0);
+                if ((kb & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         float delta = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < MAXKB; ++kb)
-            if (kb < nkb) {
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = kb * 16 + 4 * g + e;
-                    const float p = key < T ? __expf(s[kb][e] * scale - l) : 0.f;
-                    s[kb][e] = p;
-                    delta += p * dp[kb][e];
-                }
+            for (int e = 0; e < 4; ++e) {
+                float p = __builtin_amdgcn_exp2f(s[kb][e] * sl2 - l2);
+                if (kb == NKB - 1 && kb * 16 + 4 * g + e >= T) p = 0.f;
+                s[kb][e] = p;
+                delta += p * dp[kb][e];
             }
         delta = group_sum(delta);
         if (q < T) {
             const size_t row = (((size_t)b * H + h) * T + q) * ldp;
 #pragma unroll
-            for (int kb = 0; kb < MAXKB; ++kb)
-                if (kb < nkb) {
-                    float d[4];
+            for (int kb = 0; kb < NKB; ++kb) {
+                float d[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) d[e] = s[kb][e] * (dp[kb][e] - delta) * scale;
-                    *(u32x2*)(P + row + kb * 16 + 4 * g) = (u32x2){pack_bf2(s[kb][0], s[kb][1]), pack_bf2(s[kb][2], s[kb][3])};
-                    *(u32x2*)(dS + row + kb * 16 + 4 * g) = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
-                }
+                for (int e = 0; e < 4; ++e) d[e] = s[kb][e] * (dp[kb][e] - delta) * scale;
+                *(u32x2*)(P + row + kb * 16 + 4 * g) = (u32x2){pack_bf2(s[kb][0], s[kb][1]), pack_bf2(s[kb][2], s[kb][3])};
+                *(u32x2*)(dS + row + kb * 16 + 4 * g) = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+            }
         }
     }
 }
@@ -195,10 +224,19 @@ extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* ls
     }
     const int nkb = (T + 15) / 16, nks = (T + 31) / 32;
     const int lds = nkb * 16 * 128 + nks * 32 * 128;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024); attr = true; }
     NkbProfScope prof(NKB_K_ATTN, stream, 4.0 * B * H * (double)T * T * DH);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale);
+#define NKB_ATTN_FWD(N)                                                                                                      \
+    case N: {                                                                                                                \
+        static bool attr = false;                                                                                            \
+        if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024); attr = true; } \
+        hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * H), dim3(256), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale); \
+        break;                                                                                                               \
+    }
+    switch (nkb) {
+        NKB_ATTN_FWD(1) NKB_ATTN_FWD(2) NKB_ATTN_FWD(3) NKB_ATTN_FWD(4) NKB_ATTN_FWD(5) NKB_ATTN_FWD(6) NKB_ATTN_FWD(7) NKB_ATTN_FWD(8)
+        NKB_ATTN_FWD(9) NKB_ATTN_FWD(10) NKB_ATTN_FWD(11) NKB_ATTN_FWD(12) NKB_ATTN_FWD(13) NKB_ATTN_FWD(14) NKB_ATTN_FWD(15) NKB_ATTN_FWD(16)
+    }
+#undef NKB_ATTN_FWD
     return nkb_check_launch("attn_forward");
 }
 
@@ -210,10 +248,19 @@ extern "C" int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout
     }
     const int nkb = (T + 15) / 16;
     const int lds = 2 * nkb * 16 * 128;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; }
     NkbProfScope prof(NKB_K_ATTN, stream, 4.0 * B * H * (double)T * T * DH);
-    hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B * H), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                       (bf16_t*)P, (bf16_t*)dS, ldp, T, H, scale);
+#define NKB_ATTN_BWD(N)                                                                                                      \
+    case N: {                                                                                                                \
+        static bool attr = false;                                                                                            \
+        if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; } \
+        hipLaunchKernelGGL(attn_bwd_ds_kernel<N>, dim3(B * H), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, \
+                           (bf16_t*)P, (bf16_t*)dS, ldp, T, H, scale);                                                       \
+        break;                                                                                                               \
+    }
+    switch (nkb) {
+        NKB_ATTN_BWD(1) NKB_ATTN_BWD(2) NKB_ATTN_BWD(3) NKB_ATTN_BWD(4) NKB_ATTN_BWD(5) NKB_ATTN_BWD(6) NKB_ATTN_BWD(7) NKB_ATTN_BWD(8)
+        NKB_ATTN_BWD(9) NKB_ATTN_BWD(10) NKB_ATTN_BWD(11) NKB_ATTN_BWD(12) NKB_ATTN_BWD(13) NKB_ATTN_BWD(14) NKB_ATTN_BWD(15) NKB_ATTN_BWD(16)
+    }
+#undef NKB_ATTN_BWD
     return nkb_check_launch("attn_backward_ds");
 }
