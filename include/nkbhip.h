@@ -180,8 +180,10 @@ int nkb_attn_softmax(int dtype, int backward, const float* s, int lds, const voi
  * recomputes P from Q, K, LSE and writes P and dS = P o (dP - rowsum(P o dP)) * scale as [B*H][T][ldp] bf16. */
 int nkb_attn_forward(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int dh, float scale,
                      nkb_stream_t stream);
+/* dq != NULL: the same pass also forms dQ = dS K and stores it at dq[(b*T + q) * ld_dq + h*64 ..] (e.g. the Q third of the
+ * d_qkv matrix, ld_dq = 3*H*64), so that only dV = P^T dO and dK = dS^T Q remain as separate GEMMs. */
 int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout, const float* lse, void* P, void* dS, int ldp, int B,
-                         int T, int H, int dh, float scale, nkb_stream_t stream);
+                         int T, int H, int dh, float scale, void* dq, long long ld_dq, nkb_stream_t stream);
 int nkb_head_transpose(int dtype, const void* in, int ld_in, long long sio, long long sii, int outer, int inner, void* out,
                        int T, int dh, int ldt, nkb_stream_t stream);
 /* token assembly: forward x[b][t] = (t == 0 ? cls : tok[b][t-1]) + pos[t]; cls == NULL (unicom layout, no class token):

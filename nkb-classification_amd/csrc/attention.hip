@@ -148,19 +148,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NKB>
+template <int NKB, bool DQ>
 __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, bf16_t* __restrict__ P,
-                                                          bf16_t* __restrict__ dS, int ldp, int T, int H, float scale) {
+                                                          bf16_t* __restrict__ dS, int ldp, int T, int H, float scale,
+                                                          bf16_t* __restrict__ dq, long long ld_dq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int D = H * DH;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    constexpr int TK = NKB * 16;
+    constexpr int TK = NKB * 16, NKS = (NKB + 1) / 2;
+    constexpr int KROWS = DQ ? NKS * 32 : TK;            // dQ = dS K walks the K image in 32-key steps (zero rows beyond T)
     unsigned char* Ks = smem;
-    unsigned char* Vs = smem + TK * 128;
+    unsigned char* Vs = smem + KROWS * 128;
     const long long rs = 3ll * D;
     const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
-    load_kv(Ks, Vs, base + D, base + 2 * D, rs, T, TK, TK);
+    load_kv(Ks, Vs, base + D, base + 2 * D, rs, T, KROWS, TK);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
@@ -200,15 +202,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(const bf16_t* __res
                 delta += p * dp[kb][e];
             }
         delta = group_sum(delta);
-        if (q < T) {
-            const size_t row = (((size_t)b * H + h) * T + q) * ldp;
+        u32x2 pd[2 * NKS];                                  // dS of this query, packed: also the B operand of dQ^T = K^T dS^T
+        const size_t row = (((size_t)b * H + h) * T + (q < T ? q : 0)) * ldp;
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
-                float d[4];
+        for (int kb = 0; kb < NKB; ++kb) {
+            float d[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = s[kb][e] * (dp[kb][e] - delta) * scale;
+            for (int e = 0; e < 4; ++e) d[e] = s[kb][e] * (dp[kb][e] - delta) * scale;
+            pd[kb] = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+            if (q < T) {
                 *(u32x2*)(P + row + kb * 16 + 4 * g) = (u32x2){pack_bf2(s[kb][0], s[kb][1]), pack_bf2(s[kb][2], s[kb][3])};
-                *(u32x2*)(dS + row + kb * 16 + 4 * g) = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+                *(u32x2*)(dS + row + kb * 16 + 4 * g) = pd[kb];
+            }
+        }
+        if constexpr (DQ) {
+            // dQ[q][dh] = sum_key dS[q][key] K[key][dh], computed as dQ^T = K^T (A, transposing LDS reads of the K image)
+            // x dS^T (B = the packed registers, exactly as the forward pass forms O^T = V^T P^T)
+            if (2 * NKS > NKB) pd[2 * NKS - 1] = (u32x2){0u, 0u};
+            f32x4 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int vr = 4 * g + (fr >> 2), pc = fr & 3;
+#pragma unroll
+            for (int t = 0; t < NKS; ++t) {
+                const u32x4 pb = {pd[2 * t][0], pd[2 * t][1], pd[2 * t + 1][0], pd[2 * t + 1][1]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(Ks + 4096 * t + kswz(vr, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
+                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(Ks + 4096 * t + kswz(vr + 16, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
+                    const u32x2 lo = __builtin_bit_cast(u32x2, lo4), hi = __builtin_bit_cast(u32x2, hi4);
+                    const u32x4 ka = {lo[0], lo[1], hi[0], hi[1]};
+                    o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, pb), o[i], 0, 0, 0);
+                }
+            }
+            if (q < T) {
+                bf16_t* orow = dq + ((size_t)b * T + q) * ld_dq + h * DH;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *(u32x2*)(orow + 16 * i + 4 * g) = (u32x2){pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
             }
         }
     }
@@ -241,26 +274,28 @@ extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* ls
 }
 
 extern "C" int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout, const float* lse, void* P, void* dS, int ldp,
-                                    int B, int T, int H, int dh, float scale, hipStream_t stream) {
+                                    int B, int T, int H, int dh, float scale, void* dq, long long ld_dq, hipStream_t stream) {
     if (dtype != NKB_DT_BF16 || dh != DH || T > 16 * MAXKB || T < 1 || ldp % 4 != 0 || ldp < (T + 15) / 16 * 16) {
         nkb_set_error("attn_backward_ds: fused path needs bf16, head dim 64, T <= 256, ldp >= roundup(T,16)");
         return 1;
     }
-    const int nkb = (T + 15) / 16;
-    const int lds = 2 * nkb * 16 * 128;
-    NkbProfScope prof(NKB_K_ATTN, stream, 4.0 * B * H * (double)T * T * DH);
-#define NKB_ATTN_BWD(N)                                                                                                      \
-    case N: {                                                                                                                \
+    if (dq != nullptr && (ld_dq % 4 != 0 || ld_dq < (long long)H * DH)) { nkb_set_error("attn_backward_ds: bad ld_dq"); return 1; }
+    const int nkb = (T + 15) / 16, nks = (T + 31) / 32;
+    const int lds = (dq ? nks * 32 : nkb * 16) * 128 + nkb * 16 * 128;
+    NkbProfScope prof(NKB_K_ATTN, stream, (dq ? 6.0 : 4.0) * B * H * (double)T * T * DH);
+#define NKB_ATTN_BWD1(N, Q)                                                                                                   \
+    {                                                                                                                        \
         static bool attr = false;                                                                                            \
-        if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; } \
-        hipLaunchKernelGGL(attn_bwd_ds_kernel<N>, dim3(B * H), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, \
-                           (bf16_t*)P, (bf16_t*)dS, ldp, T, H, scale);                                                       \
-        break;                                                                                                               \
+        if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<N, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024); attr = true; } \
+        hipLaunchKernelGGL((attn_bwd_ds_kernel<N, Q>), dim3(B * H), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, \
+                           (bf16_t*)P, (bf16_t*)dS, ldp, T, H, scale, (bf16_t*)dq, ld_dq);                                   \
     }
+#define NKB_ATTN_BWD(N) case N: if (dq) NKB_ATTN_BWD1(N, true) else NKB_ATTN_BWD1(N, false) break;
     switch (nkb) {
         NKB_ATTN_BWD(1) NKB_ATTN_BWD(2) NKB_ATTN_BWD(3) NKB_ATTN_BWD(4) NKB_ATTN_BWD(5) NKB_ATTN_BWD(6) NKB_ATTN_BWD(7) NKB_ATTN_BWD(8)
         NKB_ATTN_BWD(9) NKB_ATTN_BWD(10) NKB_ATTN_BWD(11) NKB_ATTN_BWD(12) NKB_ATTN_BWD(13) NKB_ATTN_BWD(14) NKB_ATTN_BWD(15) NKB_ATTN_BWD(16)
     }
 #undef NKB_ATTN_BWD
+#undef NKB_ATTN_BWD1
     return nkb_check_launch("attn_backward_ds");
 }

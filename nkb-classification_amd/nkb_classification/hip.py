@@ -64,7 +64,7 @@ _SIGS = {
     "nkb_scale_rows": (i32, [i32, vp, vp, vp, vp, i32, i64, vp]),
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
     "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
-    "nkb_attn_backward_ds": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "nkb_attn_backward_ds": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, i64, vp]),
     "nkb_head_transpose": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, i32, i32, i32, vp]),
     "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_dropout": (i32, [i32, i32, vp, vp, vp, vp, i64, f32, C.c_ulonglong, vp]),
@@ -395,9 +395,9 @@ def attn_forward(dtype, qkv, out, lse, B, T, H, dh, scale):
     check(load().nkb_attn_forward(dtype, ptr(qkv), ptr(out), ptr(lse), B, T, H, dh, scale, stream()), "attn_forward")
 
 
-def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale):
+def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale, dq=None, ld_dq=0):
     check(load().nkb_attn_backward_ds(dtype, ptr(qkv), ptr(dout), ptr(lse), ptr(P), ptr(dS), ldp, B, T, H, dh, scale,
-                                      stream()), "attn_backward_ds")
+                                      ptr(dq), ld_dq, stream()), "attn_backward_ds")
 
 
 def linear_gelu(dtype, act, x, w, bias, aux, y, y2, M, K, N):

@@ -28,6 +28,7 @@ _FUSE_MIN_C = int(os.environ.get("NKB_FUSE_MIN_C", "65"))
 # residual-closing stages keep a 1-bit/element ReLU mask; backward reads it instead of the activation and the masked
 # block-output gradient is never materialised (consumers apply the bits on the fly)
 _RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
+_ATTN_FUSED_DQ = os.environ.get("NKB_ATTN_FUSED_DQ", "1") != "0"   # dQ inside the attention backward-dS kernel
 _EVAL_FOLD = os.environ.get("NKB_EVAL_FOLD", "1") != "0"     # eval mode: BatchNorm folded into the conv (one launch per stage)
 
 
@@ -756,8 +757,13 @@ class HipEngine:
             # P and dS are recomputed in one pass (pad columns beyond roundup(T,16) stay zero from allocation)
             P = self.ws.get("attn.Pbwd", (B * H, T, Tp), self.T, zero=True)
             dS = self.ws.get("attn.dS", (B * H, T, Tp), self.T, zero=True)
-            hip.attn_backward_ds(self.d, qkv, d_o, sv["lse"], P, dS, Tp, B, T, H, dh, dh ** -0.5)
+            # the same pass forms dQ = dS K (into the Q third of dqkv); dV and dK stay batched GEMMs on P / dS
+            hip.attn_backward_ds(self.d, qkv, d_o, sv["lse"], P, dS, Tp, B, T, H, dh, dh ** -0.5,
+                                 dq=dqkv if _ATTN_FUSED_DQ else None, ld_dq=3 * D)
             hip.gemm_tn_batched(self.d, P, d_o, dqkv[:, 2 * D:], T, T, dh, Tp, D, 3 * D, B, H, sp, so, sq)
+            if _ATTN_FUSED_DQ:
+                hip.gemm_tn_batched(self.d, dS, q, dqkv[:, D:], T, T, dh, Tp, 3 * D, 3 * D, B, H, sp, sq, sq)
+                return dqkv
         else:
             P = sv["P"]
             dP = self.ws.get("attn.S", (B * H, T, Tp), torch.float32)

@@ -17,9 +17,9 @@ for (B, T, H) in [(256, 197, 12), (128, 256, 16)]:
     o = torch.empty(B * T, D, device=dev, dtype=torch.bfloat16); lse = torch.empty(B * H, T, device=dev)
     do = torch.randn(B * T, D, device=dev).to(torch.bfloat16)
     Tp = (T + 63) // 64 * 64
-    P = torch.zeros(B * H, T, Tp, device=dev, dtype=torch.bfloat16); dS = torch.zeros_like(P)
+    P = torch.zeros(B * H, T, Tp, device=dev, dtype=torch.bfloat16); dS = torch.zeros_like(P); dqb = torch.empty_like(qkv)
     tf = timeit(lambda: hip.attn_forward(hip.BF16, qkv, o, lse, B, T, H, dh, dh ** -0.5))
-    tb = timeit(lambda: hip.attn_backward_ds(hip.BF16, qkv, do, lse, P, dS, Tp, B, T, H, dh, dh ** -0.5))
+    tb = timeit(lambda: hip.attn_backward_ds(hip.BF16, qkv, do, lse, P, dS, Tp, B, T, H, dh, dh ** -0.5, dq=dqb, ld_dq=3 * D))
     gf = 4.0 * B * H * T * T * dh / 1e9
     mb = (qkv.numel() + o.numel()) * 2 / 1e6
     print(f"B={B} T={T} H={H}: fwd {tf:7.1f} us ({gf / tf * 1e3:6.1f} TF/s, {mb / tf:5.2f} TB/s of qkv+o) | bwd_ds {tb:7.1f} us")
