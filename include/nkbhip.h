@@ -184,6 +184,11 @@ int nkb_attn_forward(int dtype, const void* qkv, void* out, float* lse, int B, i
  * d_qkv matrix, ld_dq = 3*H*64), so that only dV = P^T dO and dK = dS^T Q remain as separate GEMMs. */
 int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout, const float* lse, void* P, void* dS, int ldp, int B,
                          int T, int H, int dh, float scale, void* dq, long long ld_dq, nkb_stream_t stream);
+/* Whole attention backward in one pass per (image, head): dQ, dK, dV written into the three thirds of dqkv
+ * ([B*T][3*H*64], same layout as qkv).  Reads qkv, dout, the forward output `out` (for delta = rowsum(dout o out)) and lse;
+ * no score matrix reaches memory (bf16, head dim 64, T <= 256). */
+int nkb_attn_backward(int dtype, const void* qkv, const void* dout, const void* out, const float* lse, void* dqkv, int B, int T,
+                      int H, int dh, float scale, nkb_stream_t stream);
 int nkb_head_transpose(int dtype, const void* in, int ld_in, long long sio, long long sii, int outer, int inner, void* out,
                        int T, int dh, int ldt, nkb_stream_t stream);
 /* token assembly: forward x[b][t] = (t == 0 ? cls : tok[b][t-1]) + pos[t]; cls == NULL (unicom layout, no class token):

@@ -14,6 +14,10 @@
 
 namespace {
 
+#ifndef NKB_ATTN_BWD_THREADS
+#define NKB_ATTN_BWD_THREADS 1024
+#endif
+
 constexpr int MAXKB = 16;                    // 16-key blocks per row (T <= 256)
 constexpr int DH = 64;
 
@@ -247,6 +251,185 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(const bf16_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Whole attention backward for one (image, head) in one workgroup: dQ, dK, dV straight into the three thirds of d_qkv, no
+// P / dS round trip through HBM (the split version writes and re-reads 2 x [T][T] bf16 per head: 620 MB per ViT-B/16 layer).
+//   prologue: Q, K, V, dO -> four swizzled row images in LDS (padded to 32-row steps with zero rows);
+//             delta[q] = sum_dh dO[q][dh] * O[q][dh]  (= rowsum(P o dP), from the forward output: no score pass needed),
+//             lse2[q] = lse[q] * log2(e), +inf for rows >= T (so that P = 0 there).
+//   pass A (a wave per query block, orientation D[key][query] as in the forward kernel): streams over key-block pairs,
+//             P -> dS -> dQ^T += K^T dS^T; nothing but the four dQ accumulators lives across key blocks.
+//   pass B (a wave per key block, orientation D[query][key] = Q_rows * K_rows^T: the same two operands, swapped): P and dS
+//             of a (32-query, 16-key) tile — a lane now owning ONE key and 4 queries per block — are exactly the B
+//             operands of dV^T += dO^T P and dK^T += Q^T dS, with dO^T / Q^T read through the transposing LDS read in the
+//             matching query permutation.
+// The passes need no barrier between them (delta comes from the prologue), so the waves drift through both independently.
+template <int NKB>
+__global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+    const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NKS = (NKB + 1) / 2, ROWS = NKS * 32, IMG = ROWS * 128;
+    constexpr int NT = NKB_ATTN_BWD_THREADS, NW = NT / 64;
+    constexpr int IT = (ROWS * 8 + NT - 1) / NT;
+    const int D = H * DH;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    unsigned char* Qs = smem;
+    unsigned char* Ks = smem + IMG;
+    unsigned char* Vs = smem + 2 * IMG;
+    unsigned char* Ds = smem + 3 * IMG;
+    float* l2s = (float*)(smem + 4 * IMG);
+    float* dls = l2s + ROWS;
+    const long long rs = 3ll * D;
+    const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
+    const bf16_t* dbase = dout + (size_t)b * T * D + h * DH;
+    const bf16_t* obase = out + (size_t)b * T * D + h * DH;
+    for (int r = threadIdx.x; r < ROWS; r += NT) {
+        l2s[r] = r < T ? lse[((size_t)b * H + h) * T + r] * 1.4426950408889634f : INFINITY;
+        dls[r] = 0.f;
+    }
+    __syncthreads();
+    {
+        u32x4 rq[IT], rk[IT], rv[IT], rd[IT], ro[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = threadIdx.x + NT * i, row = c >> 3, ch = c & 7;
+            rq[i] = rk[i] = rv[i] = rd[i] = ro[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (row < T) {
+                const bf16_t* p = base + (size_t)row * rs + ch * 8;
+                rq[i] = *(const u32x4*)p;
+                rk[i] = *(const u32x4*)(p + D);
+                rv[i] = *(const u32x4*)(p + 2 * D);
+                rd[i] = *(const u32x4*)(dbase + (size_t)row * D + ch * 8);
+                ro[i] = *(const u32x4*)(obase + (size_t)row * D + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = threadIdx.x + NT * i, row = c >> 3, ch = c & 7;
+            if (row >= ROWS) break;
+            *(u32x4*)(Qs + kswz(row, ch)) = rq[i];
+            *(u32x4*)(Ks + kswz(row, ch)) = rk[i];
+            *(u32x4*)(Vs + kswz(row, ch)) = rv[i];
+            *(u32x4*)(Ds + kswz(row, ch)) = rd[i];
+            if (row < T) {
+                float fd[8], fo[8], t = 0.f;
+                unpack8(rd[i], fd);
+                unpack8(ro[i], fo);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t += fd[e] * fo[e];
+                atomicAdd(dls + row, t);                       // 8 chunk partials per row
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    const float sl2 = scale * 1.4426950408889634f;
+    const int o0 = kswz(fr, g), o1 = kswz(fr, 4 + g);          // fragment offsets of row fr; +2048 per 16-row block
+    const int vr = 4 * g + (fr >> 2), pc = fr & 3;
+    // transposed fragment for dh block i of 32-row step t (rows vr and vr + 16 of the step)
+    auto tr_frag = [&](const unsigned char* img, int t, int i) -> bf16x8 {
+        const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) bf16x4*)(img + 4096 * t + kswz(vr, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
+        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) bf16x4*)(img + 4096 * t + kswz(vr + 16, 2 * i + (pc >> 1)) + 8 * (pc & 1)));
+        const u32x2 lo = __builtin_bit_cast(u32x2, lo4), hi = __builtin_bit_cast(u32x2, hi4);
+        const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    // ---- pass A: dQ, one query block per wave at a time --------------------------------------------------------------
+    for (int qb = wave; qb < NKB; qb += NW) {
+        const int q = qb * 16 + fr;
+        const bf16x8 q0 = *(const bf16x8*)(Qs + 2048 * qb + o0), q1 = *(const bf16x8*)(Qs + 2048 * qb + o1);
+        const bf16x8 d0 = *(const bf16x8*)(Ds + 2048 * qb + o0), d1 = *(const bf16x8*)(Ds + 2048 * qb + o1);
+        const float l2 = l2s[q], delta = dls[q];
+        f32x4 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1                                        // rolled: a full unroll lets the scheduler hoist every LDS read
+        for (int t = 0; t < NKS; ++t) {                    // of the pass above the MFMAs (250+ spilled VGPRs)
+            u32x2 pd[2];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const int kb = 2 * t + hb;               // a block past T: zero K / V rows, masked below
+                const bf16x8 ka = *(const bf16x8*)(Ks + 2048 * kb + o0), kc = *(const bf16x8*)(Ks + 2048 * kb + o1);
+                const bf16x8 va = *(const bf16x8*)(Vs + 2048 * kb + o0), vc = *(const bf16x8*)(Vs + 2048 * kb + o1);
+                f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, q0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, d0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, q1, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc, d1, dp, 0, 0, 0);
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float p = __builtin_amdgcn_exp2f(s[e] * sl2 - l2);
+                    if (kb >= NKB - 1 && kb * 16 + 4 * g + e >= T) p = 0.f;
+                    d[e] = p * (dp[e] - delta) * scale;
+                }
+                pd[hb] = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+            }
+            const u32x4 pb = {pd[0][0], pd[0][1], pd[1][0], pd[1][1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ks, t, i), __builtin_bit_cast(bf16x8, pb), o[i], 0, 0, 0);
+        }
+        if (q < T) {
+            bf16_t* orow = dqkv + ((size_t)b * T + q) * rs + h * DH;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(u32x2*)(orow + 16 * i + 4 * g) = (u32x2){pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
+        }
+    }
+
+    // ---- pass B: dK and dV, one key block per wave at a time ---------------------------------------------------------
+    for (int kb = wave; kb < NKB; kb += NW) {
+        const bf16x8 kf0 = *(const bf16x8*)(Ks + 2048 * kb + o0), kf1 = *(const bf16x8*)(Ks + 2048 * kb + o1);
+        const bf16x8 vf0 = *(const bf16x8*)(Vs + 2048 * kb + o0), vf1 = *(const bf16x8*)(Vs + 2048 * kb + o1);
+        f32x4 ov[4], ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ov[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; ok[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1                                        // rolled: a full unroll lets the scheduler hoist every LDS read
+        for (int t = 0; t < NKS; ++t) {                    // of the pass above the MFMAs (250+ spilled VGPRs)
+            u32x2 pkp[2], pks[2];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const int qb = 2 * t + hb;              // rows of a block past T are zero images with lse = +inf: P = dS = 0
+                const bf16x8 qa0 = *(const bf16x8*)(Qs + 2048 * qb + o0), qa1 = *(const bf16x8*)(Qs + 2048 * qb + o1);
+                const bf16x8 da0 = *(const bf16x8*)(Ds + 2048 * qb + o0), da1 = *(const bf16x8*)(Ds + 2048 * qb + o1);
+                f32x4 S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                f32x4 dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, vf0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf1, S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, vf1, dP, 0, 0, 0);
+                const f32x4 l4 = *(const f32x4*)(l2s + qb * 16 + 4 * g), d4 = *(const f32x4*)(dls + qb * 16 + 4 * g);
+                float pv[4], dv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pv[e] = __builtin_amdgcn_exp2f(S[e] * sl2 - l4[e]);
+                    dv[e] = pv[e] * (dP[e] - d4[e]) * scale;
+                }
+                pkp[hb] = (u32x2){pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
+                pks[hb] = (u32x2){pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3])};
+            }
+            const u32x4 pbp = {pkp[0][0], pkp[0][1], pkp[1][0], pkp[1][1]};
+            const u32x4 pbs = {pks[0][0], pks[0][1], pks[1][0], pks[1][1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ov[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ds, t, i), __builtin_bit_cast(bf16x8, pbp), ov[i], 0, 0, 0);
+                ok[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qs, t, i), __builtin_bit_cast(bf16x8, pbs), ok[i], 0, 0, 0);
+            }
+        }
+        const int key = kb * 16 + fr;
+        if (key < T) {
+            bf16_t* krow = dqkv + ((size_t)b * T + key) * rs + D + h * DH;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(u32x2*)(krow + 16 * i + 4 * g) = (u32x2){pack_bf2(ok[i][0], ok[i][1]), pack_bf2(ok[i][2], ok[i][3])};
+                *(u32x2*)(krow + D + 16 * i + 4 * g) = (u32x2){pack_bf2(ov[i][0], ov[i][1]), pack_bf2(ov[i][2], ov[i][3])};
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int dh, float scale,
@@ -298,4 +481,29 @@ extern "C" int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout
 #undef NKB_ATTN_BWD
 #undef NKB_ATTN_BWD1
     return nkb_check_launch("attn_backward_ds");
+}
+
+extern "C" int nkb_attn_backward(int dtype, const void* qkv, const void* dout, const void* out, const float* lse, void* dqkv,
+                                 int B, int T, int H, int dh, float scale, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 || dh != DH || T > 16 * MAXKB || T < 1) {
+        nkb_set_error("attn_backward: fused path needs bf16, head dim 64, T <= 256 (got dtype %d, dh %d, T %d)", dtype, dh, T);
+        return 1;
+    }
+    const int nkb = (T + 15) / 16, rows = (nkb + 1) / 2 * 32;
+    const int lds = 4 * rows * 128 + 2 * rows * 4;
+    NkbProfScope prof(NKB_K_ATTN, stream, 14.0 * B * H * (double)T * T * DH);     // S, dP twice; dQ, dK, dV once
+#define NKB_ATTN_BWDF(N)                                                                                                     \
+    case N: {                                                                                                                \
+        static bool attr = false;                                                                                            \
+        if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024); attr = true; } \
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<N>, dim3(B * H), dim3(NKB_ATTN_BWD_THREADS), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)out, lse, \
+                           (bf16_t*)dqkv, T, H, scale);                                                                      \
+        break;                                                                                                               \
+    }
+    switch (nkb) {
+        NKB_ATTN_BWDF(1) NKB_ATTN_BWDF(2) NKB_ATTN_BWDF(3) NKB_ATTN_BWDF(4) NKB_ATTN_BWDF(5) NKB_ATTN_BWDF(6) NKB_ATTN_BWDF(7) NKB_ATTN_BWDF(8)
+        NKB_ATTN_BWDF(9) NKB_ATTN_BWDF(10) NKB_ATTN_BWDF(11) NKB_ATTN_BWDF(12) NKB_ATTN_BWDF(13) NKB_ATTN_BWDF(14) NKB_ATTN_BWDF(15) NKB_ATTN_BWDF(16)
+    }
+#undef NKB_ATTN_BWDF
+    return nkb_check_launch("attn_backward");
 }

@@ -65,6 +65,7 @@ _SIGS = {
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
     "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "nkb_attn_backward_ds": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, i64, vp]),
+    "nkb_attn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "nkb_head_transpose": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, i32, i32, i32, vp]),
     "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_dropout": (i32, [i32, i32, vp, vp, vp, vp, i64, f32, C.c_ulonglong, vp]),
@@ -393,6 +394,11 @@ def dropout(dtype, backward, src, add, out, mask, n, p, seed=0):
 
 def attn_forward(dtype, qkv, out, lse, B, T, H, dh, scale):
     check(load().nkb_attn_forward(dtype, ptr(qkv), ptr(out), ptr(lse), B, T, H, dh, scale, stream()), "attn_forward")
+
+
+def attn_backward(dtype, qkv, dout, out, lse, dqkv, B, T, H, dh, scale):
+    check(load().nkb_attn_backward(dtype, ptr(qkv), ptr(dout), ptr(out), ptr(lse), ptr(dqkv), B, T, H, dh, scale, stream()),
+          "attn_backward")
 
 
 def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale, dq=None, ld_dq=0):

@@ -28,6 +28,7 @@ _FUSE_MIN_C = int(os.environ.get("NKB_FUSE_MIN_C", "65"))
 # residual-closing stages keep a 1-bit/element ReLU mask; backward reads it instead of the activation and the masked
 # block-output gradient is never materialised (consumers apply the bits on the fly)
 _RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
+_ATTN_FUSED_BWD = os.environ.get("NKB_ATTN_FUSED_BWD", "1") != "0"  # whole attention backward in one kernel
 _ATTN_FUSED_DQ = os.environ.get("NKB_ATTN_FUSED_DQ", "1") != "0"   # dQ inside the attention backward-dS kernel
 _EVAL_FOLD = os.environ.get("NKB_EVAL_FOLD", "1") != "0"     # eval mode: BatchNorm folded into the conv (one launch per stage)
 
@@ -725,7 +726,7 @@ class HipEngine:
             lse = self.ws.get(key + ".lse", (B * H, T), torch.float32)
             hip.attn_forward(self.d, qkv, o, lse, B, T, H, dh, dh ** -0.5)
             if train:
-                self.saved[key] = dict(qkv=qkv, lse=lse, B=B, T=T, H=H, fused=True)
+                self.saved[key] = dict(qkv=qkv, lse=lse, o=o, B=B, T=T, H=H, fused=True)
             return o
         S = self.ws.get("attn.S", (B * H, T, Tp), torch.float32)
         P = self.ws.get(key + ".P", (B * H, T, Tp), self.T)
@@ -753,6 +754,10 @@ class HipEngine:
         Kt = self.ws.get("attn.Vt", (B * H, dh, Tp), self.T)
         q, k, v = qkv, qkv[:, D:], qkv[:, 2 * D:]
         sq, sp, so = (T * 3 * D, dh), (H * T * Tp, T * Tp), (T * D, dh)
+        if sv.get("fused") and _ATTN_FUSED_BWD:
+            # dQ, dK, dV in one kernel per layer: P and dS never reach HBM
+            hip.attn_backward(self.d, qkv, d_o, sv["o"], sv["lse"], dqkv, B, T, H, dh, dh ** -0.5)
+            return dqkv
         if sv.get("fused"):
             # P and dS are recomputed in one pass (pad columns beyond roundup(T,16) stay zero from allocation)
             P = self.ws.get("attn.Pbwd", (B * H, T, Tp), self.T, zero=True)

@@ -20,6 +20,7 @@ for (B, T, H) in [(256, 197, 12), (128, 256, 16)]:
     P = torch.zeros(B * H, T, Tp, device=dev, dtype=torch.bfloat16); dS = torch.zeros_like(P); dqb = torch.empty_like(qkv)
     tf = timeit(lambda: hip.attn_forward(hip.BF16, qkv, o, lse, B, T, H, dh, dh ** -0.5))
     tb = timeit(lambda: hip.attn_backward_ds(hip.BF16, qkv, do, lse, P, dS, Tp, B, T, H, dh, dh ** -0.5, dq=dqb, ld_dq=3 * D))
+    tbf = timeit(lambda: hip.attn_backward(hip.BF16, qkv, do, o, lse, dqb, B, T, H, dh, dh ** -0.5))
     gf = 4.0 * B * H * T * T * dh / 1e9
     mb = (qkv.numel() + o.numel()) * 2 / 1e6
-    print(f"B={B} T={T} H={H}: fwd {tf:7.1f} us ({gf / tf * 1e3:6.1f} TF/s, {mb / tf:5.2f} TB/s of qkv+o) | bwd_ds {tb:7.1f} us")
+    print(f"B={B} T={T} H={H}: fwd {tf:7.1f} us ({gf / tf * 1e3:6.1f} TF/s, {mb / tf:5.2f} TB/s of qkv+o) | bwd_ds+dQ {tb:7.1f} us | fused bwd {tbf:7.1f} us")
