@@ -160,13 +160,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # rehearsal knobs (not used by the driver): NKB_BENCH_DEVICE pins every rank to one GPU and NKB_DIST_BACKEND=gloo moves
+    # the collectives through the host, so that the multi-rank control flow can be exercised on a one-GPU box
+    dev_index = int(os.environ.get("NKB_BENCH_DEVICE", local))
+    backend = os.environ.get("NKB_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     force_dist = os.environ.get("NKB_FORCE_REDUCER") == "1"     # rehearse the RCCL path with a single rank
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from nkb_classification import hip
     from nkb_classification.logging import softmax_argmax
@@ -262,6 +269,11 @@ def main():
     feed = None
     roofline = None
     prof = {}
+    if not args.no_roofline and rank != 0:
+        # the profiled steps below exchange gradients like any other step, so every rank takes them; only rank 0 profiles
+        for _ in range(min(args.steps, 5)):
+            step()
+        torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
         # same step, re-run with one HIP-event pair per launch on the launch stream (perturbs wall time, so it is
         # kept out of the timed region above)
