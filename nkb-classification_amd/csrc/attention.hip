@@ -26,13 +26,14 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((c
 // cooperative load of one head's K and V rows into two swizzled 128-byte-row LDS images; rows >= T are zero.  All global
 // loads are issued before the first LDS store (one memory latency per workgroup; the rolled load->store loop paid one
 // per 256 chunks: 13 round trips for T = 197).
+template <int NT>
 __device__ __forceinline__ void load_kv(unsigned char* ks, unsigned char* vs, const bf16_t* __restrict__ ksrc,
                                         const bf16_t* __restrict__ vsrc, long long row_stride, int T, int krows, int vrows) {
-    constexpr int IT = MAXKB * 16 * 8 / 256;        // 8 chunks of 16 B per row, 256 threads
+    constexpr int IT = MAXKB * 16 * 8 / NT;         // 8 chunks of 16 B per row, NT threads
     u32x4 kv[IT], vv[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int c = threadIdx.x + 256 * i, row = c >> 3, ch = c & 7;
+        const int c = threadIdx.x + NT * i, row = c >> 3, ch = c & 7;
         kv[i] = (u32x4){0u, 0u, 0u, 0u};
         vv[i] = (u32x4){0u, 0u, 0u, 0u};
         if (row < T) {
@@ -42,7 +43,7 @@ __device__ __forceinline__ void load_kv(unsigned char* ks, unsigned char* vs, co
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int c = threadIdx.x + 256 * i, row = c >> 3, ch = c & 7;
+        const int c = threadIdx.x + NT * i, row = c >> 3, ch = c & 7;
         if (row < krows) *(u32x4*)(ks + kswz(row, ch)) = kv[i];
         if (row < vrows) *(u32x4*)(vs + kswz(row, ch)) = vv[i];
     }
@@ -70,7 +71,7 @@ __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v,
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NKB>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TK = NKB * 16, NKS = (NKB + 1) / 2;   // 32-key steps of the P*V product
@@ -84,17 +85,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     // this wave's first query rows are requested before the K / V staging so that their latency hides behind it
     auto qrow = [&](int qb) { const int q = qb * 16 + fr; return base + (size_t)(q < T ? q : T - 1) * rs; };
     bf16x8 q0 = *(const bf16x8*)(qrow(wave) + g * 8), q1 = *(const bf16x8*)(qrow(wave) + (4 + g) * 8);
-    load_kv(Ks, Vs, base + D, base + 2 * D, rs, T, TK, NKS * 32);
+    load_kv<512>(Ks, Vs, base + D, base + 2 * D, rs, T, TK, NKS * 32);
     __syncthreads();
 
     const float sl2 = scale * 1.4426950408889634f;   // exp(x) = exp2(x log2 e): the hardware exponential is base 2
-    for (int qb = wave; qb * 16 < T; qb += 4) {
+    for (int qb = wave; qb * 16 < T; qb += 8) {            // 8 waves per workgroup, 2 workgroups per CU: 4 waves per SIMD
         const int q = qb * 16 + fr;
         f32x4 acc[NKB];
         score_tile<NKB>(Ks, q0, q1, acc);
-        if ((qb + 4) * 16 < T) {                        // next block's queries: in flight during this block's softmax
-            q0 = *(const bf16x8*)(qrow(qb + 4) + g * 8);
-            q1 = *(const bf16x8*)(qrow(qb + 4) + (4 + g) * 8);
+        if ((qb + 8) * 16 < T) {                        // next block's queries: in flight during this block's softmax
+            q0 = *(const bf16x8*)(qrow(qb + 8) + g * 8);
+            q1 = *(const bf16x8*)(qrow(qb + 8) + (4 + g) * 8);
         }
         float m = -INFINITY;
 #pragma unroll
@@ -114,23 +115,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         sum = group_sum(sum);
         const float inv = 1.f / sum;
         if (g == 0 && q < T) lse[((size_t)b * H + h) * T + q] = m * 0.6931471805599453f + __logf(sum);
-        // P -> packed bf16, two 16-key blocks per 32-key step
-        u32x2 pk[2 * NKS];
-#pragma unroll
-        for (int kb = 0; kb < 2 * NKS; ++kb) {
-            pk[kb] = (u32x2){0u, 0u};
-            if (kb < NKB) pk[kb] = (u32x2){pack_bf2(acc[kb][0] * inv, acc[kb][1] * inv), pack_bf2(acc[kb][2] * inv, acc[kb][3] * inv)};
-        }
         f32x4 o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // V^T fragments straight from the row-major V image with the transposing LDS read: the 16-lane group g fetches keys
         // 32t + 4g + {0..3} (then +16) x dh 16i..16i+15, lane fr receives column dh = 16i + fr.  (32 t + c) & 7 == c & 7,
-        // so the swizzled offsets are lane constants per i and a step is +4096 B.
+        // so the swizzled offsets are lane constants per i and a step is +4096 B.  P is packed to bf16 two key blocks at a
+        // time, right before the step that consumes it (a whole-row packed copy cost 32 more live registers).
         const int vr = 4 * g + (fr >> 2), pc = fr & 3;
 #pragma unroll
         for (int t = 0; t < NKS; ++t) {
-            const u32x4 pb = {pk[2 * t][0], pk[2 * t][1], pk[2 * t + 1][0], pk[2 * t + 1][1]};
+            u32x4 pb = {pack_bf2(acc[2 * t][0] * inv, acc[2 * t][1] * inv), pack_bf2(acc[2 * t][2] * inv, acc[2 * t][3] * inv), 0u, 0u};
+            if (2 * t + 1 < NKB) {
+                pb[2] = pack_bf2(acc[2 * t + 1][0] * inv, acc[2 * t + 1][1] * inv);
+                pb[3] = pack_bf2(acc[2 * t + 1][2] * inv, acc[2 * t + 1][3] * inv);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -141,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 const u32x4 va = {lo[0], lo[1], hi[0], hi[1]};
                 o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, pb), o[i], 0, 0, 0);
             }
+            if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (q < T) {
             bf16_t* orow = out + ((size_t)b * T + q) * D + h * DH;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(const bf16_t* __res
     unsigned char* Vs = smem + KROWS * 128;
     const long long rs = 3ll * D;
     const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
-    load_kv(Ks, Vs, base + D, base + 2 * D, rs, T, KROWS, TK);
+    load_kv<256>(Ks, Vs, base + D, base + 2 * D, rs, T, KROWS, TK);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
@@ -445,7 +445,7 @@ extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* ls
     case N: {                                                                                                                \
         static bool attr = false;                                                                                            \
         if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024); attr = true; } \
-        hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * H), dim3(256), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale); \
+        hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * H), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale); \
         break;                                                                                                               \
     }
     switch (nkb) {
