@@ -371,8 +371,10 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
         bf16_t* o = (bf16_t*)p.y + yoff + (size_t)mrow * p.ldy + co;
         const size_t ostep = (size_t)RPP * p.ldy;
         const unsigned char* lrow = smem + er * EROW + eg * 32;
-        auto rows = [&](auto HS, auto HB) {
-            constexpr bool hs = decltype(HS)::value, hb = decltype(HB)::value;
+        const bf16_t* ad = (const bf16_t*)p.add + (size_t)mrow * p.ldadd + co;     // full-grid residual operand (ViT: x + f(x))
+        const size_t astep = (size_t)RPP * p.ldadd;
+        auto rows = [&](auto HS, auto HB, auto HA) {
+            constexpr bool hs = decltype(HS)::value, hb = decltype(HB)::value, ha = decltype(HA)::value;
 #pragma unroll
             for (int ri = 0; ri < RPH; ++ri) {
                 if (mrow + RPP * ri >= p.M) break;
@@ -382,6 +384,12 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 if constexpr (hb) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                }
+                if constexpr (ha) {
+                    float af[8];
+                    unpack8(*(const u32x4*)(ad + ri * astep), af);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += af[e];
                 }
                 if (p.relu) {
 #pragma unroll
@@ -403,8 +411,16 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             }
         };
         if (co < p.Cout) {
-            if (p.stats) { if (p.bias) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
-            else { if (p.bias) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+            if (p.add) {                       // residual form (no statistics on that path: transformer Linear layers)
+                if (p.bias) rows(std::false_type{}, std::true_type{}, std::true_type{});
+                else rows(std::false_type{}, std::false_type{}, std::true_type{});
+            } else if (p.stats) {
+                if (p.bias) rows(std::true_type{}, std::true_type{}, std::false_type{});
+                else rows(std::true_type{}, std::false_type{}, std::false_type{});
+            } else {
+                if (p.bias) rows(std::false_type{}, std::true_type{}, std::false_type{});
+                else rows(std::false_type{}, std::false_type{}, std::false_type{});
+            }
         }
     } else
 #pragma unroll
@@ -874,7 +890,8 @@ template <typename T, int TC, int TP>
 static int launch_conv_auto(ConvParams& p, hipStream_t stream, int batch = 1) {
     if constexpr (sizeof(T) == 2) {
         static const int lean_on = [] { const char* e = getenv("NKB_LEAN_EPILOGUE"); return e ? atoi(e) : 1; }();
-        const bool plain = lean_on && p.add == nullptr && p.act == 0 && p.sub_h == 0 && !p.out_f32 && (p.Cout & 7) == 0 &&
+        const bool add_ok = p.add == nullptr || (p.stats == nullptr && p.add_h == 0 && p.add_bits == nullptr && (p.ldadd & 7) == 0);
+        const bool plain = lean_on && add_ok && p.act == 0 && p.sub_h == 0 && !p.out_f32 && (p.Cout & 7) == 0 &&
                            (p.ldy & 7) == 0;
         if (plain) return launch_conv<T, TC, TP, 3>(p, stream, batch);
     }
