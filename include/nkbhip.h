@@ -38,7 +38,7 @@ int nkb_version(void);
  * mode 0 (forward):  y[n,p,q,co] = sum_{r,s,ci} x[n, p*stride+r-pad, q*stride+s-pad, ci] * w[co,r,s,ci]
  * mode 1 (dgrad):    y[n,h,w,co] = sum_{r,s,ci} x[n, (h+pad-r)/stride, (w+pad-s)/stride, ci] * w[co,r,s,ci]
  *                    (terms with a non-integral source coordinate are skipped; pass the [Cin][R][S][Cout] filter)
- * Epilogue: + bias[co], + add[m][co], relu, optional fp32 output, optional per-row-tile channel sums
+ * Epilogue: + bias[co], + add[m][co], relu (1: ReLU, 2: ReLU6), optional fp32 output, optional per-row-tile channel sums
  * stats[tile][0][co] = sum y, stats[tile][1][co] = sum y^2 (tile count: nkb_conv_gemm_stat_tiles).
  * Cin must be a multiple of 64 (bf16) / 32 (fp32); stride in {1,2}. */
 int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, const void* add, const float* bias,
@@ -161,7 +161,8 @@ int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y, int M, in
 int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int M, int Na, int Nb, int lda, int ldb,
                         int ldo, int outer, int inner, long long sao, long long sai, long long sbo, long long sbi,
                         long long soo, long long soi, nkb_stream_t stream);
-/* Linear layer with fused exact-erf GELU epilogue. act 1: y2 = xW^T+b, y = gelu(y2). act 2: y = (xW^T) * gelu'(aux). */
+/* Linear layer with a fused activation epilogue. act 1: y2 = xW^T+b, y = gelu(y2) (exact erf). act 2: y = (xW^T) * gelu'(aux).
+ * act 3: y = (xW^T) where 0 < aux < 6, else 0 (ReLU6 backward; aux = the ReLU6 output, whose forward is nkb_conv_gemm(relu = 2)). */
 int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y, void* y2,
                     int M, int K, int N, nkb_stream_t stream);
 /* LayerNorm over the last dim (biased variance). backward=0: in = x -> out = y, writes mean/rstd.

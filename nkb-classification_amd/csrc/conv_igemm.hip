@@ -394,6 +394,10 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 if (p.relu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    if (p.relu == 2) {             // ReLU6
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fminf(v[e], 6.f);
+                    }
                 }
                 const u32x4 pk = pack8(v);
                 *(u32x4*)(o + ri * ostep) = pk;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
         }
         if (!BNB && p.relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
         }
         if (!BNB && p.act == 1) {          // GELU forward: keep the pre-activation in y2 (for backward), store gelu(v) in y
             T* o2 = (T*)p.y2 + orow * p.ldy + co;
@@ -548,6 +552,14 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             for (int e = 0; e < 8; ++e) {
                 const float a = (co + e < p.Cout) ? DT<T>::ld(ax + e) : 0.f;
                 v[e] *= 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * expf(-0.5f * a * a);
+            }
+        }
+        else if (!BNB && p.act == 3) {     // ReLU6 backward (unicom Mlp.act): aux = the clamped forward output u; 0 < u < 6 <=> 0 < pre < 6
+            const T* ax = (const T*)p.aux + orow * p.ldy + co;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = (co + e < p.Cout) ? DT<T>::ld(ax + e) : 0.f;
+                if (!(a > 0.f && a < 6.f)) v[e] = 0.f;
             }
         }
         if ((!BNB && p.out_f32) || sizeof(T) == 4) {
@@ -1049,11 +1061,13 @@ extern "C" int nkb_conv_dgrad_s2class(int dtype, const void* dy, const void* w_c
 // Linear layer with a fused exact-erf GELU epilogue (timm ViT MLP):
 //   act 1: pre = x W^T + b -> y2 = pre, y = gelu(pre)        (fc1 forward)
 //   act 2: y = (x W^T) * gelu'(aux)                           (fc2 data-gradient, aux = fc1's pre-activation)
+//   act 3: y = (x W^T) where 0 < aux < 6, else 0              (unicom fc2 data-gradient, aux = fc1's ReLU6 output; the
+//          forward half is nkb_conv_gemm(relu = 2))
 extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y,
                                void* y2, int M, int K, int N, hipStream_t stream) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
     const int kte = 128 / esz;
-    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (act != 1 && act != 2) || K % kte != 0 || N % 8 != 0) {
+    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (act < 1 || act > 3) || K % kte != 0 || N % 8 != 0) {
         nkb_set_error("linear_gelu: unsupported dtype/act/shape (K=%d N=%d)", K, N);
         return 1;
     }

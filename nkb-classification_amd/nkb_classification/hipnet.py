@@ -587,6 +587,32 @@ class HipEngine:
                       add=add, ldadd=K if add is not None else 0)
         return dx
 
+    def linear_relu6(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool) -> torch.Tensor:
+        """u = relu6(x @ W^T + b) with the clamp in the GEMM epilogue (unicom Mlp: fc1 -> ReLU6); only u is kept."""
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        u = self.ws.get(key + ".y", (M, N), self.T)
+        hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), u, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
+                      bias=self.arena.param_flat(lin.bias) if lin.bias is not None else None, relu=2)
+        if train:
+            self.saved[key] = dict(x=x, lin=lin, u=u)
+        return u
+
+    def linear_backward_through_relu6(self, key_next: str, key_act: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        """For u = relu6(pre), y = u @ W2^T + b2: weight/bias gradient of W2 (side stream) and d_pre = (g @ W2) masked by
+        0 < u < 6 in one GEMM epilogue."""
+        sv = self.saved[key_next]
+        x, lin = sv["x"], sv["lin"]          # x = u (ReLU6 output), lin = fc2
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        a = self.arena
+        self.on_side(lambda: hip.conv_wgrad(
+            self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+            dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
+        d_pre = self.scratch(slot, (M, K))
+        hip.linear_gelu(self.d, 3, g, self._wd[id(lin.weight)], None, self.saved[key_act]["u"], d_pre, None, M, N, K)
+        return d_pre
+
     def linear_gelu(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool) -> torch.Tensor:
         """u = gelu(x @ W^T + b) with the GELU in the GEMM epilogue; the pre-activation is kept for backward."""
         M, K = x.shape

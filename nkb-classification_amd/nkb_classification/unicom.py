@@ -20,12 +20,16 @@ of HBM the activations of the B=128 configuration are simply kept.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
 from . import hip
 from .backbones import _ParamOnly
 from .hipnet import HipEngine
+
+_FUSED_RELU6 = os.environ.get("NKB_FUSED_RELU6", "1") != "0"   # ReLU6 in the fc1 epilogue, its mask in the fc2 data gradient
 
 
 class _PatchEmbedding(_ParamOnly):
@@ -134,7 +138,10 @@ class HipUnicomViT(_ParamOnly):
             else:
                 x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x)
             h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train)
-            u = eng.relu6(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train)
+            if _FUSED_RELU6:
+                u = eng.linear_relu6(f"b{i}.fc1", h, mlp.fc1, train)
+            else:
+                u = eng.relu6(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train)
             if dp > 0:
                 x = eng.drop_path(f"b{i}.dp2", eng.linear(f"b{i}.fc2", u, mlp.fc2, train), dp, train, B, add=x)
             else:
@@ -167,8 +174,11 @@ class HipUnicomViT(_ParamOnly):
             blk = self.blocks[i]
             eng.begin_block(i)
             g2 = eng.drop_path_backward(f"b{i}.dp2", gx, "g2")              # branch gradient; the residual path keeps gx
-            d_u = eng.linear_backward(f"b{i}.fc2", g2, "du")
-            d_a = eng.relu6_backward(f"b{i}.act", d_u, "da")
+            if _FUSED_RELU6:
+                d_a = eng.linear_backward_through_relu6(f"b{i}.fc2", f"b{i}.fc1", g2, "da")
+            else:
+                d_u = eng.linear_backward(f"b{i}.fc2", g2, "du")
+                d_a = eng.relu6_backward(f"b{i}.act", d_u, "da")
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
             gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
             d_o = eng.linear_backward(f"b{i}.proj", eng.drop_path_backward(f"b{i}.dp1", gmid, "g1"), "do")
