@@ -162,7 +162,8 @@ int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int 
                         int ldo, int outer, int inner, long long sao, long long sai, long long sbo, long long sbi,
                         long long soo, long long soi, nkb_stream_t stream);
 /* Linear layer with a fused activation epilogue. act 1: y2 = xW^T+b, y = gelu(y2) (exact erf). act 2: y = (xW^T) * gelu'(aux).
- * act 3: y = (xW^T) where 0 < aux < 6, else 0 (ReLU6 backward; aux = the ReLU6 output, whose forward is nkb_conv_gemm(relu = 2)). */
+ * act 3: y = (xW^T) where 0 < aux < 6, else 0 (ReLU6 backward; aux = the ReLU6 output, whose forward is nkb_conv_gemm(relu = 2)).
+ * act 4: y = (xW^T) * aux (GELU backward with aux = gelu'(pre) kept by nkb_gelu_fwd_dgelu). */
 int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y, void* y2,
                     int M, int K, int N, nkb_stream_t stream);
 /* LayerNorm over the last dim (biased variance). backward=0: in = x -> out = y, writes mean/rstd.
@@ -173,6 +174,8 @@ int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, 
                   nkb_stream_t stream);
 size_t nkb_layernorm_workspace_floats(int D); /* backward: optional scratch for the deterministic dgamma/dbeta reduction */
 /* exact-erf GELU: dy == NULL -> out = gelu(x); else out = dy * gelu'(x) */
+/* forward that also stores gelu'(x) (timm Mlp.act, backward then is the act-4 epilogue of nkb_linear_gelu) */
+int nkb_gelu_fwd_dgelu(int dtype, const void* x, void* y, void* gp, long long n, nkb_stream_t stream);
 int nkb_gelu(int dtype, const void* x, const void* dy, void* out, long long n, nkb_stream_t stream);
 /* softmax over fp32 score rows (forward: p = softmax(scale*s); backward: ds = scale*p*(dp - sum dp*p)), zero padded to ldp */
 int nkb_attn_softmax(int dtype, int backward, const float* s, int lds, const void* p_in, void* out, int ldp,

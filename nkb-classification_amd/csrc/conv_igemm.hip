@@ -562,6 +562,18 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 if (!(a > 0.f && a < 6.f)) v[e] = 0.f;
             }
         }
+        else if (!BNB && p.act == 4) {     // multiply by a saved derivative (GELU backward with gelu'(pre) kept by the forward pass)
+            const T* ax = (const T*)p.aux + orow * p.ldy + co;
+            if (vec_ok && sizeof(T) == 2) {
+                float af[8];
+                unpack8(*(const u32x4*)ax, af);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= af[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= (co + e < p.Cout) ? DT<T>::ld(ax + e) : 0.f;
+            }
+        }
         if ((!BNB && p.out_f32) || sizeof(T) == 4) {
             float* o = (float*)p.y + yoff + orow * p.ldy + co;
             if (vec_ok) {
@@ -1063,11 +1075,12 @@ extern "C" int nkb_conv_dgrad_s2class(int dtype, const void* dy, const void* w_c
 //   act 2: y = (x W^T) * gelu'(aux)                           (fc2 data-gradient, aux = fc1's pre-activation)
 //   act 3: y = (x W^T) where 0 < aux < 6, else 0              (unicom fc2 data-gradient, aux = fc1's ReLU6 output; the
 //          forward half is nkb_conv_gemm(relu = 2))
+//   act 4: y = (x W^T) * aux                                  (fc2 data-gradient, aux = gelu'(pre) from nkb_gelu_fwd_dgelu)
 extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y,
                                void* y2, int M, int K, int N, hipStream_t stream) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
     const int kte = 128 / esz;
-    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (act < 1 || act > 3) || K % kte != 0 || N % 8 != 0) {
+    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (act < 1 || act > 4) || K % kte != 0 || N % 8 != 0) {
         nkb_set_error("linear_gelu: unsupported dtype/act/shape (K=%d N=%d)", K, N);
         return 1;
     }

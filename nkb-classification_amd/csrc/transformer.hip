@@ -260,6 +260,37 @@ extern "C" int nkb_gelu(int dtype, const void* x, const void* dy, void* out, lon
     return nkb_check_launch("gelu");
 }
 
+// GELU forward that also emits gelu'(x) (same dtype): the backward pass then is a plain multiply, done in the epilogue of
+// the fc2 data-gradient GEMM (nkb_linear_gelu act 4) instead of a separate erf/exp pass over dy and x.
+template <typename T>
+__global__ void gelu_fwd_dgelu_kernel(const T* x, T* __restrict__ y, T* gp, size_t nvec) {   // gp may alias x (in place)
+    constexpr int N = V16<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        float a[N], o[N], d[N];
+        V16<T>::ld(x + i * N, a);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float c = 0.5f * (1.f + erff(a[e] * 0.70710678118654752f));
+            o[e] = a[e] * c;
+            d[e] = c + a[e] * 0.3989422804014327f * expf(-0.5f * a[e] * a[e]);
+        }
+        V16<T>::st(y + i * N, o);
+        V16<T>::st(gp + i * N, d);
+    }
+}
+extern "C" int nkb_gelu_fwd_dgelu(int dtype, const void* x, void* y, void* gp, long long n, hipStream_t stream) {
+    const int N = dtype == NKB_DT_BF16 ? 8 : 4;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("gelu_fwd_dgelu: bad dtype %d", dtype); return 1; }
+    if (n % N) { nkb_set_error("gelu_fwd_dgelu: element count %lld not a multiple of %d", n, N); return 1; }
+    NkbProfScope prof(NKB_K_GELU, stream, 0);
+    size_t nvec = (size_t)n / N, g = (nvec + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(gelu_fwd_dgelu_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)gp, nvec);
+    else hipLaunchKernelGGL(gelu_fwd_dgelu_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)x, (float*)y, (float*)gp, nvec);
+    return nkb_check_launch("gelu_fwd_dgelu");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // ReLU6 (the MLP activation of the unicom transformer blocks): forward y = min(max(x, 0), 6); backward dx = dy where
 // 0 < x < 6 (strict on both ends, torch's hardtanh_backward) and 0 elsewhere.

@@ -61,6 +61,7 @@ _SIGS = {
     "nkb_wfold": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "nkb_image_prep": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp]),
     "nkb_relu6": (i32, [i32, vp, vp, vp, i64, vp]),
+    "nkb_gelu_fwd_dgelu": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_scale_rows": (i32, [i32, vp, vp, vp, vp, i32, i64, vp]),
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
     "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
@@ -360,6 +361,10 @@ def image_prep(src, sizes, flags, out, B, Hs, Ws, Ho, Wo, mean, std, fill=0.0):
     m, sd = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
     check(load().nkb_image_prep(ptr(src), ptr(sizes), ptr(flags), ptr(out), B, Hs, Ws, Ho, Wo, C.cast(m, C.c_void_p),
                                 C.cast(sd, C.c_void_p), float(fill), stream()), "image_prep")
+
+
+def gelu_fwd_dgelu(dtype, x, y, gp, n):
+    check(load().nkb_gelu_fwd_dgelu(dtype, ptr(x), ptr(y), ptr(gp), n, stream()), "gelu_fwd_dgelu")
 
 
 def relu6(dtype, x, dy, out, n):

@@ -664,12 +664,33 @@ class HipEngine:
                           out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), sv["rows"], D, workspace=work)
         return out
 
-    def gelu(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:
+    def gelu(self, key: str, x: torch.Tensor, train: bool, keep_derivative: bool = False) -> torch.Tensor:
+        """keep_derivative: the forward pass also stores gelu'(x), overwriting x (the pre-activation is not needed again);
+        the backward pass is then linear_backward_through_saved_derivative instead of gelu_backward."""
         y = self.ws.get(key + ".y", x.shape, self.T)
+        if train and keep_derivative:
+            hip.gelu_fwd_dgelu(self.d, x, y, x, x.numel())
+            self.saved[key] = dict(gp=x)
+            return y
         hip.gelu(self.d, x, None, y, x.numel())
         if train:
             self.saved[key] = dict(x=x)
         return y
+
+    def linear_backward_through_saved_derivative(self, key_next: str, key_act: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+        """For u = act(pre), y = u @ W2^T + b2 with act'(pre) kept by the forward pass: weight/bias gradient of W2 (side
+        stream) and d_pre = (g @ W2) * act'(pre) in one GEMM epilogue."""
+        sv = self.saved[key_next]
+        x, lin = sv["x"], sv["lin"]
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        a = self.arena
+        self.on_side(lambda: hip.conv_wgrad(
+            self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+            dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
+        d_pre = self.scratch(slot, (M, K))
+        hip.linear_gelu(self.d, 4, g, self._wd[id(lin.weight)], None, self.saved[key_act]["gp"], d_pre, None, M, N, K)
+        return d_pre
 
     def gelu_backward(self, key: str, g: torch.Tensor, slot: str) -> torch.Tensor:
         x = self.saved[key]["x"]

@@ -16,6 +16,7 @@ from . import hip
 from .backbones import _ParamOnly
 from .hipnet import HipEngine
 
+_GELU_KEEP_DERIV = os.environ.get("NKB_GELU_KEEP_DERIV", "1") != "0"   # forward stores gelu'(pre); backward = fc2-dgrad epilogue multiply
 _FUSED_GELU = os.environ.get("NKB_FUSED_GELU", "0") != "0"   # measured: erf in the GEMM epilogue costs more than the pass it saves (66.3 vs 65.9 ms)
 
 
@@ -120,7 +121,8 @@ class HipViT(_ParamOnly):
             if _FUSED_GELU:
                 u = eng.linear_gelu(f"b{i}.fc1", h, mlp.fc1, train)        # GELU fused into the fc1 epilogue
             else:
-                u = eng.gelu(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train)
+                keep = _GELU_KEEP_DERIV and not (train and mlp.drop1.p > 0)
+                u = eng.gelu(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train, keep_derivative=keep)
             u = eng.dropout(f"b{i}.mlp_drop", u, mlp.drop1.p, train)
             if train and mlp.drop2.p > 0:
                 x = eng.dropout(f"b{i}.mlp2_drop", eng.linear(f"b{i}.fc2", u, mlp.fc2, train), mlp.drop2.p, train, add=x)
@@ -150,8 +152,11 @@ class HipViT(_ParamOnly):
             if _FUSED_GELU:   # gelu' fused into the fc2 data-gradient epilogue
                 d_a = eng.linear_backward_through_gelu(f"b{i}.fc2", f"b{i}.fc1", g2, "da")
             else:
-                d_u = eng.dropout_backward(f"b{i}.mlp_drop", eng.linear_backward(f"b{i}.fc2", g2, "du"), "du2")
-                d_a = eng.gelu_backward(f"b{i}.act", d_u, "da")
+                if "gp" in eng.saved[f"b{i}.act"]:
+                    d_a = eng.linear_backward_through_saved_derivative(f"b{i}.fc2", f"b{i}.act", g2, "da")
+                else:
+                    d_u = eng.dropout_backward(f"b{i}.mlp_drop", eng.linear_backward(f"b{i}.fc2", g2, "du"), "du2")
+                    d_a = eng.gelu_backward(f"b{i}.act", d_u, "da")
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
             gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
             d_o = eng.linear_backward(f"b{i}.proj", eng.dropout_backward(f"b{i}.proj_drop", gmid, "g1"), "do")
