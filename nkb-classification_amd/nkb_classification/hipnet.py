@@ -77,8 +77,10 @@ class HipEngine:
         if self._wver == a.version and (not need_dgrad or self._dgrad_ready):
             return
         if self.T == torch.bfloat16:
+            fresh = a.shadow is not None and getattr(a, "shadow_version", -1) == a.version     # written by the fused optimizer
             a.ensure_shadow()
-            hip.wprep(self.d, a.flat_param, a.shadow, 1, 1, a.total, a.total, 0)
+            if not fresh:
+                hip.wprep(self.d, a.flat_param, a.shadow, 1, 1, a.total, a.total, 0)
         for conv in self._stems:
             w = conv.weight
             if self.packed_stem(conv):

@@ -103,6 +103,7 @@ class FusedOptimizer(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         touched_arena = False
+        shadowed = 0            # arena elements whose bf16 shadow this step's launches rewrote
         for group, gstate in zip(self.param_groups, self._gstate):
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
@@ -121,6 +122,8 @@ class FusedOptimizer(torch.optim.Optimizer):
                 hip.optim_step(kcode, a.flat_param[lo:hi], a.flat_grad[lo:hi], m[lo:hi], v[lo:hi], shadow, hi - lo,
                                lr, wd, beta1, beta2, eps, self.grad_scale, *sc)
                 touched_arena = True
+                if shadow is not None and len(live) == len(group["params"]):
+                    shadowed += hi - lo
                 continue
             for p in live:
                 hip.require_device(p, "optimizer.step")
@@ -139,6 +142,10 @@ class FusedOptimizer(torch.optim.Optimizer):
                     touched_arena = True
         if touched_arena:
             self.arena.mark_dirty()
+            if shadowed == self.arena.total:
+                # every parameter went through a launch that also wrote its bf16 shadow: the engine's own refresh of the
+                # whole shadow (one more pass over the arena per step) is redundant for this version
+                self.arena.shadow_version = self.arena.version
         return loss
 
 
