@@ -3,7 +3,7 @@
 3x224x224 batches, ResNet-50 single-task, bs=256 per GPU, bf16 compute with fp32 master weights
 (BASELINE.json configs[1]) — one process per GPU, RCCL gradient all-reduce over xGMI for N>1.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -81,8 +81,8 @@ def usable_cpus() -> int:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # >= 10 warm-up, >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--classes", type=int, default=1000)
