@@ -560,3 +560,33 @@ def test_multitask_bench_shape_runs_bf16():
         losses.append(loss["loss"].item())
     assert [tuple(out[t].shape) for t in classes] == [(32, 2), (32, 3), (32, 5), (32, 14)]
     assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0] * 1.5
+
+
+def test_train_epoch_through_device_loader(tmp_path):
+    """engine.train_epoch fed by get_dataset(device_pipeline=True): PNG folder -> uint8 canvases -> async H2D -> nkb_image_prep
+    -> the HIP model; the batches the engine sees equal the host-side float pipeline of the same folder."""
+    import numpy as np
+    from PIL import Image
+    from nkb_classification.dataset import get_dataset
+    rng = np.random.default_rng(1)
+    for cls, n in (("a", 5), ("b", 3)):
+        (tmp_path / cls).mkdir()
+        for i in range(n):
+            Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(tmp_path / cls / f"{i}.png")
+    base = dict(root=str(tmp_path), size=64, batch_size=4, num_workers=0, shuffle=False)
+    dev_loader = get_dataset(dict(base, device_pipeline=True, device=DEV))
+    host_loader = get_dataset(dict(base))
+    assert dev_loader.dataset.classes == ["a", "b"] and len(dev_loader) == len(host_loader) == 2
+    for (xd, yd), (xh, yh) in zip(dev_loader, host_loader):
+        assert xd.is_cuda and yd.is_cuda and yd.cpu().tolist() == yh.tolist()
+        torch.testing.assert_close(xd.cpu(), xh, rtol=1e-5, atol=1e-5)        # square images: no resize / pad difference
+    cfg_model = dict(model="resnet_tiny_basic", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    torch.manual_seed(0)
+    model = get_model(cfg_model, ["a", "b"], DEV)
+    opt = get_optimizer(model, dict(type="sgd", lr=0.01))
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    logger = BaseLogger(_cfg("single"), ["a", "b"])
+    res = train_epoch(model, dev_loader, opt, None, torch.amp.GradScaler("cuda", enabled=False), crit, DEV, _cfg("single"), logger)
+    assert len(res["running_loss"]) == 2 and all(math.isfinite(v) for v in res["running_loss"])
+    assert len(res["predictions"]) == 8
