@@ -190,6 +190,8 @@ class _HipClassifier(nn.Module):
         hip.require_device(x, "model.forward")
         if x.dim() != 4 or x.dtype != torch.float32:
             raise RuntimeError(f"expected a float32 NCHW image batch, got {tuple(x.shape)} {x.dtype}")
+        if x.shape[0] == 0 or x.shape[1] != 3:
+            raise RuntimeError(f"expected a non-empty batch of 3-channel images, got {tuple(x.shape)}")
         x = x.contiguous()
         self._active = self._engine(x.device, self._compute_dtype())
         self._fwd_token += 1

@@ -230,6 +230,23 @@ def test_frozen_backbone_only_updates_head():
     torch.testing.assert_close(model.emb_model.bn1.running_mean.cpu(), oracle.emb_model.bn1.running_mean, rtol=1e-4, atol=1e-5)
 
 
+def test_degenerate_batches_fail_loudly_or_run():
+    """An empty batch or a non-RGB input is a clear error (no zero-sized kernel launch); a single-image batch (the last
+    partial batch of an epoch) trains — BatchNorm over one image and all."""
+    cfg_model = dict(model="resnet_tiny_bottleneck", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    model = get_model(cfg_model, ["a", "b", "c"], DEV).train()
+    with pytest.raises(RuntimeError, match="non-empty batch"):
+        model(torch.zeros(0, 3, 64, 64, device=DEV))
+    with pytest.raises(RuntimeError, match="3-channel"):
+        model(torch.zeros(2, 1, 64, 64, device=DEV))
+    out = model(torch.randn(1, 3, 64, 64, device=DEV))
+    out.sum().backward()
+    torch.cuda.synchronize()
+    assert out.shape == (1, 3) and torch.isfinite(out).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 def test_cpu_forward_fails_loudly():
     cfg_model = dict(model="resnet_tiny_basic", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
                      classifier_initialization="kaiming_normal_", task="single")
