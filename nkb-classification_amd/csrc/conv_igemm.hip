@@ -57,8 +57,18 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
 
     const unsigned nwg = gridDim.x;
     const unsigned lid = xcd_remap(blockIdx.x, nwg);
-    const int tile_n = lid % p.tilesN;
-    const int tile_m = lid / p.tilesN;
+    int tile_n = lid % p.tilesN;
+    int tile_m = lid / p.tilesN;
+    if (p.group_m > 1) {
+        // grouped walk: the workgroups resident on an XCD at one time (consecutive ids) cover group_m row tiles x a few channel
+        // tiles instead of a few row tiles x ALL channel tiles, so the filter rows they share fit in that XCD's 4 MB L2
+        const int gsz = p.group_m * p.tilesN;
+        const int grp = (int)lid / gsz, first_m = grp * p.group_m;
+        const int gm = min(p.group_m, p.tilesM - first_m);
+        const int r = (int)lid - grp * gsz;
+        tile_m = first_m + r % gm;
+        tile_n = r / gm;
+    }
     const int m0 = tile_m * TP;
     const int c0 = tile_n * TC;
 
@@ -882,6 +892,16 @@ template <typename T, int TC, int TP, int BNB, bool HALO>
 static int launch_conv_impl(ConvParams& p, hipStream_t stream, int batch) {
     p.tilesM = (p.M + TP - 1) / TP;
     p.tilesN = (p.Cout + TC - 1) / TC;
+    {
+        // When the whole filter matrix does not fit next to the activation rows in one XCD's L2 (4 MB), walking "all channel
+        // tiles of a few row tiles" streams the filter through L2 once per row tile.  Groups of 8 row tiles keep 8 activation
+        // tiles resident and let each filter tile serve 8 workgroups at once.
+        static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
+        const double wbytes = (double)p.Cout * p.R * p.S * p.Cin * sizeof(T);
+        // (measured, ViT-B/16 shapes: N = 3072 334.9 -> 316.2 us, N = 2304 282.5 -> 274.9; with <= 6 channel tiles all of them are
+        // resident at once either way and the grouped walk is 1-2 % slower, so it only engages for wide outputs)
+        p.group_m = (gm_env > 1 && batch == 1 && wbytes > 1.5e6 && p.tilesN >= 12 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
+    }
     constexpr int xrows = HALO ? 32 * ((TP + 2 + 31) / 32) : TP;
     constexpr int stage = (TC + xrows) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1);
     constexpr int epi = (TP / 2) * (TC * 4 + 16);

@@ -17,6 +17,7 @@ struct ConvParams {
     int relu;           // clamp at 0 in the epilogue
     int out_f32;        // write fp32 regardless of the compute dtype
     int tilesM, tilesN;
+    int group_m = 0;     // > 1: tiles are walked in groups of group_m row tiles x all channel tiles, row tile fastest (see launch_conv_impl)
     FastDiv divPQ, divQ;
     // batched GEMM (attention): blockIdx.y = zo*inner + zi; element offsets zo*s?o + zi*s?i on x / w / y
     int add_h, add_w;   // > 0: `add` is [N][add_h][add_w][ldadd] on the stride-2 sub-grid of the output (zero elsewhere)
