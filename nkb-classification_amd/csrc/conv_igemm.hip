@@ -901,7 +901,7 @@ static int launch_conv_impl(ConvParams& p, hipStream_t stream, int batch) {
         // (measured, ViT-B/16 shapes: N = 3072 334.9 -> 316.2 us, N = 2304 282.5 -> 274.9; with <= 6 channel tiles all of them are
         // resident at once either way and the grouped walk is 1-2 % slower, so it only engages for wide outputs)
         static const int gm_min_n = [] { const char* e = getenv("NKB_GROUP_MIN_N"); return e ? atoi(e) : 12; }();
-        p.group_m = (gm_env > 1 && batch == 1 && wbytes > 1.5e6 && p.tilesN >= gm_min_n && p.tilesM >= 2 * gm_env) ? gm_env : 0;
+        p.group_m = (gm_env > 1 && batch == 1 && wbytes > 3.0e6 && p.tilesN >= gm_min_n && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     }
     constexpr int xrows = HALO ? 32 * ((TP + 2 + 31) / 32) : TP;
     constexpr int stage = (TC + xrows) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1);
