@@ -899,3 +899,60 @@ def test_device_loader_double_buffers_uint8_batches():
         seen += 1
     assert seen == nb
     assert list(DeviceLoader([], DEV, size)) == []
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gelu_forward_keeping_derivative_and_epilogue_multiply(dtype):
+    """nkb_gelu_fwd_dgelu (y = gelu(x), gp = gelu'(x), gp may alias x) and the act-4 GEMM epilogue y = (g W^T) * gp that
+    replaces the separate GELU backward pass; act 3 is the ReLU6 mask variant, relu = 2 the ReLU6 forward epilogue."""
+    torch.manual_seed(21)
+    M, K, N = 200, 128, 192
+    d = hip.dt(dtype)
+    x = rnd(torch.randn(M, N) * 2, dtype).requires_grad_(True)
+    y_ref = torch.nn.functional.gelu(x)
+    y_ref.sum().backward()
+    gp_ref = x.grad.clone()
+    xd = x.detach().to(DEV, dtype)
+    yd = torch.empty_like(xd)
+    hip.gelu_fwd_dgelu(d, xd, yd, xd, M * N)                     # in place: xd now holds gelu'(x)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(yd.float().cpu(), y_ref.detach(), **tol(dtype))
+    torch.testing.assert_close(xd.float().cpu(), gp_ref, **tol(dtype))
+    # d_pre = (g @ W2) * gelu'(pre): W2 is [K, N] (fc2: N -> K), its data-gradient operand is W2^T = [N, K]
+    g = rnd(torch.randn(M, K), dtype)
+    w2 = rnd(torch.randn(K, N) / math.sqrt(N), dtype)
+    wt = w2.t().contiguous()                                      # [N, K]: rows = outputs of the data-gradient GEMM
+    ref = (g @ w2) * xd.float().cpu()
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    hip.linear_gelu(d, 4, g.to(DEV, dtype), wt.to(DEV, dtype), None, xd, out, None, M, K, N)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.float().cpu(), ref, **tol(dtype, K))
+    # ReLU6: forward clamp in the epilogue (relu = 2), backward mask from the clamped output (act 3)
+    xin = rnd(torch.randn(M, K), dtype)
+    w1 = rnd(torch.randn(N, K) * 0.6, dtype)
+    b1 = torch.randn(N)
+    u_ref = torch.nn.functional.relu6(xin @ w1.t() + b1)
+    u = torch.empty(M, N, device=DEV, dtype=dtype)
+    hip.conv_gemm(d, 0, xin.to(DEV, dtype), w1.to(DEV, dtype), u, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
+                  bias=b1.to(DEV), relu=2)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(u.float().cpu(), u_ref, **tol(dtype, K))
+    assert u.float().max().item() <= 6.0 and u.float().min().item() >= 0.0 and (u.float() == 6.0).any()
+    uc = u.float().cpu()
+    ref3 = (g @ w2) * ((uc > 0) & (uc < 6)).float()
+    out3 = torch.empty(M, N, device=DEV, dtype=dtype)
+    hip.linear_gelu(d, 3, g.to(DEV, dtype), wt.to(DEV, dtype), None, u, out3, None, M, K, N)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out3.float().cpu(), ref3, **tol(dtype, K))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wfold_eval_batchnorm_folding(dtype):
+    """nkb_wfold: dst[co][k] = w[co][k] * scale[co] in the compute dtype (eval-mode BatchNorm folded into the filter)."""
+    torch.manual_seed(22)
+    Cout, K = 37, 3 * 3 * 16
+    w, scale = torch.randn(Cout, K), torch.rand(Cout) + 0.5
+    dst = torch.empty(Cout, K, device=DEV, dtype=dtype)
+    hip.wfold(hip.dt(dtype), w.to(DEV), scale.to(DEV), dst, Cout, K)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dst.float().cpu(), rnd(w * scale[:, None], dtype), rtol=0, atol=0)
