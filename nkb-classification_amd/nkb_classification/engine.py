@@ -68,78 +68,56 @@ def _grad_norms(model, log):
     log["Gradients/Total"].append(total)
 
 
-def train_epoch(
-    model,
-    train_loader,
-    optimizer,
-    scheduler,
-    scaler,
-    criterion,
-    device,
-    cfg,
-    epoch_logger,
-):
+def _upload(target, device):
+    """Labels follow the image to the device (engine.py:41 leaves dict targets to the criterion / logger)."""
+    if isinstance(target, dict):
+        return {name: labels.to(device, non_blocking=True) for name, labels in target.items()}
+    return target.to(device, non_blocking=True)
+
+
+def _forward_and_loss(model, criterion, img, target, device, cfg):
+    """engine.py:43-51: autocast region around model(img) and criterion(preds, target)."""
+    with torch.autocast(device_type="cuda", dtype=_amp_dtype(cfg), enabled=cfg.enable_mixed_presicion):
+        preds = model(img)
+        labels = _upload(target, device) if isinstance(target, torch.Tensor) else target
+        return preds, labels, criterion(preds, labels)
+
+
+def train_epoch(model, train_loader, optimizer, scheduler, scaler, criterion, device, cfg, epoch_logger):
+    """One training epoch (engine.py:20-85), positional arguments in the reference's order."""
     model.train()
     epoch_logger.init_iter_logs()
-    metrics_grad_log = defaultdict(list) if cfg.log_gradients else None
-    pbar = TrainPbar(train_loader, leave=False, desc="Training", cfg=cfg)
-
-    for img, target in pbar:
+    grad_log = defaultdict(list) if cfg.log_gradients else None
+    bar = TrainPbar(train_loader, leave=False, desc="Training", cfg=cfg)
+    for img, target in bar:
         img = img.to(device, non_blocking=True)
         optimizer.zero_grad()
-
-        with torch.autocast(device_type="cuda", dtype=_amp_dtype(cfg), enabled=cfg.enable_mixed_presicion):
-            preds = model(img)
-            if isinstance(target, torch.Tensor):
-                target = target.to(device, non_blocking=True)
-            loss = criterion(preds, target)
-
-        pbar.update_loss(loss)
-
-        scaler.scale(loss["loss"] if isinstance(loss, dict) else loss).backward()
+        preds, target, loss = _forward_and_loss(model, criterion, img, target, device, cfg)
+        bar.update_loss(loss)                              # prints the previous step's loss: no sync between fwd and bwd
+        total = loss["loss"] if isinstance(loss, dict) else loss
+        scaler.scale(total).backward()
         scaler.step(optimizer)
         scaler.update()
-
-        if isinstance(target, dict):
-            target = {k: v.to(device, non_blocking=True) for k, v in target.items()}
-        epoch_logger.log_iter(preds, target, loss)
-
-        if metrics_grad_log is not None:
-            _grad_norms(model, metrics_grad_log)
-
+        epoch_logger.log_iter(preds, _upload(target, device) if isinstance(target, dict) else target, loss)
+        if grad_log is not None:
+            _grad_norms(model, grad_log)
         epoch_logger.log_images_if_needed(img)
-
-    if scheduler is not None:
+    if scheduler is not None:                              # per-epoch policy (engine.py:77-78)
         scheduler.step()
-
     results = epoch_logger.get_epoch_results()
-    if metrics_grad_log is not None:
-        results["metrics_grad_log"] = metrics_grad_log
+    if grad_log is not None:
+        results["metrics_grad_log"] = grad_log
     return results
 
 
 @torch.no_grad()
-def val_epoch(
-    model,
-    val_loader,
-    criterion,
-    device,
-    cfg,
-    epoch_logger,
-):
+def val_epoch(model, val_loader, criterion, device, cfg, epoch_logger):
+    """One evaluation pass (engine.py:88-117): forward + loss in eval mode, same logger protocol."""
     model.eval()
     epoch_logger.init_iter_logs()
-
     for img, target in tqdm(val_loader, leave=False, desc="Evaluating"):
         img = img.to(device, non_blocking=True)
-        with torch.autocast(device_type="cuda", dtype=_amp_dtype(cfg), enabled=cfg.enable_mixed_presicion):
-            preds = model(img)
-            if isinstance(target, torch.Tensor):
-                target = target.to(device, non_blocking=True)
-            loss = criterion(preds, target)
-        if isinstance(target, dict):
-            target = {k: v.to(device, non_blocking=True) for k, v in target.items()}
-        epoch_logger.log_iter(preds, target, loss)
+        preds, target, loss = _forward_and_loss(model, criterion, img, target, device, cfg)
+        epoch_logger.log_iter(preds, _upload(target, device) if isinstance(target, dict) else target, loss)
         epoch_logger.log_images_if_needed(img)
-
     return epoch_logger.get_epoch_results()
