@@ -205,6 +205,11 @@ int nkb_relu6(int dtype, const void* x, const void* dy, void* out, long long n, 
 /* stochastic depth (unicom Block.drop_path): out[r][i] = x[r][i] * scale[r] (+ add[r][i]); also its own backward */
 int nkb_scale_rows(int dtype, const void* x, const void* add, void* out, const float* scale, int rows, long long inner,
                    nkb_stream_t stream);
+/* Split-K Linear layer, second half: partial[z][m][n] (fp32, from nkb_gemm_batched with one batch entry per K slice) ->
+ * y[m][n] = sum_z partial + bias[n] in the compute dtype, and the per-128-row-tile channel sums nkb_bn_finalize expects
+ * (stats may be NULL).  For skinny GEMMs with a very long reduction (unicom feature[0]: 128 x 262144 -> 1024). */
+int nkb_splitk_reduce(int dtype, const float* partial, int splits, int M, int N, void* y, int ldy, const float* bias,
+                      float* stats, nkb_stream_t stream);
 /* Eval-mode BatchNorm folding (val_epoch, engine.py:88-117): dst[Cout][K] = w[Cout][K] * scale[Cout] in the compute dtype;
  * the folded filter + bias = shift + the conv epilogue's residual add / ReLU replace conv -> bn -> act in eval mode. */
 int nkb_wfold(int dtype, const float* w, const float* scale, void* dst, int Cout, int K, nkb_stream_t stream);

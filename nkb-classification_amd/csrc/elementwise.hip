@@ -793,6 +793,41 @@ extern "C" int nkb_wfold(int dtype, const float* w, const float* scale, void* ds
     return nkb_check_launch("wfold");
 }
 
+// Second half of a split-K Linear layer (skinny GEMMs with a huge reduction, e.g. the unicom `feature[0]` Linear: 128 x 262 144
+// -> 1 024 is 8 output tiles with 4 096 k-steps each): partial[z][m][n] fp32 from nkb_gemm_batched (one batch entry per K
+// slice) -> y[m][n] = T(sum_z partial + bias[n]) plus the per-128-row-tile channel sums BatchNorm expects from a conv epilogue
+// (stats[tile][0][n] = sum y, stats[tile][1][n] = sum y^2 of the stored values).
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N, T* __restrict__ y, int ldy,
+                                     const float* __restrict__ bias, float* __restrict__ stats) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * 128, m1 = min(M, m0 + 128);
+    const float b = bias ? bias[n] : 0.f;
+    float s = 0.f, ss = 0.f;
+    for (int m = m0; m < m1; ++m) {
+        float v = b;
+        for (int z = 0; z < S; ++z) v += partial[((size_t)z * M + m) * N + n];
+        v = DT<T>::rnd(v);
+        DT<T>::st(y + (size_t)m * ldy + n, v);
+        s += v; ss += v * v;
+    }
+    if (stats) {
+        stats[((size_t)blockIdx.y * 2) * N + n] = s;
+        stats[((size_t)blockIdx.y * 2 + 1) * N + n] = ss;
+    }
+}
+extern "C" int nkb_splitk_reduce(int dtype, const float* partial, int splits, int M, int N, void* y, int ldy, const float* bias,
+                                 float* stats, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("splitk_reduce: bad dtype %d", dtype); return 1; }
+    if (splits < 1 || M < 1 || N < 1 || ldy < N) { nkb_set_error("splitk_reduce: bad shape"); return 1; }
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    dim3 grid((N + 255) / 256, (M + 127) / 128);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, dim3(256), 0, stream, partial, splits, M, N, (bf16_t*)y, ldy, bias, stats);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, dim3(256), 0, stream, partial, splits, M, N, (float*)y, ldy, bias, stats);
+    return nkb_check_launch("splitk_reduce");
+}
+
 // strided 2-D fp32 copy-add: dst[r][0..cols) (ld_dst) += src[r][0..cols) (ld_src); used to fold the padded stem
 // weight gradient back into the parameter gradient.
 __global__ void add2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int ld_src, int ld_dst) {

@@ -58,6 +58,7 @@ _SIGS = {
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp]),
     "nkb_layernorm_workspace_floats": (sz, [i32]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
+    "nkb_splitk_reduce": (i32, [i32, vp, i32, i32, i32, vp, i32, vp, vp, vp]),
     "nkb_wfold": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "nkb_image_prep": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp]),
     "nkb_relu6": (i32, [i32, vp, vp, vp, i64, vp]),
@@ -351,6 +352,10 @@ def layernorm_ws(D):
 
 def gelu(dtype, x, dy, out, n):
     check(load().nkb_gelu(dtype, ptr(x), ptr(dy), ptr(out), n, stream()), "gelu")
+
+
+def splitk_reduce(dtype, partial, splits, M, N, y, ldy, bias, stats):
+    check(load().nkb_splitk_reduce(dtype, ptr(partial), splits, M, N, ptr(y), ldy, ptr(bias), ptr(stats), stream()), "splitk_reduce")
 
 
 def wfold(dtype, w, scale, dst, Cout, K):

@@ -30,6 +30,7 @@ _FUSE_MIN_C = int(os.environ.get("NKB_FUSE_MIN_C", "65"))
 _RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
 _ATTN_FUSED_BWD = os.environ.get("NKB_ATTN_FUSED_BWD", "1") != "0"  # whole attention backward in one kernel
 _ATTN_FUSED_DQ = os.environ.get("NKB_ATTN_FUSED_DQ", "1") != "0"   # dQ inside the attention backward-dS kernel
+_SPLITK = os.environ.get("NKB_SPLITK", "1") != "0"              # split-K for skinny Linear layers with K >= 32768
 _EVAL_FOLD = os.environ.get("NKB_EVAL_FOLD", "1") != "0"     # eval mode: BatchNorm folded into the conv (one launch per stage)
 
 
@@ -207,6 +208,14 @@ class HipEngine:
         stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
         if packed:
             hip.stem_conv(self.d, x, self.w_fwd(w), c, stats, N, H, W, co, co)
+        elif w.dim() == 2 and _SPLITK and rows <= 256 and ci >= 32768 and co > 64 and ci % (self.kte * 32) == 0:
+            # skinny Linear with a very long reduction (unicom feature[0]: 128 x 262 144 -> 1 024 would be 8 workgroups of
+            # 4 096 k-steps): 32 K-slices as one batched launch, then one pass that sums them and forms the BN statistics
+            S = 32
+            part = self.ws.get(key + ".splitk", (S, rows, co), torch.float32)
+            hip.gemm_batched(self.d, x, self.w_fwd(w), part, rows, co, ci // S, ci, ci, co, S, 1, (ci // S, 0), (ci // S, 0),
+                             (rows * co, 0), out_f32=True)
+            hip.splitk_reduce(self.d, part, S, rows, co, c, co, None, stats)
         else:
             hip.conv_gemm(self.d, 0, x, self.w_fwd(w), c, stats=stats, **geom)
         sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)

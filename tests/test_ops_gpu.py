@@ -956,3 +956,27 @@ def test_wfold_eval_batchnorm_folding(dtype):
     hip.wfold(hip.dt(dtype), w.to(DEV), scale.to(DEV), dst, Cout, K)
     torch.cuda.synchronize()
     torch.testing.assert_close(dst.float().cpu(), rnd(w * scale[:, None], dtype), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_splitk_linear_with_batchnorm_statistics(dtype):
+    """Skinny Linear with a long reduction as K-slices (nkb_gemm_batched, fp32 partials) + nkb_splitk_reduce: output, bias and
+    the per-128-row-tile channel sums that feed nkb_bn_finalize (unicom feature[0] path)."""
+    torch.manual_seed(23)
+    M, K, N, S = 130, 4096, 192, 8
+    d = hip.dt(dtype)
+    x = rnd(torch.randn(M, K), dtype); w = rnd(torch.randn(N, K) / math.sqrt(K), dtype); b = torch.randn(N)
+    ref = x @ w.t() + b
+    part = torch.empty(S, M, N, device=DEV)
+    hip.gemm_batched(d, x.to(DEV, dtype), w.to(DEV, dtype), part, M, N, K // S, K, K, N, S, 1, (K // S, 0), (K // S, 0), (M * N, 0),
+                     out_f32=True)
+    y = torch.empty(M, N, device=DEV, dtype=dtype)
+    tiles = (M + 127) // 128
+    stats = torch.zeros(tiles, 2, N, device=DEV)
+    hip.splitk_reduce(d, part, S, M, N, y, N, b.to(DEV), stats)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.float().cpu(), ref, **tol(dtype, K))
+    got = y.float()
+    torch.testing.assert_close(stats.sum(0)[0].cpu(), got.sum(0).cpu(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(stats.sum(0)[1].cpu(), (got * got).sum(0).cpu(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(stats[1, 0].cpu(), got[128:].sum(0).cpu(), rtol=1e-4, atol=1e-3)     # second row tile: rows 128..129
