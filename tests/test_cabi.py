@@ -36,3 +36,16 @@ def test_argument_validation_without_gpu():
     assert rc != 0 and b"stride" in lib.nkb_last_error()
     rc = lib.nkb_bn_apply(1, None, None, None, None, None, 10, 12, 0, None, None, None, None)
     assert rc != 0 and b"C=12" in lib.nkb_last_error()
+
+
+def test_binding_arity_matches_header():
+    """Every ctypes signature in hip._SIGS has as many arguments as the prototype in include/nkbhip.h (a changed entry point
+    whose binding was not updated would otherwise corrupt the call's argument registers silently)."""
+    text = (ROOT / "include" / "nkbhip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = dict(re.findall(r"\b(nkb_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    assert len(protos) >= 50
+    for name, (_, argtypes) in hip._SIGS.items():
+        params = protos[name].strip()
+        n = 0 if params in ("", "void") else len([a for a in params.split(",") if a.strip()])
+        assert n == len(argtypes), f"{name}: header has {n} parameters, binding {len(argtypes)}"
