@@ -200,7 +200,14 @@ class HipEngine:
                 ent = self._fold[key] = (self.fold_key, wf, shift)
             y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
             assert res_affine is None or res_affine[0] is None
-            hip.conv_gemm(self.d, 0, x, ent[1], y, bias=ent[2], relu=relu, add=res, ldadd=co if res is not None else 0, **geom)
+            if w.dim() == 2 and self._splitk_ok(rows, ci, co) and res is None and not relu:
+                S = 32                      # skinny Linear with a very long reduction: K-slices + one summing pass (see below)
+                part = self.ws.get(key + ".splitk", (S, rows, co), torch.float32)
+                hip.gemm_batched(self.d, x, ent[1], part, rows, co, ci // S, ci, ci, co, S, 1, (ci // S, 0), (ci // S, 0),
+                                 (rows * co, 0), out_f32=True)
+                hip.splitk_reduce(self.d, part, S, rows, co, y, co, ent[2], None)
+            else:
+                hip.conv_gemm(self.d, 0, x, ent[1], y, bias=ent[2], relu=relu, add=res, ldadd=co if res is not None else 0, **geom)
             return (y, None, None) if defer_apply else y
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
         bits = None
@@ -208,7 +215,7 @@ class HipEngine:
         stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
         if packed:
             hip.stem_conv(self.d, x, self.w_fwd(w), c, stats, N, H, W, co, co)
-        elif w.dim() == 2 and _SPLITK and rows <= 256 and ci >= 32768 and co > 64 and ci % (self.kte * 32) == 0:
+        elif w.dim() == 2 and self._splitk_ok(rows, ci, co):
             # skinny Linear with a very long reduction (unicom feature[0]: 128 x 262 144 -> 1 024 would be 8 workgroups of
             # 4 096 k-steps): 32 K-slices as one batched launch, then one pass that sums them and forms the BN statistics
             S = 32
@@ -250,6 +257,9 @@ class HipEngine:
                                    rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None,
                                    pool_idx=idx, stem_packed=bool(packed), bits=bits)
         return y
+
+    def _splitk_ok(self, rows: int, ci: int, co: int) -> bool:
+        return _SPLITK and rows <= 256 and ci >= 32768 and co > 64 and ci % (self.kte * 32) == 0
 
     def maxpool(self, key: str, x: torch.Tensor, train: bool) -> torch.Tensor:
         N, H, W, C = x.shape
