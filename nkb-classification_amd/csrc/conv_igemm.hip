@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     int xoff[NPX];
     unsigned hmask[NPX], wmask[NPX];                    // bit r / bit s set: filter row r / column s lands inside the image
     const int hsign = p.mode == 0 ? 1 : -1;             // halo: source row of filter row r = own row + hsign * (r - 1)
+    const bool plain1x1 = !HALO && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.stem_cprw == 0 && p.H == p.P && p.W == p.Q;
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
         const int m = HALO ? m0 - 1 + srow + 32 * j : m0 + srow + 32 * j;
@@ -107,6 +108,12 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 for (int rr = 0; rr < 3; ++rr)
                     if ((unsigned)(pp + hsign * (rr - 1)) < (unsigned)p.H) hmask[j] |= 1u << rr;
             }
+            continue;
+        }
+        if (plain1x1) {
+            // 1x1 / stride 1 / no padding: output pixel m reads input pixel m — no (n, p, q) decode, one always-valid tap.
+            // (On the one-k-tile shapes the decode below was a large part of a workgroup's ~450 VALU instructions per wave.)
+            if (m < p.M) { xoff[j] = m * p.ldx * ESZ + cc * 16; hmask[j] = 1u; wmask[j] = 1u; }
             continue;
         }
         if (m < p.M) {
