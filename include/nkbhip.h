@@ -225,19 +225,30 @@ int nkb_dropout(int dtype, int backward, const void* in, const void* add, void* 
                 float p, unsigned long long seed, nkb_stream_t stream);
 int nkb_colsum2d(int dtype, const void* x, float* out, long long rows, int C, long long ld, nkb_stream_t stream);
 
-/* Losses (kind 0: CrossEntropyLoss(weight) mean; kind 1: FocalLoss(alpha, gamma) mean over un-ignored rows).
- * out2[0] = loss, out2[1] = 1/normaliser.  probs/argmax double as the logger's softmax/argmax. */
+/* Losses (kind 0: CrossEntropyLoss(weight); kind 1: FocalLoss(alpha, gamma) over un-ignored rows, losses.py:59-94).
+ * reduction 0 "mean": out2[0] = loss, out2[1] = 1/normaliser; 1 "sum" / 2 "none": out2[0] = sum, out2[1] = 1 (the per-row
+ * losses of "none" are row_state[i].loss, three floats per row).  A label outside [0, C) that is not ignore_index makes the
+ * loss NaN (torch asserts on the device there).  probs/argmax double as the logger's softmax/argmax. */
 int nkb_loss_forward(int kind, const float* logits, int ld, const long long* target, int B, int C,
                      const float* class_weight, float gamma, long long ignore_index, float* probs, int ldp,
-                     int* argmax, void* row_state, float* out2, nkb_stream_t stream);
+                     int* argmax, void* row_state, float* out2, int reduction, nkb_stream_t stream);
 size_t nkb_loss_row_state_bytes(int B);
 int nkb_loss_backward(const float* probs, int ldp, const long long* target, const void* row_state, const float* out2,
-                      const float* grad_out, int B, int C, float* dlogits, int ldd, nkb_stream_t stream);
+                      const float* grad_out, int grad_out_per_row, int B, int C, float* dlogits, int ldd,
+                      nkb_stream_t stream);
 
-/* Fused flat-arena optimizer step. kind: 0 adam, 1 nadam (decoupled wd), 2 radam, 3 sgd. */
+/* Fused flat-arena optimizer step. kind: 0 adam, 1 nadam (decoupled wd), 2 radam, 3 sgd.
+ * skip_flag (device float, may be NULL): the launch does nothing when *skip_flag != 0 — the skipped step of
+ * GradScaler.step (engine.py:59) decided on the device. */
 int nkb_optim_step(int kind, float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n, float lr,
                    float wd, float beta1, float beta2, float eps, float grad_scale, float c0, float c1, float c2,
-                   float c3, nkb_stream_t stream);
+                   float c3, const float* skip_flag, nkb_stream_t stream);
+/* Gradient scaler (train.py:37 torch.cuda.amp.GradScaler; engine.py:55-60): in-place g *= 1 / *scale with an inf/nan check
+ * (*found_inf = 1 when any unscaled value is not finite), and the scale / growth-tracker update of GradScaler.update();
+ * the update also copies found_inf to *last_found_inf and clears found_inf.  scale, found_inf: device floats. */
+int nkb_grad_unscale_check(float* g, long long n, const float* scale, float* found_inf, nkb_stream_t stream);
+int nkb_scaler_update(float* scale, int* growth_tracker, float* found_inf, float* last_found_inf, float growth,
+                      float backoff, int interval, nkb_stream_t stream);
 int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float* out, nkb_stream_t stream);
 
 /* Per-launch HIP-event profiler (bench.py's roofline leg). */

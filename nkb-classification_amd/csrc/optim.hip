@@ -16,7 +16,10 @@ struct OptimArgs {
 };
 
 __global__ void optim_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                  float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n, const OptimArgs a) {
+                                  float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n, const OptimArgs a,
+                                  const float* __restrict__ skip) {
+    // skipped step of the gradient scaler (engine.py:59, GradScaler.step): decided on the device, no host round trip
+    if (skip && *skip != 0.f) return;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float w = p[i];
         float grad = g[i] * a.grad_scale;
@@ -50,7 +53,7 @@ __global__ void optim_step_kernel(float* __restrict__ p, const float* __restrict
 
 extern "C" int nkb_optim_step(int kind, float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n,
                               float lr, float wd, float beta1, float beta2, float eps, float grad_scale, float c0,
-                              float c1, float c2, float c3, hipStream_t stream) {
+                              float c1, float c2, float c3, const float* skip_flag, hipStream_t stream) {
     if (n <= 0) return 0;
     OptimArgs a;
     a.kind = kind; a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
@@ -59,7 +62,7 @@ extern "C" int nkb_optim_step(int kind, float* p, const float* g, float* m, floa
     if (grid > 256 * 16) grid = 256 * 16;
     NkbProfScope prof(NKB_K_OPTIM, stream, 0);
     hipLaunchKernelGGL(optim_step_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16,
-                       (size_t)n, a);
+                       (size_t)n, a, skip_flag);
     return nkb_check_launch("optim_step");
 }
 
@@ -90,4 +93,66 @@ extern "C" int nkb_segment_sumsq(const float* x, const long long* offsets, int n
     NkbProfScope prof(NKB_K_MISC, stream, 0);
     hipLaunchKernelGGL(seg_sumsq_kernel, dim3(nseg), dim3(256), 0, stream, x, offsets, nseg, out);
     return nkb_check_launch("segment_sumsq");
+}
+
+// ---- gradient scaler (torch.cuda.amp.GradScaler as used by /root/reference/train.py:37 and engine.py:55-60) ------------------
+// unscale + inf/nan check over a flat gradient range, in place: g *= 1 / *scale; *found_inf = 1 when any result is not
+// finite (torch's _amp_foreach_non_finite_check_and_unscale_).  The scale lives on the device, so nothing waits for the host.
+__global__ void grad_unscale_check_kernel(float* __restrict__ g, size_t n, const float* __restrict__ scale,
+                                          float* __restrict__ found_inf) {
+    const float inv = 1.f / *scale;
+    bool bad = false;
+    const size_t n4 = n >> 2;
+    f32x4* g4 = (f32x4*)g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = g4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] *= inv; bad |= !(fabsf(v[e]) <= 3.402823466e38f); }
+        g4[i] = v;
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = g[i] * inv;
+        bad |= !(fabsf(v) <= 3.402823466e38f);
+        g[i] = v;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.f;
+}
+extern "C" int nkb_grad_unscale_check(float* g, long long n, const float* scale, float* found_inf, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (((uintptr_t)g & 15) != 0) { nkb_set_error("grad_unscale_check: gradient range must be 16-byte aligned"); return 1; }
+    size_t grid = ((size_t)n / 4 + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (grid < 1) grid = 1;
+    NkbProfScope prof(NKB_K_OPTIM, stream, 0, 8.0 * n);
+    hipLaunchKernelGGL(grad_unscale_check_kernel, dim3((unsigned)grid), dim3(256), 0, stream, g, (size_t)n, scale, found_inf);
+    return nkb_check_launch("grad_unscale_check");
+}
+// scale / growth-tracker update of GradScaler.update() (torch's _amp_update_scale_), then found_inf -> *last_found_inf
+// (what the host reads back one step later to keep its step counters exact) and found_inf = 0 for the next step
+__global__ void scaler_update_kernel(float* scale, int* growth_tracker, float* found_inf, float* last_found_inf,
+                                     float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float f = *found_inf;
+    if (f != 0.f) {
+        *scale = *scale * backoff;
+        *growth_tracker = 0;
+    } else {
+        const int t = *growth_tracker + 1;
+        if (t == interval) {
+            const float ns = *scale * growth;
+            if (fabsf(ns) <= 3.402823466e38f) *scale = ns;
+            *growth_tracker = 0;
+        } else {
+            *growth_tracker = t;
+        }
+    }
+    *last_found_inf = f;
+    *found_inf = 0.f;
+}
+extern "C" int nkb_scaler_update(float* scale, int* growth_tracker, float* found_inf, float* last_found_inf, float growth,
+                                 float backoff, int interval, hipStream_t stream) {
+    NkbProfScope prof(NKB_K_OPTIM, stream, 0);
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, stream, scale, growth_tracker, found_inf, last_found_inf,
+                       growth, backoff, interval);
+    return nkb_check_launch("scaler_update");
 }

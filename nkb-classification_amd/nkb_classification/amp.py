@@ -1,0 +1,151 @@
+"""Gradient scaler for the HIP engine — the `scaler` argument of engine.train_epoch
+(/root/reference/train.py:37 `torch.cuda.amp.GradScaler(enabled=cfg.enable_gradient_scaler)`, used at
+/root/reference/nkb_classification/engine.py:55-60: `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`).
+
+Same constructor arguments, methods and state dict as torch's GradScaler; what differs is where the decision is taken.
+torch reads `found_inf` back to the host inside `step()` — one blocking device->host copy per train step, which would stop
+the enqueue loop from running ahead of the GPU.  Here
+  * `nkb_grad_unscale_check` unscales the flat gradient arena in place and raises a device flag on inf / nan,
+  * the fused optimizer launch (`nkb_optim_step(..., skip_flag)`) tests that flag on the device and does nothing when set,
+  * `nkb_scaler_update` grows / backs off the scale on the device,
+  * the host learns about a skipped step ONE STEP LATE, from a pinned copy of the flag that is normally complete by then, and
+    only to keep the optimizer's step counters (bias corrections) exactly as torch would have them: a skipped step must not
+    advance them, so the counters of the previous call are rolled back before the next one is evaluated.
+With a torch optimizer (or parameters outside the arena) the scaler defers to torch.amp.GradScaler.
+Under data parallelism the gradient exchange has finished before `step()` is called (model._backward_impl waits for the
+reducer), so every rank tests identical reduced gradients and takes the same decision.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip
+
+
+class HipGradScaler:
+    def __init__(self, device="cuda", init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 enabled=True):
+        if growth_factor <= 1.0 or not 0.0 < backoff_factor < 1.0:
+            raise ValueError("growth_factor must be > 1 and backoff_factor in (0, 1)")
+        self._enabled = bool(enabled) and torch.cuda.is_available()
+        self._init_scale, self._growth_factor = float(init_scale), float(growth_factor)
+        self._backoff_factor, self._growth_interval = float(backoff_factor), int(growth_interval)
+        self._state: Optional[torch.Tensor] = None      # device [scale, found_inf, last_found_inf] fp32
+        self._tracker: Optional[torch.Tensor] = None    # device int32 growth tracker
+        self._host = None                               # pinned mirror of last_found_inf
+        self._host_event = None
+        self._last_opt = None                           # optimizer whose previous step may have been skipped
+        self._unscaled = set()
+        self._torch = None                              # fallback for non-fused optimizers
+        self._init_growth_tracker = 0
+
+    # ---- torch.amp.GradScaler surface ----------------------------------------------------------------------
+    def is_enabled(self) -> bool:
+        return self._enabled
+
+    def _lazy_init(self, device):
+        if self._state is None:
+            self._state = torch.tensor([self._init_scale, 0.0, 0.0], device=device, dtype=torch.float32)
+            self._tracker = torch.full((1,), self._init_growth_tracker, device=device, dtype=torch.int32)
+            self._host = torch.zeros(1, dtype=torch.float32).pin_memory()
+
+    def scale(self, outputs):
+        if not self._enabled:
+            return outputs
+        if isinstance(outputs, torch.Tensor):
+            self._lazy_init(outputs.device)
+            return outputs * self._state[0].to(outputs.dtype)
+        return type(outputs)(self.scale(o) for o in outputs)
+
+    def get_scale(self) -> float:
+        if not self._enabled:
+            return 1.0
+        return self._init_scale if self._state is None else float(self._state[0].item())
+
+    def _fused(self, optimizer):
+        from .utils import FusedOptimizer
+        return isinstance(optimizer, FusedOptimizer) and optimizer.arena is not None and optimizer.arena.packed
+
+    def _fallback(self):
+        if self._torch is None:
+            self._torch = torch.amp.GradScaler("cuda", init_scale=self.get_scale(), growth_factor=self._growth_factor,
+                                               backoff_factor=self._backoff_factor,
+                                               growth_interval=self._growth_interval, enabled=True)
+        return self._torch
+
+    def _settle(self):
+        """Apply what the PREVIOUS step's flag says: a skipped step must not have advanced the optimizer's counters."""
+        if self._host_event is None:
+            return
+        self._host_event.synchronize()                 # one step old: complete unless the host is a whole step ahead
+        self._host_event = None
+        if self._host[0] != 0.0 and self._last_opt is not None:
+            self._last_opt.rollback_last_step()
+        self._last_opt = None
+
+    def unscale_(self, optimizer):
+        if not self._enabled:
+            return
+        if not self._fused(optimizer):
+            return self._fallback().unscale_(optimizer)
+        if id(optimizer) in self._unscaled:
+            raise RuntimeError("unscale_() has already been called on this optimizer since the last update().")
+        a = optimizer.arena
+        self._lazy_init(a.flat_grad.device)
+        with torch.cuda.device(a.flat_grad.device):
+            hip.grad_unscale_check(a.flat_grad, a.total, self._state[0:1], self._state[1:2])
+        self._unscaled.add(id(optimizer))
+
+    def step(self, optimizer, *args, **kwargs):
+        if not self._enabled:
+            return optimizer.step(*args, **kwargs)
+        if not self._fused(optimizer):
+            return self._fallback().step(optimizer, *args, **kwargs)
+        self._settle()
+        if id(optimizer) not in self._unscaled:
+            self.unscale_(optimizer)
+        out = optimizer.step(*args, skip_flag=self._state[1:2], **kwargs)
+        self._last_opt = optimizer
+        return out
+
+    def update(self, new_scale=None):
+        if not self._enabled:
+            return
+        if self._torch is not None and self._state is None:
+            return self._torch.update(new_scale)
+        if self._state is None:
+            return
+        if new_scale is not None:
+            self._state[0] = float(new_scale)
+        with torch.cuda.device(self._state.device):
+            hip.scaler_update(self._state[0:1], self._tracker, self._state[1:2], self._state[2:3], self._growth_factor,
+                              self._backoff_factor, self._growth_interval)
+            self._host.copy_(self._state[2:3], non_blocking=True)
+            self._host_event = torch.cuda.Event()
+            self._host_event.record()
+        self._unscaled.clear()
+
+    def state_dict(self):
+        if not self._enabled:
+            return {}
+        tracker = self._init_growth_tracker if self._tracker is None else int(self._tracker.item())
+        return {"scale": self.get_scale(), "growth_factor": self._growth_factor, "backoff_factor": self._backoff_factor,
+                "growth_interval": self._growth_interval, "_growth_tracker": tracker}
+
+    def load_state_dict(self, state):
+        if not self._enabled:
+            return
+        self._init_scale = float(state["scale"])
+        self._growth_factor, self._backoff_factor = float(state["growth_factor"]), float(state["backoff_factor"])
+        self._growth_interval = int(state["growth_interval"])
+        self._init_growth_tracker = int(state["_growth_tracker"])
+        if self._state is not None:
+            self._state[0] = self._init_scale
+            self._tracker.fill_(self._init_growth_tracker)
+
+
+def GradScaler(device="cuda", **kwargs):
+    """torch.amp.GradScaler(device, ...) spelling for call sites written against torch's class."""
+    return HipGradScaler(device, **kwargs)

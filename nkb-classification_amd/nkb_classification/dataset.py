@@ -209,7 +209,8 @@ class DeviceLoader:
 
 def get_dataset(data, pipeline=None):
     """dataset.py:541-629.  Extra keys: `device_pipeline=True` (+ `device`, `hflip_p`, `vflip_p`, `mean`, `std`) wraps the
-    folder loader in a DeviceLoader; `rank` / `world` shard the data for one-process-per-GPU training."""
+    folder loader in a DeviceLoader; `rank` / `world` (+ `shard_seed`, the seed of the permutation all ranks share) shard the data for one-process-per-GPU
+    training."""
     kind = data.get("type", "folder")
     size = data.get("size", 224)
     on_device = bool(data.get("device_pipeline", False))
@@ -225,9 +226,10 @@ def get_dataset(data, pipeline=None):
     rank, world = int(data.get("rank", 0)), int(data.get("world", 1))
     sampler, shuffle = None, data.get("shuffle", False)
     if data.get("weighted_sampling", False):              # dataset.py:607-617
-        sampler, shuffle = ImbalancedDatasetSampler(ds, seed=data.get("seed") if world > 1 else None, rank=rank, world=world), False
+        sampler, shuffle = ImbalancedDatasetSampler(ds, seed=data.get("shard_seed", 0) if world > 1 else None, rank=rank,
+                                                    world=world), False
     elif world > 1:
-        sampler, shuffle = ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=data.get("seed", 0)), False
+        sampler, shuffle = ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=data.get("shard_seed", 0)), False
     loader = DataLoader(ds, batch_size=data["batch_size"], shuffle=shuffle, sampler=sampler,
                         num_workers=data.get("num_workers", 0), drop_last=data.get("drop_last", False), pin_memory=True)
     if on_device:

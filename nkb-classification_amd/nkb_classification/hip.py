@@ -72,10 +72,12 @@ _SIGS = {
     "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_dropout": (i32, [i32, i32, vp, vp, vp, vp, i64, f32, C.c_ulonglong, vp]),
     "nkb_colsum2d": (i32, [i32, vp, vp, i64, i32, i64, vp]),
-    "nkb_loss_forward": (i32, [i32, vp, i32, vp, i32, i32, vp, f32, i64, vp, i32, vp, vp, vp, vp]),
+    "nkb_loss_forward": (i32, [i32, vp, i32, vp, i32, i32, vp, f32, i64, vp, i32, vp, vp, vp, i32, vp]),
     "nkb_loss_row_state_bytes": (sz, [i32]),
-    "nkb_loss_backward": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
-    "nkb_optim_step": (i32, [i32, vp, vp, vp, vp, vp, i64] + [f32] * 10 + [vp]),
+    "nkb_loss_backward": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp]),
+    "nkb_optim_step": (i32, [i32, vp, vp, vp, vp, vp, i64] + [f32] * 10 + [vp, vp]),
+    "nkb_grad_unscale_check": (i32, [vp, i64, vp, vp, vp]),
+    "nkb_scaler_update": (i32, [vp, vp, vp, vp, f32, f32, i32, vp]),
     "nkb_segment_sumsq": (i32, [vp, vp, i32, vp, vp]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
@@ -124,6 +126,8 @@ def ptr(t):
 
 
 def stream():
+    # the current stream of the CURRENT device: entry points run under torch.cuda.device(<tensor device>) (model._logits,
+    # FusedOptimizer.step, train.py's set_device), so this is the stream of the device that holds the operands
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -277,19 +281,31 @@ def pad_cast(dtype, src, dst, rows, C_, ld_src, ld_dst, mul=1.0):
     check(load().nkb_pad_cast(dtype, ptr(src), ptr(dst), rows, C_, ld_src, ld_dst, mul, stream()), "pad_cast")
 
 
-def loss_forward(kind, logits, ld, target, B, C_, class_weight, gamma, ignore_index, probs, ldp, argmax, row_state, out2):
+def loss_forward(kind, logits, ld, target, B, C_, class_weight, gamma, ignore_index, probs, ldp, argmax, row_state, out2,
+                 reduction=0):
     check(load().nkb_loss_forward(kind, ptr(logits), ld, ptr(target), B, C_, ptr(class_weight), gamma, ignore_index,
-                                  ptr(probs), ldp, ptr(argmax), ptr(row_state), ptr(out2), stream()), "loss_forward")
+                                  ptr(probs), ldp, ptr(argmax), ptr(row_state), ptr(out2), reduction, stream()),
+          "loss_forward")
 
 
-def loss_backward(probs, ldp, target, row_state, out2, grad_out, B, C_, dlogits, ldd):
-    check(load().nkb_loss_backward(ptr(probs), ldp, ptr(target), ptr(row_state), ptr(out2), ptr(grad_out), B, C_,
-                                   ptr(dlogits), ldd, stream()), "loss_backward")
+def loss_backward(probs, ldp, target, row_state, out2, grad_out, B, C_, dlogits, ldd, per_row=False):
+    check(load().nkb_loss_backward(ptr(probs), ldp, ptr(target), ptr(row_state), ptr(out2), ptr(grad_out), int(per_row), B,
+                                   C_, ptr(dlogits), ldd, stream()), "loss_backward")
 
 
-def optim_step(kind, p, g, m, v, shadow, n, lr, wd, beta1, beta2, eps, grad_scale, c0=0.0, c1=0.0, c2=0.0, c3=0.0):
+def optim_step(kind, p, g, m, v, shadow, n, lr, wd, beta1, beta2, eps, grad_scale, c0=0.0, c1=0.0, c2=0.0, c3=0.0,
+               skip_flag=None):
     check(load().nkb_optim_step(kind, ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, lr, wd, beta1, beta2, eps,
-                                grad_scale, c0, c1, c2, c3, stream()), "optim_step")
+                                grad_scale, c0, c1, c2, c3, ptr(skip_flag), stream()), "optim_step")
+
+
+def grad_unscale_check(g, n, scale, found_inf):
+    check(load().nkb_grad_unscale_check(ptr(g), n, ptr(scale), ptr(found_inf), stream()), "grad_unscale_check")
+
+
+def scaler_update(scale, tracker, found_inf, last_found_inf, growth, backoff, interval):
+    check(load().nkb_scaler_update(ptr(scale), ptr(tracker), ptr(found_inf), ptr(last_found_inf), growth, backoff,
+                                   interval, stream()), "scaler_update")
 
 
 def segment_sumsq(x, offsets, nseg, out):

@@ -109,41 +109,47 @@ class BaseLogger:
 
 
 class LocalExperiment:
-    """metrics.csv writer with the reference's file contract (logging.py:18-38): tab-separated, one row per epoch."""
+    """Scalar-metric sink of a run directory.  File contract of the reference's writer (logging.py:18-38), which the eval /
+    plotting tooling around it reads: `<path>/metrics.csv`, tab-separated, header `Epoch` followed by the metric names in
+    sorted order, one row per epoch, missing values left empty, file rewritten whenever a value arrives."""
 
     def __init__(self, path=""):
-        import pandas as pd
         self.path = Path(path)
-        self.metrics = pd.DataFrame([], columns=["Epoch"])
+        self._rows = {}          # epoch -> {column: value}
 
     def log_metric(self, name, value, epoch=0, step=None, prefix=None):
-        import pandas as pd
-        if prefix is not None:
-            name = f"{prefix}/{name}"
-        if isinstance(value, Sequence):
-            value = np.mean(value)
-        self.metrics.loc[epoch, name] = value
-        self.metrics.loc[:, "Epoch"] = range(len(self.metrics))
-        first = self.metrics.iloc[:, 0]
-        rest = self.metrics.iloc[:, 1:].reindex(sorted(self.metrics.columns[1:]), axis=1)
-        self.metrics = pd.concat([first, rest], axis=1)
-        self.metrics.to_csv(self.path / "metrics.csv", index=False, sep="\t")
+        column = name if prefix is None else f"{prefix}/{name}"
+        self._rows.setdefault(epoch, {})[column] = float(np.mean(value)) if isinstance(value, Sequence) else value
+        self._write()
 
     def log_metrics(self, metrics_dict, epoch=0, step=None, prefix=None):
         for name, value in metrics_dict.items():
-            self.log_metric(name, value, epoch=epoch, prefix=prefix)
+            self._rows.setdefault(epoch, {})[name if prefix is None else f"{prefix}/{name}"] = \
+                float(np.mean(value)) if isinstance(value, Sequence) else value
+        self._write()
+
+    def _write(self):
+        columns = sorted({c for row in self._rows.values() for c in row})
+        lines = ["\t".join(["Epoch"] + columns)]
+        for i, epoch in enumerate(sorted(self._rows)):
+            row = self._rows[epoch]
+            lines.append("\t".join([str(i)] + ["" if row.get(c) is None else repr(float(row[c])) for c in columns]))
+        (self.path / "metrics.csv").write_text("\n".join(lines) + "\n")
 
 
 def get_local_experiment(cfg_exp):
+    """Fresh run directory `<path>`, `<path>1`, `<path>2`, ... with a `weights/` sub-directory (logging.py:56-66).  Called by
+    rank 0 only under data parallelism (train.py)."""
     assert cfg_exp is not None and "path" in cfg_exp.keys()
-    exp_path = Path(cfg_exp["path"])
-    n = 1
-    while exp_path.exists():
-        exp_path = Path(cfg_exp["path"] + str(n))
-        n += 1
-    exp_path.mkdir(parents=True)
-    (exp_path / "weights").mkdir()
-    return LocalExperiment(exp_path)
+    base, n = cfg_exp["path"], 0
+    while True:
+        run = Path(base if n == 0 else f"{base}{n}")
+        try:
+            run.mkdir(parents=True, exist_ok=False)
+            (run / "weights").mkdir()
+            return LocalExperiment(run)
+        except FileExistsError:
+            n += 1
 
 
 class TrainLogger(BaseLogger):

@@ -22,7 +22,7 @@ DEFAULT_FOCAL_GAMMA = 2.0
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, target: Tensor, kind: int, weight: Optional[Tensor], gamma: float,
-                ignore_index: int):
+                ignore_index: int, reduction: int = 0):
         B, C = logits.shape
         dev = logits.device
         ld = logits.stride(0)
@@ -30,10 +30,13 @@ class _LossFn(torch.autograd.Function):
         argmax = torch.empty(B, device=dev, dtype=torch.int32)
         rows = torch.empty(hip.load().nkb_loss_row_state_bytes(B), device=dev, dtype=torch.uint8)
         out2 = torch.empty(2, device=dev, dtype=torch.float32)
-        hip.loss_forward(kind, logits, ld, target, B, C, weight, gamma, ignore_index, probs, C, argmax, rows, out2)
+        hip.loss_forward(kind, logits, ld, target, B, C, weight, gamma, ignore_index, probs, C, argmax, rows, out2,
+                         reduction)
         ctx.save_for_backward(probs, target, rows, out2)
         ctx.shape = (B, C)
-        loss = out2[0].clone()
+        ctx.per_row = reduction == 2
+        # "none": one loss per row (rows labelled ignore_index carry 0 here; FocalLoss.forward drops them afterwards)
+        loss = rows.view(torch.float32).view(B, 3)[:, 0].clone() if ctx.per_row else out2[0].clone()
         ctx.mark_non_differentiable(probs, argmax)
         return loss, probs, argmax
 
@@ -42,8 +45,8 @@ class _LossFn(torch.autograd.Function):
         probs, target, rows, out2 = ctx.saved_tensors
         B, C = ctx.shape
         dl = torch.empty(B, C, device=probs.device, dtype=torch.float32)
-        hip.loss_backward(probs, C, target, rows, out2, gout.contiguous().float(), B, C, dl, C)
-        return dl, None, None, None, None, None
+        hip.loss_backward(probs, C, target, rows, out2, gout.contiguous().float(), B, C, dl, C, per_row=ctx.per_row)
+        return dl, None, None, None, None, None, None
 
 
 class _HipLoss(nn.Module):
@@ -52,7 +55,7 @@ class _HipLoss(nn.Module):
     def _class_weight(self) -> Optional[Tensor]:
         return None
 
-    def _run(self, x: Tensor, y: Tensor, gamma: float, ignore_index: int) -> Tensor:
+    def _run(self, x: Tensor, y: Tensor, gamma: float, ignore_index: int, reduction: int = 0) -> Tensor:
         hip.require_device(x, type(self).__name__)
         if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
             raise RuntimeError(f"{type(self).__name__}: expected fp32 logits [batch, classes], got {tuple(x.shape)} {x.dtype}")
@@ -60,7 +63,7 @@ class _HipLoss(nn.Module):
         w = self._class_weight()
         if w is not None and w.device != x.device:
             w = w.to(x.device)
-        loss, probs, argmax = _LossFn.apply(x, y, self.kind, w, float(gamma), int(ignore_index))
+        loss, probs, argmax = _LossFn.apply(x, y, self.kind, w, float(gamma), int(ignore_index), reduction)
         # by-products for the epoch logger (logging.py:268-281): softmax confidences and argmax of these logits
         x._nkb_side = (probs, argmax)
         return loss
@@ -90,8 +93,6 @@ class FocalLoss(_HipLoss):
                  ignore_index: int = -100):
         if reduction not in ("mean", "sum", "none"):
             raise ValueError('Reduction must be one of: "mean", "sum", "none".')
-        if reduction != "mean":
-            raise NotImplementedError("the HIP focal loss implements reduction='mean' (what get_loss constructs)")
         super().__init__()
         self.register_buffer("alpha", alpha)
         self.gamma = gamma
@@ -110,7 +111,16 @@ class FocalLoss(_HipLoss):
             c = x.shape[1]
             x = x.permute(0, *range(2, x.ndim), 1).reshape(-1, c)
             y = y.view(-1)
-        return self._run(x, y, self.gamma, self.ignore_index)
+        if self.reduction == "mean":
+            return self._run(x, y, self.gamma, self.ignore_index)
+        # losses.py:66-70 / 89-94: "sum" adds the un-ignored rows' losses, "none" returns them row by row; an input whose
+        # rows are all ignored yields a CPU scalar 0 (this branch reads the mask on the host, as the reference does)
+        keep = y != self.ignore_index
+        if not bool(keep.any()):
+            return torch.tensor(0.0)
+        if self.reduction == "sum":
+            return self._run(x, y, self.gamma, self.ignore_index, reduction=1)
+        return self._run(x, y, self.gamma, self.ignore_index, reduction=2)[keep.to(x.device)]
 
 
 class MultitaskCriterion:

@@ -39,7 +39,8 @@ class _NetFn(torch.autograd.Function):
         if ctx.token != owner._fwd_token:
             raise RuntimeError("HIP engine: backward() called after a newer forward overwrote the saved "
                                "activations (only the most recent forward can be differentiated)")
-        owner._backward_impl(glogits)
+        with torch.cuda.device(glogits.device):
+            owner._backward_impl(glogits)
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
@@ -54,6 +55,7 @@ class _HipClassifier(nn.Module):
         self._active: HipEngine = None
         self._nbt_flat = None
         self.grad_ready_hook = None   # set by parallel.GradReducer: called as hook(lo, hi) while backward runs
+        self.grad_done_hook = None    # set by parallel.GradReducer: called once at the end of backward
 
     # ---- reference API -------------------------------------------------------------------
     @staticmethod
@@ -184,6 +186,11 @@ class _HipClassifier(nn.Module):
                         hook(*rng, side_event=eng.side_event())
             self.emb_model.run_backward(eng, g_emb, on_done)
         eng.wait_side()
+        if self.grad_done_hook is not None:
+            # data parallel: the remaining buckets go out and the compute stream is made to wait for the exchange HERE, so
+            # whatever reads the gradients next (GradScaler.unscale_, gradient-norm logging, the optimizer) sees the reduced
+            # values on every rank — not inside optimizer.step, which a scaler may skip on one rank only
+            self.grad_done_hook()
         arena.publish_grads(wanted)
 
     def _logits(self, x: torch.Tensor) -> torch.Tensor:
@@ -193,13 +200,15 @@ class _HipClassifier(nn.Module):
         if x.shape[0] == 0 or x.shape[1] != 3:
             raise RuntimeError(f"expected a non-empty batch of 3-channel images, got {tuple(x.shape)}")
         x = x.contiguous()
-        self._active = self._engine(x.device, self._compute_dtype())
-        self._fwd_token += 1
-        params = [p for p in self.parameters() if p.requires_grad]
-        if torch.is_grad_enabled() and self.training and params:
-            return _NetFn.apply(self, x, *params)
-        with torch.no_grad():
-            return self._forward_impl(x)
+        # every launch below goes to the current stream of the CURRENT device (hip.stream()): make that the images' device
+        with torch.cuda.device(x.device):
+            self._active = self._engine(x.device, self._compute_dtype())
+            self._fwd_token += 1
+            params = [p for p in self.parameters() if p.requires_grad]
+            if torch.is_grad_enabled() and self.training and params:
+                return _NetFn.apply(self, x, *params)
+            with torch.no_grad():
+                return self._forward_impl(x)
 
 
 class SingletaskClassifier(_HipClassifier):

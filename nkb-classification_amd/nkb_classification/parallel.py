@@ -10,6 +10,7 @@ BatchNorm statistics stay per-GPU (no SyncBN), as in standard DDP.
 """
 from __future__ import annotations
 
+from collections import defaultdict
 from typing import List, Optional
 
 import torch
@@ -29,9 +30,10 @@ class GradReducer:
         self._side_event = None
         self._stream: Optional[torch.cuda.Stream] = None
         model.grad_ready_hook = self.on_range_ready
+        model.grad_done_hook = self.wait          # end of backward: nothing reads a gradient before the exchange is done
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
-            self._wrap_step(optimizer)
+            self._wrap_step(optimizer)        # idempotent second wait for models that do not call grad_done_hook
 
     # -- start-of-training synchronisation: parameters and BN buffers from rank 0 --------------------
     def broadcast_state(self, flat_param: torch.Tensor, buffers=()):
@@ -118,3 +120,43 @@ class GradReducer:
             return inner(*a, **k)
 
         optimizer.step = step
+
+
+# ---- helpers for the config-driven entry point (train.py) ------------------------------------------------------------------
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def attach(model, optimizer, device) -> GradReducer:
+    """Make `model` a data-parallel replica: pack its parameter arena on `device`, copy rank 0's parameters, BatchNorm
+    running statistics and `num_batches_tracked` to every rank, and hook the gradient exchange into backward."""
+    device = torch.device(device)
+    if not model.arena.still_packed() or model.arena.device != device:
+        model._pack(device)                                       # parameters become views of one flat buffer
+    reducer = GradReducer(model, optimizer)
+    buffers = [b for name, b in model.named_buffers() if not name.endswith("num_batches_tracked")]
+    nbt = getattr(model, "_nbt_flat", None)
+    reducer.broadcast_state(model.arena.flat_param, buffers + ([nbt] if nbt is not None else []))
+    model.arena.mark_dirty()                                      # shadows / folded filters follow the received values
+    return reducer
+
+
+def gather_epoch_results(results: dict) -> dict:
+    """Concatenate the per-rank result lists of engine.train_epoch / val_epoch (logging.py:287-294) in rank order, so that
+    metrics.compute_metrics sees the whole epoch on every rank.  Single-process runs pass through."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return results
+    keys = ("running_loss", "confidences", "predictions", "ground_truth")
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, {k: results[k] for k in keys})
+    out = dict(results)
+    for k in keys:
+        if isinstance(results[k], dict):
+            merged = defaultdict(list)
+            for part in parts:
+                for task, vals in part[k].items():
+                    merged[task].extend(vals)
+            out[k] = merged
+        else:
+            out[k] = [v for part in parts for v in part[k]]
+    return out

@@ -96,12 +96,30 @@ class FusedOptimizer(torch.optim.Optimizer):
             return None
         return lo, hi
 
+    def rollback_last_step(self):
+        """Undo the host-side bookkeeping of the most recent step() (its step counters and NAdam's mu_product): the
+        gradient scaler found that the device skipped that step (amp.HipGradScaler), and torch does not count skipped steps."""
+        if self._prev_gstate is not None:
+            self._gstate = self._prev_gstate
+            self._prev_gstate = None
+
+    _prev_gstate = None
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, skip_flag=None):
+        """skip_flag: device float; when it is non-zero at execution time the launches of this step do nothing."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._prev_gstate = [dict(g) for g in self._gstate]
+        dev = next((p.device for g in self.param_groups for p in g["params"] if p.is_cuda), None)
+        if dev is not None and dev != torch.device("cuda", torch.cuda.current_device()):
+            with torch.cuda.device(dev):        # kernels go to the stream of the device that holds the parameters
+                return self._step_impl(loss, skip_flag)
+        return self._step_impl(loss, skip_flag)
+
+    def _step_impl(self, loss, skip_flag):
         touched_arena = False
         shadowed = 0            # arena elements whose bf16 shadow this step's launches rewrote
         for group, gstate in zip(self.param_groups, self._gstate):
@@ -120,7 +138,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                 m, v = a.moments()
                 shadow = a.shadow[lo:hi] if a.shadow is not None else None
                 hip.optim_step(kcode, a.flat_param[lo:hi], a.flat_grad[lo:hi], m[lo:hi], v[lo:hi], shadow, hi - lo,
-                               lr, wd, beta1, beta2, eps, self.grad_scale, *sc)
+                               lr, wd, beta1, beta2, eps, self.grad_scale, *sc, skip_flag=skip_flag)
                 touched_arena = True
                 if shadow is not None and len(live) == len(group["params"]):
                     shadowed += hi - lo
@@ -137,7 +155,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                 if not (_dense(p) and _dense(g) and p.stride() == g.stride()):
                     raise RuntimeError("FusedOptimizer: parameter/gradient must be dense with equal strides")
                 hip.optim_step(kcode, p, g, st.get("exp_avg"), st.get("exp_avg_sq"), None, p.numel(), lr, wd, beta1,
-                               beta2, eps, self.grad_scale, *sc)
+                               beta2, eps, self.grad_scale, *sc, skip_flag=skip_flag)
                 if self.arena is not None and self.arena.owns(p):
                     touched_arena = True
         if touched_arena:

@@ -7,7 +7,12 @@ backbone freeze policy, train_epoch / val_epoch, compute_metrics, best-by-valida
 checkpoints under <experiment>/weights/.  Checkpoints are state dicts with timm-compatible keys
 (`best.pth`, `last.pth`) plus the TorchScript archives `scripted_best.pt` / `scripted_last.pt` of train.py:66-73,
 scripted from a plain-torch module with the same architecture and weights (nkb_classification/scripted.py).
-Launch under `torch.distributed.run` to train data-parallel (one process per GPU, RCCL gradient all-reduce).
+Launch under `torch.distributed.run` to train data-parallel (one process per GPU, RCCL gradient all-reduce): the reference is
+single-device (train.py:98), so everything rank-aware here is new — rank 0's parameters and BatchNorm buffers are broadcast
+before the first step, every rank reads its own shard of the data (`rank` / `world` injected into cfg.train_data /
+cfg.val_data), the per-epoch result lists are gathered from all ranks before `compute_metrics`, and only rank 0 creates the
+experiment directory, writes metrics.csv / classes.json and saves checkpoints.  Optional config keys: `seed` (default 0).
+Environment (tests / rehearsals): NKB_DDP_BACKEND (default "nccl" = RCCL), NKB_DDP_ONE_GPU=1 (every rank on cuda:0).
 """
 from __future__ import annotations
 
@@ -32,23 +37,31 @@ from nkb_classification.metrics import compute_metrics  # noqa: E402
 from nkb_classification.model import get_model  # noqa: E402
 from nkb_classification.scripted import save_scripted  # noqa: E402
 from nkb_classification.utils import get_optimizer, get_scheduler, read_py_config  # noqa: E402
+from nkb_classification.amp import HipGradScaler  # noqa: E402
+from nkb_classification import parallel  # noqa: E402
 
 
 def train(model, train_loader, val_loader, optimizer, scheduler, criterion, comet_experiment, local_experiment, device,
           cfg):
-    model_path = local_experiment.path / "weights"
+    """Epoch driver with the reference's signature (train.py:19-73).  local_experiment is None on ranks other than 0."""
+    rank0 = parallel.rank() == 0
+    model_path = local_experiment.path / "weights" if local_experiment is not None else None
     best_val_acc = 0
     classes = train_loader.dataset.classes
     train_logger = TrainLogger(cfg, comet_experiment, local_experiment, classes)
     train_logger.log_images_at_start(train_loader)
-    scaler = torch.amp.GradScaler("cuda", enabled=cfg.enable_gradient_scaler)
-    rank0 = (not torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
+    scaler = HipGradScaler("cuda", enabled=cfg.enable_gradient_scaler)
 
-    for epoch in tqdm(range(cfg.n_epochs), desc="Training epochs"):
+    for epoch in tqdm(range(cfg.n_epochs), desc="Training epochs", disable=not rank0):
         if epoch in cfg.backbone_state_policy.keys():
             model.set_backbone_state(cfg.backbone_state_policy[epoch])
-        train_results = train_epoch(model, train_loader, optimizer, scheduler, scaler, criterion, device, cfg, train_logger)
-        val_results = val_epoch(model, val_loader, criterion, device, cfg, train_logger)
+        for loader in (train_loader, val_loader):
+            sampler = getattr(getattr(loader, "loader", loader), "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)                 # data parallel: the shared permutation is re-drawn per epoch
+        train_results = parallel.gather_epoch_results(
+            train_epoch(model, train_loader, optimizer, scheduler, scaler, criterion, device, cfg, train_logger))
+        val_results = parallel.gather_epoch_results(val_epoch(model, val_loader, criterion, device, cfg, train_logger))
         train_results["metrics"] = compute_metrics(cfg, train_results)
         val_results["metrics"] = compute_metrics(cfg, val_results)
         epoch_val_acc = val_results["metrics"]["epoch_acc"]
@@ -61,6 +74,15 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, come
             save_scripted(model, Path(model_path, "scripted_best.pt"))
         torch.save(model.state_dict(), Path(model_path, "last.pth"))
         save_scripted(model, Path(model_path, "scripted_last.pt"))
+    dump = os.environ.get("NKB_DUMP_PARAMS")
+    if dump:         # test hook (tests/test_step_semantics_gpu.py): what THIS rank ended up with
+        sampler = getattr(getattr(train_loader, "loader", train_loader), "sampler", None)
+        gt = train_results["ground_truth"]
+        torch.save(dict(flat_param=model.arena.flat_param.cpu(), buffers={k: v.cpu() for k, v in model.named_buffers()},
+                        head_weight=model.state_dict()["classifier.1.weight"].cpu() if cfg.task == "single" else None,
+                        n_train=len(gt) if isinstance(gt, list) else len(next(iter(gt.values()))),
+                        dataset_len=len(train_loader.dataset), shard_len=len(sampler) if sampler is not None else -1),
+                   Path(dump, f"params_rank{parallel.rank()}.pt"))
 
 
 def main():
@@ -69,27 +91,35 @@ def main():
     args = parser.parse_args()
     exec(read_py_config(args.config), globals(), globals())
     world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
     device = torch.device(cfg.device)  # noqa: F821 (cfg is bound by the exec above, as in the reference)
     if world > 1:
-        local = int(os.environ.get("LOCAL_RANK", 0))
+        local = 0 if os.environ.get("NKB_DDP_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", 0))
         device = torch.device("cuda", local)
-        torch.cuda.set_device(device)
-        torch.distributed.init_process_group("nccl", device_id=device)
-    train_loader = get_dataset(cfg.train_data, getattr(cfg, "train_pipeline", None))  # noqa: F821
+    if device.type == "cuda":
+        torch.cuda.set_device(device)          # hip.stream() is the current device's stream: make it the model's device
+    if world > 1:
+        backend = os.environ.get("NKB_DDP_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+    seed = int(getattr(cfg, "seed", 0))  # noqa: F821
+    torch.manual_seed(seed)                    # same initial weights everywhere even before the broadcast below
+    shard = {"rank": rank, "world": world, "shard_seed": seed} if world > 1 else {}
+    train_loader = get_dataset({**cfg.train_data, **shard}, getattr(cfg, "train_pipeline", None))  # noqa: F821
     classes = train_loader.dataset.classes
-    if "classes" not in cfg.val_data.keys():  # noqa: F821
-        cfg.val_data = {**cfg.val_data, "classes": classes}  # noqa: F821
-    val_loader = get_dataset(cfg.val_data, getattr(cfg, "val_pipeline", None))  # noqa: F821
+    val_data = cfg.val_data if "classes" in cfg.val_data.keys() else {**cfg.val_data, "classes": classes}  # noqa: F821
+    val_loader = get_dataset({**val_data, **shard}, getattr(cfg, "val_pipeline", None))
     model = get_model(cfg.model, classes, device, compile=cfg.compile)  # noqa: F821
     optimizer = get_optimizer(model, cfg_optimizer=cfg.optimizer)  # noqa: F821
     scheduler = get_scheduler(optimizer, cfg.lr_policy)  # noqa: F821
     criterion = get_loss(cfg.criterion, device)  # noqa: F821
     if world > 1:
-        from nkb_classification.parallel import GradReducer
-        GradReducer(model, optimizer)
-    local_experiment = get_local_experiment(cfg.experiment["local"])  # noqa: F821
+        parallel.attach(model, optimizer, device)
+        torch.manual_seed(seed + 1 + rank)     # dropout / stochastic-depth draws differ per rank from here on
+    # train.py:104-108: only rank 0 owns the run directory (no exists()->mkdir race, one metrics.csv)
+    local_experiment = get_local_experiment(cfg.experiment["local"]) if rank == 0 else None  # noqa: F821
     train(model, train_loader, val_loader, optimizer, scheduler, criterion, None, local_experiment, device, cfg)  # noqa: F821
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -271,11 +271,76 @@ def g4_engine(ref_engine, ref_losses, ref_utils):
     return out
 
 
+def _import_ref_logging():
+    """logging.py imports comet_ml / torchvision / matplotlib at module level only for its Comet and image-grid sinks; none of
+    them is installed here.  Empty stand-in modules satisfy those imports; BaseLogger itself — the code
+    the goldens come from — uses none of them."""
+    import importlib
+    import types
+    for name, attrs in (("comet_ml", {"Experiment": object}), ("torchvision", {}), ("torchvision.transforms", {}),
+                        ("torchvision.utils", {"make_grid": None}), ("matplotlib", {}), ("matplotlib.pyplot", {})):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            mod = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(mod, k, v)
+            sys.modules[name] = mod
+            if "." in name:
+                setattr(sys.modules[name.split(".")[0]], name.split(".")[1], mod)
+    from nkb_classification import logging as ref_logging
+    assert str(REF) in ref_logging.__file__
+    return ref_logging
+
+
 def g5_logger():
-    # logging.py:261-281 cannot be imported here (comet_ml / torchvision / matplotlib absent);
-    # these are the values SURVEY.md §8(c) G5 recorded from its probe of BaseLogger.log_iter.
-    return dict(preds=[[.1, .9], [2, -1]], confidences=[[0.3100255, 0.6899744], [0.9525741, 0.0474259]],
-                predictions=[1, 0], source="SURVEY.md §8(c) G5 probe values")
+    """BaseLogger.init_iter_logs / log_iter / get_epoch_results (logging.py:245-294) run on fixed inputs: the probe rows of
+    SURVEY.md §8(c), a seeded multi-batch single-task case, and a multi-task case.  The multi-task CONSTRUCTOR reads an
+    attribute that is never assigned (logging.py:243) and cannot run at reference HEAD, so that instance is created without
+    it and its four attributes set by hand; everything recorded below is then produced by the reference's own methods."""
+    ref_logging = _import_ref_logging()
+    from types import SimpleNamespace
+    out = {}
+    lg = ref_logging.BaseLogger(SimpleNamespace(task="single"), ["a", "b"])
+    lg.init_iter_logs()
+    preds = torch.tensor([[.1, .9], [2., -1.]])
+    lg.log_iter(preds, torch.tensor([1, 1]), torch.tensor(0.75))
+    res = lg.get_epoch_results()
+    out["probe"] = dict(preds=preds.tolist(), true=[1, 1], loss=0.75, running_loss=res["running_loss"],
+                        confidences=res["confidences"], predictions=res["predictions"], ground_truth=res["ground_truth"])
+    g = torch.Generator().manual_seed(5)
+    lg.init_iter_logs()
+    batches = []
+    for b in (8, 8, 5):
+        x = torch.randn(b, 7, generator=g) * 3
+        y = torch.randint(0, 7, (b,), generator=g)
+        loss = torch.rand((), generator=g)
+        lg.log_iter(x, y, loss)
+        batches.append(dict(preds=x.tolist(), true=y.tolist(), loss=float(loss)))
+    lg.log_images_if_needed(torch.zeros(1, 3, 2, 2))
+    res = lg.get_epoch_results()
+    out["single"] = dict(batches=batches, running_loss=res["running_loss"], confidences=res["confidences"],
+                         predictions=res["predictions"], ground_truth=res["ground_truth"],
+                         images_shape=list(res["images"].shape))
+    classes = {"shape": ["a", "b", "c"], "color": ["r", "g"]}
+    mt = ref_logging.BaseLogger.__new__(ref_logging.BaseLogger)
+    mt.cfg, mt.task, mt.classes, mt.target_names = SimpleNamespace(task="multi"), "multi", classes, sorted(classes)
+    mt.init_iter_logs()
+    batches = []
+    for b in (4, 3):
+        pred = {t: torch.randn(b, len(c), generator=g) for t, c in classes.items()}
+        true = {t: torch.randint(0, len(c), (b,), generator=g) for t, c in classes.items()}
+        loss = {t: torch.rand((), generator=g) for t in classes}
+        loss["loss"] = sum(loss.values())
+        mt.log_iter(pred, true, loss)
+        batches.append(dict(preds={t: v.tolist() for t, v in pred.items()}, true={t: v.tolist() for t, v in true.items()},
+                            loss={t: float(v) for t, v in loss.items()}))
+    res = mt.get_epoch_results()
+    out["multi"] = dict(classes=classes, batches=batches, running_loss=dict(res["running_loss"]),
+                        confidences=dict(res["confidences"]), predictions=dict(res["predictions"]),
+                        ground_truth=dict(res["ground_truth"]))
+    out["source"] = "reference BaseLogger (logging.py:218-294) imported with stand-in modules for comet_ml / torchvision / matplotlib"
+    return out
 
 
 def main():
@@ -289,8 +354,11 @@ def main():
     assert str(REF) in ref_engine.__file__
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
-    blobs = dict(g1_losses=g1_losses(ref_losses), g2_optim=g2_optim(ref_utils), g3_metrics=g3_metrics(ref_metrics),
-                 g4_engine=g4_engine(ref_engine, ref_losses, ref_utils), g5_logger=g5_logger())
+    makers = dict(g1_losses=lambda: g1_losses(ref_losses), g2_optim=lambda: g2_optim(ref_utils),
+                  g3_metrics=lambda: g3_metrics(ref_metrics),
+                  g4_engine=lambda: g4_engine(ref_engine, ref_losses, ref_utils), g5_logger=g5_logger)
+    only = sys.argv[1:]                     # e.g. `python oracle/make_golden.py g5_logger` regenerates one fixture
+    blobs = {name: make() for name, make in makers.items() if not only or name in only}
     for name, blob in blobs.items():
         blob["_meta"] = dict(torch=torch.__version__, generator="oracle/make_golden.py",
                              reference="nkb-tech/nkb-classification @ /root/reference")

@@ -44,9 +44,68 @@ CONV_CASES = [
 ]
 
 
+# every distinct convolution shape of timm's ResNet-50 after the stem: Cin, Cout, k, stride, H_in.
+# At batch 8 they reach the paths the small cases above cannot: the shared-tile (halo) 3x3 form at 56/28/14/7, the 64x256
+# tile for Cout = 64, the XCD-remapped multi-round grids at 56x56, deep-K 1x1 layers up to Cin = 2048, the strided 1x1
+# shortcut convolutions and the 256x256 weight-gradient tile (Cin, Cout multiples of 256).
+RN50_SHAPES = [
+    (64, 64, 1, 1, 56), (64, 64, 3, 1, 56), (64, 256, 1, 1, 56), (256, 64, 1, 1, 56), (256, 128, 1, 1, 56),
+    (128, 128, 3, 2, 56), (128, 512, 1, 1, 28), (256, 512, 1, 2, 56), (512, 128, 1, 1, 28), (128, 128, 3, 1, 28),
+    (512, 256, 1, 1, 28), (256, 256, 3, 2, 28), (256, 1024, 1, 1, 14), (512, 1024, 1, 2, 28), (1024, 256, 1, 1, 14),
+    (256, 256, 3, 1, 14), (1024, 512, 1, 1, 14), (512, 512, 3, 2, 14), (512, 2048, 1, 1, 7), (1024, 2048, 1, 2, 14),
+    (2048, 512, 1, 1, 7), (512, 512, 3, 1, 7),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", RN50_SHAPES, ids=lambda s: "%d-%d_k%ds%d_%d" % s)
+def test_resnet50_conv_shapes_fwd_dgrad_wgrad(shape, dtype):
+    """All 22 post-stem ResNet-50 shapes (the 23rd, the 7x7 stem, is test_packed_stem_conv_fwd_wgrad) against torch CPU."""
+    Cin, Cout, k, st, H = shape
+    _check_conv((8, H, Cin, Cout, k, st, k // 2), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_grouped_tile_walk_wide_filter(dtype):
+    """1024 -> 2048, 1x1 / stride 2 at batch 48: a 4 MB (bf16) / 8 MB filter with 16+ channel tiles and 19 row tiles — the
+    launch that takes the grouped tile walk of conv_igemm_kernel (group_m = 8), which batch 8 is too small to reach."""
+    _check_conv((48, 14, 1024, 2048, 1, 2, 0), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(128, 128, 56), (256, 256, 28), (512, 512, 14)], ids=lambda s: "%d-%d_%d" % s)
+def test_s2_dgrad_parity_classes_resnet50_shapes_vs_torch(shape, dtype):
+    """The four parity-class launches the train step uses for 3x3 / stride-2 data gradients, at the three ResNet-50 shapes,
+    against torch's own conv2d backward (the H = 12 / 13 test below compares them with the gather form only)."""
+    Cin, Cout, H = shape
+    N = 4
+    torch.manual_seed(3)
+    x = torch.zeros(N, Cin, H, H, requires_grad=True)
+    w = rnd(torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9), dtype)
+    y = F.conv2d(x, w, stride=2, padding=1)
+    P = y.shape[2]
+    dy = rnd(torch.randn_like(y), dtype)
+    y.backward(dy)
+    d = hip.dt(dtype)
+    wm = nhwc(w).to(DEV)                                            # fp32 master [Cout][R][S][Cin]
+    dyd = nhwc(dy).to(DEV, dtype)
+    dx = torch.full((N, H, H, Cin), float("nan"), device=DEV, dtype=dtype)
+    for kcls in range(4):
+        wc = torch.empty(Cin, (2 if kcls >> 1 else 1) * (2 if kcls & 1 else 1), Cout, device=DEV, dtype=dtype)
+        hip.wprep(d, wm, wc, Cout, 9, Cin, Cout, 2 + kcls)
+        hip.conv_dgrad_s2class(d, dyd, wc, dx, None, None, None, None, None, None, N, P, P, Cout, Cout, H, H, Cin, Cin, 0,
+                               kcls >> 1, kcls & 1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dx.float().cpu(), nhwc(x.grad), **tol(dtype, Cout * 9))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, dtype):
+    _check_conv(case, dtype)
+
+
+def _check_conv(case, dtype):
     N, H, Cin, Cout, k, st, pad = case
     torch.manual_seed(0)
     x = rnd(torch.randn(N, Cin, H, H), dtype).requires_grad_(True)

@@ -145,14 +145,37 @@ def test_g4_engine_trajectory_config1_resnet18(golden):
 
 
 def test_g5_logger_lists(golden):
+    """Lists produced by the REFERENCE's BaseLogger.log_iter / get_epoch_results (logging.py:245-294, captured by
+    oracle/make_golden.py with stand-in modules for its unrelated imports) vs the oracle's epoch log."""
     g5 = golden("g5_logger")
+    probe = g5["probe"]
     log = oe.EpochLog(False)
-    pred = torch.tensor(g5["preds"])
-    log.add(pred, torch.tensor([1, 0]), torch.tensor(0.25))
+    log.add(torch.tensor(probe["preds"]), torch.tensor(probe["true"]), torch.tensor(probe["loss"]))
     res = log.results()
-    np.testing.assert_allclose(res["confidences"], g5["confidences"], rtol=1e-6)
-    assert res["predictions"] == g5["predictions"] and res["ground_truth"] == [1, 0] and res["running_loss"] == [0.25]
+    np.testing.assert_allclose(res["confidences"], probe["confidences"], rtol=1e-6)
+    assert res["predictions"] == probe["predictions"] == [1, 0] and res["ground_truth"] == probe["ground_truth"]
+    assert res["running_loss"] == probe["running_loss"] == [0.75]
     assert set(res) == {"running_loss", "confidences", "predictions", "ground_truth", "images"}
+    single = g5["single"]
+    log = oe.EpochLog(False)
+    for b in single["batches"]:
+        log.add(torch.tensor(b["preds"]), torch.tensor(b["true"]), torch.tensor(b["loss"]))
+    res = log.results()
+    np.testing.assert_allclose(res["confidences"], single["confidences"], rtol=1e-6)
+    np.testing.assert_allclose(res["running_loss"], single["running_loss"], rtol=1e-7)
+    assert res["predictions"] == single["predictions"] and res["ground_truth"] == single["ground_truth"]
+    multi = g5["multi"]
+    log = oe.EpochLog(True)
+    for b in multi["batches"]:
+        log.add({t: torch.tensor(v) for t, v in b["preds"].items()}, {t: torch.tensor(v) for t, v in b["true"].items()},
+                {t: torch.tensor(v) for t, v in b["loss"].items()})
+    res = log.results()
+    assert set(res["running_loss"]) == set(multi["running_loss"]) == {"shape", "color", "loss"}
+    for t in multi["classes"]:
+        np.testing.assert_allclose(res["confidences"][t], multi["confidences"][t], rtol=1e-6)
+        assert res["predictions"][t] == multi["predictions"][t] and res["ground_truth"][t] == multi["ground_truth"][t]
+    for t in multi["running_loss"]:
+        np.testing.assert_allclose(res["running_loss"][t], multi["running_loss"][t], rtol=1e-7)
 
 
 def test_backbone_invariants():

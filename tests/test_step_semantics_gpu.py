@@ -1,0 +1,271 @@
+"""Step-level semantics around the kernels: gradient scaler (engine.py:55-60), logger lists (logging.py:245-294), focal-loss
+reductions (losses.py:89-94), label validation, and the data-parallel entry point (train.py under torch.distributed.run)."""
+import json
+import os
+import subprocess
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from nkb_classification.amp import HipGradScaler  # noqa: E402
+from nkb_classification.logging import BaseLogger  # noqa: E402
+from nkb_classification.losses import FocalLoss, get_loss  # noqa: E402
+from nkb_classification.model import get_model  # noqa: E402
+from nkb_classification.utils import get_optimizer  # noqa: E402
+from oracle import torch_engine as oe  # noqa: E402
+
+DEV = "cuda:0"
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _tiny(seed=0, classes=("a", "b", "c")):
+    cfg_model = dict(model="resnet_tiny_bottleneck", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    torch.manual_seed(seed)
+    return get_model(cfg_model, list(classes), DEV)
+
+
+# ---------------------------------------------------------------------------------------------- gradient scaler ----
+@pytest.mark.parametrize("kind", ["nadam", "adam", "sgd"])
+def test_grad_scaler_normal_overflow_and_recovery(kind):
+    """A15: scale(loss).backward() / step / update.  Step 1 (finite) must equal the unscaled step of a twin model; step 2
+    gets an inf injected into the gradients: parameters, moments and the optimizer's step counter stay put and the scale
+    halves; step 3 (finite again) must equal the twin's SECOND step — i.e. the skipped step left no trace."""
+    a, b = _tiny(), _tiny()
+    b.load_state_dict(a.state_dict())
+    cfg_opt = dict(type=kind, lr=1e-2, weight_decay=0.01)
+    oa, ob = get_optimizer(a, cfg_opt), get_optimizer(b, cfg_opt)
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(4, 3, 64, 64, generator=g).to(DEV) for _ in range(3)]
+    ys = [torch.randint(0, 3, (4,), generator=g).to(DEV) for _ in range(3)]
+    scaler = HipGradScaler("cuda", init_scale=1024.0, growth_interval=2)
+    a.train(); b.train()
+
+    def twin_step(i):
+        ob.zero_grad()
+        crit(b(xs[i]), ys[i]).backward()
+        ob.step()
+
+    def scaled_step(i, poison=False):
+        oa.zero_grad()
+        scaler.scale(crit(a(xs[i]), ys[i])).backward()
+        if poison:
+            a.arena.flat_grad[a.arena.total // 2] = float("inf")
+        scaler.step(oa)
+        scaler.update()
+
+    scaled_step(0)
+    twin_step(0)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a.arena.flat_param, b.arena.flat_param, rtol=2e-5, atol=1e-6)
+    assert scaler.get_scale() == 1024.0
+    before = a.arena.flat_param.clone()
+    m_before = a.arena.moments()[0].clone()
+    scaled_step(1, poison=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a.arena.flat_param, before) and torch.equal(a.arena.moments()[0], m_before)   # skipped on the device
+    assert scaler.get_scale() == 512.0                                                                # backoff 0.5
+    scaled_step(0 + 1)                           # same batch as the twin's second step
+    twin_step(1)
+    torch.cuda.synchronize()
+    assert oa._gstate[0]["step"] == ob._gstate[0]["step"] == 2            # the skipped step was rolled back on the host
+    torch.testing.assert_close(a.arena.flat_param, b.arena.flat_param, rtol=5e-5, atol=2e-6)
+    sd = scaler.state_dict()
+    assert sd["scale"] == 512.0 and sd["_growth_tracker"] == 1
+    scaled_step(2)
+    assert scaler.get_scale() == 1024.0          # growth after growth_interval = 2 clean steps
+
+
+def test_grad_scaler_unscale_exposes_true_gradients():
+    """unscale_() before step (the gradient-clipping idiom): gradients read afterwards are the unscaled ones, step() does not
+    unscale twice, a second unscale_() raises like torch's."""
+    a, b = _tiny(), _tiny()
+    b.load_state_dict(a.state_dict())
+    oa = get_optimizer(a, dict(type="sgd", lr=0.1))
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    x, y = torch.randn(4, 3, 64, 64).to(DEV), torch.tensor([0, 1, 2, 1]).to(DEV)
+    a.train(); b.train()
+    crit(b(x), y).backward()
+    scaler = HipGradScaler("cuda", init_scale=4096.0)
+    scaler.scale(crit(a(x), y)).backward()
+    scaler.unscale_(oa)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a.arena.flat_grad, b.arena.flat_grad, rtol=1e-4, atol=1e-7)
+    with pytest.raises(RuntimeError, match="already been called"):
+        scaler.unscale_(oa)
+    p0 = a.arena.flat_param.clone()
+    scaler.step(oa)
+    scaler.update()
+    torch.testing.assert_close(a.arena.flat_param, p0 - 0.1 * b.arena.flat_grad, rtol=1e-4, atol=1e-6)
+    assert HipGradScaler(enabled=False).scale(x) is x and HipGradScaler(enabled=False).get_scale() == 1.0
+
+
+# ------------------------------------------------------------------------------------------------------ logger ----
+def test_logger_lists_match_reference_golden(golden):
+    """A16 / G5: the device-side logger returns the lists the reference's BaseLogger produced for the same inputs."""
+    g5 = golden("g5_logger")
+    single = g5["single"]
+    lg = BaseLogger(types.SimpleNamespace(task="single"), list("abcdefg"))
+    lg.init_iter_logs()
+    for b in single["batches"]:
+        lg.log_iter(torch.tensor(b["preds"]).to(DEV), torch.tensor(b["true"]).to(DEV), torch.tensor(b["loss"]).to(DEV))
+    lg.log_images_if_needed(torch.zeros(1, 3, 2, 2, device=DEV))
+    res = lg.get_epoch_results()
+    np.testing.assert_allclose(res["confidences"], single["confidences"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(res["running_loss"], single["running_loss"], rtol=1e-7)
+    assert res["predictions"] == single["predictions"] and res["ground_truth"] == single["ground_truth"]
+    assert list(res["images"].shape) == single["images_shape"] and res["images"].device.type == "cpu"
+    multi = g5["multi"]
+    lg = BaseLogger(types.SimpleNamespace(task="multi"), multi["classes"])      # constructor works (logging.py:243 does not)
+    assert lg.target_names == sorted(multi["classes"])
+    lg.init_iter_logs()
+    for b in multi["batches"]:
+        lg.log_iter({t: torch.tensor(v).to(DEV) for t, v in b["preds"].items()},
+                    {t: torch.tensor(v).to(DEV) for t, v in b["true"].items()},
+                    {t: torch.tensor(v).to(DEV) for t, v in b["loss"].items()})
+    res = lg.get_epoch_results()
+    assert set(res["running_loss"]) == {"shape", "color", "loss"}
+    for t in multi["classes"]:
+        np.testing.assert_allclose(res["confidences"][t], multi["confidences"][t], rtol=2e-6, atol=1e-9)
+        assert res["predictions"][t] == multi["predictions"][t] and res["ground_truth"][t] == multi["ground_truth"][t]
+    for t in multi["running_loss"]:
+        np.testing.assert_allclose(res["running_loss"][t], multi["running_loss"][t], rtol=1e-7)
+
+
+# -------------------------------------------------------------------------------------------------- focal loss ----
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+@pytest.mark.parametrize("gamma", [2.0, 0.5])
+def test_focal_loss_reductions_and_gradients(reduction, gamma):
+    """losses.py:59-94 for all three reductions, with ignored rows and class weights, values and d/dlogits vs the oracle."""
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(37, 6, generator=g) * 2).requires_grad_(True)
+    y = torch.randint(0, 6, (37,), generator=g)
+    y[[3, 17, 30]] = -100
+    alpha = torch.rand(6, generator=g) + 0.5
+    ref = oe.focal_loss(x, y, alpha=alpha, gamma=gamma, reduction=reduction)
+    w = torch.randn(ref.shape, generator=g) if reduction == "none" else torch.tensor(1.7)
+    (ref * w).sum().backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    out = FocalLoss(alpha.to(DEV), gamma, reduction=reduction).to(DEV)(xd, y.to(DEV))
+    assert out.shape == ref.shape
+    (out * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=2e-4, atol=1e-6)
+    # every row ignored: a CPU scalar zero in every reduction (losses.py:69-70)
+    z = FocalLoss(None, gamma, reduction=reduction)(xd.detach(), torch.full((37,), -100, device=DEV))
+    assert z.item() == 0.0
+
+
+def test_focal_loss_saturated_row_small_gamma_has_finite_gradient():
+    """0 < gamma < 1 and p_target == 1: (1-p)^(gamma-1) * log p is 0 * inf when evaluated literally."""
+    x = torch.tensor([[80.0, -80.0, -80.0], [0.3, 0.1, -0.2]], device=DEV, requires_grad=True)
+    loss = FocalLoss(None, 0.5)(x, torch.tensor([0, 1], device=DEV))
+    loss.backward()
+    assert torch.isfinite(loss).item() and torch.isfinite(x.grad).all().item() and x.grad[0].abs().max().item() == 0.0
+
+
+def test_out_of_range_label_poisons_the_loss():
+    """torch asserts on the device for a label outside [0, C); the sync-free kernel cannot, so the loss becomes NaN instead
+    of silently training on the remaining rows."""
+    x = torch.randn(5, 4, device=DEV, requires_grad=True)
+    for crit in (get_loss(dict(task="single", type="CrossEntropyLoss"), DEV), FocalLoss(None, 2.0)):
+        assert torch.isnan(crit(x, torch.tensor([0, 1, 7, 2, 3], device=DEV))).item()
+        assert torch.isfinite(crit(x, torch.tensor([0, 1, 3, 2, 3], device=DEV))).item()
+
+
+# ------------------------------------------------------------------------------------- data-parallel entry point ----
+def _launch_train(tmp_path, nproc, extra_env=None):
+    root = ROOT / "nkb-classification_amd"
+    cfg = (root / "configs" / "synthetic_singletask_config.py").read_text().replace(
+        '"runs/synthetic_single"', repr(str(tmp_path / "exp"))).replace(
+        "enable_gradient_scaler = False", "enable_gradient_scaler = True")
+    assert "enable_gradient_scaler = True" in cfg
+    (tmp_path / "cfg_ddp.py").write_text(cfg)
+    env = dict(os.environ, NKB_DDP_BACKEND="gloo", NKB_DDP_ONE_GPU="1", NKB_DUMP_PARAMS=str(tmp_path), **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29900 + os.getpid() % 500), str(root / "train.py"), "-cfg",
+           str(tmp_path / "cfg_ddp.py")]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+
+
+def test_train_py_under_torchrun_two_ranks(tmp_path):
+    """train.py launched as the driver launches bench.py (torch.distributed.run, 2 ranks; gloo transport, both ranks on the
+    one GPU of this box): no manual seeding by the caller, rank 0's initial state is broadcast, each rank trains on its own
+    shard with the gradient scaler ENABLED (the reference configs ship enable_gradient_scaler=True), and afterwards
+      * both ranks hold bit-identical parameters and BatchNorm buffers,
+      * exactly one run directory exists, written by rank 0, with one metrics row per epoch,
+      * the metrics of an epoch cover the whole dataset (gathered from both ranks), not one shard."""
+    r = _launch_train(tmp_path, 2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exp = tmp_path / "exp"
+    assert exp.exists() and not (tmp_path / "exp1").exists()
+    assert (exp / "weights" / "last.pth").exists() and (exp / "classes.json").exists()
+    lines = (exp / "metrics.csv").read_text().strip().splitlines()
+    assert len(lines) == 3 and lines[0].split("\t")[0] == "Epoch"
+    d0, d1 = (torch.load(tmp_path / f"params_rank{r}.pt") for r in (0, 1))
+    assert torch.equal(d0["flat_param"], d1["flat_param"])
+    for k in d0["buffers"]:
+        if "running" in k:
+            continue        # BatchNorm statistics stay per GPU (no SyncBN), as in standard DDP
+        assert torch.equal(d0["buffers"][k], d1["buffers"][k]), k
+    assert d0["n_train"] == d1["n_train"] == d0["dataset_len"] > d0["shard_len"]     # gathered epoch covers every image
+    sd = torch.load(exp / "weights" / "last.pth", map_location="cpu")
+    torch.testing.assert_close(sd["classifier.1.weight"], d1["head_weight"])          # rank 1 agrees with rank 0's checkpoint
+
+
+def _scaler_ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nkb_classification import parallel
+        model = _tiny(seed=rank)                        # different initial weights on purpose: attach() must fix that
+        opt = get_optimizer(model, dict(type="nadam", lr=1e-3))
+        parallel.attach(model, opt, DEV)
+        crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+        scaler = HipGradScaler("cuda", init_scale=256.0)
+        g = torch.Generator().manual_seed(50 + rank)
+        model.train()
+        trace = []
+        for step in range(3):
+            x, y = torch.randn(4, 3, 64, 64, generator=g).to(DEV), torch.randint(0, 3, (4,), generator=g).to(DEV)
+            opt.zero_grad()
+            loss = crit(model(x), y)
+            if step == 1 and rank == 1:
+                loss = loss * float("inf")                 # overflow on ONE rank only
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            torch.cuda.synchronize()
+            trace.append((scaler.get_scale(), float(model.arena.flat_param.double().sum())))
+        q.put((rank, trace, opt._gstate[0]["step"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_scaler_with_reducer_overflow_on_one_rank():
+    """the exchange finishes before anything reads the gradients, so an overflow on one rank is seen by
+    both (same skip decision, same scale, same parameters, no stranded collective)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_scaler_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, t0, s0), (_, t1, s1) = res
+    assert t0 == t1                                       # identical scale and parameter checksum after every step
+    assert [s for s, _ in t0] == [256.0, 128.0, 128.0]   # step 1 skipped on both ranks
+    assert t0[0][1] == t0[1][1] != t0[2][1]              # parameters untouched by the skipped step, moved by the next
+    assert s0 == s1 == 2                                  # the skipped step does not count (rolled back when settled)
