@@ -55,7 +55,13 @@ void nkb_set_ring(int mode); /* 0: register-staged kernel only; 1: persistent LD
 /* Weight gradient: dw[co][r][s][ci] += sum_{n,p,q} dy[n,p,q,co] * x[n, p*stride+r-pad, q*stride+s-pad, ci] (fp32 atomics);
  * optional bias gradient dbias[co] += sum_{n,p,q} dy[n,p,q,co] from the same pass over dy. */
 int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin, int ldx,
-                   int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad, nkb_stream_t stream);
+                   int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad, float* workspace,
+                   long long workspace_floats, nkb_stream_t stream);
+/* Workspace that makes nkb_conv_wgrad deterministic (bit-identical across runs): every (tile, pixel-split) workgroup stores
+ * its fp32 partial tile into its own slab and a second launch adds the slabs to dw (and the bias partials to dbias) in
+ * split order.  workspace == NULL keeps the single-launch form that accumulates with fp32 atomics. */
+long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, int Q, int Cin, int Cout, int R, int S, int stride, int pad,
+                                          int has_bias);
 
 /* BatchNorm2d (torch semantics: biased var to normalise, unbiased var into running_var, momentum blend). */
 int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma, const float* beta,
@@ -135,7 +141,8 @@ int nkb_stem_weight_cols(int dtype);
 int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y, float* stats, int N, int H, int W, int Cout,
                   int ldy, nkb_stream_t stream);
 int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N, int H, int W, int Cout, int lddy,
-                   nkb_stream_t stream);
+                   float* workspace, long long workspace_floats, nkb_stream_t stream);
+long long nkb_stem_wgrad_workspace_floats(int dtype, int N, int H, int W, int Cout);
 int nkb_stem_wfold(int dtype, const float* dwp, float* dw, int Cout, int C, nkb_stream_t stream);
 
 /* fp32 master filter [A][B][C] -> compute-dtype copy (mode 0: rows padded to ld; mode 1: transposed [C][B][ld];
@@ -223,7 +230,8 @@ int nkb_image_prep(const unsigned char* src, const int* sizes, const unsigned ch
 /* out = keep ? in/(1-p) : 0 (+ add); forward draws keep from a hash of (seed, index) and stores it in mask */
 int nkb_dropout(int dtype, int backward, const void* in, const void* add, void* out, unsigned char* mask, long long n,
                 float p, unsigned long long seed, nkb_stream_t stream);
-int nkb_colsum2d(int dtype, const void* x, float* out, long long rows, int C, long long ld, nkb_stream_t stream);
+int nkb_colsum2d(int dtype, const void* x, float* out, long long rows, int C, long long ld, float* workspace,
+                 nkb_stream_t stream);   /* workspace: NULL (atomics) or >= 256 * C floats (ordered two-stage sum) */
 
 /* Losses (kind 0: CrossEntropyLoss(weight); kind 1: FocalLoss(alpha, gamma) over un-ignored rows, losses.py:59-94).
  * reduction 0 "mean": out2[0] = loss, out2[1] = 1/normaliser; 1 "sum" / 2 "none": out2[0] = sum, out2[1] = 1 (the per-row

@@ -95,6 +95,6 @@ extern "C" int nkb_prof_collect_raw(int* kid, double* ms, double* work, int cap)
 extern "C" const char* nkb_kernel_name(int kid) {
     static const char* names[] = {"conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "bn_apply", "bn_bwd_reduce",
                                   "bn_bwd_apply", "bn_finalize", "maxpool", "avgpool", "im2row", "wprep", "loss",
-                                  "optim", "misc", "layernorm", "attention", "gelu"};
+                                  "optim", "misc", "layernorm", "attention", "gelu", "wgrad_reduce"};
     return (kid >= 0 && kid < NKB_K_COUNT) ? names[kid] : "?";
 }

@@ -101,6 +101,9 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 // ---- host-side error plumbing ----
 void nkb_set_error(const char* fmt, ...);
 int nkb_check_launch(const char* what);
+// dst[i] += sum over s < splits of part[s * slab + i], i < n, in split order (conv_igemm.hip): second stage of the
+// deterministic weight gradients
+int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float* dst, long long n, hipStream_t stream);
 
 // per-launch HIP-event profiler (enabled from bench.py); see api.hip
 struct NkbProfScope {
@@ -112,5 +115,5 @@ struct NkbProfScope {
 enum NkbKernelId {
     NKB_K_CONV_FWD = 0, NKB_K_CONV_DGRAD, NKB_K_CONV_WGRAD, NKB_K_BN_APPLY, NKB_K_BN_BWD_REDUCE, NKB_K_BN_BWD_APPLY,
     NKB_K_BN_FINALIZE, NKB_K_MAXPOOL, NKB_K_AVGPOOL, NKB_K_IM2COL, NKB_K_WPREP, NKB_K_LOSS, NKB_K_OPTIM, NKB_K_MISC,
-    NKB_K_LN, NKB_K_ATTN, NKB_K_GELU, NKB_K_COUNT
+    NKB_K_LN, NKB_K_ATTN, NKB_K_GELU, NKB_K_WGRAD_REDUCE, NKB_K_COUNT
 };

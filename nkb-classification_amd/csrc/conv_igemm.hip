@@ -660,6 +660,12 @@ struct WgradParams {
     void* out_t;
     int ldo, inner;
     long long sdo, sdi, sxo, sxi, soo, soi;
+    // deterministic form: every (tile, split) workgroup stores its fp32 tile into its own slab part[split][Cout][Ntot]
+    // (plain stores, no atomics) and wgrad_reduce_kernel adds the slabs to dw in split order; bias partial sums go to
+    // bpart[split * tilesN + tile_n][Cout]
+    float* part = nullptr;
+    long long slab = 0;
+    float* bpart = nullptr;
 };
 
 __device__ __forceinline__ int lds_swz256(int row, int ch) {
@@ -842,7 +848,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
         __syncthreads();                                      // every wave is done reading the stage
         if (st + 1 < nstage) { store_tile(0); __syncthreads(); }
     }
-    if (nstage == 0) return;
+    if (nstage == 0 && p.part == nullptr) return;   // (with slabs an empty split still stores its zero tile)
 
     if (has_bias) {  // fold the 16 row-groups that share a column chunk, one atomic per column per workgroup
         float* red = (float*)smem;             // [16 srow][16 cc][8]
@@ -854,7 +860,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
             float t = 0.f;
             for (int rr = 0; rr < 16; ++rr) t += red[(rr * 16 + c) * 8 + e];
             const int col = c0 + c * EPC + e;
-            if (col < p.Cout) atomicAdd(p.dbias + col, t);
+            if (col < p.Cout) {
+                if (p.bpart) p.bpart[(size_t)(split * p.tilesN + tile_n) * p.Cout + col] = t;
+                else atomicAdd(p.dbias + col, t);
+            }
         }
         __syncthreads();
     }
@@ -885,12 +894,38 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
                 if (n < p.Ntot) {
                     const float v = *(const float*)(smem + row * EROW + col * 4);
                     if (out) DT<T>::st(out + (size_t)co * p.ldo + n, v);
+                    else if (p.part) p.part[(size_t)split * p.slab + (size_t)co * p.Ntot + n] = v;
                     else atomicAdd(p.dw + (size_t)co * p.Ntot + n, v);
                 }
             }
         }
         __syncthreads();
     }
+}
+
+// dst[i] += sum_s part[s][i] in split order: the deterministic second stage of the weight-gradient kernels
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, long long slab, int splits, float* __restrict__ dst,
+                                    long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 a = *(const f32x4*)(part + 4 * i);
+        for (int s = 1; s < splits; ++s) a += *(const f32x4*)(part + (size_t)s * slab + 4 * i);
+        f32x4* d = (f32x4*)(dst + 4 * i);
+        *d = *d + a;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float a = part[i];
+        for (int s = 1; s < splits; ++s) a += part[(size_t)s * slab + i];
+        dst[i] += a;
+    }
+}
+int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float* dst, long long n, hipStream_t stream) {
+    if (n <= 0 || splits <= 0) return 0;
+    long long grid = (n / 4 + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
+    return nkb_check_launch("wgrad_reduce");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1167,9 +1202,44 @@ extern "C" int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout) {
     return (M + tp - 1) / tp;
 }
 
+// pixel split of the 128 x 128 (bf16) / 64 x 64 (fp32) weight-gradient kernel for a given problem
+struct WgradPlan { int TW, tilesC, tilesN, splits, rows_per_split; };
+static WgradPlan wgrad_plan(int esz, int M, int Cout, int Ntot, int target) {
+    WgradPlan g;
+    g.TW = 256 / esz;
+    g.tilesC = (Cout + g.TW - 1) / g.TW;
+    g.tilesN = (Ntot + g.TW - 1) / g.TW;
+    const int tiles = g.tilesC * g.tilesN;
+    int splits = (target + tiles - 1) / tiles;
+    const int max_splits = (M + 255) / 256;  // at least 4 pipeline stages per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rps = (M + splits - 1) / splits;
+    rps = (rps + 63) / 64 * 64;
+    g.splits = (M + rps - 1) / rps;
+    g.rows_per_split = rps;
+    return g;
+}
+static int wgrad_target_wgs() {
+    // swept (128..768) on ResNet-50 and ViT-B/16: fewer splits = less competition with the main stream
+    static const int target_wgs = [] { const char* e = getenv("NKB_WGRAD_WGS"); return e ? atoi(e) : 256; }();
+    return target_wgs;
+}
+
+// floats of workspace that make nkb_conv_wgrad deterministic for this problem (slabs of per-split partial tiles + bias
+// partials); 0 is never returned for a valid problem
+extern "C" long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, int Q, int Cin, int Cout, int R, int S, int stride,
+                                                     int pad, int has_bias) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int M = N * P * Q;
+    if (nkb_wgrad256_eligible(dtype, M, Cin, Cout, R, S, stride, pad)) return nkb_wgrad256_workspace_floats(M, Cin, Cout, has_bias);
+    const WgradPlan g = wgrad_plan(esz, M, Cout, R * S * Cin, wgrad_target_wgs());
+    return (long long)g.splits * Cout * R * S * Cin + (has_bias ? (long long)g.splits * g.tilesN * Cout : 0);
+}
+
 extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
                               int Cin, int ldx, int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad,
-                              hipStream_t stream) {
+                              float* workspace, long long workspace_floats, hipStream_t stream) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
     const int epc = 16 / esz;
     if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_wgrad: bad dtype %d", dtype); return 1; }
@@ -1182,34 +1252,38 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
         nkb_set_error("conv_wgrad: tensor exceeds 2^31 elements");
         return 1;
     }
+    const long long need = nkb_conv_wgrad_workspace_floats(dtype, N, P, Q, Cin, Cout, R, S, stride, pad, dbias != nullptr);
+    if (workspace != nullptr && workspace_floats < need) {
+        nkb_set_error("conv_wgrad: workspace of %lld floats given, %lld needed (nkb_conv_wgrad_workspace_floats)",
+                      workspace_floats, need);
+        return 1;
+    }
     if (nkb_wgrad256_eligible(dtype, N * P * Q, Cin, Cout, R, S, stride, pad)) {
         // wide Linear layers: 256 x 256 tiles (wgrad256.hip)
         const int M = N * P * Q;
         NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * M * (double)Cout * Cin,
                           ((double)M * Cin + (double)M * Cout) * esz + 2.0 * 4.0 * Cout * Cin);
-        return nkb_launch_wgrad256(dy, x, dw, dbias, M, Cin, ldx, Cout, lddy, stream);
+        return nkb_launch_wgrad256(dy, x, dw, dbias, M, Cin, ldx, Cout, lddy, workspace, stream);
     }
     WgradParams p;
     p.dy = dy; p.x = x; p.dw = dw; p.dbias = dbias;
     p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.lddy = lddy;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.Ntot = R * S * Cin;
     p.stride_w = stride; p.pad_w = pad;
-    const int TW = 256 / esz;
-    p.tilesC = (Cout + TW - 1) / TW;
-    p.tilesN = (p.Ntot + TW - 1) / TW;
+    const WgradPlan g = wgrad_plan(esz, p.M, Cout, p.Ntot, wgrad_target_wgs());
+    const int TW = g.TW;
+    p.tilesC = g.tilesC; p.tilesN = g.tilesN;
     const int tiles = p.tilesC * p.tilesN;
-    static const int target_wgs = [] { const char* e = getenv("NKB_WGRAD_WGS"); return e ? atoi(e) : 256; }();   // swept (128..768) on ResNet-50 and ViT-B/16: fewer splits = fewer float atomics and less competition with the main stream
-    int splits = (target_wgs + tiles - 1) / tiles;
-    const int max_splits = (p.M + 255) / 256;  // at least 4 pipeline stages per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int rps = (p.M + splits - 1) / splits;
-    rps = (rps + 63) / 64 * 64;
-    splits = (p.M + rps - 1) / rps;
-    p.splits = splits; p.rows_per_split = rps;
+    const int splits = g.splits;
+    p.splits = splits; p.rows_per_split = g.rows_per_split;
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.divCin = make_fastdiv((unsigned)Cin); p.divS = make_fastdiv((unsigned)S);
     p.out_t = nullptr; p.ldo = 0; p.inner = 1; p.sdo = p.sdi = p.sxo = p.sxi = p.soo = p.soi = 0;
+    const long long slab = (long long)Cout * p.Ntot;
+    if (workspace) {
+        p.part = workspace; p.slab = slab;
+        p.bpart = dbias ? workspace + (size_t)splits * slab : nullptr;
+    }
     const int lds = 2 * 64 * 256 > (TW / 2) * (TW * 4 + 16) ? 2 * 64 * 256 : (TW / 2) * (TW * 4 + 16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1217,12 +1291,19 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
         hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot,
-                      ((double)N * H * W * Cin + (double)p.M * Cout) * esz + 2.0 * 4.0 * Cout * p.Ntot);
-    dim3 grid((unsigned)tiles * (unsigned)splits);
-    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
-    return nkb_check_launch("conv_wgrad");
+    {
+        NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot,
+                          ((double)N * H * W * Cin + (double)p.M * Cout) * esz + 2.0 * 4.0 * Cout * p.Ntot);
+        dim3 grid((unsigned)tiles * (unsigned)splits);
+        if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
+        const int rc = nkb_check_launch("conv_wgrad");
+        if (rc || !workspace) return rc;
+    }
+    NkbProfScope prof(NKB_K_WGRAD_REDUCE, stream, 0, 4.0 * ((double)splits + 2.0) * slab);
+    int rc = nkb_launch_wgrad_reduce(workspace, slab, splits, dw, slab, stream);
+    if (!rc && dbias) rc = nkb_launch_wgrad_reduce(p.bpart, Cout, splits * p.tilesN, dbias, Cout, stream);
+    return rc;
 }
 
 // Batched "transposed-A" GEMM  out[z][a][b] = sum_m A[z][m][a] * B[z][m][b]  (both operands m-major, e.g. attention
@@ -1310,8 +1391,22 @@ extern "C" int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y,
 }
 
 // dwp[Cout][7*cprw*EPC] (fp32, caller-zeroed) += dY^T * window(xp); fold into the parameter gradient with nkb_stem_wfold
+static int stem_wgrad_splits(int esz, int M, int Cout, int Ntot, int* rps_out) {
+    // this is the last kernel of the backward pass (it needs the stem's BN-backward output) and runs alone on the GPU:
+    // three workgroups per CU instead of the one the shared-GPU split target would give (408 -> ~150 us of pure tail)
+    static const int stem_wgs = [] { const char* e = getenv("NKB_STEM_WGRAD_WGS"); return e ? atoi(e) : 768; }();
+    const WgradPlan g = wgrad_plan(esz, M, Cout, Ntot, stem_wgs);
+    if (rps_out) *rps_out = g.rows_per_split;
+    return g.splits;
+}
+extern "C" long long nkb_stem_wgrad_workspace_floats(int dtype, int N, int H, int W, int Cout) {
+    const StemGeom g = stem_geom(dtype, (W + 1) & ~1);
+    const int P = (H + 6 - 7) / 2 + 1, Q = (W + 6 - 7) / 2 + 1, Ntot = 7 * g.cprw * g.epc;
+    return (long long)stem_wgrad_splits(dtype == NKB_DT_BF16 ? 2 : 4, N * P * Q, Cout, Ntot, nullptr) * Cout * Ntot;
+}
+
 extern "C" int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N, int H, int W, int Cout, int lddy,
-                              hipStream_t stream) {
+                              float* workspace, long long workspace_floats, hipStream_t stream) {
     if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("stem_wgrad: bad dtype %d", dtype); return 1; }
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
     const StemGeom g = stem_geom(dtype, (W + 1) & ~1);
@@ -1325,16 +1420,12 @@ extern "C" int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* 
     p.tilesC = (Cout + TW - 1) / TW;
     p.tilesN = (p.Ntot + TW - 1) / TW;
     const int tiles = p.tilesC * p.tilesN;
-    // this is the last kernel of the backward pass (it needs the stem's BN-backward output) and runs alone on the GPU:
-    // three workgroups per CU instead of the one the shared-GPU split target would give (408 -> ~150 us of pure tail)
-    static const int stem_wgs = [] { const char* e = getenv("NKB_STEM_WGRAD_WGS"); return e ? atoi(e) : 768; }();
-    int splits = (stem_wgs + tiles - 1) / tiles;
-    const int max_splits = (p.M + 255) / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int rps = (p.M + splits - 1) / splits;
-    rps = (rps + 63) / 64 * 64;
-    splits = (p.M + rps - 1) / rps;
+    int rps = 0;
+    const int splits = stem_wgrad_splits(esz, p.M, Cout, p.Ntot, &rps);
+    if (workspace) {
+        if (workspace_floats < (long long)splits * Cout * p.Ntot) { nkb_set_error("stem_wgrad: workspace too small"); return 1; }
+        p.part = workspace; p.slab = (long long)Cout * p.Ntot;
+    }
     p.splits = splits; p.rows_per_split = rps;
     p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
     p.divCin = make_fastdiv((unsigned)g.epc); p.divS = make_fastdiv((unsigned)g.cprw);
@@ -1346,9 +1437,14 @@ extern "C" int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* 
         hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot);
-    dim3 grid((unsigned)tiles * (unsigned)splits);
-    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
-    return nkb_check_launch("stem_wgrad");
+    {
+        NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * p.M * (double)Cout * p.Ntot);
+        dim3 grid((unsigned)tiles * (unsigned)splits);
+        if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
+        const int rc = nkb_check_launch("stem_wgrad");
+        if (rc || !workspace) return rc;
+    }
+    NkbProfScope prof(NKB_K_WGRAD_REDUCE, stream, 0, 4.0 * ((double)splits + 2.0) * p.slab);
+    return nkb_launch_wgrad_reduce(workspace, p.slab, splits, dwp, p.slab, stream);
 }

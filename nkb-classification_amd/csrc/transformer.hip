@@ -456,7 +456,8 @@ extern "C" int nkb_vit_assemble(int dtype, int backward, void* tok, const float*
 // Column sums with a 2-D grid (rows split across blockIdx.y) and one float atomic per column per block:
 // bias gradients of the transformer's Linear layers (rows = B*T tokens).
 template <typename T>
-__global__ void colsum2d_kernel(const T* __restrict__ x, float* __restrict__ out, long long rows, int C, long long ld, int rpb) {
+__global__ void colsum2d_kernel(const T* __restrict__ x, float* __restrict__ out, long long rows, int C, long long ld, int rpb,
+                                float* __restrict__ part_out) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
     __shared__ float red[4][64];
@@ -465,18 +466,26 @@ __global__ void colsum2d_kernel(const T* __restrict__ x, float* __restrict__ out
     if (c < C) for (long long r = r0 + part; r < r1; r += 4) t += DT<T>::ld(x + (size_t)r * ld + c);
     red[part][threadIdx.x & 63] = t;
     __syncthreads();
-    if (part == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part == 0 && c < C) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (part_out) part_out[(size_t)blockIdx.y * C + c] = v;      // summed in block order by the reduce launch
+        else atomicAdd(out + c, v);
+    }
 }
-extern "C" int nkb_colsum2d(int dtype, const void* x, float* out, long long rows, int C, long long ld, hipStream_t stream) {
+// workspace (optional, >= 256 * C floats): per-row-block partial sums + an ordered second stage instead of float atomics
+extern "C" int nkb_colsum2d(int dtype, const void* x, float* out, long long rows, int C, long long ld, float* workspace,
+                            hipStream_t stream) {
     NkbProfScope prof(NKB_K_MISC, stream, 0);
     int ry = (int)((rows + 255) / 256);
     if (ry > 256) ry = 256;
     if (ry < 1) ry = 1;
     const int rpb = (int)((rows + ry - 1) / ry);
     dim3 grid((C + 63) / 64, ry);
-    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(colsum2d_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, out, rows, C, ld, rpb);
-    else hipLaunchKernelGGL(colsum2d_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, out, rows, C, ld, rpb);
-    return nkb_check_launch("colsum2d");
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(colsum2d_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, out, rows, C, ld, rpb, workspace);
+    else hipLaunchKernelGGL(colsum2d_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, out, rows, C, ld, rpb, workspace);
+    const int rc = nkb_check_launch("colsum2d");
+    if (rc || !workspace) return rc;
+    return nkb_launch_wgrad_reduce(workspace, C, ry, out, C, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

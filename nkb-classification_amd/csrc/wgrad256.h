@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 bool nkb_wgrad256_eligible(int dtype, int M, int Cin, int Cout, int R, int S, int stride, int pad);
-// dw[Cout][Cin] += dy[M][lddy]^T x[M][ldx], dbias[Cout] += column sums of dy when given (bf16 operands, fp32 atomics);
-// returns nkb_check_launch's code
+// dw[Cout][Cin] += dy[M][lddy]^T x[M][ldx], dbias[Cout] += column sums of dy when given (bf16 operands).  With a workspace
+// of nkb_wgrad256_workspace_floats() floats the per-split tiles go to slabs that a second launch adds in split order
+// (deterministic); without one they are added with fp32 atomics.  Returns nkb_check_launch's code.
 int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, int M, int Cin, int ldx, int Cout, int lddy,
-                        hipStream_t stream);
+                        float* workspace, hipStream_t stream);
+long long nkb_wgrad256_workspace_floats(int M, int Cin, int Cout, int has_bias);

@@ -29,6 +29,10 @@ struct W256Params {
     float* dbias;        // optional [Cout]: column sums of dY, accumulated with atomics by the tile_n == 0 workgroups
     int M, lddy, ldx, Ntot;
     int tilesC, tilesN, splits, rows_per_split;
+    float* part;         // optional slabs [splits][Cout][Ntot]: plain stores instead of atomics (deterministic form)
+    long long slab;
+    float* bpart;        // optional [splits][Cout] bias partial sums
+    int Cout;
 };
 
 __global__ __launch_bounds__(512, 1) void wgrad256_kernel(const W256Params p) {
@@ -137,7 +141,10 @@ __global__ __launch_bounds__(512, 1) void wgrad256_kernel(const W256Params p) {
             float t = bsum[i];
             t += __shfl_xor(t, 16);
             t += __shfl_xor(t, 32);
-            if (lane < 16) atomicAdd(p.dbias + c0 + wr * 128 + 16 * i + lane, t);
+            if (lane < 16) {
+                if (p.bpart) p.bpart[(size_t)split * p.Cout + c0 + wr * 128 + 16 * i + lane] = t;
+                else atomicAdd(p.dbias + c0 + wr * 128 + 16 * i + lane, t);
+            }
         }
     }
 
@@ -159,6 +166,12 @@ __global__ __launch_bounds__(512, 1) void wgrad256_kernel(const W256Params p) {
             }
         }
         __syncthreads();
+        if (p.part) {
+            for (int row = wave; row < 64; row += 8) {
+                float* dst = p.part + (size_t)split * p.slab + (size_t)(c0 + pass * 64 + row) * p.Ntot + n0;
+                *(f32x4*)(dst + 4 * lane) = *(const f32x4*)(smem + row * EROW + 16 * lane);
+            }
+        } else
         for (int row = wave; row < 64; row += 8) {
             float* dst = p.dw + (size_t)(c0 + pass * 64 + row) * p.Ntot + n0;
 #pragma unroll
@@ -197,8 +210,14 @@ bool nkb_wgrad256_eligible(int dtype, int M, int Cin, int Cout, int R, int S, in
     return tiles >= 6 && wgrad256_stages_per_split(M, tiles, nullptr) >= 24;
 }
 
+long long nkb_wgrad256_workspace_floats(int M, int Cin, int Cout, int has_bias) {
+    int splits = 1;
+    wgrad256_stages_per_split(M, (Cout / 256) * (Cin / 256), &splits);
+    return (long long)splits * Cout * Cin + (has_bias ? (long long)splits * Cout : 0);
+}
+
 int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, int M, int Cin, int ldx, int Cout, int lddy,
-                        hipStream_t stream) {
+                        float* workspace, hipStream_t stream) {
     W256Params p;
     p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw; p.dbias = dbias;
     p.M = M; p.lddy = lddy; p.ldx = ldx; p.Ntot = Cin;
@@ -206,6 +225,10 @@ int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, 
     const int tiles = p.tilesC * p.tilesN;
     const int sps = wgrad256_stages_per_split(M, tiles, &p.splits);
     p.rows_per_split = sps * 64;
+    p.Cout = Cout;
+    p.slab = (long long)Cout * Cin;
+    p.part = workspace;
+    p.bpart = (workspace && dbias) ? workspace + (size_t)p.splits * p.slab : nullptr;
     constexpr int lds = 2 * 4 * 64 * 256;                        // two stages of 64 KB
     static bool attr_set = false;
     if (!attr_set) {
@@ -213,5 +236,9 @@ int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, 
         attr_set = true;
     }
     hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
-    return nkb_check_launch("wgrad256");
+    int rc = nkb_check_launch("wgrad256");
+    if (rc || !workspace) return rc;
+    rc = nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
+    if (!rc && dbias) rc = nkb_launch_wgrad_reduce(p.bpart, Cout, p.splits, dbias, Cout, stream);
+    return rc;
 }

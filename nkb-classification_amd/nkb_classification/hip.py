@@ -25,7 +25,9 @@ _SIGS = {
     "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 18 + [vp, vp]),
     "nkb_conv_gemm_stat_tiles": (i32, [i32, i32, i32]),
     "nkb_set_ring": (None, [i32]),
-    "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp]),
+    "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp, i64, vp]),
+    "nkb_conv_wgrad_workspace_floats": (i64, [i32] * 11),
+    "nkb_stem_wgrad_workspace_floats": (i64, [i32] * 5),
     "nkb_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     "nkb_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp]),
     "nkb_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
@@ -41,7 +43,7 @@ _SIGS = {
     "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_stem_weight_cols": (i32, [i32]),
     "nkb_stem_conv": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "nkb_stem_wgrad": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nkb_stem_wgrad": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
     "nkb_stem_wfold": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_maxpool3x3s2": (i32, [i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nkb_bn_relu_maxpool": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
@@ -71,7 +73,7 @@ _SIGS = {
     "nkb_head_transpose": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, i32, i32, i32, vp]),
     "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_dropout": (i32, [i32, i32, vp, vp, vp, vp, i64, f32, C.c_ulonglong, vp]),
-    "nkb_colsum2d": (i32, [i32, vp, vp, i64, i32, i64, vp]),
+    "nkb_colsum2d": (i32, [i32, vp, vp, i64, i32, i64, vp, vp]),
     "nkb_loss_forward": (i32, [i32, vp, i32, vp, i32, i32, vp, f32, i64, vp, i32, vp, vp, vp, i32, vp]),
     "nkb_loss_row_state_bytes": (sz, [i32]),
     "nkb_loss_backward": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp]),
@@ -154,9 +156,20 @@ def stat_tiles(dtype, M, Cout):
     return load().nkb_conv_gemm_stat_tiles(dtype, M, Cout)
 
 
-def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0, dbias=None):
+def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0, dbias=None,
+               workspace=None):
+    """workspace: fp32 scratch of at least conv_wgrad_workspace(...) floats -> deterministic two-stage accumulation; None ->
+    fp32 atomics."""
     check(load().nkb_conv_wgrad(dtype, ptr(dy), ptr(x), ptr(dw), ptr(dbias), N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad,
-                                stream()), "conv_wgrad")
+                                ptr(workspace), workspace.numel() if workspace is not None else 0, stream()), "conv_wgrad")
+
+
+def conv_wgrad_workspace(dtype, *, N, P, Q, Cin, Cout, R=1, S=1, stride=1, pad=0, has_bias=False) -> int:
+    return int(load().nkb_conv_wgrad_workspace_floats(dtype, N, P, Q, Cin, Cout, R, S, stride, pad, int(has_bias)))
+
+
+def stem_wgrad_workspace(dtype, N, H, W, Cout) -> int:
+    return int(load().nkb_stem_wgrad_workspace_floats(dtype, N, H, W, Cout))
 
 
 def bn_finalize(partials, tiles, C_, count, gamma, beta, rm, rv, momentum, eps, training, scale, shift, mean, invstd):
@@ -241,8 +254,9 @@ def stem_conv(dtype, xp, wp, y, stats, N, H, W, Cout, ldy):
     check(load().nkb_stem_conv(dtype, ptr(xp), ptr(wp), ptr(y), ptr(stats), N, H, W, Cout, ldy, stream()), "stem_conv")
 
 
-def stem_wgrad(dtype, dy, xp, dwp, N, H, W, Cout, lddy):
-    check(load().nkb_stem_wgrad(dtype, ptr(dy), ptr(xp), ptr(dwp), N, H, W, Cout, lddy, stream()), "stem_wgrad")
+def stem_wgrad(dtype, dy, xp, dwp, N, H, W, Cout, lddy, workspace=None):
+    check(load().nkb_stem_wgrad(dtype, ptr(dy), ptr(xp), ptr(dwp), N, H, W, Cout, lddy, ptr(workspace),
+                                workspace.numel() if workspace is not None else 0, stream()), "stem_wgrad")
 
 
 def stem_wfold(dtype, dwp, dw, Cout, C_):
@@ -410,8 +424,10 @@ def vit_assemble(dtype, backward, tok, cls, pos, x, B, Tn, D):
     check(load().nkb_vit_assemble(dtype, int(backward), ptr(tok), ptr(cls), ptr(pos), ptr(x), B, Tn, D, stream()), "vit_assemble")
 
 
-def colsum2d(dtype, x, out, rows, C_, ld):
-    check(load().nkb_colsum2d(dtype, ptr(x), ptr(out), rows, C_, ld, stream()), "colsum2d")
+def colsum2d(dtype, x, out, rows, C_, ld, workspace=None):
+    if workspace is not None and workspace.numel() < 256 * C_:
+        raise RuntimeError("colsum2d: workspace needs 256 * C floats")
+    check(load().nkb_colsum2d(dtype, ptr(x), ptr(out), rows, C_, ld, ptr(workspace), stream()), "colsum2d")
 
 
 def dropout(dtype, backward, src, add, out, mask, n, p, seed=0):

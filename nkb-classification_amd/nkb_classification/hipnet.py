@@ -32,6 +32,8 @@ _ATTN_FUSED_BWD = os.environ.get("NKB_ATTN_FUSED_BWD", "1") != "0"  # whole atte
 _ATTN_FUSED_DQ = os.environ.get("NKB_ATTN_FUSED_DQ", "1") != "0"   # dQ inside the attention backward-dS kernel
 _SPLITK = os.environ.get("NKB_SPLITK", "1") != "0"              # split-K for skinny Linear layers with K >= 32768
 _EVAL_FOLD = os.environ.get("NKB_EVAL_FOLD", "1") != "0"     # eval mode: BatchNorm folded into the conv (one launch per stage)
+# weight / bias gradients through per-split slabs + an ordered second stage instead of fp32 atomics: bit-identical across runs
+_DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
 
 
 class HipEngine:
@@ -312,6 +314,27 @@ class HipEngine:
         return logits
 
     # ------------------------------------------------------------------ backward ops ----
+    def _stream_tag(self) -> str:
+        # launches of one stream run in order, so one scratch buffer per stream is race-free
+        return "side" if self._side is not None and torch.cuda.current_stream() == self._side else "main"
+
+    def wgrad(self, dy, x, dw, *, dbias=None, **geom):
+        """nkb_conv_wgrad into the gradient arena, deterministic (slabs + ordered reduce) unless NKB_DET_WGRAD=0."""
+        work = None
+        if _DET_WGRAD:
+            need = hip.conv_wgrad_workspace(self.d, N=geom["N"], P=geom["P"], Q=geom["Q"], Cin=geom["Cin"], Cout=geom["Cout"],
+                                            R=geom.get("R", 1), S=geom.get("S", 1), stride=geom.get("stride", 1),
+                                            pad=geom.get("pad", 0), has_bias=dbias is not None)
+            work = self.ws.at_least("wgrad.slabs." + self._stream_tag(), need, torch.float32)
+        hip.conv_wgrad(self.d, dy, x, dw, dbias=dbias, workspace=work, **geom)
+
+    def colsum2d(self, x, out, rows, C_, ld):
+        """Column sums over many rows (bias / position-embedding gradients), ordered two-stage sum when rows span blocks."""
+        work = None
+        if _DET_WGRAD and rows > 256:
+            work = self.ws.at_least("colsum.part." + self._stream_tag(), 256 * C_, torch.float32)
+        hip.colsum2d(self.d, x, out, rows, C_, ld, workspace=work)
+
     def scratch(self, slot: str, shape) -> torch.Tensor:
         return self.ws.get("grad.%s%s.%s" % (slot, self._suffix, "x".join(str(int(v)) for v in shape)), shape, self.T)
 
@@ -378,7 +401,7 @@ class HipEngine:
             glogits = glogits.contiguous()
         hip.pad_cast(self.d, glogits, dl, B, ctot, ctot, cp)
         lo = a.offset_of(hw[0])
-        hip.conv_wgrad(self.d, dl, emb, a.flat_grad[lo:lo + ctot * E], N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1,
+        self.wgrad(dl, emb, a.flat_grad[lo:lo + ctot * E], N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1,
                        Cout=ctot, lddy=cp)
         bo = a.offset_of(hb[0])
         hip.colsum(self.d, dl, a.flat_grad[bo:bo + ctot], B, ctot, cp)
@@ -405,7 +428,7 @@ class HipEngine:
             cpt = self.kpad(n_t)
             dl = self.ws.get(f"head.dl{t}", (B, cpt), self.T)
             hip.pad_cast(self.d, glogits[:, lo_c:], dl, B, n_t, ctot, cpt)
-            hip.conv_wgrad(self.d, dl, sv["dropped"][t], a.grad_flat(w), N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1, Cout=n_t,
+            self.wgrad(dl, sv["dropped"][t], a.grad_flat(w), N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1, Cout=n_t,
                            lddy=cpt)
             hip.colsum(self.d, dl, a.grad_flat(hb[t]), B, n_t, cpt)
             if need_demb:
@@ -510,7 +533,11 @@ class HipEngine:
 
             def packed_wgrad():
                 dwp.zero_()
-                hip.stem_wgrad(self.d, g_c, sv["x"], dwp, geom["N"], geom["H"], geom["W"], co, co)
+                work = None
+                if _DET_WGRAD:
+                    work = self.ws.at_least("wgrad.slabs." + self._stream_tag(),
+                                            hip.stem_wgrad_workspace(self.d, geom["N"], geom["H"], geom["W"], co), torch.float32)
+                hip.stem_wgrad(self.d, g_c, sv["x"], dwp, geom["N"], geom["H"], geom["W"], co, co, workspace=work)
                 hip.stem_wfold(self.d, dwp, a.grad_flat(w), co, w.shape[1])
             self.on_side(packed_wgrad)
             return None
@@ -522,12 +549,12 @@ class HipEngine:
 
             def stem_wgrad():
                 dwp.zero_()
-                hip.conv_wgrad(self.d, g_c, sv["x"], dwp, N=geom["N"], H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, lddy=co)
+                self.wgrad(g_c, sv["x"], dwp, N=geom["N"], H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, lddy=co)
                 hip.add2d(dwp, a.grad_flat(w), co, K, kp, K)
             self.on_side(stem_wgrad)
             return None
-        self.on_side(lambda: hip.conv_wgrad(
-            self.d, g_c, sv["x"], a.grad_flat(w), N=geom["N"], H=geom["H"], W=geom["W"], Cin=geom["Cin"], ldx=geom["ldx"],
+        self.on_side(lambda: self.wgrad(
+            g_c, sv["x"], a.grad_flat(w), N=geom["N"], H=geom["H"], W=geom["W"], Cin=geom["Cin"], ldx=geom["ldx"],
             P=geom["P"], Q=geom["Q"], Cout=geom["Cout"], lddy=geom["Cout"], R=geom["R"], S=geom["S"],
             stride=geom["stride"], pad=geom["pad"]))
         if slot is None:
@@ -598,8 +625,8 @@ class HipEngine:
         N = lin.weight.shape[0]
         a = self.arena
 
-        self.on_side(lambda: hip.conv_wgrad(
-            self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+        self.on_side(lambda: self.wgrad(
+            g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
             dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
         if slot is None:
             return None
@@ -627,8 +654,8 @@ class HipEngine:
         M, K = x.shape
         N = lin.weight.shape[0]
         a = self.arena
-        self.on_side(lambda: hip.conv_wgrad(
-            self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+        self.on_side(lambda: self.wgrad(
+            g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
             dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
         d_pre = self.scratch(slot, (M, K))
         hip.linear_gelu(self.d, 3, g, self._wd[id(lin.weight)], None, self.saved[key_act]["u"], d_pre, None, M, N, K)
@@ -653,8 +680,8 @@ class HipEngine:
         M, K = x.shape                      # K = hidden width
         N = lin.weight.shape[0]
         a = self.arena
-        self.on_side(lambda: hip.conv_wgrad(
-            self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+        self.on_side(lambda: self.wgrad(
+            g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
             dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
         d_pre = self.scratch(slot, (M, K))
         hip.linear_gelu(self.d, 2, g, self._wd[id(lin.weight)], None, self.saved[key_act]["pre"], d_pre, None, M, N, K)
@@ -706,8 +733,8 @@ class HipEngine:
         M, K = x.shape
         N = lin.weight.shape[0]
         a = self.arena
-        self.on_side(lambda: hip.conv_wgrad(
-            self.d, g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+        self.on_side(lambda: self.wgrad(
+            g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
             dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
         d_pre = self.scratch(slot, (M, K))
         hip.linear_gelu(self.d, 4, g, self._wd[id(lin.weight)], None, self.saved[key_act]["gp"], d_pre, None, M, N, K)

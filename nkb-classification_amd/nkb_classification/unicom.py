@@ -191,18 +191,18 @@ class HipUnicomViT(_ParamOnly):
                 on_done(blk)
         eng.begin_block(-1)
         # embedding: d_pos = sum_b gx[b]; the token gradient is gx itself (no class token)
-        hip.colsum2d(eng.d, gx, a.grad_flat(self.pos_embed), B, T * D, T * D)
+        eng.colsum2d(gx, a.grad_flat(self.pos_embed), B, T * D, T * D)
         pr = self.patch_embed.proj
         kp, K = sv["kp"], sv["K"]
         if kp == K:
-            hip.conv_wgrad(eng.d, gx, sv["col"], a.grad_flat(pr.weight), N=M, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D,
+            eng.wgrad(gx, sv["col"], a.grad_flat(pr.weight), N=M, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D,
                            lddy=D, dbias=a.grad_flat(pr.bias))
         else:
             dwp = eng.ws.get("pe.dwpad", (D, kp), torch.float32)
             dwp.zero_()
-            hip.conv_wgrad(eng.d, gx, sv["col"], dwp, N=M, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D, lddy=D)
+            eng.wgrad(gx, sv["col"], dwp, N=M, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D, lddy=D)
             hip.add2d(dwp, a.grad_flat(pr.weight), D, K, kp, K)
-            hip.colsum2d(eng.d, gx, a.grad_flat(pr.bias), M, D, D)
+            eng.colsum2d(gx, a.grad_flat(pr.bias), M, D, D)
         if on_done is not None:
             on_done(self.patch_embed)
             on_done([self.pos_embed])

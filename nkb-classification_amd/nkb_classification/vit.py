@@ -170,22 +170,22 @@ class HipViT(_ParamOnly):
         eng.begin_block(-1)
         gx = eng.dropout_backward("pos_drop", gx, "gpos")
         # embedding: d_pos = sum_b gx[b], d_cls = sum_b gx[b, 0], d_tok = gx[:, 1:], then the patch projection
-        hip.colsum2d(eng.d, gx, a.grad_flat(self.pos_embed), B, T * D, T * D)
-        hip.colsum2d(eng.d, gx, a.grad_flat(self.cls_token), B, D, T * D)
+        eng.colsum2d(gx, a.grad_flat(self.pos_embed), B, T * D, T * D)
+        eng.colsum2d(gx, a.grad_flat(self.cls_token), B, D, T * D)
         npatch = T - 1
         d_tok = eng.scratch("dtok", (B * npatch, D))
         hip.vit_assemble(eng.d, True, d_tok, None, None, gx, B, T, D)
         pr = self.patch_embed.proj
         kp, K = sv["kp"], sv["K"]
         if kp == K:
-            hip.conv_wgrad(eng.d, d_tok, sv["col"], a.grad_flat(pr.weight), N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1,
+            eng.wgrad(d_tok, sv["col"], a.grad_flat(pr.weight), N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1,
                            Q=1, Cout=D, lddy=D, dbias=a.grad_flat(pr.bias))
         else:
             dwp = eng.ws.get("pe.dwpad", (D, kp), torch.float32)
             dwp.zero_()
-            hip.conv_wgrad(eng.d, d_tok, sv["col"], dwp, N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D, lddy=D)
+            eng.wgrad(d_tok, sv["col"], dwp, N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D, lddy=D)
             hip.add2d(dwp, a.grad_flat(pr.weight), D, K, kp, K)
-            hip.colsum2d(eng.d, d_tok, a.grad_flat(pr.bias), B * npatch, D, D)
+            eng.colsum2d(d_tok, a.grad_flat(pr.bias), B * npatch, D, D)
         if on_done is not None:
             on_done(self.patch_embed)
             on_done([self.cls_token, self.pos_embed])

@@ -152,6 +152,21 @@ def _check_conv(case, dtype):
     if dtype == torch.bfloat16:
         t = dict(rtol=1e-3, atol=1e-3 * math.sqrt(N * P * P))
     torch.testing.assert_close(dwd.cpu(), nhwc(w.grad), **t)
+    # deterministic form (what the train step uses): per-split slabs + an ordered second stage; accumulates into dw like the
+    # atomic form and is bit-identical from run to run
+    need = hip.conv_wgrad_workspace(d, N=N, P=P, Q=P, Cin=Cin, Cout=Cout, R=k, S=k, stride=st, pad=pad, has_bias=True)
+    work = torch.full((need + 7,), float("nan"), device=DEV)
+    runs = []
+    for _ in range(2):
+        dw2, db2 = torch.ones(Cout, k, k, Cin, device=DEV), torch.ones(Cout, device=DEV)
+        hip.conv_wgrad(d, dyd, xd, dw2, N=N, H=H, W=H, Cin=Cin, ldx=Cin, P=P, Q=P, Cout=Cout, lddy=Cout, R=k, S=k,
+                       stride=st, pad=pad, dbias=db2, workspace=work)
+        torch.cuda.synchronize()
+        runs.append((dw2, db2))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert torch.isnan(work[need:]).all()                       # nothing written past the advertised size
+    torch.testing.assert_close(runs[0][0].cpu() - 1.0, nhwc(w.grad), **t)
+    torch.testing.assert_close(runs[0][1].cpu() - 1.0, dy.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * math.sqrt(N * P * P))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -797,6 +812,18 @@ def test_linear_wgrad_256_tile_kernel(shape):
     hip.conv_wgrad(d, dy.to(DEV), x.to(DEV), dw, N=M, H=1, W=1, Cin=Cin, ldx=Cin + padc, P=1, Q=1, Cout=Cout,
                    lddy=Cout + padc, R=1, S=1, stride=1, pad=0, dbias=db)
     torch.cuda.synchronize()
+    # the deterministic form of the same launch (slabs + ordered reduce): same result, bit-identical when repeated
+    work = torch.empty(hip.conv_wgrad_workspace(d, N=M, P=1, Q=1, Cin=Cin, Cout=Cout, has_bias=True), device=DEV)
+    det = []
+    for _ in range(2):
+        dw2, db2 = pre.to(DEV).clone(), torch.zeros(Cout, device=DEV)
+        hip.conv_wgrad(d, dy.to(DEV), x.to(DEV), dw2, N=M, H=1, W=1, Cin=Cin, ldx=Cin + padc, P=1, Q=1, Cout=Cout,
+                       lddy=Cout + padc, R=1, S=1, stride=1, pad=0, dbias=db2, workspace=work)
+        torch.cuda.synchronize()
+        det.append((dw2, db2))
+    assert torch.equal(det[0][0], det[1][0]) and torch.equal(det[0][1], det[1][1])
+    torch.testing.assert_close(det[0][0], dw, rtol=1e-5, atol=1e-5 * ref.abs().max().item())
+    torch.testing.assert_close(det[0][1], db, rtol=1e-5, atol=1e-5 * refb.abs().max().item())
     scale = ref.abs().max().item()
     assert (dw.cpu() - ref).abs().max().item() < 2e-5 * scale * math.sqrt(M / 4096)      # fp32 accumulation order only
     torch.testing.assert_close(db.cpu(), refb, rtol=1e-4, atol=1e-2)
