@@ -15,6 +15,7 @@
 // ------------------------------------------------------------------------------------------
 #include "conv_params.h"
 #include "wgrad256.h"
+#include "gemm8p.h"
 
 // 64x256 tile (Cout <= 64) as ONE LDS stage with the pixel fragments streamed through a single register set: 164 VGPRs
 // -> 3 workgroups per CU like the 128x128 tile (was: two LDS stages, 188 VGPRs, 2 per CU).  ResNet-50 layer1 shapes
@@ -1024,6 +1025,7 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
                          (double)p.M * Cout * (out_f32 ? 4 : esz) * (add ? 2 : 1);
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops, bytes);
     if (add_h == 0 && nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
+    if (nkb_gemm8p_eligible(p, dtype, 1)) return nkb_launch_gemm8p(p, stream);       // wide plain GEMMs: 256^2 eight-phase core
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream) : launch_conv_auto<bf16_t, 128, 128>(p, stream);
@@ -1160,6 +1162,7 @@ extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w,
     p.add_h = 0; p.add_w = 0; p.act = act; p.aux = aux; p.y2 = y2;
     p.ldw = K; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     NkbProfScope prof(act == 1 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
+    if (nkb_gemm8p_eligible(p, dtype, 1)) return nkb_launch_gemm8p(p, stream);
     const bool narrow = N <= 64;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream) : launch_conv_auto<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv_auto<float, 64, 256>(p, stream) : launch_conv_auto<float, 128, 128>(p, stream);

@@ -1,0 +1,320 @@
+// Dense bf16 GEMM core for the wide contractions of the train step — Linear forward / data gradient of the ViT and unicom
+// blocks (timm Attention.qkv / proj, Mlp.fc1 / fc2 reached from /root/reference/nkb_classification/engine.py:48, 55-58) and
+// the deep 1x1 convolutions of ResNet layer3 / layer4:
+//
+//     y[pixel][cout] = sum_k x[pixel][k] * w[cout][k]   (+ bias, + residual, * saved derivative, ReLU / ReLU6, BN partial sums)
+//
+// Structure (CDNA4 guide, "the 256^2 8-phase template", re-derived for this kernel's operand order):
+//   * 256 (cout) x 256 (pixel) x 64 tile per 512-thread workgroup, 8 waves as 2 (cout) x 4 (pixel), each 128 x 64 of the tile
+//     = 32 accumulator tiles of 16x16 (128 VGPRs); one workgroup per CU, two waves per SIMD.
+//   * 128 KB of LDS = 2 k-tile buffers x 4 half-tiles (X rows 0-127 | X rows 128-255 | W rows 0-127 | W rows 128-255) of
+//     16 KB; half-tiles are moved HBM/L2 -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write), two DMA
+//     instructions per thread per half-tile, the XOR swizzle (chunk ^ (row & 7)) applied on the SOURCE address because the DMA
+//     destination is lane-linear.
+//   * the k-loop is cut into FOUR phases per k-tile, each = {LDS fragment reads + ONE half-tile DMA issue, s_barrier,
+//     16 MFMAs under s_setprio(1), s_barrier}.  Phase 1 reads the 8 X fragments of the k-tile (kept for all four phases) and
+//     half of the W fragments; phases 2 and 3 re-fill the W fragment registers that the previous phase's MFMAs released.
+//   * DMA runs SEVEN half-tiles ahead of the reads: phase j of k-tile t issues half-tile 4t + 7 + j, i.e. the last half of
+//     k-tile t+1 and the first three of k-tile t+2 — the latter into the buffer that is being read, each into a half-tile
+//     whose last LDS read is already retired (X: read in phase 1 only, retired by lgkmcnt(8) before that phase's barrier;
+//     W: last read in phase 3, retired by lgkmcnt(0) before that phase's barrier; restaged in phases 2, 3 / 4, 1').
+//   * ONE counted wait per k-tile: s_waitcnt vmcnt(6) in phase 4 leaves the three youngest half-tiles in flight across the
+//     barriers and retires k-tile t+1, which is read from the next phase on.  Never vmcnt(0) inside the loop (except for the
+//     second-to-last k-tile, which has nothing younger in flight).
+//   * the two wave groups (cout halves) run one barrier apart, so on every SIMD one wave issues MFMAs while the other waits
+//     for its LDS fragments.
+// All LDS lives in one extern array (a second __shared__ object makes hipcc drain vmcnt before every ds_read).
+#include "common.h"
+#include "conv_params.h"
+#include "gemm8p.h"
+
+namespace {
+
+struct G8Params {
+    const bf16_t* x;      // [M][ldx]    pixel-major activations
+    const bf16_t* w;      // [N][ldw]    cout-major weights (K contiguous)
+    bf16_t* y;            // [M][ldy]
+    const float* bias;    // optional [N]
+    const bf16_t* add;    // optional [M][ldadd] residual operand
+    const bf16_t* aux;    // optional [M][ldy]: result is multiplied by it (saved activation derivative)
+    float* stats;         // optional [ceil(M/128)][2][N] sums of y and y^2 per 128 pixel rows (BatchNorm partials, same
+                          // granularity as the 128 x 128 kernel so nkb_conv_gemm_stat_tiles stays a function of (M, Cout))
+    int M, N, K, ldx, ldw, ldy, ldadd;
+    int relu;             // 0 none, 1 ReLU, 2 ReLU6
+    int tilesM, tilesN, group_m;
+};
+
+__device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// raw s_barrier (no vmcnt drain, unlike __syncthreads) between two compiler-level memory barriers
+#define G8_BARRIER()                                 \
+    do {                                             \
+        asm volatile("" ::: "memory");               \
+        __builtin_amdgcn_s_barrier();                \
+        asm volatile("" ::: "memory");               \
+    } while (0)
+#define G8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define G8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
+    constexpr int HT = 128 * 128;                 // bytes of one half-tile (128 rows x 64 bf16)
+    constexpr int BUF = 4 * HT;                   // one k-tile: X lo | X hi | W lo | W hi
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;      // cout half, pixel quarter
+
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    int tile_n = lid % p.tilesN, tile_m = lid / p.tilesN;
+    if (p.group_m > 1) {                          // grouped walk (see conv_igemm.hip): row tile fastest inside a group
+        const int gsz = p.group_m * p.tilesN;
+        const int grp = (int)lid / gsz, first_m = grp * p.group_m;
+        const int gm = min(p.group_m, p.tilesM - first_m);
+        const int r = (int)lid - grp * gsz;
+        tile_m = first_m + r % gm;
+        tile_n = r / gm;
+    }
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int KT = p.K >> 6, NH = 4 * KT;         // k-tiles, half-tiles in the DMA stream
+
+    // ---- DMA source offsets: piece = 8 rows x 128 B; this thread moves pieces (wave, wave + 8) of every half-tile
+    const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+    unsigned xo[2][2], wo[2][2];                  // [half][piece] element offsets of this lane's 16 bytes at k = 0
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = h * 128 + (wave + 8 * q) * 8 + lrow;
+            const int xm = min(m0 + row, p.M - 1);            // rows past M are loaded from the last row and discarded
+            xo[h][q] = (unsigned)xm * (unsigned)p.ldx + chunk * 8;
+            wo[h][q] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
+        }
+    // half-tile hh (0, 1: X lo / hi; 2, 3: W lo / hi) of k-tile tt
+#define G8_ISSUE(tt, hh)                                                                                              \
+    do {                                                                                                              \
+        unsigned char* d_ = smem + ((tt) & 1) * BUF + (hh) * HT + wave * 1024;                                       \
+        const bf16_t* s_ = ((hh) < 2 ? p.x : p.w) + (size_t)(tt) * 64;                                               \
+        glds16(s_ + ((hh) < 2 ? xo[(hh) & 1][0] : wo[(hh) & 1][0]), d_);                                             \
+        glds16(s_ + ((hh) < 2 ? xo[(hh) & 1][1] : wo[(hh) & 1][1]), d_ + 8192);                                      \
+    } while (0)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addresses: lane (frow, fgrp) reads 16 B of row 16 i + frow, chunk 4 ks + fgrp (swizzled)
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fo0 = frow * 128 + ((fgrp ^ (frow & 7)) << 4), fo1 = frow * 128 + (((4 + fgrp) ^ (frow & 7)) << 4);
+    const int a_base = (2 + wr) * HT;                                  // this wave's W half-tile
+    const int b_base = (wc >> 1) * HT + (wc & 1) * 8192;               // this wave's 64 X rows
+
+    // ---- prologue: seven half-tiles in flight, the first k-tile landed
+    if (0 < NH) G8_ISSUE(0, 0);
+    if (1 < NH) G8_ISSUE(0, 1);
+    if (2 < NH) G8_ISSUE(0, 2);
+    if (3 < NH) G8_ISSUE(0, 3);
+    if (4 < NH) G8_ISSUE(1, 0);
+    if (5 < NH) G8_ISSUE(1, 1);
+    if (6 < NH) G8_ISSUE(1, 2);
+    if (NH > 4) G8_VMCNT(6); else G8_VMCNT(0);
+    G8_BARRIER();
+    if (wr == 1) G8_BARRIER();    // stagger: the second wave group runs one barrier behind
+
+    bf16x8 a[4][2], b[4][2];
+#define G8_MMA(slot, ii)                                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+            acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[slot][ks], b[j][ks], acc[ii][j], 0, 0, 0)
+
+    for (int t = 0; t < KT; ++t) {
+        const unsigned char* base = smem + (t & 1) * BUF;
+        const unsigned char* pa = base + a_base;
+        const unsigned char* pb = base + b_base;
+        // ---------------- phase 1: all X fragments + W fragments 0-3; DMA: W hi of k-tile t+1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j][0] = *(const bf16x8*)(pb + fo0 + 2048 * j);
+            b[j][1] = *(const bf16x8*)(pb + fo1 + 2048 * j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i][0] = *(const bf16x8*)(pa + fo0 + 2048 * i);
+            a[i][1] = *(const bf16x8*)(pa + fo1 + 2048 * i);
+        }
+        if (4 * t + 7 < NH) G8_ISSUE(t + 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        G8_LGKM(8);                                // the X reads are retired: their half-tiles may be restaged next phase
+        G8_BARRIER();
+        G8_LGKM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        G8_MMA(0, 0); G8_MMA(1, 1);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BARRIER();
+        // ---------------- phase 2: W fragments 4, 5 into the released registers; DMA: X lo of k-tile t+2
+        a[0][0] = *(const bf16x8*)(pa + fo0 + 2048 * 4); a[0][1] = *(const bf16x8*)(pa + fo1 + 2048 * 4);
+        a[1][0] = *(const bf16x8*)(pa + fo0 + 2048 * 5); a[1][1] = *(const bf16x8*)(pa + fo1 + 2048 * 5);
+        if (4 * t + 8 < NH) G8_ISSUE(t + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        G8_BARRIER();
+        G8_LGKM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        G8_MMA(2, 2); G8_MMA(3, 3);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BARRIER();
+        // ---------------- phase 3: W fragments 6, 7; DMA: X hi of k-tile t+2
+        a[2][0] = *(const bf16x8*)(pa + fo0 + 2048 * 6); a[2][1] = *(const bf16x8*)(pa + fo1 + 2048 * 6);
+        a[3][0] = *(const bf16x8*)(pa + fo0 + 2048 * 7); a[3][1] = *(const bf16x8*)(pa + fo1 + 2048 * 7);
+        if (4 * t + 9 < NH) G8_ISSUE(t + 2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        G8_LGKM(0);                                // last reads of this k-tile's W halves: retired before the barrier, so
+        G8_BARRIER();              // phase 4 (either wave group) may restage them
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        G8_MMA(0, 4); G8_MMA(1, 5);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BARRIER();
+        // ---------------- phase 4: no reads; DMA: W lo of k-tile t+2; the counted wait that retires k-tile t+1
+        if (4 * t + 10 < NH) G8_ISSUE(t + 2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < KT) G8_VMCNT(6);
+        else if (t + 1 < KT) G8_VMCNT(0);
+        G8_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        G8_MMA(2, 6); G8_MMA(3, 7);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BARRIER();
+    }
+    if (wr == 0) G8_BARRIER();
+    __syncthreads();                              // every wave is done with the staging buffers
+
+    // ---- epilogue: four passes of 64 pixel rows through LDS [64][256 f32 + pad] -> bf16 rows of 512 B
+    constexpr int EROW = 256 * 4 + 16;
+    const int eg = tid & 31, er = tid >> 5;       // 32 chunks of 8 channels per row, 16 rows per trip
+    const int co = n0 + eg * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[co + e] : 0.f;
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    for (int pass = 0; pass < 4; ++pass) {
+        if (wc == pass) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(f32x4*)(smem + (16 * j + frow) * EROW + (wr * 128 + 16 * i + fgrp * 4) * 4) = acc[i][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr) {
+            const int row = er + 16 * tr;
+            const int m = m0 + pass * 64 + row;
+            if (m < p.M) {
+                const f32x4 lo = *(const f32x4*)(smem + row * EROW + eg * 32), hi = *(const f32x4*)(smem + row * EROW + eg * 32 + 16);
+                float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3],
+                              hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
+                if (p.add) {
+                    float af[8];
+                    unpack8(*(const u32x4*)(p.add + (size_t)m * p.ldadd + co), af);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += af[e];
+                }
+                if (p.aux) {
+                    float af[8];
+                    unpack8(*(const u32x4*)(p.aux + (size_t)m * p.ldy + co), af);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= af[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
+                }
+                const u32x4 pk = pack8(v);
+                *(u32x4*)(p.y + (size_t)m * p.ldy + co) = pk;
+                if (p.stats) {                     // statistics see the stored (rounded) value
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r0 = __uint_as_float(pk[e] << 16), r1 = __uint_as_float(pk[e] & 0xffff0000u);
+                        ssum[2 * e] += r0; ssum[2 * e + 1] += r1;
+                        ssq[2 * e] += r0 * r0; ssq[2 * e + 1] += r1 * r1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (p.stats && (pass & 1)) {               // 128 pixel rows done: deterministic partial sums, reduced later by bn_finalize
+            const int srow = tile_m * 2 + (pass >> 1);
+            float* red = (float*)smem;             // [16 er][32 eg][16]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(er * 32 + eg) * 16 + e] = ssum[e];
+                red[(er * 32 + eg) * 16 + 8 + e] = ssq[e];
+                ssum[e] = 0.f; ssq[e] = 0.f;
+            }
+            __syncthreads();
+            const int which = tid >> 8, ch = tid & 255;
+            float tsum = 0.f;
+            for (int rr = 0; rr < 16; ++rr) tsum += red[(rr * 32 + (ch >> 3)) * 16 + which * 8 + (ch & 7)];
+            if (srow * 128 < p.M) p.stats[((size_t)srow * 2 + which) * p.N + n0 + ch] = tsum;
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+static int g8_on = [] { const char* e = getenv("NKB_GEMM8P"); return e ? atoi(e) : 1; }();
+static int g8_min_tiles = [] { const char* e = getenv("NKB_GEMM8P_MIN_TILES"); return e ? atoi(e) : 192; }();
+static int g8_min_k = [] { const char* e = getenv("NKB_GEMM8P_MIN_K"); return e ? atoi(e) : 256; }();
+static int gemm8p_on() { return g8_on; }
+// run-time override of the envelope (tests and same-process A/B timing): on = 0 / 1, minimum tile count and reduction depth
+extern "C" void nkb_gemm8p_config(int on, int min_tiles, int min_k) {
+    g8_on = on;
+    if (min_tiles > 0) g8_min_tiles = min_tiles;
+    if (min_k > 0) g8_min_k = min_k;
+}
+
+bool nkb_gemm8p_eligible(const ConvParams& p, int dtype, int batch) {
+    if (!gemm8p_on() || dtype != NKB_DT_BF16 || batch != 1) return false;
+    if (!(p.R == 1 && p.S == 1 && p.stride == 1 && p.stride_w == 1 && p.pad == 0 && p.pad_w == 0 && p.stem_cprw == 0 &&
+          p.sub_h == 0 && p.H == p.P && p.W == p.Q && p.mode == 0))
+        return false;
+    if (p.out_f32 || p.add_h != 0 || p.add_bits != nullptr || p.y2 != nullptr || (p.act != 0 && p.act != 4)) return false;
+    if (p.Cout % 256 != 0 || p.Cin % 64 != 0 || p.Cin < 128 || p.ldy % 8 != 0 || p.ldx % 8 != 0 || p.ldw % 8 != 0) return false;
+    if (p.add && p.ldadd % 8 != 0) return false;
+    if (p.add && p.stats) return false;
+    // one workgroup per CU: worth it from a full wave of tiles up, and when the k-loop is long enough to amortise the
+    // seven-half-tile prologue
+    const long long tiles = (long long)((p.M + 255) / 256) * (p.Cout / 256);
+    return tiles >= g8_min_tiles && p.Cin >= g8_min_k;
+}
+
+int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
+    G8Params p;
+    p.x = (const bf16_t*)cp.x; p.w = (const bf16_t*)cp.w; p.y = (bf16_t*)cp.y; p.bias = cp.bias;
+    p.add = (const bf16_t*)cp.add; p.aux = cp.act == 4 ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
+    p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
+    p.relu = cp.relu;
+    p.tilesM = (p.M + 255) / 256; p.tilesN = p.N / 256;
+    static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
+    const double wbytes = (double)p.N * p.K * 2.0;
+    p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
+    constexpr int lds = 2 * 4 * 128 * 128;        // 128 KB (>= the 66.5 KB epilogue tile)
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm8p_kernel, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(512), lds, stream, p);
+    return nkb_check_launch("gemm8p");
+}

@@ -81,6 +81,7 @@ _SIGS = {
     "nkb_grad_unscale_check": (i32, [vp, i64, vp, vp, vp]),
     "nkb_scaler_update": (i32, [vp, vp, vp, vp, f32, f32, i32, vp]),
     "nkb_segment_sumsq": (i32, [vp, vp, i32, vp, vp]),
+    "nkb_gemm8p_config": (None, [i32, i32, i32]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
     "nkb_prof_collect_raw": (i32, [vp, vp, vp, i32]),
@@ -324,6 +325,10 @@ def scaler_update(scale, tracker, found_inf, last_found_inf, growth, backoff, in
 
 def segment_sumsq(x, offsets, nseg, out):
     check(load().nkb_segment_sumsq(ptr(x), ptr(offsets), nseg, ptr(out), stream()), "segment_sumsq")
+
+
+def gemm8p_config(on: bool, min_tiles: int = 0, min_k: int = 0):
+    load().nkb_gemm8p_config(int(on), min_tiles, min_k)
 
 
 def prof_enable(on: bool):

@@ -1066,3 +1066,75 @@ def test_splitk_linear_with_batchnorm_statistics(dtype):
     torch.testing.assert_close(stats.sum(0)[0].cpu(), got.sum(0).cpu(), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(stats.sum(0)[1].cpu(), (got * got).sum(0).cpu(), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(stats[1, 0].cpu(), got[128:].sum(0).cpu(), rtol=1e-4, atol=1e-3)     # second row tile: rows 128..129
+
+
+# ---- 256 x 256 eight-phase GEMM core (csrc/gemm8p.hip) ---------------------------------------------------------------
+@pytest.fixture
+def gemm8p_everywhere():
+    hip.gemm8p_config(True, 1, 128)          # let small problems take the kernel
+    yield
+    hip.gemm8p_config(True, 192, 256)
+
+
+@pytest.mark.parametrize("shape", [(1000, 256, 128), (2048 + 37, 768, 192), (4096, 512, 768), (777, 256, 1024), (256, 1024, 64 * 7)],
+                         ids=lambda s: "M%d_N%d_K%d" % s)
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_add", "relu6", "stats", "mul"])
+def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
+    """y = x w^T through nkb_conv_gemm / nkb_linear_gelu with the eight-phase kernel forced on: ragged M (rows past M are
+    loaded clamped and never stored), 2 to 16 k-tiles (the DMA stream's prologue / tail cases), every epilogue the kernel
+    carries; against the fp32 product of the same bf16 operands, and bit-identical to a second run (LDS-DMA + counted
+    vmcnt + raw barriers: a mis-placed wait shows up as run-to-run differences long before it shows up as a wrong mean)."""
+    M, N, K = shape
+    torch.manual_seed(11)
+    d = hip.BF16
+    x = torch.randn(M, K).to(torch.bfloat16)
+    w = (torch.randn(N, K) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N)
+    add = torch.randn(M, N).to(torch.bfloat16)
+    aux = torch.randn(M, N).to(torch.bfloat16)
+    ref = x.float() @ w.float().t()
+    xd, wd = x.to(DEV), w.to(DEV)
+    geom = dict(N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N)
+    outs = []
+    for _ in range(2):
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        stats = None
+        if epi == "plain":
+            hip.conv_gemm(d, 0, xd, wd, y, **geom)
+        elif epi == "bias_relu":
+            hip.conv_gemm(d, 0, xd, wd, y, bias=bias.to(DEV), relu=True, **geom)
+        elif epi == "bias_add":
+            hip.conv_gemm(d, 0, xd, wd, y, bias=bias.to(DEV), add=add.to(DEV), ldadd=N, **geom)
+        elif epi == "relu6":
+            hip.conv_gemm(d, 0, xd, wd, y, relu=2, **geom)
+        elif epi == "stats":
+            tiles = hip.stat_tiles(d, M, N)
+            stats = torch.full((tiles, 2, N), float("nan"), device=DEV)
+            hip.conv_gemm(d, 0, xd, wd, y, stats=stats, **geom)
+        else:
+            hip.linear_gelu(d, 4, xd, wd, None, aux.to(DEV), y, None, M, K, N)
+        torch.cuda.synchronize()
+        outs.append((y, stats))
+    assert torch.equal(outs[0][0], outs[1][0])
+    want = {"plain": ref, "bias_relu": (ref + bias).clamp_min(0), "bias_add": ref + bias + add.float(),
+            "relu6": ref.clamp(0, 6), "stats": ref, "mul": ref * aux.float()}[epi]
+    torch.testing.assert_close(outs[0][0].float().cpu(), want, **tol(torch.bfloat16, K))
+    if epi == "stats":
+        got = outs[0][0].float()
+        st = outs[0][1]
+        assert torch.isfinite(st).all()
+        torch.testing.assert_close(st.sum(0)[0], got.sum(0), rtol=1e-4, atol=1e-2)
+        torch.testing.assert_close(st.sum(0)[1], (got * got).sum(0), rtol=1e-4, atol=1e-2)
+        assert torch.equal(st, outs[1][1])
+
+
+def test_gemm8p_envelope_falls_back_cleanly(gemm8p_everywhere):
+    """Launches outside the kernel's envelope (Cout not a multiple of 256, K < 128, fp32 output) keep taking the 128 x 128
+    kernel and still give the right answer."""
+    torch.manual_seed(12)
+    for (M, N, K, f32) in [(512, 192, 256, False), (512, 256, 64, False), (300, 256, 256, True)]:
+        x, w = torch.randn(M, K).to(torch.bfloat16), (torch.randn(N, K) / math.sqrt(K)).to(torch.bfloat16)
+        y = torch.empty(M, N, device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+        hip.conv_gemm(hip.BF16, 0, x.to(DEV), w.to(DEV), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N, out_f32=f32)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y.float().cpu(), x.float() @ w.float().t(), **tol(torch.bfloat16, K))

@@ -269,3 +269,31 @@ def test_grad_scaler_with_reducer_overflow_on_one_rank():
     assert [s for s, _ in t0] == [256.0, 128.0, 128.0]   # step 1 skipped on both ranks
     assert t0[0][1] == t0[1][1] != t0[2][1]              # parameters untouched by the skipped step, moved by the next
     assert s0 == s1 == 2                                  # the skipped step does not count (rolled back when settled)
+
+
+# ------------------------------------------------------------------------------------------------- determinism ----
+@pytest.mark.parametrize("backbone,amp", [("resnet18", False), ("resnet_tiny_bottleneck", True), ("vit_tiny_test", True),
+                                          ("vit_tiny_test", False)])
+def test_train_step_gradients_are_bit_reproducible(backbone, amp):
+    """SURVEY §7 'deterministic summation order': the same step twice gives bit-identical gradients (weight gradients go
+    through per-split slabs + an ordered second stage, statistics through per-tile partials; no float atomics on the path)."""
+    cfg_model = dict(model=backbone, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    torch.manual_seed(0)
+    model = get_model(cfg_model, ["a", "b", "c"], DEV)
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    g = torch.Generator().manual_seed(9)
+    hw = 96 if backbone == "resnet18" else 64
+    x, y = torch.randn(16, 3, hw, hw, generator=g).to(DEV), torch.randint(0, 3, (16,), generator=g).to(DEV)
+    model.train()
+    grads = []
+    for _ in range(3):
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            loss = crit(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append(model.arena.flat_grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    assert grads[0].abs().max().item() > 0
