@@ -260,7 +260,7 @@ int nkb_scaler_update(float* scale, int* growth_tracker, float* found_inf, float
 int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float* out, nkb_stream_t stream);
 
 /* Envelope of the 256 x 256 eight-phase GEMM core that nkb_conv_gemm / nkb_linear_gelu use for wide plain 1x1 / Linear launches
- * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 256).  Tests and A/B timing. */
+ * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 768).  Tests and A/B timing. */
 void nkb_gemm8p_config(int on, int min_tiles, int min_k);
 
 /* Per-launch HIP-event profiler (bench.py's roofline leg). */

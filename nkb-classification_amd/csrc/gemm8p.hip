@@ -275,7 +275,9 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 
 static int g8_on = [] { const char* e = getenv("NKB_GEMM8P"); return e ? atoi(e) : 1; }();
 static int g8_min_tiles = [] { const char* e = getenv("NKB_GEMM8P_MIN_TILES"); return e ? atoi(e) : 192; }();
-static int g8_min_k = [] { const char* e = getenv("NKB_GEMM8P_MIN_K"); return e ? atoi(e) : 256; }();
+// measured (scripts/gemm8p_bench.py, same process, interleaved): K >= 768 wins on every shape with >= 192 tiles (+5..50 %);
+// K = 256 / 512 lose (one workgroup per CU: the 7-half-tile prologue and the 128 KB tile store are not hidden by a neighbour)
+static int g8_min_k = [] { const char* e = getenv("NKB_GEMM8P_MIN_K"); return e ? atoi(e) : 768; }();
 static int gemm8p_on() { return g8_on; }
 // run-time override of the envelope (tests and same-process A/B timing): on = 0 / 1, minimum tile count and reduction depth
 extern "C" void nkb_gemm8p_config(int on, int min_tiles, int min_k) {

@@ -1073,7 +1073,7 @@ def test_splitk_linear_with_batchnorm_statistics(dtype):
 def gemm8p_everywhere():
     hip.gemm8p_config(True, 1, 128)          # let small problems take the kernel
     yield
-    hip.gemm8p_config(True, 192, 256)
+    hip.gemm8p_config(True, 192, 768)
 
 
 @pytest.mark.parametrize("shape", [(1000, 256, 128), (2048 + 37, 768, 192), (4096, 512, 768), (777, 256, 1024), (256, 1024, 64 * 7)],
