@@ -181,6 +181,227 @@ __global__ __launch_bounds__(512, 1) void wgrad256_kernel(const W256Params p) {
     }
 }
 
+
+// ---- the same contraction on the eight-phase schedule of gemm8p.hip ------------------------------------------------------
+// One 64-token stage = four 16 KB half-tiles (X channels 0-127 | X 128-255 | dY 0-127 | dY 128-255); LDS-DMA runs seven
+// half-tiles ahead of the fragment reads, one counted s_waitcnt vmcnt(6) per stage, raw barriers, the two wave groups
+// (cout halves) one barrier apart.  Phase 1 reads every X fragment of the stage (kept for its four phases) and the dY
+// fragments of cout blocks 0-3; phases 2 / 3 re-fill the dY registers the previous phase's MFMAs released (blocks 4-5, 6-7).
+// Restaging follows gemm8p.hip: X halves (last read in phase 1, retired by the lgkmcnt before that phase's barrier) in
+// phases 2 and 3, dY halves (last read in phase 3, retired before its barrier) in phase 4 and the next phase 1.
+#define W8_BARRIER()                                 \
+    do {                                             \
+        asm volatile("" ::: "memory");               \
+        __builtin_amdgcn_s_barrier();                \
+        asm volatile("" ::: "memory");               \
+    } while (0)
+#define W8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define W8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
+    constexpr int SUB = 64 * 256;                 // one [64 tokens][128 channels] half-tile
+    constexpr int STG = 4 * SUB;                  // X lo | X hi | dY lo | dY hi
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wn = wave & 3;      // wave tile: cout [128 wr, +128) x n [64 wn, +64)
+
+    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
+    const int tile_c = tile % p.tilesC, tile_n = tile / p.tilesC;
+    const int c0 = tile_c * 256, n0 = tile_n * 256;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int KT = (m_end - m_begin) / 64;        // host guarantees whole stages, at least one
+    const int NH = 4 * KT;
+    if (KT <= 0) return;
+
+    // DMA: a half-tile = 16 pieces of 1 KiB (4 token rows x 256 B); this thread moves pieces (wave, wave + 8)
+    const int lrow = lane >> 4, lslot = lane & 15;
+    unsigned xs[2], ys[2];                        // element offsets of this lane's 16 bytes in channel half 0 (half 1: + 128)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave + 8 * q) * 4 + lrow;
+        const int ch = lslot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        xs[q] = (unsigned)(m_begin + row) * (unsigned)p.ldx + n0 + ch * 8;        // < 2^31 elements (checked by the host)
+        ys[q] = (unsigned)(m_begin + row) * (unsigned)p.lddy + c0 + ch * 8;
+    }
+    const unsigned xstep = 64u * (unsigned)p.ldx, ystep = 64u * (unsigned)p.lddy;
+#define W8_ISSUE(tt, hh)                                                                                              \
+    do {                                                                                                              \
+        unsigned char* d_ = smem + ((tt) & 1) * STG + (hh) * SUB + wave * 1024;                                      \
+        const bf16_t* s_ = ((hh) < 2 ? p.x : p.dy) + ((hh) & 1) * 128;                                               \
+        const unsigned o_ = (unsigned)(tt) * ((hh) < 2 ? xstep : ystep);                                             \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + (((hh) < 2 ? xs[0] : ys[0]) + o_)), \
+                                         (__attribute__((address_space(3))) void*)d_, 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + (((hh) < 2 ? xs[1] : ys[1]) + o_)), \
+                                         (__attribute__((address_space(3))) void*)(d_ + 8192), 16, 0, 0);            \
+    } while (0)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+    // fragment of channel block `blk` (16 channels), tokens 32 kk + 8 g + q4 (+ 4): byte offset inside a half-tile
+    //   swz256(row, 2 blk + c) + 8 (p4 & 1) = 256 row + 32 (blk ^ kx) + 16 (c ^ hi) + 8 (p4 & 1),   kx = (q4 << 1) | (g & 1)
+    // (the swizzle key of row 8 g + q4 + 4 hi is (q4 << 2) | ((2 g + hi) & 3): its low bit is hi, the rest kx) — so two lane
+    // constants (lo / hi row) plus one XOR per block replace 24 precomputed addresses, which is what kept this kernel from
+    // fitting its 256 registers
+    const int row0 = 8 * g + q4;
+    const int fb_lo = 256 * row0 + 16 * (p4 >> 1) + 8 * (p4 & 1);
+    const int fb_hi = 256 * (row0 + 4) + 16 * ((p4 >> 1) ^ 1) + 8 * (p4 & 1);
+    const int kx32 = ((q4 << 1) | (g & 1)) << 5;
+    const int bblk0 = (wn & 1) * 4;
+    auto frag = [&](const unsigned char* tile_, int kx, int kk, int blk32) -> bf16x8 {
+        const int o = (blk32 ^ kx) + 8192 * kk;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile_ + fb_lo + o));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile_ + fb_hi + o));
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    const bool do_bias = p.dbias != nullptr && tile_n == 0 && wn == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    if (0 < NH) W8_ISSUE(0, 0);
+    if (1 < NH) W8_ISSUE(0, 1);
+    if (2 < NH) W8_ISSUE(0, 2);
+    if (3 < NH) W8_ISSUE(0, 3);
+    if (4 < NH) W8_ISSUE(1, 0);
+    if (5 < NH) W8_ISSUE(1, 1);
+    if (6 < NH) W8_ISSUE(1, 2);
+    if (NH > 4) W8_VMCNT(6); else W8_VMCNT(0);
+    W8_BARRIER();
+    if (wr == 1) W8_BARRIER();
+
+    bf16x8 a[4][2], b[4][2];
+#define W8_MMA(slot, ii)                                                                                              \
+    do {                                                                                                              \
+        if (do_bias) {                                                                                                \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                        \
+                const u32x4 v_ = __builtin_bit_cast(u32x4, a[slot][kk]);                                              \
+                float t_ = 0.f;                                                                                       \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) t_ += __uint_as_float(v_[e] << 16) + __uint_as_float(v_[e] & 0xffff0000u); \
+                bsum[ii] += t_;                                                                                       \
+            }                                                                                                         \
+        }                                                                                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+                acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[slot][kk], b[j][kk], acc[ii][j], 0, 0, 0);     \
+    } while (0)
+
+    for (int t = 0; t < KT; ++t) {
+        const unsigned char* base = smem + (t & 1) * STG;
+        const unsigned char* A = base + (2 + wr) * SUB;
+        const unsigned char* B = base + (wn >> 1) * SUB;
+        int kxa = kx32, kxb = kx32 ^ (bblk0 << 5);
+        asm volatile("" : "+v"(kxa), "+v"(kxb));   // opaque per stage: the per-block offsets are recomputed, not kept live
+        // ---------------- phase 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j][0] = frag(B, kxb, 0, 32 * j);
+            b[j][1] = frag(B, kxb, 1, 32 * j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i][0] = frag(A, kxa, 0, 32 * i);
+            a[i][1] = frag(A, kxa, 1, 32 * i);
+        }
+        if (4 * t + 7 < NH) W8_ISSUE(t + 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        W8_LGKM(15);                               // 32 reads issued, X first: at most 15 outstanding = every X read retired
+        W8_BARRIER();
+        W8_LGKM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        W8_MMA(0, 0); W8_MMA(1, 1);
+        __builtin_amdgcn_s_setprio(0);
+        W8_BARRIER();
+        // ---------------- phase 2
+        a[0][0] = frag(A, kxa, 0, 32 * 4); a[0][1] = frag(A, kxa, 1, 32 * 4);
+        a[1][0] = frag(A, kxa, 0, 32 * 5); a[1][1] = frag(A, kxa, 1, 32 * 5);
+        if (4 * t + 8 < NH) W8_ISSUE(t + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        W8_BARRIER();
+        W8_LGKM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        W8_MMA(2, 2); W8_MMA(3, 3);
+        __builtin_amdgcn_s_setprio(0);
+        W8_BARRIER();
+        // ---------------- phase 3
+        a[2][0] = frag(A, kxa, 0, 32 * 6); a[2][1] = frag(A, kxa, 1, 32 * 6);
+        a[3][0] = frag(A, kxa, 0, 32 * 7); a[3][1] = frag(A, kxa, 1, 32 * 7);
+        if (4 * t + 9 < NH) W8_ISSUE(t + 2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        W8_LGKM(0);
+        W8_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        W8_MMA(0, 4); W8_MMA(1, 5);
+        __builtin_amdgcn_s_setprio(0);
+        W8_BARRIER();
+        // ---------------- phase 4
+        if (4 * t + 10 < NH) W8_ISSUE(t + 2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < KT) W8_VMCNT(6);
+        else if (t + 1 < KT) W8_VMCNT(0);
+        W8_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        W8_MMA(2, 6); W8_MMA(3, 7);
+        __builtin_amdgcn_s_setprio(0);
+        W8_BARRIER();
+    }
+    if (wr == 0) W8_BARRIER();
+    __syncthreads();
+
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = bsum[i];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (lane < 16) {
+                if (p.bpart) p.bpart[(size_t)split * p.Cout + c0 + wr * 128 + 16 * i + lane] = t;
+                else atomicAdd(p.dbias + c0 + wr * 128 + 16 * i + lane, t);
+            }
+        }
+    }
+    constexpr int EROW = 256 * 4 + 16;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        if (wr == (pass >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = 4 * (pass & 1) + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rbase = 16 * ii + 4 * g, col = wn * 64 + 16 * j + li;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *(float*)(smem + (rbase + e) * EROW + col * 4) = acc[i][j][e];
+                }
+            }
+        }
+        __syncthreads();
+        if (p.part) {
+            for (int row = wave; row < 64; row += 8) {
+                float* dst = p.part + (size_t)split * p.slab + (size_t)(c0 + pass * 64 + row) * p.Ntot + n0;
+                *(f32x4*)(dst + 4 * lane) = *(const f32x4*)(smem + row * EROW + 16 * lane);
+            }
+        } else
+        for (int row = wave; row < 64; row += 8) {
+            float* dst = p.dw + (size_t)(c0 + pass * 64 + row) * p.Ntot + n0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(dst + lane + 64 * c, *(const float*)(smem + row * EROW + (lane + 64 * c) * 4));
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 static int wgrad256_target_wgs() {
@@ -233,9 +454,12 @@ int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, 
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)wgrad8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
+    static const int eight_phase = [] { const char* e = getenv("NKB_WGRAD8P"); return e ? atoi(e) : 1; }();
+    if (eight_phase) hipLaunchKernelGGL(wgrad8p_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
     int rc = nkb_check_launch("wgrad256");
     if (rc || !workspace) return rc;
     rc = nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
