@@ -59,6 +59,16 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* dst) {
 #define G8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define G8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
+// DIRECT = false: one tile per workgroup, epilogue through LDS (coalesced 16-byte rows, BatchNorm partial sums).
+// DIRECT = true : persistent workgroups (grid = min(tiles, CUs), tile = id, id + grid, ...), epilogue straight from the
+//   accumulators: the W rows of a half-tile are staged in the order 32 (r >> 5) + 8 ((r >> 2) & 3) + 4 ((r >> 4) & 1) + (r & 3)
+//   (bits 4 and 3:2 of the row index swapped — a permutation of the DMA SOURCE rows only, the LDS image and its reads are
+//   unchanged), so that the accumulator tiles 2p and 2p+1 of a lane hold 8 CONSECUTIVE output channels of one pixel: one
+//   16-byte store per lane, 64 contiguous bytes per pixel and instruction, no LDS round trip and no barrier.  The next
+//   tile's seven-half-tile prologue is issued BEFORE those stores and the wait that precedes the next k-loop counts them
+//   (vmcnt(6 + 16): stores are younger than the DMAs), so the 128 KB tile store drains under the next tile's MFMAs instead
+//   of in front of them — with one workgroup per CU nothing else would hide it.
+template <bool DIRECT>
 __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     constexpr int HT = 128 * 128;                 // bytes of one half-tile (128 rows x 64 bf16)
     constexpr int BUF = 4 * HT;                   // one k-tile: X lo | X hi | W lo | W hi
@@ -66,32 +76,40 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;      // cout half, pixel quarter
-
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-    int tile_n = lid % p.tilesN, tile_m = lid / p.tilesN;
-    if (p.group_m > 1) {                          // grouped walk (see conv_igemm.hip): row tile fastest inside a group
-        const int gsz = p.group_m * p.tilesN;
-        const int grp = (int)lid / gsz, first_m = grp * p.group_m;
-        const int gm = min(p.group_m, p.tilesM - first_m);
-        const int r = (int)lid - grp * gsz;
-        tile_m = first_m + r % gm;
-        tile_n = r / gm;
-    }
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
     const int KT = p.K >> 6, NH = 4 * KT;         // k-tiles, half-tiles in the DMA stream
-
-    // ---- DMA source offsets: piece = 8 rows x 128 B; this thread moves pieces (wave, wave + 8) of every half-tile
+    const int ntiles = p.tilesM * p.tilesN;
     const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+    const int frow = lane & 15, fgrp = lane >> 4;
+    // fragment addresses: lane (frow, fgrp) reads 16 B of row 16 i + frow, chunk 4 ks + fgrp (swizzled)
+    const int fo0 = frow * 128 + ((fgrp ^ (frow & 7)) << 4), fo1 = frow * 128 + (((4 + fgrp) ^ (frow & 7)) << 4);
+    const int a_base = (2 + wr) * HT;                                  // this wave's W half-tile
+    const int b_base = (wc >> 1) * HT + (wc & 1) * 8192;               // this wave's 64 X rows
+
+    int tile_n, tile_m, m0, n0;
     unsigned xo[2][2], wo[2][2];                  // [half][piece] element offsets of this lane's 16 bytes at k = 0
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int row = h * 128 + (wave + 8 * q) * 8 + lrow;
-            const int xm = min(m0 + row, p.M - 1);            // rows past M are loaded from the last row and discarded
-            xo[h][q] = (unsigned)xm * (unsigned)p.ldx + chunk * 8;
-            wo[h][q] = (unsigned)(n0 + row) * (unsigned)p.ldw + chunk * 8;
+    auto set_tile = [&](int lid) {
+        tile_n = lid % p.tilesN; tile_m = lid / p.tilesN;
+        if (p.group_m > 1) {                      // grouped walk (see conv_igemm.hip): row tile fastest inside a group
+            const int gsz = p.group_m * p.tilesN;
+            const int grp = lid / gsz, first_m = grp * p.group_m;
+            const int gm = min(p.group_m, p.tilesM - first_m);
+            const int r = lid - grp * gsz;
+            tile_m = first_m + r % gm;
+            tile_n = r / gm;
         }
+        m0 = tile_m * 256; n0 = tile_n * 256;
+        // DMA source offsets: piece = 8 rows x 128 B; this thread moves pieces (wave, wave + 8) of every half-tile
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = (wave + 8 * q) * 8 + lrow;                   // LDS row inside the half-tile
+                const int xm = min(m0 + h * 128 + r, p.M - 1);            // rows past M: loaded from the last row, never stored
+                xo[h][q] = (unsigned)xm * (unsigned)p.ldx + chunk * 8;
+                const int wrow = DIRECT ? ((r & 0x63) | ((r & 0x0c) << 1) | ((r & 0x10) >> 2)) : r;
+                wo[h][q] = (unsigned)(n0 + h * 128 + wrow) * (unsigned)p.ldw + chunk * 8;
+            }
+    };
     // half-tile hh (0, 1: X lo / hi; 2, 3: W lo / hi) of k-tile tt
 #define G8_ISSUE(tt, hh)                                                                                              \
     do {                                                                                                              \
@@ -100,36 +118,33 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         glds16(s_ + ((hh) < 2 ? xo[(hh) & 1][0] : wo[(hh) & 1][0]), d_);                                             \
         glds16(s_ + ((hh) < 2 ? xo[(hh) & 1][1] : wo[(hh) & 1][1]), d_ + 8192);                                      \
     } while (0)
+#define G8_PROLOGUE()                                                                                                 \
+    do {                                                                                                              \
+        G8_ISSUE(0, 0); G8_ISSUE(0, 1); G8_ISSUE(0, 2); G8_ISSUE(0, 3);                                               \
+        if (NH > 4) { G8_ISSUE(1, 0); G8_ISSUE(1, 1); G8_ISSUE(1, 2); }                                               \
+    } while (0)
+
+    const int step = (int)gridDim.x;
+    int lid = (int)xcd_remap(blockIdx.x, gridDim.x);
+    set_tile(lid);
+    // ---- prologue: seven half-tiles in flight, the first k-tile landed
+    G8_PROLOGUE();
+    if (NH > 4) G8_VMCNT(6); else G8_VMCNT(0);
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ---- fragment addresses: lane (frow, fgrp) reads 16 B of row 16 i + frow, chunk 4 ks + fgrp (swizzled)
-    const int frow = lane & 15, fgrp = lane >> 4;
-    const int fo0 = frow * 128 + ((fgrp ^ (frow & 7)) << 4), fo1 = frow * 128 + (((4 + fgrp) ^ (frow & 7)) << 4);
-    const int a_base = (2 + wr) * HT;                                  // this wave's W half-tile
-    const int b_base = (wc >> 1) * HT + (wc & 1) * 8192;               // this wave's 64 X rows
-
-    // ---- prologue: seven half-tiles in flight, the first k-tile landed
-    if (0 < NH) G8_ISSUE(0, 0);
-    if (1 < NH) G8_ISSUE(0, 1);
-    if (2 < NH) G8_ISSUE(0, 2);
-    if (3 < NH) G8_ISSUE(0, 3);
-    if (4 < NH) G8_ISSUE(1, 0);
-    if (5 < NH) G8_ISSUE(1, 1);
-    if (6 < NH) G8_ISSUE(1, 2);
-    if (NH > 4) G8_VMCNT(6); else G8_VMCNT(0);
-    G8_BARRIER();
-    if (wr == 1) G8_BARRIER();    // stagger: the second wave group runs one barrier behind
-
     bf16x8 a[4][2], b[4][2];
 #define G8_MMA(slot, ii)                                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
             acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[slot][ks], b[j][ks], acc[ii][j], 0, 0, 0)
+
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    G8_BARRIER();
+    if (wr == 1) G8_BARRIER();                    // stagger: the second wave group runs one barrier behind
 
     for (int t = 0; t < KT; ++t) {
         const unsigned char* base = smem + (t & 1) * BUF;
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         if (4 * t + 9 < NH) G8_ISSUE(t + 2, 1);
         __builtin_amdgcn_sched_barrier(0);
         G8_LGKM(0);                                // last reads of this k-tile's W halves: retired before the barrier, so
-        G8_BARRIER();              // phase 4 (either wave group) may restage them
+        G8_BARRIER();                              // phase 4 (either wave group) may restage them
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         G8_MMA(0, 4); G8_MMA(1, 5);
@@ -194,44 +209,46 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         G8_BARRIER();
     }
     if (wr == 0) G8_BARRIER();
-    __syncthreads();                              // every wave is done with the staging buffers
 
-    // ---- epilogue: four passes of 64 pixel rows through LDS [64][256 f32 + pad] -> bf16 rows of 512 B
-    constexpr int EROW = 256 * 4 + 16;
-    const int eg = tid & 31, er = tid >> 5;       // 32 chunks of 8 channels per row, 16 rows per trip
-    const int co = n0 + eg * 8;
-    float bv[8];
+    if constexpr (DIRECT) {
+        // ---- epilogue straight from the accumulators; the next tile's prologue goes out first
+        const int em0 = m0, en0 = n0;
+        const bool ragged = em0 + 256 > p.M;
+        lid += step;
+        const bool more = lid < ntiles;
+        G8_BARRIER();                              // every wave is done with the staging buffers of this tile
+        if (more) { set_tile(lid); G8_PROLOGUE(); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[co + e] : 0.f;
-    float ssum[8], ssq[8];
+        for (int pr = 0; pr < 4; ++pr) {
+            const int co = en0 + wr * 128 + 32 * pr + 8 * fgrp;
+            float bv[8];
+            if (p.bias) {
+                const f32x4 b0 = *(const f32x4*)(p.bias + co), b1 = *(const f32x4*)(p.bias + co + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-    for (int pass = 0; pass < 4; ++pass) {
-        if (wc == pass) {
+                for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *(f32x4*)(smem + (16 * j + frow) * EROW + (wr * 128 + 16 * i + fgrp * 4) * 4) = acc[i][j];
-        }
-        __syncthreads();
+            for (int j = 0; j < 4; ++j) {
+                const int m = em0 + wc * 64 + 16 * j + frow;
+                float v[8];
 #pragma unroll
-        for (int tr = 0; tr < 4; ++tr) {
-            const int row = er + 16 * tr;
-            const int m = m0 + pass * 64 + row;
-            if (m < p.M) {
-                const f32x4 lo = *(const f32x4*)(smem + row * EROW + eg * 32), hi = *(const f32x4*)(smem + row * EROW + eg * 32 + 16);
-                float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3],
-                              hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
+                for (int e = 0; e < 4; ++e) { v[e] = acc[2 * pr][j][e] + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] + bv[4 + e]; }
+                const bool ok = m < p.M;
                 if (p.add) {
                     float af[8];
-                    unpack8(*(const u32x4*)(p.add + (size_t)m * p.ldadd + co), af);
+                    const u32x4 raw = ok ? *(const u32x4*)(p.add + (size_t)m * p.ldadd + co) : (u32x4){0u, 0u, 0u, 0u};
+                    unpack8(raw, af);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += af[e];
                 }
                 if (p.aux) {
                     float af[8];
-                    unpack8(*(const u32x4*)(p.aux + (size_t)m * p.ldy + co), af);
+                    const u32x4 raw = ok ? *(const u32x4*)(p.aux + (size_t)m * p.ldy + co) : (u32x4){0u, 0u, 0u, 0u};
+                    unpack8(raw, af);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= af[e];
                 }
@@ -239,36 +256,94 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
                 }
-                const u32x4 pk = pack8(v);
-                *(u32x4*)(p.y + (size_t)m * p.ldy + co) = pk;
-                if (p.stats) {                     // statistics see the stored (rounded) value
+                if (ok) *(u32x4*)(p.y + (size_t)m * p.ldy + co) = pack8(v);
+            }
+        }
+        if (!more) break;
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tile's first k-tile must have landed; its 14 DMA instructions are OLDER than the 16 stores above, so
+        // "all but the 6 youngest DMAs" = all but the 22 youngest operations.  (Ragged last row tile: some of its store
+        // instructions may not have been issued at all — wait for everything there.  The operand loads of the add / aux
+        // epilogues are consumed above, i.e. complete.)
+        if (ragged || NH <= 4) G8_VMCNT(0); else G8_VMCNT(22);
+    } else {
+        __syncthreads();                          // every wave is done with the staging buffers
+        // ---- epilogue: four passes of 64 pixel rows through LDS [64][256 f32 + pad] -> bf16 rows of 512 B
+        constexpr int EROW = 256 * 4 + 16;
+        const int eg = tid & 31, er = tid >> 5;   // 32 chunks of 8 channels per row, 16 rows per trip
+        const int co = n0 + eg * 8;
+        float bv[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float r0 = __uint_as_float(pk[e] << 16), r1 = __uint_as_float(pk[e] & 0xffff0000u);
-                        ssum[2 * e] += r0; ssum[2 * e + 1] += r1;
-                        ssq[2 * e] += r0 * r0; ssq[2 * e + 1] += r1 * r1;
+        for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[co + e] : 0.f;
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+        for (int pass = 0; pass < 4; ++pass) {
+            if (wc == pass) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *(f32x4*)(smem + (16 * j + frow) * EROW + (wr * 128 + 16 * i + fgrp * 4) * 4) = acc[i][j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tr = 0; tr < 4; ++tr) {
+                const int row = er + 16 * tr;
+                const int m = m0 + pass * 64 + row;
+                if (m < p.M) {
+                    const f32x4 lo = *(const f32x4*)(smem + row * EROW + eg * 32), hi = *(const f32x4*)(smem + row * EROW + eg * 32 + 16);
+                    float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3],
+                                  hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
+                    if (p.add) {
+                        float af[8];
+                        unpack8(*(const u32x4*)(p.add + (size_t)m * p.ldadd + co), af);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += af[e];
+                    }
+                    if (p.aux) {
+                        float af[8];
+                        unpack8(*(const u32x4*)(p.aux + (size_t)m * p.ldy + co), af);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= af[e];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
+                    }
+                    const u32x4 pk = pack8(v);
+                    *(u32x4*)(p.y + (size_t)m * p.ldy + co) = pk;
+                    if (p.stats) {                 // statistics see the stored (rounded) value
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r0 = __uint_as_float(pk[e] << 16), r1 = __uint_as_float(pk[e] & 0xffff0000u);
+                            ssum[2 * e] += r0; ssum[2 * e + 1] += r1;
+                            ssq[2 * e] += r0 * r0; ssq[2 * e + 1] += r1 * r1;
+                        }
                     }
                 }
             }
-        }
-        __syncthreads();
-        if (p.stats && (pass & 1)) {               // 128 pixel rows done: deterministic partial sums, reduced later by bn_finalize
-            const int srow = tile_m * 2 + (pass >> 1);
-            float* red = (float*)smem;             // [16 er][32 eg][16]
+            __syncthreads();
+            if (p.stats && (pass & 1)) {           // 128 pixel rows done: deterministic partial sums, reduced later by bn_finalize
+                const int srow = tile_m * 2 + (pass >> 1);
+                float* red = (float*)smem;         // [16 er][32 eg][16]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                red[(er * 32 + eg) * 16 + e] = ssum[e];
-                red[(er * 32 + eg) * 16 + 8 + e] = ssq[e];
-                ssum[e] = 0.f; ssq[e] = 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    red[(er * 32 + eg) * 16 + e] = ssum[e];
+                    red[(er * 32 + eg) * 16 + 8 + e] = ssq[e];
+                    ssum[e] = 0.f; ssq[e] = 0.f;
+                }
+                __syncthreads();
+                const int which = tid >> 8, ch = tid & 255;
+                float tsum = 0.f;
+                for (int rr = 0; rr < 16; ++rr) tsum += red[(rr * 32 + (ch >> 3)) * 16 + which * 8 + (ch & 7)];
+                if (srow * 128 < p.M) p.stats[((size_t)srow * 2 + which) * p.N + n0 + ch] = tsum;
+                __syncthreads();
             }
-            __syncthreads();
-            const int which = tid >> 8, ch = tid & 255;
-            float tsum = 0.f;
-            for (int rr = 0; rr < 16; ++rr) tsum += red[(rr * 32 + (ch >> 3)) * 16 + which * 8 + (ch & 7)];
-            if (srow * 128 < p.M) p.stats[((size_t)srow * 2 + which) * p.N + n0 + ch] = tsum;
-            __syncthreads();
         }
+        break;
     }
+  }
 }
 
 }  // namespace
@@ -312,11 +387,21 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     const double wbytes = (double)p.N * p.K * 2.0;
     p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     constexpr int lds = 2 * 4 * 128 * 128;        // 128 KB (>= the 66.5 KB epilogue tile)
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    static int cus = 0;
+    if (!cus) {
+        hipFuncSetAttribute((const void*)gemm8p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm8p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
     }
-    hipLaunchKernelGGL(gemm8p_kernel, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(512), lds, stream, p);
+    const int tiles = p.tilesM * p.tilesN;
+    // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
+    static const int direct_on = [] { const char* e = getenv("NKB_GEMM8P_DIRECT"); return e ? atoi(e) : 1; }();
+    if (p.stats == nullptr && direct_on && p.K >= 128)
+        hipLaunchKernelGGL(gemm8p_kernel<true>, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), lds, stream, p);
+    else
+        hipLaunchKernelGGL(gemm8p_kernel<false>, dim3((unsigned)tiles), dim3(512), lds, stream, p);
     return nkb_check_launch("gemm8p");
 }

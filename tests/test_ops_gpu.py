@@ -1076,7 +1076,8 @@ def gemm8p_everywhere():
     hip.gemm8p_config(True, 192, 768)
 
 
-@pytest.mark.parametrize("shape", [(1000, 256, 128), (2048 + 37, 768, 192), (4096, 512, 768), (777, 256, 1024), (256, 1024, 64 * 7)],
+@pytest.mark.parametrize("shape", [(1000, 256, 128), (2048 + 37, 768, 192), (4096, 512, 768), (777, 256, 1024), (256, 1024, 64 * 7),
+                                   (256 * 300 + 100, 512, 256)],      # 602 tiles: every persistent workgroup walks 2-3 of them
                          ids=lambda s: "M%d_N%d_K%d" % s)
 @pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_add", "relu6", "stats", "mul"])
 def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
