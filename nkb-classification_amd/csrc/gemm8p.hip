@@ -60,14 +60,16 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* dst) {
 #define G8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
 // DIRECT = false: one tile per workgroup, epilogue through LDS (coalesced 16-byte rows, BatchNorm partial sums).
-// DIRECT = true : persistent workgroups (grid = min(tiles, CUs), tile = id, id + grid, ...), epilogue straight from the
-//   accumulators: the W rows of a half-tile are staged in the order 32 (r >> 5) + 8 ((r >> 2) & 3) + 4 ((r >> 4) & 1) + (r & 3)
-//   (bits 4 and 3:2 of the row index swapped — a permutation of the DMA SOURCE rows only, the LDS image and its reads are
-//   unchanged), so that the accumulator tiles 2p and 2p+1 of a lane hold 8 CONSECUTIVE output channels of one pixel: one
-//   16-byte store per lane, 64 contiguous bytes per pixel and instruction, no LDS round trip and no barrier.  The next
-//   tile's seven-half-tile prologue is issued BEFORE those stores and the wait that precedes the next k-loop counts them
-//   (vmcnt(6 + 16): stores are younger than the DMAs), so the 128 KB tile store drains under the next tile's MFMAs instead
-//   of in front of them — with one workgroup per CU nothing else would hide it.
+// DIRECT = true : persistent workgroups (grid = min(tiles, CUs), tile = id, id + grid, ...) with ONE continuous DMA stream
+//   over all their k-tiles: the half-tiles issued during the last two k-tiles of a tile already belong to the next tile, so
+//   no tile pays the seven-half-tile ramp-up again (with a single workgroup per CU nothing else would hide it: measured
+//   5-7 us per 256 x 256 x 768 tile, ~30 % of its time).  The epilogue goes straight from the accumulators to memory between
+//   two k-tiles of that stream: the W rows of a half-tile are staged in the order 32 (r >> 5) + 8 ((r >> 2) & 3) +
+//   4 ((r >> 4) & 1) + (r & 3) (bits 4 and 3:2 of the row index swapped — a permutation of the DMA SOURCE rows only, the LDS
+//   image and its reads are unchanged), so the accumulator tiles 2p and 2p+1 of a lane hold 8 CONSECUTIVE output channels of
+//   one pixel: one 16-byte store per lane, 64 contiguous bytes per pixel and instruction, no LDS round trip, no barrier.
+//   The stores are older than every DMA issued after them, so the counted vmcnt(6) of the following k-tile's phase 4 also
+//   covers them (four phases later they have long been acknowledged) and the wave groups stay staggered across tiles.
 template <bool DIRECT>
 __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     constexpr int HT = 128 * 128;                 // bytes of one half-tile (128 rows x 64 bf16)
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;      // cout half, pixel quarter
-    const int KT = p.K >> 6, NH = 4 * KT;         // k-tiles, half-tiles in the DMA stream
+    const int KT = p.K >> 6;                      // k-tiles per tile (DIRECT: >= 2)
     const int ntiles = p.tilesM * p.tilesN;
     const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
     const int frow = lane & 15, fgrp = lane >> 4;
@@ -85,72 +87,91 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     const int a_base = (2 + wr) * HT;                                  // this wave's W half-tile
     const int b_base = (wc >> 1) * HT + (wc & 1) * 8192;               // this wave's 64 X rows
 
-    int tile_n, tile_m, m0, n0;
-    unsigned xo[2][2], wo[2][2];                  // [half][piece] element offsets of this lane's 16 bytes at k = 0
-    auto set_tile = [&](int lid) {
-        tile_n = lid % p.tilesN; tile_m = lid / p.tilesN;
+    // (tile_m, tile_n) of logical tile id
+    auto tile_of = [&](int id, int& tm, int& tn) {
+        tn = id % p.tilesN; tm = id / p.tilesN;
         if (p.group_m > 1) {                      // grouped walk (see conv_igemm.hip): row tile fastest inside a group
             const int gsz = p.group_m * p.tilesN;
-            const int grp = lid / gsz, first_m = grp * p.group_m;
+            const int grp = id / gsz, first_m = grp * p.group_m;
             const int gm = min(p.group_m, p.tilesM - first_m);
-            const int r = lid - grp * gsz;
-            tile_m = first_m + r % gm;
-            tile_n = r / gm;
+            const int r = id - grp * gsz;
+            tm = first_m + r % gm;
+            tn = r / gm;
         }
-        m0 = tile_m * 256; n0 = tile_n * 256;
-        // DMA source offsets: piece = 8 rows x 128 B; this thread moves pieces (wave, wave + 8) of every half-tile
+    };
+    // DMA source offsets of a tile: piece = 8 rows x 128 B; this thread moves pieces (wave, wave + 8) of every half-tile.
+    // [half][piece] element offsets of this lane's 16 bytes at k = 0
+    auto offsets_of = [&](int tm, int tn, unsigned (&xo_)[2][2], unsigned (&wo_)[2][2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = (wave + 8 * q) * 8 + lrow;                   // LDS row inside the half-tile
-                const int xm = min(m0 + h * 128 + r, p.M - 1);            // rows past M: loaded from the last row, never stored
-                xo[h][q] = (unsigned)xm * (unsigned)p.ldx + chunk * 8;
+                const int xm = min(tm * 256 + h * 128 + r, p.M - 1);      // rows past M: loaded from the last row, never stored
+                xo_[h][q] = (unsigned)xm * (unsigned)p.ldx + chunk * 8;
                 const int wrow = DIRECT ? ((r & 0x63) | ((r & 0x0c) << 1) | ((r & 0x10) >> 2)) : r;
-                wo[h][q] = (unsigned)(n0 + h * 128 + wrow) * (unsigned)p.ldw + chunk * 8;
+                wo_[h][q] = (unsigned)(tn * 256 + h * 128 + wrow) * (unsigned)p.ldw + chunk * 8;
             }
     };
-    // half-tile hh (0, 1: X lo / hi; 2, 3: W lo / hi) of k-tile tt
-#define G8_ISSUE(tt, hh)                                                                                              \
+    // half-tile hh (0, 1: X lo / hi; 2, 3: W lo / hi) at local k-tile kl of the tile with offsets (xo_, wo_), into the buffer
+    // of stream k-tile gk
+#define G8_ISSUE_AT(gk, kl, hh, xo_, wo_)                                                                             \
     do {                                                                                                              \
-        unsigned char* d_ = smem + ((tt) & 1) * BUF + (hh) * HT + wave * 1024;                                       \
-        const bf16_t* s_ = ((hh) < 2 ? p.x : p.w) + (size_t)(tt) * 64;                                               \
-        glds16(s_ + ((hh) < 2 ? xo[(hh) & 1][0] : wo[(hh) & 1][0]), d_);                                             \
-        glds16(s_ + ((hh) < 2 ? xo[(hh) & 1][1] : wo[(hh) & 1][1]), d_ + 8192);                                      \
-    } while (0)
-#define G8_PROLOGUE()                                                                                                 \
-    do {                                                                                                              \
-        G8_ISSUE(0, 0); G8_ISSUE(0, 1); G8_ISSUE(0, 2); G8_ISSUE(0, 3);                                               \
-        if (NH > 4) { G8_ISSUE(1, 0); G8_ISSUE(1, 1); G8_ISSUE(1, 2); }                                               \
+        unsigned char* d_ = smem + ((gk) & 1) * BUF + (hh) * HT + wave * 1024;                                       \
+        const bf16_t* s_ = ((hh) < 2 ? p.x : p.w) + (size_t)(kl) * 64;                                               \
+        glds16(s_ + ((hh) < 2 ? xo_[(hh) & 1][0] : wo_[(hh) & 1][0]), d_);                                           \
+        glds16(s_ + ((hh) < 2 ? xo_[(hh) & 1][1] : wo_[(hh) & 1][1]), d_ + 8192);                                    \
     } while (0)
 
     const int step = (int)gridDim.x;
     int lid = (int)xcd_remap(blockIdx.x, gridDim.x);
-    set_tile(lid);
+    int tile_m, tile_n;
+    tile_of(lid, tile_m, tile_n);
+    unsigned xo[2][2], wo[2][2], xn[2][2], wn_[2][2];     // current tile / next tile of this workgroup (DIRECT)
+    offsets_of(tile_m, tile_n, xo, wo);
+    int next_m = 0, next_n = 0;
+    bool has_next = false;
+    if constexpr (DIRECT) {
+        has_next = lid + step < ntiles;
+        if (has_next) { tile_of(lid + step, next_m, next_n); offsets_of(next_m, next_n, xn, wn_); }
+    }
+    // k-tiles of this workgroup's whole DMA stream
+    const int GT = DIRECT ? KT * ((ntiles - lid + step - 1) / step) : KT;
+
     // ---- prologue: seven half-tiles in flight, the first k-tile landed
-    G8_PROLOGUE();
-    if (NH > 4) G8_VMCNT(6); else G8_VMCNT(0);
+    G8_ISSUE_AT(0, 0, 0, xo, wo); G8_ISSUE_AT(0, 0, 1, xo, wo); G8_ISSUE_AT(0, 0, 2, xo, wo); G8_ISSUE_AT(0, 0, 3, xo, wo);
+    if (GT > 1) {                                  // (DIRECT: KT >= 2, so stream k-tile 1 is k-tile 1 of the first tile)
+        G8_ISSUE_AT(1, 1, 0, xo, wo); G8_ISSUE_AT(1, 1, 1, xo, wo); G8_ISSUE_AT(1, 1, 2, xo, wo);
+        G8_VMCNT(6);
+    } else {
+        G8_VMCNT(0);
+    }
+    G8_BARRIER();
+    if (wr == 1) G8_BARRIER();                    // stagger: the second wave group runs one barrier behind
 
     f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 a[4][2], b[4][2];
 #define G8_MMA(slot, ii)                                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
             acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[slot][ks], b[j][ks], acc[ii][j], 0, 0, 0)
+    // stream k-tile g + d (d = 1, 2): local k-tile t + d of the current tile, or t + d - KT of the next one
+#define G8_ISSUE_AHEAD(d, hh)                                                                                         \
+    do {                                                                                                              \
+        if (t + (d) < KT) G8_ISSUE_AT(g + (d), t + (d), hh, xo, wo);                                                  \
+        else if (DIRECT && has_next) G8_ISSUE_AT(g + (d), t + (d) - KT, hh, xn, wn_);                                 \
+    } while (0)
 
-  for (;;) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    G8_BARRIER();
-    if (wr == 1) G8_BARRIER();                    // stagger: the second wave group runs one barrier behind
-
-    for (int t = 0; t < KT; ++t) {
-        const unsigned char* base = smem + (t & 1) * BUF;
+    int t = 0;                                    // local k-tile of stream k-tile g
+    for (int g = 0; g < GT; ++g) {
+        const unsigned char* base = smem + (g & 1) * BUF;
         const unsigned char* pa = base + a_base;
         const unsigned char* pb = base + b_base;
-        // ---------------- phase 1: all X fragments + W fragments 0-3; DMA: W hi of k-tile t+1
+        // ---------------- phase 1: all X fragments + W fragments 0-3; DMA: W hi of stream k-tile g+1
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             b[j][0] = *(const bf16x8*)(pb + fo0 + 2048 * j);
@@ -162,7 +183,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             a[i][0] = *(const bf16x8*)(pa + fo0 + 2048 * i);
             a[i][1] = *(const bf16x8*)(pa + fo1 + 2048 * i);
         }
-        if (4 * t + 7 < NH) G8_ISSUE(t + 1, 3);
+        G8_ISSUE_AHEAD(1, 3);
         __builtin_amdgcn_sched_barrier(0);
         G8_LGKM(8);                                // the X reads are retired: their half-tiles may be restaged next phase
         G8_BARRIER();
@@ -172,10 +193,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         G8_MMA(0, 0); G8_MMA(1, 1);
         __builtin_amdgcn_s_setprio(0);
         G8_BARRIER();
-        // ---------------- phase 2: W fragments 4, 5 into the released registers; DMA: X lo of k-tile t+2
+        // ---------------- phase 2: W fragments 4, 5 into the released registers; DMA: X lo of stream k-tile g+2
         a[0][0] = *(const bf16x8*)(pa + fo0 + 2048 * 4); a[0][1] = *(const bf16x8*)(pa + fo1 + 2048 * 4);
         a[1][0] = *(const bf16x8*)(pa + fo0 + 2048 * 5); a[1][1] = *(const bf16x8*)(pa + fo1 + 2048 * 5);
-        if (4 * t + 8 < NH) G8_ISSUE(t + 2, 0);
+        G8_ISSUE_AHEAD(2, 0);
         __builtin_amdgcn_sched_barrier(0);
         G8_BARRIER();
         G8_LGKM(0);
@@ -184,10 +205,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         G8_MMA(2, 2); G8_MMA(3, 3);
         __builtin_amdgcn_s_setprio(0);
         G8_BARRIER();
-        // ---------------- phase 3: W fragments 6, 7; DMA: X hi of k-tile t+2
+        // ---------------- phase 3: W fragments 6, 7; DMA: X hi of stream k-tile g+2
         a[2][0] = *(const bf16x8*)(pa + fo0 + 2048 * 6); a[2][1] = *(const bf16x8*)(pa + fo1 + 2048 * 6);
         a[3][0] = *(const bf16x8*)(pa + fo0 + 2048 * 7); a[3][1] = *(const bf16x8*)(pa + fo1 + 2048 * 7);
-        if (4 * t + 9 < NH) G8_ISSUE(t + 2, 1);
+        G8_ISSUE_AHEAD(2, 1);
         __builtin_amdgcn_sched_barrier(0);
         G8_LGKM(0);                                // last reads of this k-tile's W halves: retired before the barrier, so
         G8_BARRIER();                              // phase 4 (either wave group) may restage them
@@ -196,77 +217,81 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         G8_MMA(0, 4); G8_MMA(1, 5);
         __builtin_amdgcn_s_setprio(0);
         G8_BARRIER();
-        // ---------------- phase 4: no reads; DMA: W lo of k-tile t+2; the counted wait that retires k-tile t+1
-        if (4 * t + 10 < NH) G8_ISSUE(t + 2, 2);
+        // ---------------- phase 4: no reads; DMA: W lo of stream k-tile g+2; the counted wait that retires k-tile g+1
+        G8_ISSUE_AHEAD(2, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < KT) G8_VMCNT(6);
-        else if (t + 1 < KT) G8_VMCNT(0);
+        if (g + 2 < GT) G8_VMCNT(6);
+        else if (g + 1 < GT) G8_VMCNT(0);
         G8_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         G8_MMA(2, 6); G8_MMA(3, 7);
         __builtin_amdgcn_s_setprio(0);
         G8_BARRIER();
+        ++t;
+        if constexpr (DIRECT) {
+            if (t == KT) {
+                // ---- tile done: epilogue straight from the accumulators (no LDS, no barrier), then move on in the stream
+                const int em0 = tile_m * 256, en0 = tile_n * 256;
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int co = en0 + wr * 128 + 32 * pr + 8 * fgrp;
+                    float bv[8];
+                    if (p.bias) {
+                        const f32x4 b0 = *(const f32x4*)(p.bias + co), b1 = *(const f32x4*)(p.bias + co + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = em0 + wc * 64 + 16 * j + frow;
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = acc[2 * pr][j][e] + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] + bv[4 + e]; }
+                        const bool ok = m < p.M;
+                        if (p.add) {
+                            float af[8];
+                            const u32x4 raw = ok ? *(const u32x4*)(p.add + (size_t)m * p.ldadd + co) : (u32x4){0u, 0u, 0u, 0u};
+                            unpack8(raw, af);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += af[e];
+                        }
+                        if (p.aux) {
+                            float af[8];
+                            const u32x4 raw = ok ? *(const u32x4*)(p.aux + (size_t)m * p.ldy + co) : (u32x4){0u, 0u, 0u, 0u};
+                            unpack8(raw, af);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= af[e];
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
+                        }
+                        if (ok) *(u32x4*)(p.y + (size_t)m * p.ldy + co) = pack8(v);
+                        acc[2 * pr][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc[2 * pr + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                // the next tile becomes the current one; the one after it becomes "next"
+                t = 0;
+                lid += step;
+                tile_m = next_m; tile_n = next_n;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { xo[h][q] = xn[h][q]; wo[h][q] = wn_[h][q]; }
+                has_next = lid + step < ntiles;
+                if (has_next) { tile_of(lid + step, next_m, next_n); offsets_of(next_m, next_n, xn, wn_); }
+            }
+        }
     }
     if (wr == 0) G8_BARRIER();
 
-    if constexpr (DIRECT) {
-        // ---- epilogue straight from the accumulators; the next tile's prologue goes out first
-        const int em0 = m0, en0 = n0;
-        const bool ragged = em0 + 256 > p.M;
-        lid += step;
-        const bool more = lid < ntiles;
-        G8_BARRIER();                              // every wave is done with the staging buffers of this tile
-        if (more) { set_tile(lid); G8_PROLOGUE(); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
-            const int co = en0 + wr * 128 + 32 * pr + 8 * fgrp;
-            float bv[8];
-            if (p.bias) {
-                const f32x4 b0 = *(const f32x4*)(p.bias + co), b1 = *(const f32x4*)(p.bias + co + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = em0 + wc * 64 + 16 * j + frow;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = acc[2 * pr][j][e] + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] + bv[4 + e]; }
-                const bool ok = m < p.M;
-                if (p.add) {
-                    float af[8];
-                    const u32x4 raw = ok ? *(const u32x4*)(p.add + (size_t)m * p.ldadd + co) : (u32x4){0u, 0u, 0u, 0u};
-                    unpack8(raw, af);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += af[e];
-                }
-                if (p.aux) {
-                    float af[8];
-                    const u32x4 raw = ok ? *(const u32x4*)(p.aux + (size_t)m * p.ldy + co) : (u32x4){0u, 0u, 0u, 0u};
-                    unpack8(raw, af);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= af[e];
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
-                }
-                if (ok) *(u32x4*)(p.y + (size_t)m * p.ldy + co) = pack8(v);
-            }
-        }
-        if (!more) break;
-        __builtin_amdgcn_sched_barrier(0);
-        // the next tile's first k-tile must have landed; its 14 DMA instructions are OLDER than the 16 stores above, so
-        // "all but the 6 youngest DMAs" = all but the 22 youngest operations.  (Ragged last row tile: some of its store
-        // instructions may not have been issued at all — wait for everything there.  The operand loads of the add / aux
-        // epilogues are consumed above, i.e. complete.)
-        if (ragged || NH <= 4) G8_VMCNT(0); else G8_VMCNT(22);
-    } else {
+    if constexpr (!DIRECT) {
+        const int m0 = tile_m * 256, n0 = tile_n * 256;
         __syncthreads();                          // every wave is done with the staging buffers
         // ---- epilogue: four passes of 64 pixel rows through LDS [64][256 f32 + pad] -> bf16 rows of 512 B
         constexpr int EROW = 256 * 4 + 16;
@@ -341,9 +366,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 __syncthreads();
             }
         }
-        break;
     }
-  }
 }
 
 }  // namespace
