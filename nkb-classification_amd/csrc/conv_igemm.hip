@@ -16,6 +16,7 @@
 #include "conv_params.h"
 #include "wgrad256.h"
 #include "gemm8p.h"
+#include "wgrad3x3.h"
 
 // 64x256 tile (Cout <= 64) as ONE LDS stage with the pixel fragments streamed through a single register set: 164 VGPRs
 // -> 3 workgroups per CU like the 128x128 tile (was: two LDS stages, 188 VGPRs, 2 per CU).  ResNet-50 layer1 shapes
@@ -1235,6 +1236,9 @@ extern "C" long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, in
                                                      int pad, int has_bias) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
     const int M = N * P * Q;
+    // (3x3 / stride 1 / pad 1: the input grid equals the output grid; leading dimensions do not change the slab count)
+    if (!has_bias && nkb_wgrad3x3_eligible(dtype, N, P, Q, Cin, Cout, P, Q, R, S, stride, pad, 8, 8))
+        return nkb_wgrad3x3_workspace_floats(N, P, Q, Cin, Cout);
     if (nkb_wgrad256_eligible(dtype, M, Cin, Cout, R, S, stride, pad)) return nkb_wgrad256_workspace_floats(M, Cin, Cout, has_bias);
     const WgradPlan g = wgrad_plan(esz, M, Cout, R * S * Cin, wgrad_target_wgs());
     return (long long)g.splits * Cout * R * S * Cin + (has_bias ? (long long)g.splits * g.tilesN * Cout : 0);
@@ -1260,6 +1264,12 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
         nkb_set_error("conv_wgrad: workspace of %lld floats given, %lld needed (nkb_conv_wgrad_workspace_floats)",
                       workspace_floats, need);
         return 1;
+    }
+    if (dbias == nullptr && nkb_wgrad3x3_eligible(dtype, N, H, W, Cin, Cout, P, Q, R, S, stride, pad, ldx, lddy)) {
+        // 3x3 / stride 1 / pad 1: the nine taps share one staged copy of the input (wgrad3x3.hip)
+        NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * N * P * Q * (double)Cout * 9 * Cin,
+                          ((double)N * H * W * Cin + (double)N * P * Q * Cout) * esz + 2.0 * 4.0 * Cout * 9 * Cin);
+        return nkb_launch_wgrad3x3(dy, x, dw, N, H, W, Cin, ldx, Cout, lddy, workspace, stream);
     }
     if (nkb_wgrad256_eligible(dtype, N * P * Q, Cin, Cout, R, S, stride, pad)) {
         // wide Linear layers: 256 x 256 tiles (wgrad256.hip)

@@ -1,0 +1,244 @@
+// Weight gradient of the 3x3 / stride-1 / pad-1 convolutions (timm ResNet BasicBlock / Bottleneck conv2, reached from
+// loss.backward() at /root/reference/nkb_classification/engine.py:55-58):
+//
+//     dW[co][r][s][ci] = sum over (n, p, q) of dY[n][p][q][co] * X[n][p + r - 1][q + s - 1][ci]
+//
+// The generic weight-gradient kernel (conv_igemm.hip) treats the nine taps as nine independent column blocks of a GEMM: it
+// re-gathers X once per tap, its 128-wide channel tile is half empty for 64-channel layers, and one 64-pixel stage feeds
+// only 32 MFMAs per wave from 32 KB of operands (64 FLOP per byte moved into LDS) — 150-370 TFLOP/s on the ResNet-50 shapes,
+// the slowest kernel family of the step (profiles/r01i).  Here the nine taps SHARE one staged copy of X:
+//
+//   * both tensors are viewed as one long "strip" of PW-slot image rows over the whole batch (PW = 8 / 16 / 32 / 64 >= W + 1, a
+//     slot = one pixel's 64 channels = 128 bytes).  dY strip: rows 0..H-1 of every image followed by ONE zero row; X strip:
+//     one zero row, then per image its H rows followed by one zero row; column slot 0 of an X row is a zero, pixel j sits in
+//     slot j + 1, the slots past the row's last pixel are zeros.  With that layout the X operand of tap (r, s) for the dY
+//     slots [a, a + 64) is simply the X slots [a + r PW + s, + 64): every padding case (top / bottom row, left / right
+//     column, image boundaries) reads a zero slot, and where a dY slot is padding the product is zero whatever X holds.
+//   * a k-step = 64 consecutive strip slots (1, 2, 4 or 8 image rows).  A workgroup owns a 64 (cout) x 9 x 64 (cin) block of
+//     dW in registers — wave w: cin block w x 9 taps x 4 cout blocks = 36 accumulator tiles (144 VGPRs) — and walks a range
+//     of k-steps: per k-step 8 KB of dY and 8 KB of X arrive by LDS-DMA (buffer_load ... lds, out-of-range = zero fill does
+//     the padding), 8 dY fragments + 18 X fragments per wave come out of LDS through ds_read_b64_tr_b16, and feed 72 MFMAs:
+//     288 FLOP per byte moved into LDS, 4.5x the generic kernel.
+//   * X lives in a ring of four 64-slot chunks (+ a mirror of chunk position 0 behind the ring, so that a fragment that
+//     starts near the end of the ring needs no wrap-around arithmetic); a k-step reads chunks k, k+1, k+2 while chunk k+3
+//     and the next dY chunk are in flight.
+//   * LDS rows are 128 bytes; the 32-byte channel block cb of slot r is stored at block position cb ^ s(r),
+//     s(r) = bit 1 of r | bit 3 of r << 1: conflict-free for the transposing read at ANY slot shift (checked exhaustively).
+//   * partial results go to per-split slabs that nkb_launch_wgrad_reduce adds in split order (deterministic), or to dW with
+//     fp32 atomics when no workspace is given.
+#include "common.h"
+#include "wgrad3x3.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+
+struct W3Params {
+    const bf16_t* dy;     // [N][H][W][lddy]
+    const bf16_t* x;      // [N][H][W][ldx]
+    float* dw;            // [Cout][3][3][Cin] fp32 (atomics) when part == nullptr
+    float* part;          // slabs [splits][Cout][3][3][Cin]
+    long long slab;
+    int N, H, W, Cin, Cout, ldx, lddy;
+    int pw_shift;         // PW = 1 << pw_shift
+    int tilesCo, tilesCi, splits, ksteps_per_split, ksteps;
+    FastDiv divH1;        // H + 1
+};
+
+__device__ __forceinline__ int swz3(int slot) { return ((slot >> 1) & 1) | (((slot >> 3) & 1) << 1); }
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Params p) {
+    constexpr int CH = 64 * 128;                  // one 64-slot chunk
+    constexpr int XRING = 5 * CH;                 // four ring positions + the mirror of position 0
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [X ring 40 KB][dY 2 x 8 KB]
+    unsigned char* const dybuf = smem + XRING;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int PW = 1 << p.pw_shift;
+
+    const unsigned ntile = (unsigned)(p.tilesCo * p.tilesCi);
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);      // consecutive ids = the tiles of one k-range share an L2
+    const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
+    const int co0 = (tile % p.tilesCo) * 64, ci0 = (tile / p.tilesCo) * 64;
+    const int k_begin = split * p.ksteps_per_split;
+    const int nk = min(p.ksteps, k_begin + p.ksteps_per_split) - k_begin;
+    if (nk <= 0) return;
+
+    // ---- DMA: a chunk = 8 pieces of 1 KiB (8 slots); wave w moves pieces w and w + 4.  Lane: slot (lane >> 3) of the piece,
+    // 16-byte position (lane & 7) of the slot's 128-byte row, which holds source chunk ((pos >> 1) ^ s(slot)) * 2 + (pos & 1).
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, OOB, 0x00020000);
+    const int lslot = lane >> 3, lpos = lane & 7;
+    const int H1 = p.H + 1;
+    auto src_chunk = [&](int slot) { return (((lpos >> 1) ^ swz3(slot)) << 1) | (lpos & 1); };
+    // X strip slot -> byte offset of this lane's 16 bytes (or OOB = zero fill)
+    auto x_off = [&](int sigma) -> unsigned {
+        const int R = sigma >> p.pw_shift, c = sigma & (PW - 1);
+        const int n = (int)fdiv((unsigned)R, p.divH1), ri = R - n * H1;
+        if (sigma < 0 || ri == 0 || c == 0 || c > p.W || n >= p.N) return OOB;
+        return (unsigned)((((n * p.H + ri - 1) * p.W + c - 1) * p.ldx + ci0 + src_chunk(sigma) * 8) * 2);
+    };
+    auto dy_off = [&](int a) -> unsigned {
+        const int R = a >> p.pw_shift, c = a & (PW - 1);
+        const int n = (int)fdiv((unsigned)R, p.divH1), ri = R - n * H1;
+        if (ri == p.H || c >= p.W || n >= p.N) return OOB;
+        return (unsigned)((((n * p.H + ri) * p.W + c) * p.lddy + co0 + src_chunk(a) * 8) * 2);
+    };
+    auto issue_x = [&](int chunk) {               // X strip chunk -> ring position chunk & 3 (+ mirror)
+        const int pos = chunk & 3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pc = wave + 4 * q;
+            const unsigned off = x_off(chunk * 64 + pc * 8 + lslot);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(smem + pos * CH + pc * 1024), 16,
+                                                     (int)off, 0, 0, 0);
+            if (pos == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(smem + 4 * CH + pc * 1024),
+                                                         16, (int)off, 0, 0, 0);
+        }
+    };
+    auto issue_dy = [&](int chunk, int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pc = wave + 4 * q;
+            const unsigned off = dy_off(chunk * 64 + pc * 8 + lslot);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)(dybuf + buf * CH + pc * 1024), 16,
+                                                     (int)off, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addressing (transposing read): lane (g, q4, p4) supplies slot 8 g + q4 (+ 4), bytes 8 p4 of a 32-byte block
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+    const int L0 = 8 * g + q4;
+    // dY: slot L (+ 32 kk + 64 buf), cout block i at block position i ^ s(L)
+    int ta[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) ta[hi] = (L0 + 4 * hi) * 128 + 8 * p4;
+    const int sa0 = swz3(L0) << 5, sa1 = swz3(L0 + 4) << 5;
+    // X: slot (o & 15) + L relative to a 16-slot-aligned uniform base; this wave's cin block = wave.  Low bits of the tap
+    // offset o = r PW + s: s for PW >= 16, 8 (r & 1) + s for PW = 8 -> six classes cover both
+    int tb[6][2];
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int V = (c >= 3 ? 8 + c - 3 : c) + L0 + 4 * hi;
+            tb[c][hi] = V * 128 + ((wave ^ swz3(V)) << 5) + 8 * p4;
+        }
+    auto tr8 = [&](const unsigned char* lo, const unsigned char* hi) -> bf16x8 {
+        const bf16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)lo);
+        const bf16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)hi);
+        return (bf16x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+    };
+
+    // ---- prologue: dY chunk k_begin, X chunks k_begin .. k_begin + 2
+    issue_dy(k_begin, 0);
+    issue_x(k_begin); issue_x(k_begin + 1); issue_x(k_begin + 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {
+        const int gk = k_begin + k;
+        if (k + 1 < nk) { issue_dy(gk + 1, (k + 1) & 1); issue_x(gk + 3); }
+        const unsigned char* A = dybuf + (k & 1) * CH;
+        const int ubase = (gk & 3) * 64;          // ring slot of X strip slot 64 gk
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = tr8(A + ta[0] + ((i << 5) ^ sa0) + 4096 * kk, A + ta[1] + ((i << 5) ^ sa1) + 4096 * kk);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s = t - 3 * r;
+                const int o = (r << p.pw_shift) + s;                      // tap offset in slots (wave-uniform)
+                const int cls = (p.pw_shift == 3 ? 3 * (r & 1) : 0) + s;
+                const int u = ((ubase + (o & ~15) + 32 * kk) & 255) * 128; // 16-slot-aligned ring position; + V <= 286 < 320
+                const int c0 = cls < 3 ? cls : cls - 3;
+                // (static tap index, run-time class only through pw_shift: select between two compile-time table rows)
+                const int tlo = (p.pw_shift == 3 && (r & 1)) ? tb[3 + s][0] : tb[s][0];
+                const int thi = (p.pw_shift == 3 && (r & 1)) ? tb[3 + s][1] : tb[s][1];
+                (void)c0; (void)cls;
+                const bf16x8 b = tr8(smem + u + tlo, smem + u + thi);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][t], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next k-step's chunks have landed
+        __syncthreads();                                        // ... and every wave is done with this one's
+    }
+
+    // ---- epilogue: acc[i][t][e] = dW[co0 + 16 i + 4 g + e][tap t][ci0 + 16 wave + (lane & 15)]
+    const int ci = ci0 + 16 * wave + li;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const size_t idx = ((size_t)(co0 + 16 * i + 4 * g + e) * 9 + t) * p.Cin + ci;
+                if (p.part) p.part[(size_t)split * p.slab + idx] = acc[i][t][e];
+                else atomicAdd(p.dw + idx, acc[i][t][e]);
+            }
+}
+
+}  // namespace
+
+static int w3_pw_shift(int W) { return W + 1 <= 8 ? 3 : W + 1 <= 16 ? 4 : W + 1 <= 32 ? 5 : 6; }
+static int w3_target() {
+    static const int t = [] { const char* e = getenv("NKB_WGRAD3X3_WGS"); return e ? atoi(e) : 512; }();
+    return t;
+}
+static void w3_plan(int N, int H, int W, int Cin, int Cout, int* ksteps, int* splits, int* per_split) {
+    const int pw = 1 << w3_pw_shift(W);
+    const long long slots = (long long)N * (H + 1) * pw;
+    const int ks = (int)((slots + 63) / 64);
+    const int tiles = (Cout / 64) * (Cin / 64);
+    int sp = (w3_target() + tiles - 1) / tiles;
+    if (sp > ks / 4) sp = ks / 4 > 0 ? ks / 4 : 1;               // at least four k-steps per workgroup
+    if (sp < 1) sp = 1;
+    const int per = (ks + sp - 1) / sp;
+    *ksteps = ks; *per_split = per; *splits = (ks + per - 1) / per;
+}
+
+bool nkb_wgrad3x3_eligible(int dtype, int N, int H, int W, int Cin, int Cout, int P, int Q, int R, int S, int stride, int pad,
+                           int ldx, int lddy) {
+    static const int on = [] { const char* e = getenv("NKB_WGRAD3X3"); return e ? atoi(e) : 1; }();
+    return on && dtype == NKB_DT_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && P == H && Q == W && Cin % 64 == 0 &&
+           Cout % 64 == 0 && W + 1 <= 64 && ldx % 8 == 0 && lddy % 8 == 0 &&
+           (long long)N * H * W * ldx * 2 < 0xFFFFFF00ll && (long long)N * H * W * lddy * 2 < 0xFFFFFF00ll;
+}
+
+long long nkb_wgrad3x3_workspace_floats(int N, int H, int W, int Cin, int Cout) {
+    int ks, sp, per;
+    w3_plan(N, H, W, Cin, Cout, &ks, &sp, &per);
+    return (long long)sp * Cout * 9 * Cin;
+}
+
+int nkb_launch_wgrad3x3(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int ldx, int Cout, int lddy,
+                        float* workspace, hipStream_t stream) {
+    W3Params p;
+    p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw; p.part = workspace;
+    p.slab = (long long)Cout * 9 * Cin;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ldx = ldx; p.lddy = lddy;
+    p.pw_shift = w3_pw_shift(W);
+    p.tilesCo = Cout / 64; p.tilesCi = Cin / 64;
+    w3_plan(N, H, W, Cin, Cout, &p.ksteps, &p.splits, &p.ksteps_per_split);
+    p.divH1 = make_fastdiv((unsigned)(H + 1));
+    constexpr int lds = 5 * 64 * 128 + 2 * 64 * 128;            // X ring + mirror, two dY buffers: 56 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)(p.tilesCo * p.tilesCi * p.splits)), dim3(256), lds, stream, p);
+    int rc = nkb_check_launch("wgrad3x3");
+    if (rc || !workspace) return rc;
+    return nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
+}

@@ -28,7 +28,8 @@ for (ci, co, k, s, h, cnt) in SHAPES:
     stats = torch.empty(hip.bn_stats_floats(max(hip.stat_tiles(d, B * P * P, co), (B * P * P + 127) // 128 * 8), co), device=dev)
     fwd = lambda: hip.conv_gemm(d, 0, x, w, y, N=B, H=h, W=h, Cin=ci, ldx=ci, P=P, Q=P, Cout=co, ldy=co, R=k, S=k, stride=s, pad=pad, stats=stats)
     dgr = lambda: hip.conv_gemm(d, 1, y, wt, dx, N=B, H=P, W=P, Cin=co, ldx=co, P=h, Q=h, Cout=ci, ldy=ci, R=k, S=k, stride=s, pad=pad)
-    wgr = lambda: hip.conv_wgrad(d, y, x, dw, N=B, H=h, W=h, Cin=ci, ldx=ci, P=P, Q=P, Cout=co, lddy=co, R=k, S=k, stride=s, pad=pad)
+    work = torch.empty(hip.conv_wgrad_workspace(d, N=B, P=P, Q=P, Cin=ci, Cout=co, R=k, S=k, stride=s, pad=pad), device=dev)
+    wgr = lambda: hip.conv_wgrad(d, y, x, dw, N=B, H=h, W=h, Cin=ci, ldx=ci, P=P, Q=P, Cout=co, lddy=co, R=k, S=k, stride=s, pad=pad, workspace=work)
     tf, tg, tw = timeit(fwd), timeit(dgr), timeit(wgr)
     gf = 2 * B * P * P * co * ci * k * k / 1e9
     mb = (x.numel() + y.numel() + w.numel()) * 2 / 1e6
