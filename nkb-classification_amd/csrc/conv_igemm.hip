@@ -905,28 +905,69 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
     }
 }
 
-// dst[i] += sum_s part[s][i] in split order: the deterministic second stage of the weight-gradient kernels
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, long long slab, int splits, float* __restrict__ dst,
-                                    long long n) {
+// dst[i] += sum_s part[s][i]: the deterministic second stage of the weight-gradient kernels.  A thread column owns four
+// consecutive elements; SG threads share a column and each sums the splits s = sg, sg + SG, ... in order, then the SG partial
+// sums are combined in a fixed order through LDS — the association is a function of (splits, SG) only, never of timing.
+// (With one thread per column a 256-split / 4 K-element gradient took 60 us of serial dependent loads.)
+template <int SG>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long slab, int splits,
+                                                           float* __restrict__ dst, long long n) {
+    constexpr int COLS = 256 / SG;
+    __shared__ f32x4 red[SG > 1 ? 256 : 1];
+    const int cx = threadIdx.x % COLS, sg = threadIdx.x / COLS;
     const long long n4 = n >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        f32x4 a = *(const f32x4*)(part + 4 * i);
-        for (int s = 1; s < splits; ++s) a += *(const f32x4*)(part + (size_t)s * slab + 4 * i);
-        f32x4* d = (f32x4*)(dst + 4 * i);
-        *d = *d + a;
+    for (long long c0 = (long long)blockIdx.x * COLS; c0 < n4; c0 += (long long)gridDim.x * COLS) {
+        const long long i = c0 + cx;
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < n4)
+            for (int s = sg; s < splits; s += SG) a += *(const f32x4*)(part + (size_t)s * slab + 4 * i);
+        if constexpr (SG > 1) {
+            __syncthreads();
+            red[threadIdx.x] = a;
+            __syncthreads();
+            if (sg == 0) {
+                for (int k = 1; k < SG; ++k) a += red[k * COLS + cx];
+            }
+        }
+        if (sg == 0 && i < n4) {
+            f32x4* d = (f32x4*)(dst + 4 * i);
+            *d = *d + a;
+        }
     }
-    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float a = part[i];
-        for (int s = 1; s < splits; ++s) a += part[(size_t)s * slab + i];
+    // tail (n not a multiple of 4): one thread per element, splits in order
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += part[(size_t)s * slab + i];
+        dst[i] += a;
+    }
+}
+// unaligned slabs / destinations (a bias vector in the middle of a parameter block): one thread per element, splits in order
+__global__ void wgrad_reduce_scalar_kernel(const float* __restrict__ part, long long slab, int splits, float* __restrict__ dst,
+                                           long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += part[(size_t)s * slab + i];
         dst[i] += a;
     }
 }
 int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float* dst, long long n, hipStream_t stream) {
     if (n <= 0 || splits <= 0) return 0;
-    long long grid = (n / 4 + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    if ((slab & 3) != 0 || (((uintptr_t)part | (uintptr_t)dst) & 15) != 0) {
+        long long g = (n + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((unsigned)g), dim3(256), 0, stream, part, slab, splits, dst, n);
+        return nkb_check_launch("wgrad_reduce");
+    }
+    const long long n4 = n >> 2;
+    const int sg = splits >= 48 ? 16 : splits >= 6 ? 4 : 1;
+    const int cols = 256 / sg;
+    long long grid = (n4 + cols - 1) / cols;
+    if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
+    if (sg == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
+    else if (sg == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
     return nkb_check_launch("wgrad_reduce");
 }
 
