@@ -425,10 +425,13 @@ bool nkb_wgrad256_eligible(int dtype, int M, int Cin, int Cout, int R, int S, in
     if (!(on && dtype == NKB_DT_BF16 && R == 1 && S == 1 && stride == 1 && pad == 0 && Cout % 256 == 0 && Cin % 256 == 0 &&
           M % 64 == 0 && M >= 4096))
         return false;
-    // a split must be long enough to amortise its 256 KB of float atomics (measured: 12 stages per split is slower than
-    // the 128 x 128 kernel, 28 is 20 % faster)
+    // with fp32 atomics a split had to be >= 24 stages long to amortise its 256 KB tile; with slabs + the ordered reduce the
+    // eight-phase kernel wins from 2 tiles and 6 stages per split up (ResNet-50 layer3/4 1x1 shapes: 63 -> 50 us, 512 -> 256
+    // at 28x28 125 -> 99 us; scripts/wgrad_profile.py)
     const int tiles = (Cout / 256) * (Cin / 256);
-    return tiles >= 6 && wgrad256_stages_per_split(M, tiles, nullptr) >= 24;
+    static const int min_tiles = [] { const char* e = getenv("NKB_WGRAD256_MIN_TILES"); return e ? atoi(e) : 2; }();
+    static const int min_stages = [] { const char* e = getenv("NKB_WGRAD256_MIN_STAGES"); return e ? atoi(e) : 6; }();
+    return tiles >= min_tiles && wgrad256_stages_per_split(M, tiles, nullptr) >= min_stages;
 }
 
 long long nkb_wgrad256_workspace_floats(int M, int Cin, int Cout, int has_bias) {
