@@ -96,6 +96,8 @@ def lib_path() -> Path:
 def load():
     """Load libnkbhip.so once; raise loudly when it is absent (no fallback exists)."""
     global _LIB
+    if _REC is not None:
+        return _REC_LIB
     if _LIB is not None:
         return _LIB
     path = lib_path()
@@ -115,6 +117,123 @@ def load():
 
 def exported_symbols():
     return sorted(_SIGS)
+
+
+# ---- launch plans --------------------------------------------------------------------------------------------------------
+# One train step is ~600 kernel launches, each reached through a few layers of Python (geometry dicts, workspace lookups,
+# pointer extraction, ctypes marshalling): 17 ms of host time per ResNet-50 step against 21 ms of GPU time (BENCH_r01).  All
+# of it is a pure function of (model, shapes, mode): every buffer lives in the persistent workspace / parameter arena, so the
+# C-ABI calls of one step can be RECORDED once — function pointer + argument tuple + the stream / event operations between
+# them — and replayed by a flat loop.  What changes from step to step is patched in: pointers into the caller's tensors
+# (input images, logits, logits gradient) and dropout seeds.
+_REC = None            # list of plan entries while recording
+_REC_LIB = None
+_PURE = frozenset({"nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_bn_stats_floats",
+                   "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
+                   "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
+                   "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
+                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_set_ring"})
+
+
+class Seed(int):
+    """A dropout seed drawn from torch's host generator; a recorded plan draws a fresh one at every replay."""
+
+
+def fresh_seed() -> "Seed":
+    return Seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+
+
+class _RecLib:
+    def __getattr__(self, name):
+        fn = getattr(_LIB, name)
+        if name in _PURE:
+            return fn
+
+        def call(*args):
+            _REC.append(["call", fn, name, list(args)])
+            return fn(*args)
+        return call
+
+
+class Plan:
+    __slots__ = ("entries", "dyn_names")
+
+    def __init__(self, entries, dyn_names):
+        self.entries, self.dyn_names = entries, dyn_names
+
+
+_REC_MAIN = None       # the compute stream of the step being recorded
+
+
+def record_begin():
+    global _REC, _REC_LIB, _REC_MAIN
+    load()
+    _REC_MAIN = torch.cuda.current_stream()
+    _REC, _REC_LIB = [], _RecLib()
+
+
+def record_abort():
+    global _REC
+    _REC = None
+
+
+def record_end(dynamic: dict) -> Plan:
+    """dynamic: {name: tensor} — every recorded pointer argument that points into one of these tensors becomes a slot that
+    replay() fills from the tensor passed under the same name."""
+    global _REC
+    rec, _REC = _REC, None
+    ranges = [(name, t.data_ptr(), t.data_ptr() + max(t.numel() * t.element_size(), 1)) for name, t in dynamic.items()]
+    entries = []
+    for e in rec:
+        if e[0] != "call":
+            entries.append((2, e[1], None, None))
+            continue
+        _, fn, name, args = e
+        patches = []
+        for i, a in enumerate(args):
+            if isinstance(a, Seed):
+                patches.append((i, None, 0))
+            elif isinstance(a, int) and a >= (1 << 32):
+                for dn, lo, hi in ranges:
+                    if lo <= a < hi:
+                        patches.append((i, dn, a - lo))
+                        break
+        entries.append((1, fn, args, tuple(patches)) if patches else (0, fn, tuple(args), name))
+    return Plan(entries, tuple(dynamic))
+
+
+def replay(plan: Plan, dynamic: dict):
+    base = {name: t.data_ptr() for name, t in dynamic.items()}
+    for kind, fn, args, extra in plan.entries:
+        if kind == 0:
+            if fn(*args):
+                raise RuntimeError(f"nkbhip {extra} failed during plan replay: {_LIB.nkb_last_error().decode()}")
+        elif kind == 1:
+            for i, dn, off in extra:
+                args[i] = base[dn] + off if dn is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+            if fn(*args):
+                raise RuntimeError(f"nkbhip call failed during plan replay: {_LIB.nkb_last_error().decode()}")
+        else:
+            fn()
+
+
+def recording() -> bool:
+    return _REC is not None
+
+
+def host_op(fn):
+    """A torch-side operation between launches (memset, counter bump, stream / event call): run now, and re-run at this
+    point of the sequence when the plan is replayed — on the stream that is current now."""
+    if _REC is not None:
+        cur = torch.cuda.current_stream()
+        if cur == _REC_MAIN:
+            _REC.append(["py", fn])
+        else:
+            def on_stream(fn=fn, cur=cur):
+                with torch.cuda.stream(cur):
+                    fn()
+            _REC.append(["py", on_stream])
+    fn()
 
 
 def dt(t) -> int:

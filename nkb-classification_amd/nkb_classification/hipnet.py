@@ -65,6 +65,9 @@ class HipEngine:
         self._suffix = ""
         self._fold: Dict[str, tuple] = {}          # stage key -> (fold_key, folded filter, shift) for eval mode
         self.fold_key = None                       # set by the owning classifier: (arena version, eval phase counter)
+        # recorded launch plans of the train step (hip.Plan): key -> (plan, workspace generation, saved-activation table)
+        self.plans: Dict[tuple, tuple] = {}
+        self.plan_seen: Dict[tuple, int] = {}      # key -> workspace generation after its last eager run
 
     # ------------------------------------------------------------------ weights ----
     def register(self, convs, stems, head_weights, head_biases):
@@ -280,7 +283,7 @@ class HipEngine:
         self.saved[key] = dict(in_shape=(N, H, W, C))
         return y
 
-    def head(self, emb: torch.Tensor, train: bool, drop_p: float = 0.0) -> torch.Tensor:
+    def head(self, emb: torch.Tensor, train: bool, drop_p: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fused classifier heads: logits[B][sum C_t] (fp32) = emb @ W_all^T + b_all.
         With classifier dropout active (train, p > 0) every head draws its own mask (model.py:104-108 gives each head
         its own nn.Dropout), so the heads run as separate GEMMs on separately dropped copies of the embedding."""
@@ -289,12 +292,12 @@ class HipEngine:
         B, E = emb.shape
         a = self.arena
         if train and drop_p > 0:
-            logits = torch.empty(B, ctot, device=self.device, dtype=torch.float32)
+            logits = out if out is not None else torch.empty(B, ctot, device=self.device, dtype=torch.float32)
             dropped, masks, lo_c = [], [], 0
             for t, w in enumerate(hw):
                 d_emb = self.ws.get(f"head.drop{t}", (B, E), self.T)
                 mask = self.ws.get(f"head.mask{t}", (B, E), torch.uint8)
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                seed = hip.fresh_seed()
                 hip.dropout(self.d, False, emb, None, d_emb, mask, B * E, drop_p, seed)
                 n_t = w.shape[0]
                 hip.conv_gemm(self.d, 0, d_emb, self.w_fwd(w), logits[:, lo_c:], N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1,
@@ -306,7 +309,7 @@ class HipEngine:
         wall = (a.shadow if self.T == torch.bfloat16 else a.flat_param)[lo:lo + ctot * E]
         bo = a.offset_of(hb[0])
         ball = a.flat_param[bo:bo + ctot]
-        logits = torch.empty(B, ctot, device=self.device, dtype=torch.float32)
+        logits = out if out is not None else torch.empty(B, ctot, device=self.device, dtype=torch.float32)
         hip.conv_gemm(self.d, 0, emb, wall, logits, N=B, H=1, W=1, Cin=E, ldx=E, P=1, Q=1, Cout=ctot, ldy=ctot,
                       bias=ball, out_f32=True)
         if train:
@@ -346,17 +349,21 @@ class HipEngine:
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._side.wait_event(ev)
-        with torch.cuda.stream(self._side):
+        ev, side = torch.cuda.Event(), self._side
+
+        def fork():
+            ev.record()
+            side.wait_event(ev)
+        hip.host_op(fork)
+        with torch.cuda.stream(side):
             fn()
 
     def join_side(self):
         """Main stream waits for everything enqueued on the side stream so far (forward-pass use; the backward pass
         tracks its weight gradients per block with begin_block / end_block instead)."""
         if self._side is not None and self.overlap_wgrad:
-            torch.cuda.current_stream().wait_stream(self._side)
+            side = self._side
+            hip.host_op(lambda: torch.cuda.current_stream().wait_stream(side))
 
     def begin_block(self, index: int):
         """Scratch gradient buffers alternate between two sets by block parity; before a set is reused the main
@@ -364,12 +371,12 @@ class HipEngine:
         self._suffix = ".p%d" % (index & 1)
         ev = self._side_done.pop(index + 2, None)
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            hip.host_op(lambda: torch.cuda.current_stream().wait_event(ev))
 
     def end_block(self, index: int):
         if self._side is not None:
-            ev = torch.cuda.Event()
-            ev.record(self._side)
+            ev, side = torch.cuda.Event(), self._side
+            hip.host_op(lambda: ev.record(side))
             self._side_done[index] = ev
 
     def side_event(self):
@@ -383,7 +390,8 @@ class HipEngine:
     def wait_side(self):
         """Main stream waits for every outstanding weight gradient (before the optimizer / the gradient exchange)."""
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            side = self._side
+            hip.host_op(lambda: torch.cuda.current_stream().wait_stream(side))
         self._side_done.clear()
         self._suffix = ""
 
@@ -532,7 +540,7 @@ class HipEngine:
             dwp = self.ws.get(key + ".dwpad", (co, 224), torch.float32)
 
             def packed_wgrad():
-                dwp.zero_()
+                hip.host_op(dwp.zero_)
                 work = None
                 if _DET_WGRAD:
                     work = self.ws.at_least("wgrad.slabs." + self._stream_tag(),
@@ -548,7 +556,7 @@ class HipEngine:
             dwp = self.ws.get(key + ".dwpad", (co, kp), torch.float32)
 
             def stem_wgrad():
-                dwp.zero_()
+                hip.host_op(dwp.zero_)
                 self.wgrad(g_c, sv["x"], dwp, N=geom["N"], H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, lddy=co)
                 hip.add2d(dwp, a.grad_flat(w), co, K, kp, K)
             self.on_side(stem_wgrad)
@@ -764,10 +772,10 @@ class HipEngine:
         (timm-style DropPath as used by the unicom blocks).  Only called when active (train and p > 0)."""
         assert train and p > 0
         ones = self.ws.get("droppath.ones", (samples,), torch.float32)
-        ones.fill_(1.0)
+        hip.host_op(lambda: ones.fill_(1.0))
         scale = self.ws.get(key + ".scale", (samples,), torch.float32)
         mask = self.ws.get(key + ".mask", (samples,), torch.uint8)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        seed = hip.fresh_seed()
         hip.dropout(hip.F32, False, ones, None, scale, mask, samples, p, seed)       # scale[b] = keep / (1 - p)
         y = self.ws.get(key + ".y", x.shape, self.T)
         hip.scale_rows(self.d, x, add, y, scale, samples, x.numel() // samples)
@@ -790,11 +798,11 @@ class HipEngine:
             if add is None:
                 return x
             y = self.ws.get(key + ".y", x.shape, self.T)
-            torch.add(x, add, out=y)
+            hip.host_op(lambda: torch.add(x, add, out=y))
             return y
         y = self.ws.get(key + ".y", x.shape, x.dtype)
         mask = self.ws.get(key + ".mask", x.shape, torch.uint8)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        seed = hip.fresh_seed()
         hip.dropout(hip.dt(x.dtype), False, x, add, y, mask, x.numel(), p, seed)
         self.saved[key] = dict(mask=mask, p=p)
         return y

@@ -12,6 +12,7 @@ which case activations / GEMM operands are bf16 with fp32 accumulation, statisti
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Union
 
 import torch
@@ -21,6 +22,10 @@ from . import hip
 from .backbones import create_backbone
 from .hipnet import HipEngine
 from .runtime import ParamArena
+
+
+# recorded launch plans for the train step (hip.Plan): 0 = every step goes through the Python layer code
+_PLANS = os.environ.get("NKB_PLAN", "1") != "0"
 
 
 class _NetFn(torch.autograd.Function):
@@ -157,10 +162,43 @@ class _HipClassifier(nn.Module):
         need_dgrad = train and any(p.requires_grad for p in self.emb_model.parameters())
         eng.refresh_weights(need_dgrad=need_dgrad)
         eng.fold_key = (self.arena.version, getattr(self, "_eval_phase", 0))
-        emb = self.emb_model.run_forward(eng, img, train)
-        if train and self._nbt_flat is not None:
-            self._nbt_flat.add_(1)
-        return eng.head(emb, train, self._classifier_dropout_p() if train else 0.0)
+        drop_p = self._classifier_dropout_p() if train else 0.0
+        ctot = sum(h.out_features for h in self._heads())
+        logits = torch.empty(img.shape[0], ctot, device=img.device, dtype=torch.float32)
+
+        def run():
+            emb = self.emb_model.run_forward(eng, img, train)
+            if train and self._nbt_flat is not None:
+                hip.host_op(lambda: self._nbt_flat.add_(1))
+            eng.head(emb, train, drop_p, out=logits)
+
+        # the backward pass of this forward: which plan it may use (None = the Python path)
+        self._fwd_key = None
+        if not (_PLANS and train):
+            run()
+            return logits
+        key = ("fwd", tuple(img.shape), need_dgrad, drop_p, eng.overlap_wgrad, self.arena.total)
+        self._fwd_key = key
+        ent = eng.plans.get(key)
+        if ent is not None and ent[1] == eng.ws.generation:
+            eng.saved = dict(ent[2])               # the activation table this plan (and its backward twin) was recorded with
+            hip.replay(ent[0], {"img": img, "logits": logits})
+            return logits
+        # record on the second consecutive run that needed no new buffers (the first one sizes the workspace)
+        record = eng.plan_seen.get(key) == eng.ws.generation
+        if record:
+            hip.record_begin()
+        try:
+            run()
+        except BaseException:
+            hip.record_abort()
+            raise
+        if record:
+            plan = hip.record_end({"img": img, "logits": logits})
+            if eng.plan_seen.get(key) == eng.ws.generation:
+                eng.plans[key] = (plan, eng.ws.generation, dict(eng.saved))
+        eng.plan_seen[key] = eng.ws.generation
+        return logits
 
     def _backward_impl(self, glogits: torch.Tensor):
         eng = self._active
@@ -170,22 +208,51 @@ class _HipClassifier(nn.Module):
         bb_params = [p for p in self.emb_model.parameters() if p.requires_grad]
         wanted = [p for p in head_params if p.requires_grad] + bb_params
         arena.begin_backward(wanted)
-        g_emb = eng.head_backward(glogits, need_demb=bool(bb_params))
+        if not glogits.is_contiguous():
+            glogits = glogits.contiguous()
         hook = self.grad_ready_hook
-        if hook is not None:
-            lo = arena.offset_of(heads[0].weight)
-            hook(lo, arena.total, side_event=eng.side_event())
-        if bb_params:
-            on_done = None
+
+        def run():
+            g_emb = eng.head_backward(glogits, need_demb=bool(bb_params))
             if hook is not None:
-                def on_done(module):
-                    # the range is final once the compute stream AND the weight-gradient stream reach this point; the
-                    # communication stream waits for both, the compute stream for neither
-                    rng = arena.range_of(list(module.parameters()) if isinstance(module, nn.Module) else list(module))
-                    if rng is not None:
-                        hook(*rng, side_event=eng.side_event())
-            self.emb_model.run_backward(eng, g_emb, on_done)
-        eng.wait_side()
+                lo = arena.offset_of(heads[0].weight)
+                hip.host_op(lambda: hook(lo, arena.total, side_event=eng.side_event()))
+            if bb_params:
+                on_done = None
+                if hook is not None:
+                    def on_done(module):
+                        # the range is final once the compute stream AND the weight-gradient stream reach this point; the
+                        # communication stream waits for both, the compute stream for neither
+                        rng = arena.range_of(list(module.parameters()) if isinstance(module, nn.Module) else list(module))
+                        if rng is not None:
+                            hip.host_op(lambda: hook(*rng, side_event=eng.side_event()))
+                self.emb_model.run_backward(eng, g_emb, on_done)
+            eng.wait_side()
+
+        fwd_key = getattr(self, "_fwd_key", None)
+        if fwd_key is None or fwd_key not in eng.plans or eng.plans[fwd_key][1] != eng.ws.generation:
+            run()                                  # no forward plan (yet): the activation table may still change
+            if fwd_key is not None:
+                eng.plan_seen.pop(("bwd", fwd_key), None)
+        else:
+            key = ("bwd", fwd_key, len(wanted), len(bb_params), hook is not None)
+            ent = eng.plans.get(key)
+            if ent is not None and ent[1] == eng.ws.generation:
+                hip.replay(ent[0], {"glogits": glogits})
+            else:
+                record = eng.plan_seen.get(key) == eng.ws.generation
+                if record:
+                    hip.record_begin()
+                try:
+                    run()
+                except BaseException:
+                    hip.record_abort()
+                    raise
+                if record:
+                    plan = hip.record_end({"glogits": glogits})
+                    if eng.plan_seen.get(key) == eng.ws.generation:
+                        eng.plans[key] = (plan, eng.ws.generation, None)
+                eng.plan_seen[key] = eng.ws.generation
         if self.grad_done_hook is not None:
             # data parallel: the remaining buckets go out and the compute stream is made to wait for the exchange HERE, so
             # whatever reads the gradients next (GradScaler.unscale_, gradient-norm logging, the optimizer) sees the reduced

@@ -175,6 +175,7 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self._bufs: Dict[str, torch.Tensor] = {}
+        self.generation = 0       # bumped by every (re)allocation: recorded launch plans hold raw pointers into these buffers
 
     def get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
         shape = tuple(int(s) for s in shape)
@@ -182,6 +183,7 @@ class Workspace:
         if t is None or t.shape != shape or t.dtype != dtype:
             t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype)
             self._bufs[name] = t
+            self.generation += 1
         return t
 
     def at_least(self, name: str, numel: int, dtype) -> torch.Tensor:
@@ -190,6 +192,7 @@ class Workspace:
         if t is None or t.numel() < numel or t.dtype != dtype:
             t = torch.empty(max(int(numel), 1), device=self.device, dtype=dtype)
             self._bufs[name] = t
+            self.generation += 1
         return t
 
     def nbytes(self) -> int:
@@ -197,3 +200,4 @@ class Workspace:
 
     def clear(self):
         self._bufs.clear()
+        self.generation += 1
