@@ -40,6 +40,7 @@ TRAIN_GFLOP_PER_IMG = {"resnet18": 10.645, "resnet50": 24.287, "vit_base_patch16
                        "unicom ViT-L/14": 485.4}   # SURVEY.md §8(d) algorithmic FLOPs (fwd + dgrad + wgrad)
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                          # HBM3E, MI355X_MICROARCH.md
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"      # regenerate with scripts/pmc_traffic.py after any kernel change
 
 
 def log(*a):
@@ -48,10 +49,10 @@ def log(*a):
 
 def pmc_traffic(args, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
-    (profiles/r01i_pmc_traffic.json, produced by scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as
-    MI355X_MICROARCH.md prescribes).  A bench run cannot profile itself, so this is the measurement on file for the
-    default workload; any other workload reports null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01i_pmc_traffic.json")
+    (PMC_TRAFFIC_FILE, produced by scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).
+    A bench run cannot profile itself (counter collection needs its own rocprofv3 passes), so this is the measurement ON FILE
+    for the default workload — the line says so in roofline.traffic_source; any other workload reports null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
     if not (args.model == "resnet50" and args.batch == 256 and args.dtype == "bf16" and os.path.exists(path)):
         return None
     try:
@@ -115,6 +116,35 @@ def build(args, device):
     return model, opt, crit
 
 
+def cpu_config0(threads):
+    """BASELINE configs[0] exactly (the reference's own CPU-runnable case): ResNet-18, 2 classes, 64 synthetic
+    224x224 images, bs 8, fp32, one epoch = 8 steps of the oracle's train step."""
+    from oracle.torch_engine import Criterion, make_optimizer
+    from oracle.torch_models import OracleClassifier
+    torch.manual_seed(0)
+    m = OracleClassifier(dict(model="resnet18", backbone_dropout=0.0, classifier_dropout=0.0), ["a", "b"])
+    opt = make_optimizer(m, dict(type="nadam", lr=1e-4, backbone_lr=1e-5, classifier_lr=1e-4, weight_decay=0.01,
+                                 backbone_weight_decay=0.01, classifier_weight_decay=0.2))
+    crit = Criterion(dict(task="single", type="CrossEntropyLoss"))
+    g = torch.Generator().manual_seed(1234)
+    xs = torch.randn(64, 3, 224, 224, generator=g)
+    ys = torch.randint(0, 2, (64,), generator=g)
+    m.train()
+
+    def epoch():
+        for i in range(0, 64, 8):
+            opt.zero_grad()
+            crit(m(xs[i:i + 8]), ys[i:i + 8]).backward()
+            opt.step()
+
+    epoch()                                        # warm-up epoch
+    t0 = time.perf_counter()
+    epoch()
+    dt = time.perf_counter() - t0
+    return dict(value=round(64 / dt, 2), unit="images/sec", cores=threads,
+                sample="configs[0]: resnet18 fp32, 2 classes, 64 images, bs=8, one timed epoch (8 steps) after one warm-up epoch")
+
+
 def cpu_baseline(args):
     """Oracle (kind 'port'): torch-CPU fp32 restatement of the same train step, bounded sample."""
     from oracle.torch_engine import Criterion, make_optimizer
@@ -145,9 +175,15 @@ def cpu_baseline(args):
         step()
         log(f"cpu step done at {time.perf_counter() - t0:.1f}s")
     dt = time.perf_counter() - t0
-    return dict(value=round(args.cpu_batch * args.cpu_steps / dt, 2), unit="images/sec", cores=torch.get_num_threads(),
-                kind="port", sample=f"{args.model} fp32 train step, bs={args.cpu_batch}, {args.cpu_steps} timed steps "
-                                   f"after 1 warm-up, torch {torch.__version__} CPU")
+    out = dict(value=round(args.cpu_batch * args.cpu_steps / dt, 2), unit="images/sec", cores=torch.get_num_threads(),
+               kind="port", sample=f"{args.model} fp32 train step, bs={args.cpu_batch}, {args.cpu_steps} timed steps "
+                                  f"after 1 warm-up, torch {torch.__version__} CPU")
+    try:
+        out["config0"] = cpu_config0(threads)
+        log(f"cpu configs[0] (resnet18 bs 8): {out['config0']['value']} img/s")
+    except Exception as e:                          # the headline baseline above stands on its own
+        log(f"cpu configs[0] baseline failed: {e}")
+    return out
 
 
 def main():
@@ -308,7 +344,11 @@ def main():
             peak_tf, peak_gbs = PEAK_TFLOPS[args.dtype], HBM_PEAK_GBS
             t_mfma, t_hbm = v["work"] / (peak_tf * 1e12), v.get("bytes", 0.0) / (peak_gbs * 1e9)
             total_ms = sum(x["ms"] for x in prof.values())
-            common = dict(traffic=pmc_traffic(args, name), kernel=name, launches_per_step=v["launches"] // nprof,
+            traffic = pmc_traffic(args, name)
+            common = dict(traffic=traffic,
+                          traffic_source=(f"profiles/{PMC_TRAFFIC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                          "over this command, not this run") if traffic is not None else None,
+                          kernel=name, launches_per_step=v["launches"] // nprof,
                           avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
                           share_of_gpu_time=round(v["ms"] / total_ms, 3),
                           gflop_per_launch=round(v["work"] / v["launches"] / 1e9, 3),
