@@ -259,6 +259,21 @@ int nkb_scaler_update(float* scale, int* growth_tracker, float* found_inf, float
                       float backoff, int interval, nkb_stream_t stream);
 int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float* out, nkb_stream_t stream);
 
+/* fp8 path (BASELINE configs[4] "unicom ViT-L/14 ... fp8"; the reference itself has no fp8 mode — engine.py:43-47 is fp16 autocast):
+ * per-tensor scaled OCP fp8 operands for the Linear contractions, fp32 accumulation, bf16 result.
+ *   nkb_fp8_quantize: dst[i] = fp8(src[i] * state[0]) (kind 0: e4m3, saturating at 448; kind 1: e5m2, 57344), and
+ *                     state[2] = max(state[2], max |src|) — the amax the NEXT scale is derived from (delayed scaling).
+ *   nkb_fp8_amax:     state[2] = max(state[2], max |src|) only (just-in-time scaling of weights: amax, update, quantize).
+ *   nkb_fp8_scale_update: state[0] = fp8_max / state[2], state[1] = 1 / state[0] (unchanged when no value was seen), state[2] = 0.
+ *   nkb_gemm_fp8:     y[M][N] = (xq . wq^T) * *deq_x * *deq_w (+ bias) (+ add), ReLU (1) / ReLU6 (2); mode 0: both operands
+ *                     e4m3 (forward), mode 1: xq is e5m2 (a gradient) and wq e4m3 (data gradient).  K % 128 == 0, N % 256 == 0.
+ * state: three device floats {scale, 1 / scale, running amax}. */
+int nkb_fp8_quantize(int dtype, int kind, const void* src, long long n, float* state, void* dst, nkb_stream_t stream);
+int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, nkb_stream_t stream);
+int nkb_fp8_scale_update(float* state, int kind, nkb_stream_t stream);
+int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add, const float* deq_x,
+                 const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd, int relu, nkb_stream_t stream);
+
 /* Envelope of the 256 x 256 eight-phase GEMM core that nkb_conv_gemm / nkb_linear_gelu use for wide plain 1x1 / Linear launches
  * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 768).  Tests and A/B timing. */
 void nkb_gemm8p_config(int on, int min_tiles, int min_k);

@@ -42,11 +42,32 @@ struct G8Params {
     int M, N, K, ldx, ldw, ldy, ldadd;
     int relu;             // 0 none, 1 ReLU, 2 ReLU6
     int tilesM, tilesN, group_m;
+    // fp8 operands (F8 != 0): x and w hold one byte per element (K = bytes per row); the fp32 result is multiplied by
+    // *deq_x * *deq_w (the per-tensor dequantisation factors, device floats) before bias / residual
+    const float* deq_x;
+    const float* deq_w;
 };
 
-__device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* dst) {
+__device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+typedef __attribute__((ext_vector_type(2))) long g8_i64x2;
+template <int F8>
+__device__ __forceinline__ f32x4 g8_mma(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    if constexpr (F8 == 0) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    } else {
+        const g8_i64x2 a2 = __builtin_bit_cast(g8_i64x2, a), b2 = __builtin_bit_cast(g8_i64x2, b);
+        if constexpr (F8 == 1) {
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[0], b2[0], c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[1], b2[1], c, 0, 0, 0);
+        } else {
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a2[0], b2[0], c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a2[1], b2[1], c, 0, 0, 0);
+        }
+    }
 }
 
 // raw s_barrier (no vmcnt drain, unlike __syncthreads) between two compiler-level memory barriers
@@ -70,15 +91,21 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* dst) {
 //   one pixel: one 16-byte store per lane, 64 contiguous bytes per pixel and instruction, no LDS round trip, no barrier.
 //   The stores are older than every DMA issued after them, so the counted vmcnt(6) of the following k-tile's phase 4 also
 //   covers them (four phases later they have long been acknowledged) and the wave groups stay staggered across tiles.
-template <bool DIRECT>
+// F8: 0 = bf16 operands (k-tile = 64 elements); 1 = fp8 e4m3 x e4m3, 2 = W e4m3 x X e5m2 (data gradients): a k-tile is the
+// same 128 bytes per row = 128 elements, every 16-byte fragment feeds TWO v_mfma_f32_16x16x32_fp8 (its low and high 8 bytes;
+// both operands split the same way, so the k indices pair up) — half the LDS / L2 bytes per FLOP of the bf16 form.
+template <bool DIRECT, int F8 = 0>
 __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
+    constexpr int ESZ = F8 ? 1 : 2;               // bytes per operand element
+    constexpr int KE = 128 / ESZ;                 // elements per k-tile row
+    constexpr int CE = 16 / ESZ;                  // elements per 16-byte chunk
     constexpr int HT = 128 * 128;                 // bytes of one half-tile (128 rows x 64 bf16)
     constexpr int BUF = 4 * HT;                   // one k-tile: X lo | X hi | W lo | W hi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;      // cout half, pixel quarter
-    const int KT = p.K >> 6;                      // k-tiles per tile (DIRECT: >= 2)
+    const int KT = p.K / KE;                      // k-tiles per tile (DIRECT: >= 2)
     const int ntiles = p.tilesM * p.tilesN;
     const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
     const int frow = lane & 15, fgrp = lane >> 4;
@@ -108,9 +135,9 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             for (int q = 0; q < 2; ++q) {
                 const int r = (wave + 8 * q) * 8 + lrow;                   // LDS row inside the half-tile
                 const int xm = min(tm * 256 + h * 128 + r, p.M - 1);      // rows past M: loaded from the last row, never stored
-                xo_[h][q] = (unsigned)xm * (unsigned)p.ldx + chunk * 8;
+                xo_[h][q] = (unsigned)xm * (unsigned)p.ldx + chunk * CE;
                 const int wrow = DIRECT ? ((r & 0x63) | ((r & 0x0c) << 1) | ((r & 0x10) >> 2)) : r;
-                wo_[h][q] = (unsigned)(tn * 256 + h * 128 + wrow) * (unsigned)p.ldw + chunk * 8;
+                wo_[h][q] = (unsigned)(tn * 256 + h * 128 + wrow) * (unsigned)p.ldw + chunk * CE;
             }
     };
     // half-tile hh (0, 1: X lo / hi; 2, 3: W lo / hi) at local k-tile kl of the tile with offsets (xo_, wo_), into the buffer
@@ -118,9 +145,9 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #define G8_ISSUE_AT(gk, kl, hh, xo_, wo_)                                                                             \
     do {                                                                                                              \
         unsigned char* d_ = smem + ((gk) & 1) * BUF + (hh) * HT + wave * 1024;                                       \
-        const bf16_t* s_ = ((hh) < 2 ? p.x : p.w) + (size_t)(kl) * 64;                                               \
-        glds16(s_ + ((hh) < 2 ? xo_[(hh) & 1][0] : wo_[(hh) & 1][0]), d_);                                           \
-        glds16(s_ + ((hh) < 2 ? xo_[(hh) & 1][1] : wo_[(hh) & 1][1]), d_ + 8192);                                    \
+        const unsigned char* s_ = (const unsigned char*)((hh) < 2 ? p.x : p.w) + (size_t)(kl) * 128;                 \
+        glds16(s_ + (size_t)((hh) < 2 ? xo_[(hh) & 1][0] : wo_[(hh) & 1][0]) * ESZ, d_);                             \
+        glds16(s_ + (size_t)((hh) < 2 ? xo_[(hh) & 1][1] : wo_[(hh) & 1][1]) * ESZ, d_ + 8192);                      \
     } while (0)
 
     const int step = (int)gridDim.x;
@@ -157,8 +184,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     bf16x8 a[4][2], b[4][2];
 #define G8_MMA(slot, ii)                                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
-            acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[slot][ks], b[j][ks], acc[ii][j], 0, 0, 0)
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[ii][j] = g8_mma<F8>(a[slot][ks], b[j][ks], acc[ii][j])
     // stream k-tile g + d (d = 1, 2): local k-tile t + d of the current tile, or t + d - KT of the next one
 #define G8_ISSUE_AHEAD(d, hh)                                                                                         \
     do {                                                                                                              \
@@ -233,6 +259,8 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             if (t == KT) {
                 // ---- tile done: epilogue straight from the accumulators (no LDS, no barrier), then move on in the stream
                 const int em0 = tile_m * 256, en0 = tile_n * 256;
+                float deq = 1.f;
+                if constexpr (F8 != 0) deq = *p.deq_x * *p.deq_w;
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
                     const int co = en0 + wr * 128 + 32 * pr + 8 * fgrp;
@@ -250,7 +278,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                         const int m = em0 + wc * 64 + 16 * j + frow;
                         float v[8];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = acc[2 * pr][j][e] + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] + bv[4 + e]; }
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (F8 != 0) { v[e] = acc[2 * pr][j][e] * deq + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] * deq + bv[4 + e]; }
+                            else { v[e] = acc[2 * pr][j][e] + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] + bv[4 + e]; }
+                        }
                         const bool ok = m < p.M;
                         if (p.add) {
                             float af[8];
@@ -399,26 +430,35 @@ bool nkb_gemm8p_eligible(const ConvParams& p, int dtype, int batch) {
     return tiles >= g8_min_tiles && p.Cin >= g8_min_k;
 }
 
+static int g8_cus() {
+    static int cus = 0;
+    if (!cus) {
+        constexpr int lds = 2 * 4 * 128 * 128;
+        hipFuncSetAttribute((const void*)gemm8p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm8p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm8p_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm8p_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     G8Params p;
     p.x = (const bf16_t*)cp.x; p.w = (const bf16_t*)cp.w; p.y = (bf16_t*)cp.y; p.bias = cp.bias;
     p.add = (const bf16_t*)cp.add; p.aux = cp.act == 4 ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
     p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
     p.relu = cp.relu;
+    p.deq_x = p.deq_w = nullptr;
     p.tilesM = (p.M + 255) / 256; p.tilesN = p.N / 256;
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
     const double wbytes = (double)p.N * p.K * 2.0;
     p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     constexpr int lds = 2 * 4 * 128 * 128;        // 128 KB (>= the 66.5 KB epilogue tile)
-    static int cus = 0;
-    if (!cus) {
-        hipFuncSetAttribute((const void*)gemm8p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipFuncSetAttribute((const void*)gemm8p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+    const int cus = g8_cus();
     const int tiles = p.tilesM * p.tilesN;
     // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
     static const int direct_on = [] { const char* e = getenv("NKB_GEMM8P_DIRECT"); return e ? atoi(e) : 1; }();
@@ -427,4 +467,116 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     else
         hipLaunchKernelGGL(gemm8p_kernel<false>, dim3((unsigned)tiles), dim3(512), lds, stream, p);
     return nkb_check_launch("gemm8p");
+}
+
+// ---- fp8 GEMM (BASELINE configs[4]: unicom ViT-L/14 "fp8") ------------------------------------------------------------------
+// y[M][N] (bf16) = (xq[M][K] . wq[N][K]^T) * *deq_x * *deq_w (+ bias) (+ add) (ReLU / ReLU6), fp8 operands (OCP e4m3; mode 1: the
+// activation-side operand is e5m2 — gradients), fp32 accumulation, on the eight-phase core.  K % 128 == 0, N % 256 == 0.
+extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add,
+                            const float* deq_x, const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd,
+                            int relu, hipStream_t stream) {
+    if ((mode != 0 && mode != 1) || K % 128 != 0 || K < 256 || N % 256 != 0 || ldx % 16 || ldw % 16 || ldy % 8 || (add && ldadd % 8) ||
+        M < 1 || deq_x == nullptr || deq_w == nullptr) {
+        nkb_set_error("gemm_fp8: unsupported mode %d / shape M=%d K=%d N=%d (K %% 128, N %% 256, 16-byte rows, dequant scales)", mode, M, K, N);
+        return 1;
+    }
+    if ((long long)M * ldx >= 0xFFFFFFFFll || (long long)N * ldw >= 0xFFFFFFFFll) { nkb_set_error("gemm_fp8: operand too large"); return 1; }
+    G8Params p;
+    p.x = (const bf16_t*)xq; p.w = (const bf16_t*)wq; p.y = (bf16_t*)y; p.bias = bias; p.add = (const bf16_t*)add; p.aux = nullptr;
+    p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu;
+    p.deq_x = deq_x; p.deq_w = deq_w;
+    p.tilesM = (M + 255) / 256; p.tilesN = N / 256;
+    static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
+    p.group_m = (gm_env > 1 && (double)N * K > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
+    const int cus = g8_cus();
+    constexpr int lds = 2 * 4 * 128 * 128;
+    const int tiles = p.tilesM * p.tilesN;
+    NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
+    if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<true, 1>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL((gemm8p_kernel<true, 2>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), lds, stream, p);
+    return nkb_check_launch("gemm_fp8");
+}
+
+// Per-tensor fp8 quantisation with delayed scaling.  state = {scale, 1 / scale, amax of the values seen since the last
+// nkb_fp8_scale_update} (device floats).  kind 0: e4m3 (max 448), kind 1: e5m2 (max 57344).
+namespace {
+template <typename T>
+__global__ void fp8_quantize_kernel(const T* __restrict__ src, long long n, float* __restrict__ state, unsigned char* __restrict__ dst,
+                                    int kind) {
+    const float scale = state[0];
+    const float lim = kind == 0 ? 448.f : 57344.f;
+    float amax = 0.f;
+    const long long n8 = n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float f[8];
+        if constexpr (sizeof(T) == 2) {
+            unpack8(*(const u32x4*)(src + 8 * i), f);
+        } else {
+            const f32x4 lo = *(const f32x4*)(src + 8 * i), hi = *(const f32x4*)(src + 8 * i + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+        }
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            amax = fmaxf(amax, fabsf(f[e]));
+            q[e] = fminf(fmaxf(f[e] * scale, -lim), lim);
+        }
+        unsigned w0 = 0u, w1 = 0u;                  // (the word-select argument of the conversion must be a literal)
+        if (kind == 0) {
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+        } else {
+            w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], w1, true);
+        }
+        *(u32x2*)(dst + 8 * i) = (u32x2){w0, w1};
+    }
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax((unsigned*)(state + 2), __float_as_uint(amax));   // non-negative floats order as uints
+}
+// scale <- lim / amax (amax seen since the last update; unchanged when nothing was seen), then amax <- 0
+__global__ void fp8_scale_update_kernel(float* state, int kind) {
+    const float amax = state[2];
+    if (amax > 0.f && amax < 3.0e38f) {
+        const float sc = (kind == 0 ? 448.f : 57344.f) / amax;
+        state[0] = sc; state[1] = 1.f / sc;
+    }
+    state[2] = 0.f;
+}
+template <typename T>
+__global__ void fp8_amax_kernel(const T* __restrict__ src, long long n, float* __restrict__ state) {
+    float amax = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        amax = fmaxf(amax, fabsf(DT<T>::ld(src + i)));
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax((unsigned*)(state + 2), __float_as_uint(amax));
+}
+}  // namespace
+
+extern "C" int nkb_fp8_quantize(int dtype, int kind, const void* src, long long n, float* state, void* dst, hipStream_t stream) {
+    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (kind != 0 && kind != 1) || n % 8 != 0 || n <= 0) {
+        nkb_set_error("fp8_quantize: dtype %d kind %d n %lld (n %% 8 == 0)", dtype, kind, n);
+        return 1;
+    }
+    long long g = (n / 8 + 255) / 256;
+    if (g > 4096) g = 4096;
+    NkbProfScope prof(NKB_K_MISC, stream, 0, (double)n * ((dtype == NKB_DT_BF16 ? 2 : 4) + 1));
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(fp8_quantize_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)src, n, state, (unsigned char*)dst, kind);
+    else hipLaunchKernelGGL(fp8_quantize_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, n, state, (unsigned char*)dst, kind);
+    return nkb_check_launch("fp8_quantize");
+}
+extern "C" int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, hipStream_t stream) {
+    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || n <= 0) { nkb_set_error("fp8_amax: dtype %d n %lld", dtype, n); return 1; }
+    long long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(fp8_amax_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)src, n, state);
+    else hipLaunchKernelGGL(fp8_amax_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, n, state);
+    return nkb_check_launch("fp8_amax");
+}
+extern "C" int nkb_fp8_scale_update(float* state, int kind, hipStream_t stream) {
+    NkbProfScope prof(NKB_K_MISC, stream, 0);
+    hipLaunchKernelGGL(fp8_scale_update_kernel, dim3(1), dim3(1), 0, stream, state, kind);
+    return nkb_check_launch("fp8_scale_update");
 }

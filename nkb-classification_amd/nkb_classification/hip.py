@@ -82,6 +82,10 @@ _SIGS = {
     "nkb_scaler_update": (i32, [vp, vp, vp, vp, f32, f32, i32, vp]),
     "nkb_segment_sumsq": (i32, [vp, vp, i32, vp, vp]),
     "nkb_gemm8p_config": (None, [i32, i32, i32]),
+    "nkb_fp8_quantize": (i32, [i32, i32, vp, i64, vp, vp, vp]),
+    "nkb_fp8_amax": (i32, [i32, vp, i64, vp, vp]),
+    "nkb_fp8_scale_update": (i32, [vp, i32, vp]),
+    "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
     "nkb_prof_collect_raw": (i32, [vp, vp, vp, i32]),
@@ -448,6 +452,28 @@ def segment_sumsq(x, offsets, nseg, out):
 
 def gemm8p_config(on: bool, min_tiles: int = 0, min_k: int = 0):
     load().nkb_gemm8p_config(int(on), min_tiles, min_k)
+
+
+# ---- fp8 (per-tensor scaled e4m3 / e5m2 operands, configs[4]) -----------------------------------------------------------
+E4M3, E5M2 = 0, 1
+
+
+def fp8_quantize(dtype, kind, src, n, state, dst):
+    check(load().nkb_fp8_quantize(dtype, kind, ptr(src), n, ptr(state), ptr(dst), stream()), "fp8_quantize")
+
+
+def fp8_amax(dtype, src, n, state):
+    check(load().nkb_fp8_amax(dtype, ptr(src), n, ptr(state), stream()), "fp8_amax")
+
+
+def fp8_scale_update(state, kind):
+    check(load().nkb_fp8_scale_update(ptr(state), kind, stream()), "fp8_scale_update")
+
+
+def gemm_fp8(mode, xq, wq, y, M, K, N, *, deq_x, deq_w, bias=None, add=None, ldx=None, ldw=None, ldy=None, ldadd=0, relu=0):
+    check(load().nkb_gemm_fp8(mode, ptr(xq), ptr(wq), ptr(y), ptr(bias), ptr(add), ptr(deq_x), ptr(deq_w), M, K, N,
+                              K if ldx is None else ldx, K if ldw is None else ldw, N if ldy is None else ldy, ldadd,
+                              int(relu), stream()), "gemm_fp8")
 
 
 def prof_enable(on: bool):

@@ -1139,3 +1139,75 @@ def test_gemm8p_envelope_falls_back_cleanly(gemm8p_everywhere):
         hip.conv_gemm(hip.BF16, 0, x.to(DEV), w.to(DEV), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N, out_f32=f32)
         torch.cuda.synchronize()
         torch.testing.assert_close(y.float().cpu(), x.float() @ w.float().t(), **tol(torch.bfloat16, K))
+
+
+# ---- fp8 (configs[4]) ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["e4m3", "e5m2"])
+def test_fp8_quantize_is_bit_exact_with_scaled_rne(kind):
+    """nkb_fp8_quantize vs torch's float8 cast of the same scaled, clamped values (round-to-nearest-even, OCP formats), with the
+    delayed-scaling state machine: amax accumulates across calls, scale_update turns it into the next scale."""
+    torch.manual_seed(21)
+    k = hip.E4M3 if kind == "e4m3" else hip.E5M2
+    tdt = torch.float8_e4m3fn if kind == "e4m3" else torch.float8_e5m2
+    lim = 448.0 if kind == "e4m3" else 57344.0
+    x = (torch.randn(4096 * 8) * 3).to(torch.bfloat16)
+    x[5] = 1000.0                                              # beyond the first scale's range: must saturate, not wrap / NaN
+    xd = x.to(DEV)
+    state = torch.tensor([16.0, 1 / 16.0, 0.0], device=DEV)
+    q = torch.empty(x.numel(), device=DEV, dtype=torch.uint8)
+    hip.fp8_quantize(hip.BF16, k, xd, x.numel(), state, q)
+    torch.cuda.synchronize()
+    ref = (x.float() * 16.0).clamp(-lim, lim).to(tdt)
+    assert torch.equal(q.cpu(), ref.view(torch.uint8))
+    assert state[2].item() == x.float().abs().max().item() == 1000.0
+    hip.fp8_scale_update(state, k)
+    torch.cuda.synchronize()
+    assert state.tolist() == pytest.approx([lim / 1000.0, 1000.0 / lim, 0.0], rel=1e-6)
+    hip.fp8_amax(hip.BF16, xd[:64], 64, state)                 # just-in-time path: amax only
+    torch.cuda.synchronize()
+    assert state[2].item() == x[:64].float().abs().max().item()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(1000, 256, 256), (4096 + 64, 1024, 768), (256 * 70, 4096, 256)], ids=lambda s: "M%d_K%d_N%d" % s)
+def test_gemm_fp8_matches_product_of_rounded_operands(shape, mode):
+    """configs[4]'s fp8 contraction.  Oracle = the same product evaluated in fp64 on the fp8-ROUNDED operands (torch float8
+    casts), times the two dequantisation factors — the only differences left are fp32 accumulation order and the bf16 result
+    rounding.  mode 1: the activation-side operand is e5m2 (a gradient), the weight e4m3.  'parity unpinned' applies to the
+    unicom architecture these GEMMs serve, not to this arithmetic."""
+    M, K, N = shape
+    torch.manual_seed(22)
+    x = (torch.randn(M, K) * 0.7).to(torch.bfloat16)
+    w = (torch.randn(N, K) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N)
+    add = torch.randn(M, N).to(torch.bfloat16)
+    kx = hip.E5M2 if mode == 1 else hip.E4M3
+    tx = torch.float8_e5m2 if mode == 1 else torch.float8_e4m3fn
+    limx = 57344.0 if mode == 1 else 448.0
+    sx, sw = torch.zeros(3, device=DEV), torch.zeros(3, device=DEV)
+    sx[0] = sx[1] = sw[0] = sw[1] = 1.0
+    xd, wd = x.to(DEV), w.to(DEV)
+    hip.fp8_amax(hip.BF16, xd, x.numel(), sx); hip.fp8_scale_update(sx, kx)
+    hip.fp8_amax(hip.BF16, wd, w.numel(), sw); hip.fp8_scale_update(sw, hip.E4M3)
+    xq = torch.empty(M, K, device=DEV, dtype=torch.uint8); wq = torch.empty(N, K, device=DEV, dtype=torch.uint8)
+    hip.fp8_quantize(hip.BF16, kx, xd, x.numel(), sx, xq)
+    hip.fp8_quantize(hip.BF16, hip.E4M3, wd, w.numel(), sw, wq)
+    torch.cuda.synchronize()
+    scx, scw = sx[0].item(), sw[0].item()
+    xr = (x.float() * scx).clamp(-limx, limx).to(tx)
+    wr = (w.float() * scw).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(xq.cpu(), xr.view(torch.uint8)) and torch.equal(wq.cpu(), wr.view(torch.uint8))
+    ref = (xr.double() @ wr.double().t()) * (sx[1].item() * sw[1].item())
+    outs = []
+    for _ in range(2):
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        hip.gemm_fp8(mode, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias.to(DEV), add=add.to(DEV), ldadd=N)
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    want = (ref + bias.double() + add.double()).float()
+    torch.testing.assert_close(outs[0].float().cpu(), want, rtol=1e-2, atol=1e-2)
+    # and the quantisation error itself stays at the fp8 level against the unquantised product
+    full = x.double() @ w.double().t()
+    rel = ((ref - full).norm() / full.norm()).item()
+    assert rel < (0.04 if mode == 0 else 0.1), rel
