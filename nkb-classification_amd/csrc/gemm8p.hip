@@ -500,6 +500,17 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
 // Per-tensor fp8 quantisation with delayed scaling.  state = {scale, 1 / scale, amax of the values seen since the last
 // nkb_fp8_scale_update} (device floats).  kind 0: e4m3 (max 448), kind 1: e5m2 (max 57344).
 namespace {
+// one atomic per BLOCK (same-address float atomics serialise: 16 K of them cost 160 us); non-negative floats order as uints
+__device__ __forceinline__ void fp8_block_amax(float amax, float* state) {
+    __shared__ float red[4];
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax((unsigned*)(state + 2), __float_as_uint(m));
+    }
+}
 template <typename T>
 __global__ void fp8_quantize_kernel(const T* __restrict__ src, long long n, float* __restrict__ state, unsigned char* __restrict__ dst,
                                     int kind) {
@@ -532,8 +543,7 @@ __global__ void fp8_quantize_kernel(const T* __restrict__ src, long long n, floa
         }
         *(u32x2*)(dst + 8 * i) = (u32x2){w0, w1};
     }
-    amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax((unsigned*)(state + 2), __float_as_uint(amax));   // non-negative floats order as uints
+    fp8_block_amax(amax, state);
 }
 // scale <- lim / amax (amax seen since the last update; unchanged when nothing was seen), then amax <- 0
 __global__ void fp8_scale_update_kernel(float* state, int kind) {
@@ -549,10 +559,75 @@ __global__ void fp8_amax_kernel(const T* __restrict__ src, long long n, float* _
     float amax = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         amax = fmaxf(amax, fabsf(DT<T>::ld(src + i)));
-    amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax((unsigned*)(state + 2), __float_as_uint(amax));
+    fp8_block_amax(amax, state);
+}
+
+// many tensors in one launch (the weight matrices of a model, both layouts): jobs[j] = {src, dst, n, state, kind, first block}
+struct Fp8Job { const bf16_t* src; unsigned char* dst; long long n; float* state; long long kind; long long first_block; };
+constexpr int FP8_JOB_ELEMS = 256 * 8 * 8;       // elements per block of the multi-job kernels
+__global__ void fp8_quantize_multi_kernel(const Fp8Job* __restrict__ jobs, int njobs, int amax_only) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                               // last job whose first block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const Fp8Job jb = jobs[lo];
+    const long long base = ((long long)blockIdx.x - jb.first_block) * FP8_JOB_ELEMS;
+    const float scale = jb.state[0];
+    const float lim = jb.kind == 0 ? 448.f : 57344.f;
+    float amax = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const long long i = base + (it * 256 + threadIdx.x) * 8;
+        if (i >= jb.n) break;
+        float f[8], q[8];
+        unpack8(*(const u32x4*)(jb.src + i), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { amax = fmaxf(amax, fabsf(f[e])); q[e] = fminf(fmaxf(f[e] * scale, -lim), lim); }
+        if (amax_only) continue;
+        unsigned w0 = 0u, w1 = 0u;
+        if (jb.kind == 0) {
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+        } else {
+            w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], w1, true);
+        }
+        *(u32x2*)(jb.dst + i) = (u32x2){w0, w1};
+    }
+    fp8_block_amax(amax, jb.state);
+}
+__global__ void fp8_scale_update_multi_kernel(const Fp8Job* __restrict__ jobs, int njobs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= njobs) return;
+    // several jobs may share one state (the two layouts of a weight): identical result whichever thread writes
+    float* st = jobs[j].state;
+    const float amax = st[2];
+    if (amax > 0.f && amax < 3.0e38f) {
+        const float sc = (jobs[j].kind == 0 ? 448.f : 57344.f) / amax;
+        st[0] = sc; st[1] = 1.f / sc;
+    }
+}
+__global__ void fp8_amax_clear_multi_kernel(const Fp8Job* __restrict__ jobs, int njobs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < njobs) jobs[j].state[2] = 0.f;
 }
 }  // namespace
+
+extern "C" long long nkb_fp8_job_blocks(long long n) { return (n + FP8_JOB_ELEMS - 1) / FP8_JOB_ELEMS; }
+// jobs: device array of njobs x 6 int64 {src (bf16), dst (bytes), n (multiple of 8), state (3 floats), kind, first block};
+// pass 0: amax only (state[2]); pass 1: quantise with state[0] (+ amax); pass 2: state <- scale from amax; pass 3: amax <- 0
+extern "C" int nkb_fp8_multi(int pass, const long long* jobs, int njobs, long long total_blocks, hipStream_t stream) {
+    if (njobs <= 0) return 0;
+    NkbProfScope prof(NKB_K_WPREP, stream, 0);
+    if (pass == 0 || pass == 1)
+        hipLaunchKernelGGL(fp8_quantize_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, (const Fp8Job*)jobs, njobs, pass == 0);
+    else if (pass == 2)
+        hipLaunchKernelGGL(fp8_scale_update_multi_kernel, dim3((njobs + 255) / 256), dim3(256), 0, stream, (const Fp8Job*)jobs, njobs);
+    else
+        hipLaunchKernelGGL(fp8_amax_clear_multi_kernel, dim3((njobs + 255) / 256), dim3(256), 0, stream, (const Fp8Job*)jobs, njobs);
+    return nkb_check_launch("fp8_multi");
+}
 
 extern "C" int nkb_fp8_quantize(int dtype, int kind, const void* src, long long n, float* state, void* dst, hipStream_t stream) {
     if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (kind != 0 && kind != 1) || n % 8 != 0 || n <= 0) {
@@ -560,7 +635,7 @@ extern "C" int nkb_fp8_quantize(int dtype, int kind, const void* src, long long 
         return 1;
     }
     long long g = (n / 8 + 255) / 256;
-    if (g > 4096) g = 4096;
+    if (g > 1024) g = 1024;
     NkbProfScope prof(NKB_K_MISC, stream, 0, (double)n * ((dtype == NKB_DT_BF16 ? 2 : 4) + 1));
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(fp8_quantize_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)src, n, state, (unsigned char*)dst, kind);
     else hipLaunchKernelGGL(fp8_quantize_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, n, state, (unsigned char*)dst, kind);
@@ -569,7 +644,7 @@ extern "C" int nkb_fp8_quantize(int dtype, int kind, const void* src, long long 
 extern "C" int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, hipStream_t stream) {
     if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || n <= 0) { nkb_set_error("fp8_amax: dtype %d n %lld", dtype, n); return 1; }
     long long g = (n + 255) / 256;
-    if (g > 2048) g = 2048;
+    if (g > 1024) g = 1024;
     NkbProfScope prof(NKB_K_MISC, stream, 0);
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(fp8_amax_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)src, n, state);
     else hipLaunchKernelGGL(fp8_amax_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, n, state);

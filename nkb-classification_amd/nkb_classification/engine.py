@@ -39,7 +39,10 @@ class TrainPbar(tqdm):
 
 
 def _amp_dtype(cfg):
-    return getattr(cfg, "amp_dtype", torch.bfloat16)
+    """cfg.amp_dtype: torch.bfloat16 (default) — or "fp8": bf16 autocast with the Linear contractions of transformer blocks
+    in per-tensor-scaled fp8 (BASELINE configs[4]; the reference itself only has fp16 autocast, engine.py:43-47)."""
+    d = getattr(cfg, "amp_dtype", torch.bfloat16)
+    return torch.bfloat16 if d == "fp8" else d
 
 
 def _grad_norms(model, log):
@@ -77,6 +80,8 @@ def _upload(target, device):
 
 def _forward_and_loss(model, criterion, img, target, device, cfg):
     """engine.py:43-51: autocast region around model(img) and criterion(preds, target)."""
+    if hasattr(model, "fp8_linear"):
+        model.fp8_linear = bool(cfg.enable_mixed_presicion and getattr(cfg, "amp_dtype", None) == "fp8")
     with torch.autocast(device_type="cuda", dtype=_amp_dtype(cfg), enabled=cfg.enable_mixed_presicion):
         preds = model(img)
         labels = _upload(target, device) if isinstance(target, torch.Tensor) else target

@@ -85,6 +85,8 @@ _SIGS = {
     "nkb_fp8_quantize": (i32, [i32, i32, vp, i64, vp, vp, vp]),
     "nkb_fp8_amax": (i32, [i32, vp, i64, vp, vp]),
     "nkb_fp8_scale_update": (i32, [vp, i32, vp]),
+    "nkb_fp8_job_blocks": (i64, [i64]),
+    "nkb_fp8_multi": (i32, [i32, vp, i32, i64, vp]),
     "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
@@ -136,7 +138,8 @@ _PURE = frozenset({"nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", 
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
-                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_set_ring"})
+                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_set_ring",
+                   "nkb_fp8_job_blocks"})
 
 
 class Seed(int):
@@ -468,6 +471,15 @@ def fp8_amax(dtype, src, n, state):
 
 def fp8_scale_update(state, kind):
     check(load().nkb_fp8_scale_update(ptr(state), kind, stream()), "fp8_scale_update")
+
+
+def fp8_job_blocks(n) -> int:
+    return int(load().nkb_fp8_job_blocks(n))
+
+
+def fp8_multi(pass_, jobs, njobs, total_blocks):
+    """pass 0: amax only, 1: quantise (+ amax), 2: scales from amax, 3: clear amax — over a device job table."""
+    check(load().nkb_fp8_multi(pass_, ptr(jobs), njobs, total_blocks, stream()), "fp8_multi")
 
 
 def gemm_fp8(mode, xq, wq, y, M, K, N, *, deq_x, deq_w, bias=None, add=None, ldx=None, ldw=None, ldy=None, ldadd=0, relu=0):

@@ -65,6 +65,11 @@ class HipEngine:
         self._suffix = ""
         self._fold: Dict[str, tuple] = {}          # stage key -> (fold_key, folded filter, shift) for eval mode
         self.fold_key = None                       # set by the owning classifier: (arena version, eval phase counter)
+        # fp8 Linear contractions (BASELINE configs[4]): set by the owning classifier from cfg.amp_dtype == "fp8"
+        self.fp8 = False
+        self._f8w: Dict[int, tuple] = {}           # id(weight) -> (e4m3 [N][K], e4m3 dgrad layout [K][N], state)
+        self._f8jobs = None                        # (all jobs, forward-layout jobs only) device tables for nkb_fp8_multi
+        self._f8act: Dict[str, torch.Tensor] = {}  # activation / gradient site -> scaling state {scale, 1/scale, amax}
         # recorded launch plans of the train step (hip.Plan): key -> (plan, workspace generation, saved-activation table)
         self.plans: Dict[tuple, tuple] = {}
         self.plan_seen: Dict[tuple, int] = {}      # key -> workspace generation after its last eager run
@@ -106,6 +111,8 @@ class HipEngine:
                 self._wjobs = self._build_dgrad_jobs()
             jobs, njobs, nblocks = self._wjobs
             hip.wprep_multi(self.d, a.flat_param, jobs, njobs, nblocks)
+        if self.fp8 and self.T == torch.bfloat16 and need_dgrad:
+            self._refresh_fp8_weights()
         self._dgrad_ready = need_dgrad
         self._wver = a.version
 
@@ -141,6 +148,61 @@ class HipEngine:
         add(a.offset_of(hw[0]), buf, ctot, 1, E, cp, 1)
         jobs = torch.tensor(rows, dtype=torch.int64, device=self.device)
         return jobs, len(rows), nblocks
+
+    # ------------------------------------------------------------------ fp8 ----
+    @staticmethod
+    def _fp8_shape_ok(K: int, N: int) -> bool:
+        return K % 128 == 0 and K >= 256 and N % 256 == 0
+
+    def _refresh_fp8_weights(self):
+        """e4m3 copies of every eligible Linear weight in both operand layouts, with a just-in-time per-tensor scale (the
+        amax of the freshly updated weights): four launches over a device job table, once per optimizer step."""
+        a = self.arena
+        if self._f8jobs is None:
+            rows_all, rows_fwd, nb_all, nb_fwd = [], [], 0, 0
+            for lin in self._convs:
+                w = lin.weight
+                if w.dim() != 2:
+                    continue
+                N, K = w.shape
+                # forward x[M][K] . w[N][K]^T needs (K, N) eligible; the data gradient g[M][N] . wd[K][N]^T needs (N, K)
+                if not (self._fp8_shape_ok(K, N) and self._fp8_shape_ok(N, K) and id(w) in self._wd):
+                    continue
+                st = torch.tensor([1.0, 1.0, 0.0], device=self.device)
+                wq = torch.empty(N, K, device=self.device, dtype=torch.uint8)
+                wdq = torch.empty(K, N, device=self.device, dtype=torch.uint8)
+                self._f8w[id(w)] = (wq, wdq, st)
+                n = N * K
+                for src, dst, table in ((a.shadow_flat(w), wq, "both"), (self._wd[id(w)], wdq, "all")):
+                    row = [src.data_ptr(), dst.data_ptr(), n, st.data_ptr(), hip.E4M3]
+                    rows_all.append(row + [nb_all]); nb_all += hip.fp8_job_blocks(n)
+                    if table == "both":
+                        rows_fwd.append(row + [nb_fwd]); nb_fwd += hip.fp8_job_blocks(n)
+            mk = lambda r: torch.tensor(r, dtype=torch.int64, device=self.device) if r else None    # noqa: E731
+            self._f8jobs = (mk(rows_all), len(rows_all), nb_all, mk(rows_fwd), len(rows_fwd), nb_fwd)
+        jall, nall, ball, jfwd, nfwd, bfwd = self._f8jobs
+        if nall == 0:
+            return
+        hip.fp8_multi(3, jfwd, nfwd, 0)            # amax <- 0
+        hip.fp8_multi(0, jfwd, nfwd, bfwd)         # amax of the current weights
+        hip.fp8_multi(2, jfwd, nfwd, 0)            # scale <- 448 / amax
+        hip.fp8_multi(1, jall, nall, ball)         # quantise both layouts
+
+    def _fp8_operand(self, key: str, x: torch.Tensor, kind: int):
+        """fp8 copy of an activation (e4m3) or gradient (e5m2) with delayed per-tensor scaling: the scale comes from the amax
+        the previous step's pass over this site accumulated (the first call measures it just in time)."""
+        st = self._f8act.get(key)
+        n = x.numel()
+        if st is None:
+            st = self._f8act[key] = torch.tensor([1.0, 1.0, 0.0], device=self.device)
+            hip.fp8_amax(self.d, x, n, st)
+        hip.fp8_scale_update(st, kind)
+        q = self.ws.get(key + ".q", tuple(x.shape), torch.uint8)
+        hip.fp8_quantize(self.d, kind, x, n, st, q)
+        return q, st
+
+    def _fp8_linear_ok(self, lin, M: int) -> bool:
+        return self.fp8 and self.T == torch.bfloat16 and id(lin.weight) in self._f8w
 
     @staticmethod
     def s2_classes(conv) -> bool:
@@ -619,9 +681,15 @@ class HipEngine:
         M, K = x.shape
         N = lin.weight.shape[0]
         y = self.ws.get(key + ".y", (M, N), self.T)
-        hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
-                      bias=self.arena.param_flat(lin.bias) if lin.bias is not None else None, add=add,
-                      ldadd=N if add is not None else 0)
+        bias = self.arena.param_flat(lin.bias) if lin.bias is not None else None
+        if self._fp8_linear_ok(lin, M):
+            xq, sx = self._fp8_operand(key + ".f8x", x, hip.E4M3)
+            wq, _, sw = self._f8w[id(lin.weight)]
+            hip.gemm_fp8(0, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, add=add,
+                         ldadd=N if add is not None else 0)
+        else:
+            hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
+                          bias=bias, add=add, ldadd=N if add is not None else 0)
         if train:
             self.saved[key] = dict(x=x, lin=lin)
         return y
@@ -639,8 +707,13 @@ class HipEngine:
         if slot is None:
             return None
         dx = self.scratch(slot, (M, K))
-        hip.conv_gemm(self.d, 0, g, self._wd[id(lin.weight)], dx, N=M, H=1, W=1, Cin=N, ldx=N, P=1, Q=1, Cout=K, ldy=K,
-                      add=add, ldadd=K if add is not None else 0)
+        if self._fp8_linear_ok(lin, M):
+            gq, sg = self._fp8_operand(key + ".f8g", g, hip.E5M2)
+            _, wdq, sw = self._f8w[id(lin.weight)]
+            hip.gemm_fp8(1, gq, wdq, dx, M, N, K, deq_x=sg[1:2], deq_w=sw[1:2], add=add, ldadd=K if add is not None else 0)
+        else:
+            hip.conv_gemm(self.d, 0, g, self._wd[id(lin.weight)], dx, N=M, H=1, W=1, Cin=N, ldx=N, P=1, Q=1, Cout=K, ldy=K,
+                          add=add, ldadd=K if add is not None else 0)
         return dx
 
     def linear_relu6(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool) -> torch.Tensor:
@@ -648,8 +721,14 @@ class HipEngine:
         M, K = x.shape
         N = lin.weight.shape[0]
         u = self.ws.get(key + ".y", (M, N), self.T)
-        hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), u, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
-                      bias=self.arena.param_flat(lin.bias) if lin.bias is not None else None, relu=2)
+        bias = self.arena.param_flat(lin.bias) if lin.bias is not None else None
+        if self._fp8_linear_ok(lin, M):
+            xq, sx = self._fp8_operand(key + ".f8x", x, hip.E4M3)
+            wq, _, sw = self._f8w[id(lin.weight)]
+            hip.gemm_fp8(0, xq, wq, u, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, relu=2)
+        else:
+            hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), u, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
+                          bias=bias, relu=2)
         if train:
             self.saved[key] = dict(x=x, lin=lin, u=u)
         return u

@@ -61,6 +61,9 @@ class _HipClassifier(nn.Module):
         self._nbt_flat = None
         self.grad_ready_hook = None   # set by parallel.GradReducer: called as hook(lo, hi) while backward runs
         self.grad_done_hook = None    # set by parallel.GradReducer: called once at the end of backward
+        # fp8 Linear contractions under bf16 autocast (BASELINE configs[4]; cfg.amp_dtype = "fp8"): e4m3 activations and
+        # weights forward, e5m2 gradients x e4m3 weights for the data gradients, bf16 weight gradients, fp32 masters
+        self.fp8_linear = False
 
     # ---- reference API -------------------------------------------------------------------
     @staticmethod
@@ -160,6 +163,9 @@ class _HipClassifier(nn.Module):
         eng = self._active
         train = self.training
         need_dgrad = train and any(p.requires_grad for p in self.emb_model.parameters())
+        if eng.fp8 != bool(self.fp8_linear and train):
+            eng.fp8 = bool(self.fp8_linear and train)
+            eng._wver = -1                          # the fp8 weight copies follow the switch
         eng.refresh_weights(need_dgrad=need_dgrad)
         eng.fold_key = (self.arena.version, getattr(self, "_eval_phase", 0))
         drop_p = self._classifier_dropout_p() if train else 0.0
@@ -177,7 +183,7 @@ class _HipClassifier(nn.Module):
         if not (_PLANS and train):
             run()
             return logits
-        key = ("fwd", tuple(img.shape), need_dgrad, drop_p, eng.overlap_wgrad, self.arena.total)
+        key = ("fwd", tuple(img.shape), need_dgrad, drop_p, eng.overlap_wgrad, self.arena.total, eng.fp8)
         self._fwd_key = key
         ent = eng.plans.get(key)
         if ent is not None and ent[1] == eng.ws.generation:

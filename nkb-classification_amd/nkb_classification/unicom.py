@@ -216,6 +216,8 @@ _UNICOM = {
     "vit-l/14@336px": dict(input_size=336, patch_size=14, dim=1024, embedding_size=768, depth=24, num_heads=16),
     # reduced member for the fast parity tests (same blocks, 16 tokens)
     "vit-tiny-test": dict(input_size=56, patch_size=14, dim=128, embedding_size=64, depth=2, num_heads=2),
+    # ... and one whose Linear layers are inside the fp8 GEMM envelope (K >= 256, N % 256 == 0)
+    "vit-small-test": dict(input_size=56, patch_size=14, dim=256, embedding_size=64, depth=2, num_heads=4),
 }
 
 

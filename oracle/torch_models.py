@@ -332,6 +332,7 @@ _UNICOM = {
     "vit-l/14": dict(input_size=224, patch_size=14, dim=1024, embedding_size=768, depth=24, num_heads=16),
     "vit-l/14@336px": dict(input_size=336, patch_size=14, dim=1024, embedding_size=768, depth=24, num_heads=16),
     "vit-tiny-test": dict(input_size=56, patch_size=14, dim=128, embedding_size=64, depth=2, num_heads=2),
+    "vit-small-test": dict(input_size=56, patch_size=14, dim=256, embedding_size=64, depth=2, num_heads=4),
 }
 
 

@@ -297,3 +297,61 @@ def test_train_step_gradients_are_bit_reproducible(backbone, amp):
         grads.append(model.arena.flat_grad.clone())
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
     assert grads[0].abs().max().item() > 0
+
+
+# ------------------------------------------------------------------------------------------------------- fp8 ----
+def test_unicom_fp8_train_step_tracks_bf16_and_oracle():
+    """BASELINE configs[4]'s numeric mode on a reduced unicom ViT whose Linear layers sit inside the fp8 GEMM envelope
+    (dim 256): forward e4m3 x e4m3, data gradients e5m2 x e4m3, per-tensor scaling, bf16 everything else.  The fp8 step must
+    stay close to the bf16 step (same kernels otherwise) and to the fp32 CPU oracle at the level fp8 operand rounding allows.
+    The unicom architecture itself is restated from memory: parity of the ARCHITECTURE is unpinned; this test
+    pins the arithmetic of the fp8 path against the oracle of that restatement."""
+    from oracle.torch_models import OracleClassifier
+    cfg_model = dict(model="unicom ViT-small-test", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    classes = ["a", "b", "c", "d"]
+    torch.manual_seed(0)
+    oracle = OracleClassifier(cfg_model, classes)
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(32, 3, 56, 56, generator=g), torch.randint(0, 4, (32,), generator=g)
+    for net in (oracle,):
+        for blk in net.emb_model.blocks:
+            blk.drop_path.drop_prob = 0.0
+    oracle.train()
+    ref_out = oracle(x)
+    torch.nn.functional.cross_entropy(ref_out, y).backward()
+    ref_g = {n: p.grad.clone() for n, p in oracle.named_parameters()}
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    res = {}
+    for mode in ("bf16", "fp8"):
+        model = get_model(dict(cfg_model), classes, DEV)
+        model.load_state_dict(oracle.state_dict())
+        for blk in model.emb_model.blocks:
+            blk.drop_path.drop_prob = 0.0
+        model.train()
+        model.fp8_linear = mode == "fp8"
+        for _ in range(2):                          # second pass: delayed scaling in effect (scales from the first pass's amax)
+            for p in model.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(x.to(DEV))
+                loss = crit(out, y.to(DEV))
+            loss.backward()
+        torch.cuda.synchronize()
+        eng = model._engines[torch.bfloat16]
+        assert (len(eng._f8w) == 8) == (mode == "fp8")          # 2 blocks x (qkv, proj, fc1, fc2) took the fp8 kernel
+        res[mode] = (out.detach().float().cpu(), loss.item(), {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()})
+
+    def cos(a, b):
+        num = sum((a[n].double() * b[n].double()).sum().item() for n in a)
+        return num / (sum(a[n].double().pow(2).sum().item() for n in a) * sum(b[n].double().pow(2).sum().item() for n in b)) ** 0.5
+
+    o16, l16, g16 = res["bf16"]
+    o8, l8, g8 = res["fp8"]
+    scale = ref_out.detach().abs().max().item()
+    e16 = (o16 - ref_out.detach()).abs().max().item() / scale
+    e8 = (o8 - ref_out.detach()).abs().max().item() / scale
+    c16, c8 = cos(g16, ref_g), cos(g8, ref_g)
+    print(f"\n[unicom small fp8] logits relerr bf16 {e16:.3e} fp8 {e8:.3e}; loss {l16:.4f} / {l8:.4f}; grad cosine vs oracle bf16 {c16:.5f} fp8 {c8:.5f}")
+    assert e8 < 8e-2 and abs(l8 - l16) < 3e-2 * abs(l16)
+    assert c8 > 0.97 and c16 > 0.995
