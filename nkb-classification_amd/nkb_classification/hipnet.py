@@ -67,6 +67,7 @@ class HipEngine:
         self.fold_key = None                       # set by the owning classifier: (arena version, eval phase counter)
         # fp8 Linear contractions (BASELINE configs[4]): set by the owning classifier from cfg.amp_dtype == "fp8"
         self.fp8 = False
+        self.fp8_candidates = None                 # Linear modules that run through linear() / linear_backward() (set by the model)
         self._f8w: Dict[int, tuple] = {}           # id(weight) -> (e4m3 [N][K], e4m3 dgrad layout [K][N], state)
         self._f8jobs = None                        # (all jobs, forward-layout jobs only) device tables for nkb_fp8_multi
         self._f8act: Dict[str, torch.Tensor] = {}  # activation / gradient site -> scaling state {scale, 1/scale, amax}
@@ -160,7 +161,7 @@ class HipEngine:
         a = self.arena
         if self._f8jobs is None:
             rows_all, rows_fwd, nb_all, nb_fwd = [], [], 0, 0
-            for lin in self._convs:
+            for lin in (self.fp8_candidates if self.fp8_candidates is not None else self._convs):
                 w = lin.weight
                 if w.dim() != 2:
                     continue

@@ -133,6 +133,8 @@ class _HipClassifier(nn.Module):
             heads = self._heads()
             em = self.emb_model
             eng.register(em.gemm_convs(), em.stem_convs(), [h.weight for h in heads], [h.bias for h in heads])
+            if hasattr(em, "fp8_linears"):
+                eng.fp8_candidates = em.fp8_linears()
             self._engines[dtype] = eng
         return eng
 

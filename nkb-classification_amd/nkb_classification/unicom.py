@@ -103,6 +103,10 @@ class HipUnicomViT(_ParamOnly):
     def stem_convs(self):
         return [self.patch_embed.proj]
 
+    def fp8_linears(self):
+        """The Linear layers of the transformer blocks: the contractions that cfg.amp_dtype = "fp8" moves to fp8 operands."""
+        return [m for blk in self.blocks for m in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)]
+
     @staticmethod
     def _dp(blk) -> float:
         return blk.drop_path.drop_prob if isinstance(blk.drop_path, _DropPath) else 0.0

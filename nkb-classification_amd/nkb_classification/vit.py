@@ -81,6 +81,10 @@ class HipViT(_ParamOnly):
     def stem_convs(self):
         return [self.patch_embed.proj]
 
+    def fp8_linears(self):
+        """The Linear layers of the transformer blocks: the contractions that cfg.amp_dtype = "fp8" moves to fp8 operands."""
+        return [m for blk in self.blocks for m in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)]
+
     def run_forward(self, eng: HipEngine, img: torch.Tensor, train: bool) -> torch.Tensor:
         """Dropout sites follow timm's VisionTransformer (every nn.Dropout the reference's set_dropout rewrites,
         model.py:66-72): pos_drop after the position embedding, attn_drop on the attention probabilities, proj_drop and
