@@ -50,7 +50,6 @@ int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, void* y, co
 /* add_bits (optional): ReLU bit mask of the `add` operand as written by nkb_bn_apply(relu_bits): add[m][c] only counts
  * where its bit is set (the gradient of a residual block's output, masked on the fly instead of in a separate pass). */
 int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout);
-void nkb_set_ring(int mode); /* 0: register-staged kernel only; 1: persistent LDS-DMA ring kernel where eligible */
 
 /* Weight gradient: dw[co][r][s][ci] += sum_{n,p,q} dy[n,p,q,co] * x[n, p*stride+r-pad, q*stride+s-pad, ci] (fp32 atomics);
  * optional bias gradient dbias[co] += sum_{n,p,q} dy[n,p,q,co] from the same pass over dy. */
@@ -271,6 +270,11 @@ int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float*
 int nkb_fp8_quantize(int dtype, int kind, const void* src, long long n, float* state, void* dst, nkb_stream_t stream);
 int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, nkb_stream_t stream);
 int nkb_fp8_scale_update(float* state, int kind, nkb_stream_t stream);
+/* Many tensors in one launch (a model's weight matrices): jobs = device array of njobs x 6 int64 {src (bf16), dst (bytes),
+ * n (multiple of 8), state (3 floats), kind, first block}; blocks per job from nkb_fp8_job_blocks(n).  pass 0: amax only;
+ * 1: quantise with state[0] (+ amax); 2: scale from amax; 3: amax <- 0. */
+long long nkb_fp8_job_blocks(long long n);
+int nkb_fp8_multi(int pass, const long long* jobs, int njobs, long long total_blocks, nkb_stream_t stream);
 int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add, const float* deq_x,
                  const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd, int relu, nkb_stream_t stream);
 

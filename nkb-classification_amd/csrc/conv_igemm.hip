@@ -1066,7 +1066,6 @@ extern "C" int nkb_conv_gemm(int dtype, int mode, const void* x, const void* w, 
     const double bytes = ((double)N * H * W * Cin + (double)Cout * R * S * Cin) * esz +
                          (double)p.M * Cout * (out_f32 ? 4 : esz) * (add ? 2 : 1);
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops, bytes);
-    if (add_h == 0 && nkb_conv_ring_eligible(dtype, Cout, ldy, ldadd, add != nullptr, out_f32, p.M)) return nkb_launch_conv_ring(p, stream);
     if (nkb_gemm8p_eligible(p, dtype, 1)) return nkb_launch_gemm8p(p, stream);       // wide plain GEMMs: 256^2 eight-phase core
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
@@ -1241,7 +1240,6 @@ extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y
 // number of row tiles the stats buffer must hold for a given launch: [tilesM][2][Cout] floats
 // (for the plain conv call: ldy == Cout, no residual, compute-dtype output)
 extern "C" int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout) {
-    if (nkb_conv_ring_eligible(dtype, Cout, Cout, 0, false, 0, M)) return nkb_conv_ring_stat_tiles(M, Cout);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const int tp = (Cout <= 64 && narrow_on) ? 256 : 128;
     return (M + tp - 1) / tp;

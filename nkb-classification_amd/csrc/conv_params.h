@@ -1,4 +1,4 @@
-// Parameter block shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_ring.hip).
+// Parameter block shared by the implicit-GEMM convolution kernels (conv_igemm.hip; the eight-phase core in gemm8p.hip is launched from the same block).
 #pragma once
 #include "common.h"
 
@@ -44,9 +44,3 @@ struct ConvParams {
     int inner;
     long long sxo, sxi, swo, swi, syo, syi;
 };
-
-
-// persistent LDS-DMA ring variant (conv_ring.hip); returns -1 when the problem is outside its envelope
-int nkb_launch_conv_ring(ConvParams& p, hipStream_t stream);
-int nkb_conv_ring_stat_tiles(int M, int Cout);
-bool nkb_conv_ring_eligible(int dtype, int Cout, int ldy, int ldadd, bool has_add, int out_f32, int M);

@@ -24,7 +24,6 @@ _SIGS = {
     "nkb_last_error": (C.c_char_p, []),
     "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 18 + [vp, vp]),
     "nkb_conv_gemm_stat_tiles": (i32, [i32, i32, i32]),
-    "nkb_set_ring": (None, [i32]),
     "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp, i64, vp]),
     "nkb_conv_wgrad_workspace_floats": (i64, [i32] * 11),
     "nkb_stem_wgrad_workspace_floats": (i64, [i32] * 5),
@@ -138,7 +137,7 @@ _PURE = frozenset({"nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", 
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
-                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_set_ring",
+                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config",
                    "nkb_fp8_job_blocks"})
 
 

@@ -6,7 +6,6 @@ B = 256; pad = k // 2; P = (h + 2 * pad - k) // s + 1
 dev = "cuda"; T = torch.bfloat16; d = hip.BF16
 x = torch.randn(B, h, h, ci, device=dev).to(T); w = torch.randn(co, k, k, ci, device=dev).to(T) * 0.05
 y = torch.empty(B, P, P, co, device=dev, dtype=T)
-hip.load().nkb_set_ring(mode)
 for _ in range(5):
     hip.conv_gemm(d, 0, x, w, y, N=B, H=h, W=h, Cin=ci, ldx=ci, P=P, Q=P, Cout=co, ldy=co, R=k, S=k, stride=s, pad=pad)
 torch.cuda.synchronize()

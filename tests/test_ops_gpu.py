@@ -30,7 +30,7 @@ def rnd(t, dtype):
 
 
 CONV_CASES = [
-    # N, H, Cin, Cout, k, stride, pad   (the large-M cases take the persistent LDS-DMA ring kernel in bf16)
+    # N, H, Cin, Cout, k, stride, pad
     (8, 28, 128, 128, 3, 1, 1),
     (6, 28, 64, 256, 1, 1, 0),
     (5, 28, 256, 136, 3, 2, 1),
