@@ -98,6 +98,7 @@ def parse():
                          "rates for DESIGN.md, never the headline.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-work", action="store_true", help="skip the batch-4 host-work measurement (profiler runs)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -311,7 +312,7 @@ def main():
     # queue back-pressure, not work.  The work itself is independent of the batch (same launches): time it at batch 4, where
     # the GPU finishes each step long before the host has enqueued the next.
     host_work = None
-    if rank == 0 and args.input == "hbm" and world == 1 and not force_dist:
+    if rank == 0 and args.input == "hbm" and world == 1 and not force_dist and not args.no_host_work:
         small_x, small_t = img[:4].clone(), tgt[:4].clone()
         keep = (img, tgt)
         img, tgt = small_x, small_t

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): rocprofv3 kernel-trace + stats of the default bench command, the PMC passes the
+# roofline's `traffic` and MFMA-utilisation figures come from, and the bench lines themselves; results under gpurun_out/prof_$TAG,
+# summaries are copied to profiles/ by hand afterwards (profiles/ is tracked, gpurun_out/ is scratch).
+# Usage: bash scripts/collect_profiles.sh <tag> [model]
+set -o pipefail
+TAG=${1:-r02}; MODEL=${2:-resnet50}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_${TAG}_${MODEL//[^a-zA-Z0-9]/_}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="$ROOT/bench.py --model $MODEL --no-cpu-baseline --no-host-work"
+python3 $B --steps 30 --warmup 8 > $OUT/line.json 2> $OUT/line.err && echo "line ok"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $B --steps 20 --warmup 8 > $OUT/line_under_rocprofv3.json 2> $OUT/trace.err && echo "trace ok"
+for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o pmc -- python3 $B --steps 2 --warmup 1 --no-roofline > /dev/null 2> $OUT/pmc_$C.err && echo "pmc $C ok"
+done
+cd $ROOT
+T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
+python3 scripts/profile_summary.py $T 5 $OUT/last5steps_serialized.csv > /dev/null && cp $S $OUT/kernel_stats.csv
+F=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python3 scripts/pmc_traffic.py $F $W $OUT/pmc_traffic.json 1 > $OUT/pmc_traffic.txt
+M=$(find $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv" | head -1); MT=$(find $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1)
+python3 scripts/pmc_mfma.py $M $MT $OUT/pmc_mfma.json > $OUT/pmc_mfma.txt
+rm -rf $OUT/trace/*/*.db $OUT/pmc_*/*/*.db 2>/dev/null
+du -sh $OUT; cat $OUT/line.json | head -c 600; echo; cat $OUT/pmc_mfma.txt; head -30 $OUT/pmc_traffic.txt

@@ -18,9 +18,10 @@ def load(path, counter):
 
 
 def family(name, phase):
-    if "conv_igemm_kernel" in name:
+    if "conv_igemm_kernel" in name or "gemm8p_kernel" in name:
         return "conv_igemm_fwd" if phase == "fwd" else "conv_igemm_dgrad"
-    for key, fam in (("conv_wgrad_kernel", "conv_wgrad"), ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
+    for key, fam in (("conv_wgrad_kernel", "conv_wgrad"), ("wgrad3x3_kernel", "conv_wgrad"), ("wgrad8p_kernel", "conv_wgrad"),
+                     ("wgrad256_kernel", "conv_wgrad"), ("wgrad_reduce_kernel", "wgrad_reduce"), ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
                      ("bn_apply_kernel", "bn_apply")):
         if key in name:
             return fam
