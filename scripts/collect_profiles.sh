@@ -11,9 +11,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py --model $MODEL --no-cpu-baseline --no-host-work"
 python3 $B --steps 30 --warmup 8 > $OUT/line.json 2> $OUT/line.err && echo "line ok"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $B --steps 20 --warmup 8 > $OUT/line_under_rocprofv3.json 2> $OUT/trace.err && echo "trace ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $B --steps 20 --warmup 8 > $OUT/line_under_rocprofv3.json 2> $OUT/trace.err && echo "trace ok"
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o pmc -- python3 $B --steps 2 --warmup 1 --no-roofline > /dev/null 2> $OUT/pmc_$C.err && echo "pmc $C ok"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python3 $B --steps 2 --warmup 1 --no-roofline > /dev/null 2> $OUT/pmc_$C.err && echo "pmc $C ok"
 done
 cd $ROOT
 T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
