@@ -445,7 +445,23 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 else rows(std::false_type{}, std::false_type{}, std::false_type{});
             }
         }
-    } else
+    } else {
+    // residual-closing fused epilogue (BNB == 2, bf16, full-grid residual): the `add` rows of this half are requested up front,
+    // like the c rows above — inside the row loop each of them was a dependent load in front of its row's arithmetic and the
+    // kernel ran at ~3.5 TB/s on its three large tensors (profiles/r02a: 183 us average for 15 launches per step)
+    constexpr bool APRE = BNB == 2 && sizeof(T) == 2;
+    u32x4 apre[APRE ? RPH : 1];
+    const bool apre_on = APRE && p.add != nullptr && p.add_h == 0 && p.sub_h == 0 && vec_ok;
+    if constexpr (APRE) {
+        if (apre_on) {
+#pragma unroll
+            for (int i = 0; i < RPH; ++i) {
+                const int m = m0 + half * (TP / 2) + er + RPP * i;
+                apre[i] = (u32x4){0u, 0u, 0u, 0u};
+                if (m < p.M) apre[i] = *(const u32x4*)((const bf16_t*)p.add + (size_t)m * p.ldadd + co);
+            }
+        }
+    }
 #pragma unroll
     for (int ri = 0; ri < RPH; ++ri) {
         const int row = er + RPP * ri;
@@ -496,7 +512,11 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 for (int e = 0; e < 8; ++e) if (co + e < p.Cout && ((abits >> e) & 1u)) v[e] += a[e];
             } else if (vec_ok) {
                 float fa[8];
-                unpack8(*(const u32x4*)((const bf16_t*)p.add + am * p.ldadd + co), fa);
+                if constexpr (APRE) {
+                    unpack8(apre_on ? apre[ri] : *(const u32x4*)((const bf16_t*)p.add + am * p.ldadd + co), fa);
+                } else {
+                    unpack8(*(const u32x4*)((const bf16_t*)p.add + am * p.ldadd + co), fa);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += ((abits >> e) & 1u) ? fa[e] : 0.f;
             } else {
@@ -619,6 +639,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             if constexpr (BNB == 1 || BNB == 2) ssq[e] += v[e] * cv[e];
             else ssq[e] += v[e] * v[e];
         }
+    }
     }
     __syncthreads();
   }
