@@ -391,3 +391,52 @@ def test_unicom_vit_l14_full_size_train_steps(mode):
     assert losses[-1] < losses[0], losses
     eng = model._engines[torch.bfloat16]
     assert len(eng._f8w) == (96 if mode == "fp8" else 0)
+
+
+# ------------------------------------------------------------------------------------------------- launch plans ----
+@pytest.mark.parametrize("backbone", ["resnet_tiny_bottleneck", "vit_tiny_test"])
+def test_launch_plans_replay_exactly_across_shape_and_mode_changes(backbone, monkeypatch):
+    """Recorded launch plans (hip.Plan) vs the Python path on the same sequence: full batches (recorded after two eager
+    steps, then replayed), a partial last batch (another shape: its own eager steps, workspace reallocation invalidates the
+    plans), an evaluation pass in between, a frozen-backbone step, classifier dropout (seeds drawn per replay) — the
+    parameters after the whole sequence must be bit-identical with plans on and off."""
+    from nkb_classification import model as model_mod
+    cfg_model = dict(model=backbone, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.3,
+                     classifier_initialization="kaiming_normal_", task="single")
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    g = torch.Generator().manual_seed(12)
+    xs = [torch.randn(8, 3, 64, 64, generator=g).to(DEV) for _ in range(3)] + [torch.randn(5, 3, 64, 64, generator=g).to(DEV)]
+    ys = [torch.randint(0, 3, (x.shape[0],), generator=g).to(DEV) for x in xs]
+    schedule = [0, 1, 2, 0, 1, 3, "eval", 2, 0, "freeze", 1, 2, 0, 1, "unfreeze", 2, 0, 1, 3, 3, 2]
+
+    def run(plans_on):
+        monkeypatch.setattr(model_mod, "_PLANS", plans_on)
+        torch.manual_seed(0)
+        model = get_model(dict(cfg_model), ["a", "b", "c"], DEV)
+        opt = get_optimizer(model, dict(type="nadam", lr=1e-3, weight_decay=0.01))
+        torch.manual_seed(77)                        # dropout seed stream
+        model.train()
+        used = 0
+        for item in schedule:
+            if item == "eval":
+                model.eval()
+                with torch.no_grad():
+                    model(xs[0])
+                model.train()
+                continue
+            if item in ("freeze", "unfreeze"):
+                model.set_backbone_state(item)
+                continue
+            opt.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = crit(model(xs[item]), ys[item])
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        eng = model._engines[torch.bfloat16]
+        return model.arena.flat_param.clone(), len(eng.plans)
+
+    p_on, n_on = run(True)
+    p_off, n_off = run(False)
+    assert n_off == 0 and n_on >= 2                  # at least one forward and one backward plan were recorded and replayed
+    assert torch.equal(p_on, p_off)
