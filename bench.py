@@ -192,6 +192,11 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: native libraries (the RCCL version banner, NCCL_DEBUG output) write to file
+    # descriptor 1 behind Python's back, so fd 1 is pointed at stderr for the whole run and the line goes to a saved copy
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -442,7 +447,7 @@ def main():
             "kernel_tb_per_s": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in
                                 sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if v.get("bytes", 0) > 0} if prof else None,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

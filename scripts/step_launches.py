@@ -3,12 +3,13 @@ import os, sys, torch, argparse, collections
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "nkb-classification_amd"))
 import bench
 from nkb_classification import hip
-args = argparse.Namespace(model=sys.argv[1] if len(sys.argv) > 1 else "resnet50", classes=1000, batch=256)
+args = argparse.Namespace(model=sys.argv[1] if len(sys.argv) > 1 else "resnet50", classes=1000, batch=int(os.environ.get("BS", 256)))
 dev = torch.device("cuda", 0)
 model, opt, crit = bench.build(args, dev)
 g = torch.Generator().manual_seed(1)
-img = torch.randn(256, 3, 224, 224, generator=g).to(dev); tgt = torch.randint(0, 1000, (256,), generator=g).to(dev)
+img = torch.randn(args.batch, 3, 224, 224, generator=g).to(dev); tgt = torch.randint(0, 1000, (args.batch,), generator=g).to(dev)
 model.train()
+model.fp8_linear = os.environ.get("NKB_FP8") == "1"
 def step():
     opt.zero_grad()
     with torch.autocast("cuda", dtype=torch.bfloat16):
