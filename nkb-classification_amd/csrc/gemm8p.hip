@@ -27,6 +27,7 @@
 #include "common.h"
 #include "conv_params.h"
 #include "gemm8p.h"
+#include <type_traits>
 
 namespace {
 
@@ -46,7 +47,11 @@ struct G8Params {
     // *deq_x * *deq_w (the per-tensor dequantisation factors, device floats) before bias / residual
     const float* deq_x;
     const float* deq_w;
+    int aux_mode;         // 0: the result is multiplied by aux; 1: the result is kept where 0 < aux < 6 (ReLU6 backward mask)
+    int align_epi;        // DIRECT: both wave groups run the epilogue side by side (NKB_G8_ALIGN, default 1)
 };
+
+template <int V> using G8I = std::integral_constant<int, V>;
 
 __device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -68,6 +73,24 @@ __device__ __forceinline__ f32x4 g8_mma(const bf16x8& a, const bf16x8& b, f32x4 
             return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a2[1], b2[1], c, 0, 0, 0);
         }
     }
+}
+
+// fp8 at twice the bf16 rate: ONE v_mfma_f32_16x16x128_f8f6f4 (scale operands zero = the unscaled form) consumes both 16-byte
+// fragments of a k-tile row at once.  A lane's 32 operand bytes are its chunks (fgrp, 4 + fgrp) for BOTH operands, so
+// whatever k index the hardware gives byte j of lane group fgrp, the two operands agree on it and the sum over k is complete.
+typedef int g8_i32x8 __attribute__((ext_vector_type(8)));
+typedef int g8_i32x4 __attribute__((ext_vector_type(4)));
+#ifndef NKB_F8_K128
+#define NKB_F8_K128 1
+#endif
+template <int F8>
+__device__ __forceinline__ f32x4 g8_mma128(const bf16x8& a0, const bf16x8& a1, const bf16x8& b0, const bf16x8& b1, f32x4 c) {
+    const g8_i32x4 al = __builtin_bit_cast(g8_i32x4, a0), ah = __builtin_bit_cast(g8_i32x4, a1);
+    const g8_i32x4 bl = __builtin_bit_cast(g8_i32x4, b0), bh = __builtin_bit_cast(g8_i32x4, b1);
+    const g8_i32x8 A = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+    const g8_i32x8 B = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+    // cbsz / blgp: operand formats (0 = e4m3, 1 = e5m2); F8 == 2 multiplies e4m3 weights (A) with e5m2 gradients (B)
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, F8 == 2 ? 1 : 0, 0, 0, 0, 0);
 }
 
 // raw s_barrier (no vmcnt drain, unlike __syncthreads) between two compiler-level memory barriers
@@ -92,8 +115,8 @@ __device__ __forceinline__ f32x4 g8_mma(const bf16x8& a, const bf16x8& b, f32x4 
 //   The stores are older than every DMA issued after them, so the counted vmcnt(6) of the following k-tile's phase 4 also
 //   covers them (four phases later they have long been acknowledged) and the wave groups stay staggered across tiles.
 // F8: 0 = bf16 operands (k-tile = 64 elements); 1 = fp8 e4m3 x e4m3, 2 = W e4m3 x X e5m2 (data gradients): a k-tile is the
-// same 128 bytes per row = 128 elements, every 16-byte fragment feeds TWO v_mfma_f32_16x16x32_fp8 (its low and high 8 bytes;
-// both operands split the same way, so the k indices pair up) — half the LDS / L2 bytes per FLOP of the bf16 form.
+// same 128 bytes per row = 128 elements and the two 16-byte fragments of a row go into ONE v_mfma_f32_16x16x128_f8f6f4 (twice
+// the bf16 rate; g8_mma128) — half the LDS / L2 bytes and half the MFMA cycles per FLOP of the bf16 form.
 template <bool DIRECT, int F8 = 0>
 __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     constexpr int ESZ = F8 ? 1 : 2;               // bytes per operand element
@@ -183,8 +206,15 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 a[4][2], b[4][2];
 #define G8_MMA(slot, ii)                                                                                              \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[ii][j] = g8_mma<F8>(a[slot][ks], b[j][ks], acc[ii][j])
+    do {                                                                                                              \
+        if constexpr (F8 != 0 && NKB_F8_K128) {                                                                       \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+                acc[ii][j] = g8_mma128<F8>(a[slot][0], a[slot][1], b[j][0], b[j][1], acc[ii][j]);                     \
+        } else {                                                                                                      \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[ii][j] = g8_mma<F8>(a[slot][ks], b[j][ks], acc[ii][j]); \
+        }                                                                                                             \
+    } while (0)
     // stream k-tile g + d (d = 1, 2): local k-tile t + d of the current tile, or t + d - KT of the next one
 #define G8_ISSUE_AHEAD(d, hh)                                                                                         \
     do {                                                                                                              \
@@ -192,11 +222,156 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         else if (DIRECT && has_next) G8_ISSUE_AT(g + (d), t + (d) - KT, hh, xn, wn_);                                 \
     } while (0)
 
+    // DIRECT epilogue of the current tile.  FULL / ADD / AUX / RELU are compile-time for the combinations the train step uses
+    // (value < 0: decided at run time — edge tiles and the rest): a full tile needs no row predicate, the tile origin is a
+    // scalar base and every access a 32-bit lane offset from it (one v_add per store instead of a 64-bit multiply-add), and
+    // the residual / derivative rows of a channel group are requested before the first of them is used.  Stores are
+    // non-temporal: the output is far larger than L2 and is not read again by this kernel (+6-12 % on K <= 1024).
+    [[maybe_unused]] auto epilogue = [&](auto FULL_, auto ADD_, auto AUX_, auto RELU_) {
+        constexpr int FULL = decltype(FULL_)::value, ADD = decltype(ADD_)::value, AUX = decltype(AUX_)::value, RELU = decltype(RELU_)::value;
+        const bool has_add = ADD < 0 ? p.add != nullptr : ADD != 0;
+        const int aux_kind = AUX < 0 ? (p.aux ? 1 + p.aux_mode : 0) : AUX;      // 0 none, 1 multiply, 2 ReLU6 mask (0 < aux < 6)
+        const int relu = RELU < 0 ? p.relu : RELU;
+        const int em0 = tile_m * 256, en0 = tile_n * 256;
+        float deq = 1.f;
+        if constexpr (F8 != 0) deq = *p.deq_x * *p.deq_w;
+        int lrow = wc * 64 + frow;
+        const int lcol = wr * 128 + 8 * fgrp;
+        asm volatile("" : "+v"(lrow));                 // the lane offsets are built here, per tile, not carried through the k-loop
+        unsigned char* ybase = (unsigned char*)(p.y + ((size_t)em0 * p.ldy + en0));
+        const unsigned char* xbase = (const unsigned char*)(p.aux + ((size_t)em0 * p.ldy + en0));
+        const unsigned char* abase = (const unsigned char*)(p.add + ((size_t)em0 * p.ldadd + en0));
+        const unsigned yo = ((unsigned)lrow * (unsigned)p.ldy + lcol) * 2u, ao = ((unsigned)lrow * (unsigned)p.ldadd + lcol) * 2u;
+        const unsigned ystep = 32u * (unsigned)p.ldy, astep = 32u * (unsigned)p.ldadd;   // 16 rows, in bytes
+        // vmcnt is in order: a load issued behind a store waits for that store's acknowledgement (microseconds), and a
+        // wait for ANY load also drains the DMA stream.  So the compile-time variants with an operand (PRE) work in two
+        // halves of 8 rows: request half 0; compute it into packed registers (its accumulators and operand rows die);
+        // request half 1; only then store half 0; compute and store half 1.  No load is ever behind a store, and the plain
+        // variant has no vector-memory load at all (the bias comes from LDS).  The run-time variant (edge tiles, rare
+        // combinations) loads per row.
+        constexpr bool PRE = (ADD > 0) != (AUX > 0);
+        // (the loads and their counted waits are inline assembly: with LDS-DMA in flight hipcc waits vmcnt(0) at the first use
+        // of any load result, which for half 1 would be exactly the wait on half 0's stores this order exists to avoid)
+        auto load_half = [&](int half, u32x4 (&raw)[2][4]) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned char* sb = ADD > 0 ? abase : xbase;
+                    const unsigned vo = ADD > 0 ? ao + j * astep + 64 * (2 * half + q) : yo + j * ystep + 64 * (2 * half + q);
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[q][j]) : "v"(vo), "s"(sb) : "memory");
+                }
+        };
+#define G8_WAIT_HALF(n, raw)                                                                                          \
+    asm volatile("s_waitcnt vmcnt(" #n ")"                                                                            \
+                 : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[0][3]), "+v"(raw[1][0]), "+v"(raw[1][1]), \
+                   "+v"(raw[1][2]), "+v"(raw[1][3])                                                                   \
+                 :: "memory")
+        // one (channel group, pixel block): accumulators -> the 8 packed outputs of this lane
+        auto value = [&](int pr, int j, const float (&bv)[8], u32x4 araw, u32x4 xraw) -> u32x4 {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (F8 != 0) { v[e] = acc[2 * pr][j][e] * deq + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] * deq + bv[4 + e]; }
+                else { v[e] = acc[2 * pr][j][e] + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] + bv[4 + e]; }
+            }
+            if (has_add) {
+                float af[8];
+                unpack8(araw, af);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += af[e];
+            }
+            if (aux_kind) {
+                float af[8];
+                unpack8(xraw, af);
+                if (aux_kind == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= af[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (af[e] > 0.f && af[e] < 6.f) ? v[e] : 0.f;
+                }
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
+            }
+            acc[2 * pr][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[2 * pr + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            return pack8(v);
+        };
+        auto bias_of = [&](int pr, float (&bv)[8]) {
+            if (p.bias) {                              // this wave's 128 bias values were DMA'd into LDS at the start of the tile
+                const float* bp = (const float*)(smem + 2 * BUF + wave * 512) + 32 * pr + 8 * fgrp;
+                const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+            }
+        };
+        if constexpr (PRE) {
+            u32x4 raw[2][4], pk[2][4];
+            load_half(0, raw);
+            G8_WAIT_HALF(0, raw);                      // (also the DMA stream's three youngest half-tiles, issued a k-tile ago)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float bv[8];
+                bias_of(q, bv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[q][j] = value(q, j, bv, raw[q][j], raw[q][j]);
+            }
+            load_half(1, raw);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
+            G8_WAIT_HALF(8, raw);                      // full tile: exactly the 8 stores above are younger than half 1's loads
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float bv[8];
+                bias_of(2 + q, bv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_nontemporal_store(value(2 + q, j, bv, raw[q][j], raw[q][j]), (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
+            }
+        } else {
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                float bv[8];
+                bias_of(pr, bv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = FULL > 0 || em0 + lrow + 16 * j < p.M;
+                    u32x4 araw = (u32x4){0u, 0u, 0u, 0u}, xraw = (u32x4){0u, 0u, 0u, 0u};
+                    if (has_add && ok) araw = *(const u32x4*)(abase + (ao + j * astep + 64 * pr));
+                    if (aux_kind && ok) xraw = *(const u32x4*)(xbase + (yo + j * ystep + 64 * pr));
+                    const u32x4 out = value(pr, j, bv, araw, xraw);
+                    if (ok) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                }
+            }
+        }
+    };
+
     int t = 0;                                    // local k-tile of stream k-tile g
     for (int g = 0; g < GT; ++g) {
         const unsigned char* base = smem + (g & 1) * BUF;
         const unsigned char* pa = base + a_base;
         const unsigned char* pb = base + b_base;
+        if constexpr (DIRECT) {
+            // first k-tile of a tile: this wave's 128 bias values go to its 512 bytes of LDS behind the staging buffers by DMA
+            // (no registers, and nothing in the epilogue waits on vmcnt for them: they are older than the three half-tiles
+            // this k-tile issues in phases 2-4, so its phase-4 vmcnt(6) covers them)
+            if (t == 0 && p.bias) {
+                const float* bsrc = p.bias + tile_n * 256 + wr * 128 + lane;
+                unsigned char* bdst = smem + 2 * BUF + wave * 512;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc,
+                                                 (__attribute__((address_space(3))) void*)bdst, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + 64),
+                                                 (__attribute__((address_space(3))) void*)(bdst + 256), 4, 0, 0);
+            }
+        }
         // ---------------- phase 1: all X fragments + W fragments 0-3; DMA: W hi of stream k-tile g+1
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -257,55 +432,23 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         ++t;
         if constexpr (DIRECT) {
             if (t == KT) {
-                // ---- tile done: epilogue straight from the accumulators (no LDS, no barrier), then move on in the stream
-                const int em0 = tile_m * 256, en0 = tile_n * 256;
-                float deq = 1.f;
-                if constexpr (F8 != 0) deq = *p.deq_x * *p.deq_w;
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    const int co = en0 + wr * 128 + 32 * pr + 8 * fgrp;
-                    float bv[8];
-                    if (p.bias) {
-                        const f32x4 b0 = *(const f32x4*)(p.bias + co), b1 = *(const f32x4*)(p.bias + co + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = em0 + wc * 64 + 16 * j + frow;
-                        float v[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if constexpr (F8 != 0) { v[e] = acc[2 * pr][j][e] * deq + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] * deq + bv[4 + e]; }
-                            else { v[e] = acc[2 * pr][j][e] + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] + bv[4 + e]; }
-                        }
-                        const bool ok = m < p.M;
-                        if (p.add) {
-                            float af[8];
-                            const u32x4 raw = ok ? *(const u32x4*)(p.add + (size_t)m * p.ldadd + co) : (u32x4){0u, 0u, 0u, 0u};
-                            unpack8(raw, af);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += af[e];
-                        }
-                        if (p.aux) {
-                            float af[8];
-                            const u32x4 raw = ok ? *(const u32x4*)(p.aux + (size_t)m * p.ldy + co) : (u32x4){0u, 0u, 0u, 0u};
-                            unpack8(raw, af);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] *= af[e];
-                        }
-                        if (p.relu) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
-                        }
-                        if (ok) *(u32x4*)(p.y + (size_t)m * p.ldy + co) = pack8(v);
-                        acc[2 * pr][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        acc[2 * pr + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-                }
+                // ---- tile done: epilogue straight from the accumulators (no LDS), then move on in the stream.
+                // The two wave groups drop their one-barrier stagger for it (group 0 waits one barrier before, group 1 one
+                // after): run one after the other — each overlapping only 16 MFMAs of the other — the two epilogues cost
+                // 6-10 us per tile, 18-29 % of a K = 768 / 1024 launch; side by side their store latencies overlap.
+                if (p.align_epi && wr == 0) G8_BARRIER();
+                const bool fullt = tile_m * 256 + 256 <= p.M;
+                if (!fullt) epilogue(G8I<0>{}, G8I<-1>{}, G8I<-1>{}, G8I<-1>{});
+                else if (!p.add && !p.aux) {
+                    if (p.relu == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<0>{});
+                    else if (p.relu == 2) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<2>{});
+                    else epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<1>{});
+                } else if (p.add && !p.aux && p.relu == 0) epilogue(G8I<1>{}, G8I<1>{}, G8I<0>{}, G8I<0>{});
+                else if (!p.add && p.aux && p.relu == 0) {
+                    if (p.aux_mode == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<1>{}, G8I<0>{});
+                    else epilogue(G8I<1>{}, G8I<0>{}, G8I<2>{}, G8I<0>{});
+                } else epilogue(G8I<1>{}, G8I<-1>{}, G8I<-1>{}, G8I<-1>{});
+                if (p.align_epi && wr == 1) G8_BARRIER();
                 // the next tile becomes the current one; the one after it becomes "next"
                 t = 0;
                 lid += step;
@@ -361,7 +504,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                         float af[8];
                         unpack8(*(const u32x4*)(p.aux + (size_t)m * p.ldy + co), af);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= af[e];
+                        for (int e = 0; e < 8; ++e) v[e] = p.aux_mode == 0 ? v[e] * af[e] : ((af[e] > 0.f && af[e] < 6.f) ? v[e] : 0.f);
                     }
                     if (p.relu) {
 #pragma unroll
@@ -420,7 +563,7 @@ bool nkb_gemm8p_eligible(const ConvParams& p, int dtype, int batch) {
     if (!(p.R == 1 && p.S == 1 && p.stride == 1 && p.stride_w == 1 && p.pad == 0 && p.pad_w == 0 && p.stem_cprw == 0 &&
           p.sub_h == 0 && p.H == p.P && p.W == p.Q && p.mode == 0))
         return false;
-    if (p.out_f32 || p.add_h != 0 || p.add_bits != nullptr || p.y2 != nullptr || (p.act != 0 && p.act != 4)) return false;
+    if (p.out_f32 || p.add_h != 0 || p.add_bits != nullptr || p.y2 != nullptr || (p.act != 0 && p.act != 3 && p.act != 4)) return false;
     if (p.Cout % 256 != 0 || p.Cin % 64 != 0 || p.Cin < 128 || p.ldy % 8 != 0 || p.ldx % 8 != 0 || p.ldw % 8 != 0) return false;
     if (p.add && p.ldadd % 8 != 0) return false;
     if (p.add && p.stats) return false;
@@ -430,10 +573,15 @@ bool nkb_gemm8p_eligible(const ConvParams& p, int dtype, int batch) {
     return tiles >= g8_min_tiles && p.Cin >= g8_min_k;
 }
 
+static int g8_align() {
+    static const int on = [] { const char* e = getenv("NKB_G8_ALIGN"); return e ? atoi(e) : 1; }();
+    return on;
+}
+
 static int g8_cus() {
     static int cus = 0;
     if (!cus) {
-        constexpr int lds = 2 * 4 * 128 * 128;
+        constexpr int lds = 2 * 4 * 128 * 128 + 4096;
         hipFuncSetAttribute((const void*)gemm8p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipFuncSetAttribute((const void*)gemm8p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipFuncSetAttribute((const void*)gemm8p_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -449,7 +597,8 @@ static int g8_cus() {
 int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     G8Params p;
     p.x = (const bf16_t*)cp.x; p.w = (const bf16_t*)cp.w; p.y = (bf16_t*)cp.y; p.bias = cp.bias;
-    p.add = (const bf16_t*)cp.add; p.aux = cp.act == 4 ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
+    p.add = (const bf16_t*)cp.add; p.aux = (cp.act == 4 || cp.act == 3) ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
+    p.aux_mode = cp.act == 3 ? 1 : 0; p.align_epi = g8_align();
     p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
     p.relu = cp.relu;
     p.deq_x = p.deq_w = nullptr;
@@ -457,7 +606,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
     const double wbytes = (double)p.N * p.K * 2.0;
     p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
-    constexpr int lds = 2 * 4 * 128 * 128;        // 128 KB (>= the 66.5 KB epilogue tile)
+    constexpr int lds = 2 * 4 * 128 * 128 + 4096; // 128 KB (>= the 66.5 KB epilogue tile) + 512 B of bias per wave
     const int cus = g8_cus();
     const int tiles = p.tilesM * p.tilesN;
     // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
@@ -472,24 +621,27 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
 // ---- fp8 GEMM (BASELINE configs[4]: unicom ViT-L/14 "fp8") ------------------------------------------------------------------
 // y[M][N] (bf16) = (xq[M][K] . wq[N][K]^T) * *deq_x * *deq_w (+ bias) (+ add) (ReLU / ReLU6), fp8 operands (OCP e4m3; mode 1: the
 // activation-side operand is e5m2 — gradients), fp32 accumulation, on the eight-phase core.  K % 128 == 0, N % 256 == 0.
+// aux / aux_mode: optional [M][ldy] bf16 operand of the epilogue — mode 0 multiplies the result by it (saved activation
+// derivative), mode 1 keeps the result where 0 < aux < 6 (ReLU6 backward: aux = the clamped forward output).
 extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add,
-                            const float* deq_x, const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd,
-                            int relu, hipStream_t stream) {
-    if ((mode != 0 && mode != 1) || K % 128 != 0 || K < 256 || N % 256 != 0 || ldx % 16 || ldw % 16 || ldy % 8 || (add && ldadd % 8) ||
+                            const void* aux, int aux_mode, const float* deq_x, const float* deq_w, int M, int K, int N, int ldx,
+                            int ldw, int ldy, int ldadd, int relu, hipStream_t stream) {
+    if ((mode != 0 && mode != 1) || (aux_mode != 0 && aux_mode != 1) || K % 128 != 0 || K < 256 || N % 256 != 0 || ldx % 16 || ldw % 16 || ldy % 8 || (add && ldadd % 8) ||
         M < 1 || deq_x == nullptr || deq_w == nullptr) {
         nkb_set_error("gemm_fp8: unsupported mode %d / shape M=%d K=%d N=%d (K %% 128, N %% 256, 16-byte rows, dequant scales)", mode, M, K, N);
         return 1;
     }
     if ((long long)M * ldx >= 0xFFFFFFFFll || (long long)N * ldw >= 0xFFFFFFFFll) { nkb_set_error("gemm_fp8: operand too large"); return 1; }
     G8Params p;
-    p.x = (const bf16_t*)xq; p.w = (const bf16_t*)wq; p.y = (bf16_t*)y; p.bias = bias; p.add = (const bf16_t*)add; p.aux = nullptr;
+    p.x = (const bf16_t*)xq; p.w = (const bf16_t*)wq; p.y = (bf16_t*)y; p.bias = bias; p.add = (const bf16_t*)add; p.aux = (const bf16_t*)aux;
+    p.aux_mode = aux_mode; p.align_epi = g8_align();
     p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu;
     p.deq_x = deq_x; p.deq_w = deq_w;
     p.tilesM = (M + 255) / 256; p.tilesN = N / 256;
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
     p.group_m = (gm_env > 1 && (double)N * K > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     const int cus = g8_cus();
-    constexpr int lds = 2 * 4 * 128 * 128;
+    constexpr int lds = 2 * 4 * 128 * 128 + 4096;
     const int tiles = p.tilesM * p.tilesN;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
     if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<true, 1>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), lds, stream, p);

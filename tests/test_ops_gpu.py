@@ -1079,7 +1079,7 @@ def gemm8p_everywhere():
 @pytest.mark.parametrize("shape", [(1000, 256, 128), (2048 + 37, 768, 192), (4096, 512, 768), (777, 256, 1024), (256, 1024, 64 * 7),
                                    (256 * 300 + 100, 512, 256)],      # 602 tiles: every persistent workgroup walks 2-3 of them
                          ids=lambda s: "M%d_N%d_K%d" % s)
-@pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_add", "relu6", "stats", "mul"])
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_add", "add", "relu6", "stats", "mul", "mask6"])
 def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
     """y = x w^T through nkb_conv_gemm / nkb_linear_gelu with the eight-phase kernel forced on: ragged M (rows past M are
     loaded clamped and never stored), 2 to 16 k-tiles (the DMA stream's prologue / tail cases), every epilogue the kernel
@@ -1093,6 +1093,7 @@ def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
     bias = torch.randn(N)
     add = torch.randn(M, N).to(torch.bfloat16)
     aux = torch.randn(M, N).to(torch.bfloat16)
+    u6 = (torch.randn(M, N) * 4).clamp(0, 6).to(torch.bfloat16)          # a ReLU6 output: zeros, interior values and sixes
     ref = x.float() @ w.float().t()
     xd, wd = x.to(DEV), w.to(DEV)
     geom = dict(N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N)
@@ -1106,8 +1107,12 @@ def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
             hip.conv_gemm(d, 0, xd, wd, y, bias=bias.to(DEV), relu=True, **geom)
         elif epi == "bias_add":
             hip.conv_gemm(d, 0, xd, wd, y, bias=bias.to(DEV), add=add.to(DEV), ldadd=N, **geom)
+        elif epi == "add":
+            hip.conv_gemm(d, 0, xd, wd, y, add=add.to(DEV), ldadd=N, **geom)
         elif epi == "relu6":
             hip.conv_gemm(d, 0, xd, wd, y, relu=2, **geom)
+        elif epi == "mask6":
+            hip.linear_gelu(d, 3, xd, wd, None, u6.to(DEV), y, None, M, K, N)
         elif epi == "stats":
             tiles = hip.stat_tiles(d, M, N)
             stats = torch.full((tiles, 2, N), float("nan"), device=DEV)
@@ -1118,7 +1123,8 @@ def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
         outs.append((y, stats))
     assert torch.equal(outs[0][0], outs[1][0])
     want = {"plain": ref, "bias_relu": (ref + bias).clamp_min(0), "bias_add": ref + bias + add.float(),
-            "relu6": ref.clamp(0, 6), "stats": ref, "mul": ref * aux.float()}[epi]
+            "add": ref + add.float(), "relu6": ref.clamp(0, 6), "stats": ref, "mul": ref * aux.float(),
+            "mask6": ref * ((u6.float() > 0) & (u6.float() < 6))}[epi]
     torch.testing.assert_close(outs[0][0].float().cpu(), want, **tol(torch.bfloat16, K))
     if epi == "stats":
         got = outs[0][0].float()
@@ -1207,6 +1213,16 @@ def test_gemm_fp8_matches_product_of_rounded_operands(shape, mode):
     assert torch.equal(outs[0], outs[1])
     want = (ref + bias.double() + add.double()).float()
     torch.testing.assert_close(outs[0].float().cpu(), want, rtol=1e-2, atol=1e-2)
+    # the other epilogues of the fp8 form: plain, ReLU6, multiply by / mask with a saved bf16 operand
+    aux = torch.randn(M, N).to(torch.bfloat16)
+    u6 = (torch.randn(M, N) * 4).clamp(0, 6).to(torch.bfloat16)
+    for kw, fn in [(dict(), lambda r: r), (dict(relu=2, bias=bias.to(DEV)), lambda r: (r + bias.double()).clamp(0, 6)),
+                   (dict(aux=aux.to(DEV), aux_mode=0), lambda r: r * aux.double()),
+                   (dict(aux=u6.to(DEV), aux_mode=1), lambda r: r * ((u6.double() > 0) & (u6.double() < 6)))]:
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        hip.gemm_fp8(mode, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], **kw)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y.float().cpu(), fn(ref).float(), rtol=1e-2, atol=1e-2)
     # and the quantisation error itself stays at the fp8 level against the unquantised product
     full = x.double() @ w.double().t()
     rel = ((ref - full).norm() / full.norm()).item()
