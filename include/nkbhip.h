@@ -268,6 +268,9 @@ int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float*
  *                     e4m3 (forward), mode 1: xq is e5m2 (a gradient) and wq e4m3 (data gradient).  K % 128 == 0, N % 256 == 0.
  *                     aux (optional, [M][ldy] in bf16): aux_mode 0 multiplies the result by it (saved activation derivative),
  *                     aux_mode 1 keeps the result where 0 < aux < 6 (ReLU6 backward, aux = the clamped forward output).
+ *                     yq / q_state / q_kind (optional): second output yq[M][N] bytes = fp8(y * q_state[0]) (kind as in
+ *                     nkb_fp8_quantize) with q_state[2] = max(q_state[2], max |y|) — the operand of the next fp8 GEMM without a
+ *                     separate quantisation pass over y.
  * state: three device floats {scale, 1 / scale, running amax}. */
 int nkb_fp8_quantize(int dtype, int kind, const void* src, long long n, float* state, void* dst, nkb_stream_t stream);
 int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, nkb_stream_t stream);
@@ -278,8 +281,8 @@ int nkb_fp8_scale_update(float* state, int kind, nkb_stream_t stream);
 long long nkb_fp8_job_blocks(long long n);
 int nkb_fp8_multi(int pass, const long long* jobs, int njobs, long long total_blocks, nkb_stream_t stream);
 int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add, const void* aux,
-                 int aux_mode, const float* deq_x, const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd,
-                 int relu, nkb_stream_t stream);
+                 int aux_mode, void* yq, float* q_state, int q_kind, const float* deq_x, const float* deq_w, int M, int K, int N,
+                 int ldx, int ldw, int ldy, int ldadd, int relu, nkb_stream_t stream);
 
 /* Envelope of the 256 x 256 eight-phase GEMM core that nkb_conv_gemm / nkb_linear_gelu use for wide plain 1x1 / Linear launches
  * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 768).  Tests and A/B timing. */

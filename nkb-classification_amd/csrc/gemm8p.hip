@@ -47,6 +47,11 @@ struct G8Params {
     // *deq_x * *deq_w (the per-tensor dequantisation factors, device floats) before bias / residual
     const float* deq_x;
     const float* deq_w;
+    // fp8 kernels only: optional second output — the stored (bf16-rounded) result quantised for the NEXT fp8 GEMM with that
+    // site's delayed scale: yq[M][ldq] bytes = fp8(y * q_state[0]) (q_kind 0: e4m3, 1: e5m2), q_state[2] = max(q_state[2], max |y|)
+    unsigned char* yq;
+    float* q_state;
+    int q_kind, ldq;
     int aux_mode;         // 0: the result is multiplied by aux; 1: the result is kept where 0 < aux < 6 (ReLU6 backward mask)
     int align_epi;        // DIRECT: both wave groups run the epilogue side by side (NKB_G8_ALIGN, default 1)
 };
@@ -79,6 +84,7 @@ __device__ __forceinline__ f32x4 g8_mma(const bf16x8& a, const bf16x8& b, f32x4 
 // fragments of a k-tile row at once.  A lane's 32 operand bytes are its chunks (fgrp, 4 + fgrp) for BOTH operands, so
 // whatever k index the hardware gives byte j of lane group fgrp, the two operands agree on it and the sum over k is complete.
 typedef int g8_i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short g8_u16x2 __attribute__((ext_vector_type(2)));
 typedef int g8_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef NKB_F8_K128
 #define NKB_F8_K128 1
@@ -117,8 +123,9 @@ __device__ __forceinline__ f32x4 g8_mma128(const bf16x8& a0, const bf16x8& a1, c
 // F8: 0 = bf16 operands (k-tile = 64 elements); 1 = fp8 e4m3 x e4m3, 2 = W e4m3 x X e5m2 (data gradients): a k-tile is the
 // same 128 bytes per row = 128 elements and the two 16-byte fragments of a row go into ONE v_mfma_f32_16x16x128_f8f6f4 (twice
 // the bf16 rate; g8_mma128) — half the LDS / L2 bytes and half the MFMA cycles per FLOP of the bf16 form.
-template <bool DIRECT, int F8 = 0>
+template <bool DIRECT, int F8 = 0, bool QOUT = false>
 __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
+    static_assert(!QOUT || (DIRECT && F8 != 0), "the quantised second output belongs to the persistent fp8 kernels");
     constexpr int ESZ = F8 ? 1 : 2;               // bytes per operand element
     constexpr int KE = 128 / ESZ;                 // elements per k-tile row
     constexpr int CE = 16 / ESZ;                  // elements per 16-byte chunk
@@ -177,17 +184,28 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     int lid = (int)xcd_remap(blockIdx.x, gridDim.x);
     int tile_m, tile_n;
     tile_of(lid, tile_m, tile_n);
-    unsigned xo[2][2], wo[2][2], xn[2][2], wn_[2][2];     // current tile / next tile of this workgroup (DIRECT)
+    unsigned xo[2][2], wo[2][2];                  // current tile of this workgroup
     offsets_of(tile_m, tile_n, xo, wo);
+    // one (half, piece) offset of another tile, computed where it is used: the next tile's 8 offsets would be 8 more registers
+    // live across the whole k-loop for two k-tiles' worth of use per tile
+    [[maybe_unused]] auto offset_one = [&](int tm, int tn, int hh, int q) -> unsigned {
+        const int r = (wave + 8 * q) * 8 + lrow;
+        if (hh < 2) return (unsigned)min(tm * 256 + (hh & 1) * 128 + r, p.M - 1) * (unsigned)p.ldx + chunk * CE;
+        const int wrow = DIRECT ? ((r & 0x63) | ((r & 0x0c) << 1) | ((r & 0x10) >> 2)) : r;
+        return (unsigned)(tn * 256 + (hh & 1) * 128 + wrow) * (unsigned)p.ldw + chunk * CE;
+    };
     int next_m = 0, next_n = 0;
     bool has_next = false;
     if constexpr (DIRECT) {
         has_next = lid + step < ntiles;
-        if (has_next) { tile_of(lid + step, next_m, next_n); offsets_of(next_m, next_n, xn, wn_); }
+        if (has_next) tile_of(lid + step, next_m, next_n);
     }
     // k-tiles of this workgroup's whole DMA stream
     const int GT = DIRECT ? KT * ((ntiles - lid + step - 1) / step) : KT;
 
+    if constexpr (QOUT) {
+        if (tid == 0) *(unsigned*)(smem + 2 * BUF + 4096) = 0u;    // (ordered before every wave's first epilogue by the k-loop's barriers)
+    }
     // ---- prologue: seven half-tiles in flight, the first k-tile landed
     G8_ISSUE_AT(0, 0, 0, xo, wo); G8_ISSUE_AT(0, 0, 1, xo, wo); G8_ISSUE_AT(0, 0, 2, xo, wo); G8_ISSUE_AT(0, 0, 3, xo, wo);
     if (GT > 1) {                                  // (DIRECT: KT >= 2, so stream k-tile 1 is k-tile 1 of the first tile)
@@ -219,7 +237,12 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #define G8_ISSUE_AHEAD(d, hh)                                                                                         \
     do {                                                                                                              \
         if (t + (d) < KT) G8_ISSUE_AT(g + (d), t + (d), hh, xo, wo);                                                  \
-        else if (DIRECT && has_next) G8_ISSUE_AT(g + (d), t + (d) - KT, hh, xn, wn_);                                 \
+        else if (DIRECT && has_next) {                                                                                \
+            unsigned char* d_ = smem + ((g + (d)) & 1) * BUF + (hh) * HT + wave * 1024;                               \
+            const unsigned char* s_ = (const unsigned char*)((hh) < 2 ? p.x : p.w) + (size_t)(t + (d) - KT) * 128;    \
+            glds16(s_ + (size_t)offset_one(next_m, next_n, hh, 0) * ESZ, d_);                                         \
+            glds16(s_ + (size_t)offset_one(next_m, next_n, hh, 1) * ESZ, d_ + 8192);                                  \
+        }                                                                                                             \
     } while (0)
 
     // DIRECT epilogue of the current tile.  FULL / ADD / AUX / RELU are compile-time for the combinations the train step uses
@@ -229,6 +252,9 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     // non-temporal: the output is far larger than L2 and is not read again by this kernel (+6-12 % on K <= 1024).
     [[maybe_unused]] auto epilogue = [&](auto FULL_, auto ADD_, auto AUX_, auto RELU_) {
         constexpr int FULL = decltype(FULL_)::value, ADD = decltype(ADD_)::value, AUX = decltype(AUX_)::value, RELU = decltype(RELU_)::value;
+        // fp8 second output: max |y| of this tile (a register across the whole k-loop would push the kernel into spills);
+        // reduced per wave and folded into one LDS word at the end of the epilogue, one global atomic per workgroup at the end
+        [[maybe_unused]] g8_u16x2 amax2 = {0, 0};       // |bf16| bit patterns order as unsigned integers: two magnitudes per register
         const bool has_add = ADD < 0 ? p.add != nullptr : ADD != 0;
         const int aux_kind = AUX < 0 ? (p.aux ? 1 + p.aux_mode : 0) : AUX;      // 0 none, 1 multiply, 2 ReLU6 mask (0 < aux < 6)
         const int relu = RELU < 0 ? p.relu : RELU;
@@ -243,6 +269,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         const unsigned char* abase = (const unsigned char*)(p.add + ((size_t)em0 * p.ldadd + en0));
         const unsigned yo = ((unsigned)lrow * (unsigned)p.ldy + lcol) * 2u, ao = ((unsigned)lrow * (unsigned)p.ldadd + lcol) * 2u;
         const unsigned ystep = 32u * (unsigned)p.ldy, astep = 32u * (unsigned)p.ldadd;   // 16 rows, in bytes
+        [[maybe_unused]] unsigned char* qbase = p.yq + ((size_t)em0 * p.ldq + en0);
+        [[maybe_unused]] const unsigned qo = (unsigned)lrow * (unsigned)p.ldq + lcol, qstep = 16u * (unsigned)p.ldq;
+        [[maybe_unused]] const float qscale = QOUT ? p.q_state[0] : 1.f;
+        [[maybe_unused]] const float qlim = p.q_kind == 0 ? 448.f : 57344.f;
         // vmcnt is in order: a load issued behind a store waits for that store's acknowledgement (microseconds), and a
         // wait for ANY load also drains the DMA stream.  So the compile-time variants with an operand (PRE) work in two
         // halves of 8 rows: request half 0; compute it into packed registers (its accumulators and operand rows die);
@@ -300,6 +330,29 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             acc[2 * pr + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             return pack8(v);
         };
+        // fp8 second output: the stored (bf16-rounded) row re-scaled and converted — the arithmetic of fp8_quantize_kernel
+        [[maybe_unused]] auto quant_store = [&](u32x4 pk, int pr, int j, bool ok) {
+            if constexpr (QOUT) {
+                float q[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r0 = __uint_as_float(pk[e] << 16), r1 = __uint_as_float(pk[e] & 0xffff0000u);
+                    if (ok) amax2 = __builtin_elementwise_max(amax2, __builtin_bit_cast(g8_u16x2, pk[e] & 0x7fff7fffu));
+                    q[2 * e] = fminf(fmaxf(r0 * qscale, -qlim), qlim);
+                    q[2 * e + 1] = fminf(fmaxf(r1 * qscale, -qlim), qlim);
+                }
+                unsigned w0 = 0u, w1 = 0u;
+                if (p.q_kind == 0) {
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+                } else {
+                    w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w0, true);
+                    w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], w1, true);
+                }
+                if (ok) *(u32x2*)(qbase + (qo + j * qstep + 32 * pr)) = (u32x2){w0, w1};
+                __builtin_amdgcn_sched_barrier(0);     // one row at a time: interleaved, 16 rows of temporaries do not fit
+            }
+        };
         auto bias_of = [&](int pr, float (&bv)[8]) {
             if (p.bias) {                              // this wave's 128 bias values were DMA'd into LDS at the start of the tile
                 const float* bp = (const float*)(smem + 2 * BUF + wave * 512) + 32 * pr + 8 * fgrp;
@@ -311,6 +364,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 for (int e = 0; e < 8; ++e) bv[e] = 0.f;
             }
         };
+        constexpr bool has_q = QOUT;
         if constexpr (PRE) {
             u32x4 raw[2][4], pk[2][4];
             load_half(0, raw);
@@ -323,18 +377,33 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 for (int j = 0; j < 4; ++j) pk[q][j] = value(q, j, bv, raw[q][j], raw[q][j]);
             }
             load_half(1, raw);
+            // full tile: exactly the 8 (16 with the fp8 copy) stores of half 0 are younger than half 1's loads
+            if (has_q) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
-            G8_WAIT_HALF(8, raw);                      // full tile: exactly the 8 stores above are younger than half 1's loads
+                    for (int j = 0; j < 4; ++j) {
+                        __builtin_nontemporal_store(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
+                        quant_store(pk[q][j], q, j, true);
+                    }
+                G8_WAIT_HALF(16, raw);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
+                G8_WAIT_HALF(8, raw);
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float bv[8];
                 bias_of(2 + q, bv);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    __builtin_nontemporal_store(value(2 + q, j, bv, raw[q][j], raw[q][j]), (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 out = value(2 + q, j, bv, raw[q][j], raw[q][j]);
+                    __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
+                    if (has_q) quant_store(out, 2 + q, j, true);
+                }
             }
         } else {
 #pragma unroll
@@ -349,8 +418,13 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     if (aux_kind && ok) xraw = *(const u32x4*)(xbase + (yo + j * ystep + 64 * pr));
                     const u32x4 out = value(pr, j, bv, araw, xraw);
                     if (ok) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                    if (has_q) quant_store(out, pr, j, ok);
                 }
             }
+        }
+        if constexpr (QOUT) {
+            const float m = wave_max(__uint_as_float((unsigned)(amax2[0] > amax2[1] ? amax2[0] : amax2[1]) << 16));
+            if (lane == 0) atomicMax((unsigned*)(smem + 2 * BUF + 4096), __float_as_uint(m));   // non-negative floats order as uints
         }
     };
 
@@ -438,6 +512,11 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 // 6-10 us per tile, 18-29 % of a K = 768 / 1024 launch; side by side their store latencies overlap.
                 if (p.align_epi && wr == 0) G8_BARRIER();
                 const bool fullt = tile_m * 256 + 256 <= p.M;
+                if constexpr (QOUT) {             // the two producers of the fp8 train step; everything else takes the run-time form
+                    if (fullt && !p.add && !p.aux && p.relu == 2) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<2>{});
+                    else if (fullt && !p.add && p.aux && p.aux_mode == 1 && p.relu == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<2>{}, G8I<0>{});
+                    else epilogue(G8I<0>{}, G8I<-1>{}, G8I<-1>{}, G8I<-1>{});
+                } else
                 if (!fullt) epilogue(G8I<0>{}, G8I<-1>{}, G8I<-1>{}, G8I<-1>{});
                 else if (!p.add && !p.aux) {
                     if (p.relu == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<0>{});
@@ -453,16 +532,21 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 t = 0;
                 lid += step;
                 tile_m = next_m; tile_n = next_n;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) { xo[h][q] = xn[h][q]; wo[h][q] = wn_[h][q]; }
+                offsets_of(tile_m, tile_n, xo, wo);
                 has_next = lid + step < ntiles;
-                if (has_next) { tile_of(lid + step, next_m, next_n); offsets_of(next_m, next_n, xn, wn_); }
+                if (has_next) tile_of(lid + step, next_m, next_n);
             }
         }
     }
     if (wr == 0) G8_BARRIER();
+
+    if constexpr (QOUT) {                         // one global atomicMax per workgroup
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned m = *(const unsigned*)(smem + 2 * BUF + 4096);
+            if (m) atomicMax((unsigned*)(p.q_state + 2), m);
+        }
+    }
 
     if constexpr (!DIRECT) {
         const int m0 = tile_m * 256, n0 = tile_n * 256;
@@ -581,11 +665,13 @@ static int g8_align() {
 static int g8_cus() {
     static int cus = 0;
     if (!cus) {
-        constexpr int lds = 2 * 4 * 128 * 128 + 4096;
+        constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64;
         hipFuncSetAttribute((const void*)gemm8p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipFuncSetAttribute((const void*)gemm8p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipFuncSetAttribute((const void*)gemm8p_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipFuncSetAttribute((const void*)gemm8p_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm8p_kernel<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm8p_kernel<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
@@ -599,6 +685,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     p.x = (const bf16_t*)cp.x; p.w = (const bf16_t*)cp.w; p.y = (bf16_t*)cp.y; p.bias = cp.bias;
     p.add = (const bf16_t*)cp.add; p.aux = (cp.act == 4 || cp.act == 3) ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
     p.aux_mode = cp.act == 3 ? 1 : 0; p.align_epi = g8_align();
+    p.yq = nullptr; p.q_state = nullptr; p.q_kind = 0; p.ldq = 0;
     p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
     p.relu = cp.relu;
     p.deq_x = p.deq_w = nullptr;
@@ -606,7 +693,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
     const double wbytes = (double)p.N * p.K * 2.0;
     p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
-    constexpr int lds = 2 * 4 * 128 * 128 + 4096; // 128 KB (>= the 66.5 KB epilogue tile) + 512 B of bias per wave
+    constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64; // 128 KB (>= the 66.5 KB epilogue tile) + 512 B of bias per wave + the fp8 amax word
     const int cus = g8_cus();
     const int tiles = p.tilesM * p.tilesN;
     // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
@@ -623,9 +710,12 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
 // activation-side operand is e5m2 — gradients), fp32 accumulation, on the eight-phase core.  K % 128 == 0, N % 256 == 0.
 // aux / aux_mode: optional [M][ldy] bf16 operand of the epilogue — mode 0 multiplies the result by it (saved activation
 // derivative), mode 1 keeps the result where 0 < aux < 6 (ReLU6 backward: aux = the clamped forward output).
+// yq / q_state / q_kind: optional fp8 copy of the result for the next fp8 GEMM — yq[M][N] bytes = fp8(y * q_state[0]) in e4m3
+// (q_kind 0) or e5m2 (1), and q_state[2] accumulates max |y| (what nkb_fp8_quantize would do in a second pass over y).
 extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add,
-                            const void* aux, int aux_mode, const float* deq_x, const float* deq_w, int M, int K, int N, int ldx,
-                            int ldw, int ldy, int ldadd, int relu, hipStream_t stream) {
+                            const void* aux, int aux_mode, void* yq, float* q_state, int q_kind, const float* deq_x,
+                            const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd, int relu,
+                            hipStream_t stream) {
     if ((mode != 0 && mode != 1) || (aux_mode != 0 && aux_mode != 1) || K % 128 != 0 || K < 256 || N % 256 != 0 || ldx % 16 || ldw % 16 || ldy % 8 || (add && ldadd % 8) ||
         M < 1 || deq_x == nullptr || deq_w == nullptr) {
         nkb_set_error("gemm_fp8: unsupported mode %d / shape M=%d K=%d N=%d (K %% 128, N %% 256, 16-byte rows, dequant scales)", mode, M, K, N);
@@ -635,17 +725,25 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     G8Params p;
     p.x = (const bf16_t*)xq; p.w = (const bf16_t*)wq; p.y = (bf16_t*)y; p.bias = bias; p.add = (const bf16_t*)add; p.aux = (const bf16_t*)aux;
     p.aux_mode = aux_mode; p.align_epi = g8_align();
+    p.yq = (unsigned char*)yq; p.q_state = q_state; p.q_kind = q_kind; p.ldq = N;
+    if (yq && (q_state == nullptr || (q_kind != 0 && q_kind != 1))) { nkb_set_error("gemm_fp8: quantised output needs its scaling state and kind 0 / 1"); return 1; }
     p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu;
     p.deq_x = deq_x; p.deq_w = deq_w;
     p.tilesM = (M + 255) / 256; p.tilesN = N / 256;
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
     p.group_m = (gm_env > 1 && (double)N * K > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     const int cus = g8_cus();
-    constexpr int lds = 2 * 4 * 128 * 128 + 4096;
+    constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64;
     const int tiles = p.tilesM * p.tilesN;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
-    if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<true, 1>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL((gemm8p_kernel<true, 2>), dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), lds, stream, p);
+    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+    if (yq) {
+        if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<true, 1, true>), grid, dim3(512), lds, stream, p);
+        else hipLaunchKernelGGL((gemm8p_kernel<true, 2, true>), grid, dim3(512), lds, stream, p);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<true, 1>), grid, dim3(512), lds, stream, p);
+        else hipLaunchKernelGGL((gemm8p_kernel<true, 2>), grid, dim3(512), lds, stream, p);
+    }
     return nkb_check_launch("gemm_fp8");
 }
 

@@ -256,10 +256,14 @@ __global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
     const int fb_hi = 256 * (row0 + 4) + 16 * ((p4 >> 1) ^ 1) + 8 * (p4 & 1);
     const int kx32 = ((q4 << 1) | (g & 1)) << 5;
     const int bblk0 = (wn & 1) * 4;
+    // (inline assembly, not __builtin_amdgcn_ds_read_tr16_b64: in front of the builtin hipcc puts s_waitcnt vmcnt(0) whenever an
+    // LDS-DMA is in flight — three full drains of the DMA stream per stage, 1.5x the stage time of gemm8p's plain ds_read_b128
+    // loop.  The lgkmcnt waits below are therefore all this kernel's own.)
     auto frag = [&](const unsigned char* tile_, int kx, int kk, int blk32) -> bf16x8 {
-        const int o = (blk32 ^ kx) + 8192 * kk;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile_ + fb_lo + o));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile_ + fb_hi + o));
+        const unsigned o = (unsigned)(size_t)(tile_) + (unsigned)((blk32 ^ kx) + 8192 * kk);
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(o + fb_lo));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(o + fb_hi));
         return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
     const bool do_bias = p.dbias != nullptr && tile_n == 0 && wn == 0;
@@ -401,6 +405,7 @@ __global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
         __syncthreads();
     }
 }
+
 
 }  // namespace
 

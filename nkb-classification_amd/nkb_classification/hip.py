@@ -86,7 +86,7 @@ _SIGS = {
     "nkb_fp8_scale_update": (i32, [vp, i32, vp]),
     "nkb_fp8_job_blocks": (i64, [i64]),
     "nkb_fp8_multi": (i32, [i32, vp, i32, i64, vp]),
-    "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp] + [i32] * 8 + [vp]),
+    "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp] + [i32] * 8 + [vp]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
     "nkb_prof_collect_raw": (i32, [vp, vp, vp, i32]),
@@ -481,11 +481,12 @@ def fp8_multi(pass_, jobs, njobs, total_blocks):
     check(load().nkb_fp8_multi(pass_, ptr(jobs), njobs, total_blocks, stream()), "fp8_multi")
 
 
-def gemm_fp8(mode, xq, wq, y, M, K, N, *, deq_x, deq_w, bias=None, add=None, aux=None, aux_mode=0, ldx=None, ldw=None, ldy=None,
-             ldadd=0, relu=0):
-    """aux ([M][ldy], bf16): aux_mode 0 multiplies the result by it, 1 keeps the result where 0 < aux < 6 (ReLU6 backward)."""
-    check(load().nkb_gemm_fp8(mode, ptr(xq), ptr(wq), ptr(y), ptr(bias), ptr(add), ptr(aux), int(aux_mode), ptr(deq_x), ptr(deq_w),
-                              M, K, N,
+def gemm_fp8(mode, xq, wq, y, M, K, N, *, deq_x, deq_w, bias=None, add=None, aux=None, aux_mode=0, yq=None, q_state=None, q_kind=0,
+             ldx=None, ldw=None, ldy=None, ldadd=0, relu=0):
+    """aux ([M][ldy], bf16): aux_mode 0 multiplies the result by it, 1 keeps the result where 0 < aux < 6 (ReLU6 backward).
+    yq / q_state / q_kind: optional fp8 copy of the result (scale q_state[0], amax into q_state[2]) for the next fp8 GEMM."""
+    check(load().nkb_gemm_fp8(mode, ptr(xq), ptr(wq), ptr(y), ptr(bias), ptr(add), ptr(aux), int(aux_mode), ptr(yq), ptr(q_state),
+                              int(q_kind), ptr(deq_x), ptr(deq_w), M, K, N,
                               K if ldx is None else ldx, K if ldw is None else ldw, N if ldy is None else ldy, ldadd,
                               int(relu), stream()), "gemm_fp8")
 

@@ -33,6 +33,7 @@ _ATTN_FUSED_DQ = os.environ.get("NKB_ATTN_FUSED_DQ", "1") != "0"   # dQ inside t
 _SPLITK = os.environ.get("NKB_SPLITK", "1") != "0"              # split-K for skinny Linear layers with K >= 32768
 _EVAL_FOLD = os.environ.get("NKB_EVAL_FOLD", "1") != "0"     # eval mode: BatchNorm folded into the conv (one launch per stage)
 # weight / bias gradients through per-split slabs + an ordered second stage instead of fp32 atomics: bit-identical across runs
+_FP8_FUSED_QUANT = os.environ.get("NKB_FP8_FUSED_QUANT", "1") != "0"   # fp8 operands written by the producing kernel's epilogue
 _DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
 
 
@@ -71,6 +72,7 @@ class HipEngine:
         self._f8w: Dict[int, tuple] = {}           # id(weight) -> (e4m3 [N][K], e4m3 dgrad layout [K][N], state)
         self._f8jobs = None                        # (all jobs, forward-layout jobs only) device tables for nkb_fp8_multi
         self._f8act: Dict[str, torch.Tensor] = {}  # activation / gradient site -> scaling state {scale, 1/scale, amax}
+        self._f8ready: Dict[str, torch.Tensor] = {}  # site -> fp8 copy already written by the kernel that produced the tensor
         # recorded launch plans of the train step (hip.Plan): key -> (plan, workspace generation, saved-activation table)
         self.plans: Dict[tuple, tuple] = {}
         self.plan_seen: Dict[tuple, int] = {}      # key -> workspace generation after its last eager run
@@ -192,6 +194,9 @@ class HipEngine:
     def _fp8_operand(self, key: str, x: torch.Tensor, kind: int):
         """fp8 copy of an activation (e4m3) or gradient (e5m2) with delayed per-tensor scaling: the scale comes from the amax
         the previous step's pass over this site accumulated (the first call measures it just in time)."""
+        q = self._f8ready.pop(key, None)
+        if q is not None:                           # the producing kernel wrote it (and accumulated the amax) in its epilogue
+            return q, self._f8act[key]
         st = self._f8act.get(key)
         n = x.numel()
         if st is None:
@@ -201,6 +206,19 @@ class HipEngine:
         q = self.ws.get(key + ".q", tuple(x.shape), torch.uint8)
         hip.fp8_quantize(self.d, kind, x, n, st, q)
         return q, st
+
+    def _fp8_produce(self, key: Optional[str], shape, kind: int):
+        """Second output of an fp8 GEMM: (buffer, state, kind) for the site `key` that will consume this tensor as its fp8
+        operand, or None — on the first step, while the site has no measured scale yet, the consumer quantises by itself."""
+        if key is None or not _FP8_FUSED_QUANT:
+            return None
+        st = self._f8act.get(key)
+        if st is None:
+            return None
+        hip.fp8_scale_update(st, kind)
+        q = self.ws.get(key + ".q", tuple(shape), torch.uint8)
+        self._f8ready[key] = q
+        return q, st, kind
 
     def _fp8_linear_ok(self, lin, M: int) -> bool:
         return self.fp8 and self.T == torch.bfloat16 and id(lin.weight) in self._f8w
@@ -717,8 +735,9 @@ class HipEngine:
                           add=add, ldadd=K if add is not None else 0)
         return dx
 
-    def linear_relu6(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool) -> torch.Tensor:
-        """u = relu6(x @ W^T + b) with the clamp in the GEMM epilogue (unicom Mlp: fc1 -> ReLU6); only u is kept."""
+    def linear_relu6(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool, q_for: Optional[str] = None) -> torch.Tensor:
+        """u = relu6(x @ W^T + b) with the clamp in the GEMM epilogue (unicom Mlp: fc1 -> ReLU6); only u is kept.
+        q_for: the fp8 site (key of the Linear that consumes u + ".f8x") whose operand the epilogue writes as well."""
         M, K = x.shape
         N = lin.weight.shape[0]
         u = self.ws.get(key + ".y", (M, N), self.T)
@@ -726,7 +745,9 @@ class HipEngine:
         if self._fp8_linear_ok(lin, M):
             xq, sx = self._fp8_operand(key + ".f8x", x, hip.E4M3)
             wq, _, sw = self._f8w[id(lin.weight)]
-            hip.gemm_fp8(0, xq, wq, u, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, relu=2)
+            out = self._fp8_produce(q_for, (M, N), hip.E4M3) if train else None
+            hip.gemm_fp8(0, xq, wq, u, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, relu=2,
+                         yq=out[0] if out else None, q_state=out[1] if out else None, q_kind=out[2] if out else 0)
         else:
             hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), u, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
                           bias=bias, relu=2)
@@ -734,7 +755,8 @@ class HipEngine:
             self.saved[key] = dict(x=x, lin=lin, u=u)
         return u
 
-    def linear_backward_through_relu6(self, key_next: str, key_act: str, g: torch.Tensor, slot: str) -> torch.Tensor:
+    def linear_backward_through_relu6(self, key_next: str, key_act: str, g: torch.Tensor, slot: str,
+                                      q_for: Optional[str] = None) -> torch.Tensor:
         """For u = relu6(pre), y = u @ W2^T + b2: weight/bias gradient of W2 (side stream) and d_pre = (g @ W2) masked by
         0 < u < 6 in one GEMM epilogue."""
         sv = self.saved[key_next]
@@ -746,7 +768,14 @@ class HipEngine:
             g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
             dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
         d_pre = self.scratch(slot, (M, K))
-        hip.linear_gelu(self.d, 3, g, self._wd[id(lin.weight)], None, self.saved[key_act]["u"], d_pre, None, M, N, K)
+        if self._fp8_linear_ok(lin, M):
+            gq, sg = self._fp8_operand(key_next + ".f8g", g, hip.E5M2)
+            _, wdq, sw = self._f8w[id(lin.weight)]
+            out = self._fp8_produce(q_for, (M, K), hip.E5M2)
+            hip.gemm_fp8(1, gq, wdq, d_pre, M, N, K, deq_x=sg[1:2], deq_w=sw[1:2], aux=self.saved[key_act]["u"], aux_mode=1,
+                         yq=out[0] if out else None, q_state=out[1] if out else None, q_kind=out[2] if out else 0)
+        else:
+            hip.linear_gelu(self.d, 3, g, self._wd[id(lin.weight)], None, self.saved[key_act]["u"], d_pre, None, M, N, K)
         return d_pre
 
     def linear_gelu(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool) -> torch.Tensor:

@@ -143,7 +143,7 @@ class HipUnicomViT(_ParamOnly):
                 x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x)
             h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train)
             if _FUSED_RELU6:
-                u = eng.linear_relu6(f"b{i}.fc1", h, mlp.fc1, train)
+                u = eng.linear_relu6(f"b{i}.fc1", h, mlp.fc1, train, q_for=f"b{i}.fc2.f8x")
             else:
                 u = eng.relu6(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train)
             if dp > 0:
@@ -179,7 +179,7 @@ class HipUnicomViT(_ParamOnly):
             eng.begin_block(i)
             g2 = eng.drop_path_backward(f"b{i}.dp2", gx, "g2")              # branch gradient; the residual path keeps gx
             if _FUSED_RELU6:
-                d_a = eng.linear_backward_through_relu6(f"b{i}.fc2", f"b{i}.fc1", g2, "da")
+                d_a = eng.linear_backward_through_relu6(f"b{i}.fc2", f"b{i}.fc1", g2, "da", q_for=f"b{i}.fc1.f8g")
             else:
                 d_u = eng.linear_backward(f"b{i}.fc2", g2, "du")
                 d_a = eng.relu6_backward(f"b{i}.act", d_u, "da")

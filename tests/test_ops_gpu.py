@@ -1223,6 +1223,18 @@ def test_gemm_fp8_matches_product_of_rounded_operands(shape, mode):
         hip.gemm_fp8(mode, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], **kw)
         torch.cuda.synchronize()
         torch.testing.assert_close(y.float().cpu(), fn(ref).float(), rtol=1e-2, atol=1e-2)
+    # the fused second output: the fp8 copy of y (and its amax) that a separate nkb_fp8_quantize pass over y would produce
+    for qk, kw in [(hip.E4M3, dict(relu=2, bias=bias.to(DEV))), (hip.E5M2, dict(aux=u6.to(DEV), aux_mode=1)), (hip.E4M3, dict(add=add.to(DEV), ldadd=N))]:
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        st = torch.tensor([3.0, 1.0 / 3.0, 0.0], device=DEV)
+        yq = torch.full((M, N), 0x55, device=DEV, dtype=torch.uint8)
+        hip.gemm_fp8(mode, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], yq=yq, q_state=st, q_kind=qk, **kw)
+        st2 = torch.tensor([3.0, 1.0 / 3.0, 0.0], device=DEV)
+        yq2 = torch.empty_like(yq)
+        hip.fp8_quantize(hip.BF16, qk, y, y.numel(), st2, yq2)
+        torch.cuda.synchronize()
+        assert torch.equal(yq, yq2)
+        assert st[2].item() == st2[2].item() == y.float().abs().max().item()
     # and the quantisation error itself stays at the fp8 level against the unquantised product
     full = x.double() @ w.double().t()
     rel = ((ref - full).norm() / full.norm()).item()
