@@ -274,12 +274,26 @@ int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float*
  * state: three device floats {scale, 1 / scale, running amax}. */
 int nkb_fp8_quantize(int dtype, int kind, const void* src, long long n, float* state, void* dst, nkb_stream_t stream);
 int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, nkb_stream_t stream);
+/* nkb_fp8_quantize of a [rows][C] bf16 matrix (row stride ld) that also adds the matrix's column sums to colsum[C] — the bias
+ * gradient of a Linear layer when src = dY, in the one pass that reads the unquantised values.  C % 512 == 0; workspace of
+ * nkb_fp8_quantize_colsum_workspace_floats(rows, C) floats (partial sums per row block, added in block order). */
+long long nkb_fp8_quantize_colsum_workspace_floats(long long rows, int C);
+int nkb_fp8_quantize_colsum(int kind, const void* src, long long rows, int C, long long ld, float* state, void* dst, float* colsum,
+                            float* workspace, nkb_stream_t stream);
 int nkb_fp8_scale_update(float* state, int kind, nkb_stream_t stream);
 /* Many tensors in one launch (a model's weight matrices): jobs = device array of njobs x 6 int64 {src (bf16), dst (bytes),
  * n (multiple of 8), state (3 floats), kind, first block}; blocks per job from nkb_fp8_job_blocks(n).  pass 0: amax only;
  * 1: quantise with state[0] (+ amax); 2: scale from amax; 3: amax <- 0. */
 long long nkb_fp8_job_blocks(long long n);
 int nkb_fp8_multi(int pass, const long long* jobs, int njobs, long long total_blocks, nkb_stream_t stream);
+/* fp8 weight gradient: dw[Cout][Cin] += (*deq_g * *deq_x) * sum_m gq[m][cout] * xq[m][cin] with gq = the e5m2 bytes [M][ldg] the
+ * data gradient consumed and xq = the e4m3 bytes [M][ldx] the forward GEMM consumed (reference: the autograd weight gradient of
+ * the nn.Linear layers reached from /root/reference/nkb_classification/engine.py:55-58).  M % 128 == 0, Cin % 256 == 0,
+ * Cout % 256 == 0; workspace of nkb_wgrad_fp8_workspace_floats() floats (-1: shape not supported); per-split partial tiles are
+ * added in split order (deterministic).  Bias gradients are not part of it. */
+long long nkb_wgrad_fp8_workspace_floats(int M, int Cin, int Cout);
+int nkb_wgrad_fp8(const void* gq, const void* xq, float* dw, const float* deq_g, const float* deq_x, int M, int Cin, int ldx,
+                  int Cout, int ldg, float* workspace, long long workspace_floats, nkb_stream_t stream);
 int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add, const void* aux,
                  int aux_mode, void* yq, float* q_state, int q_kind, const float* deq_x, const float* deq_w, int M, int K, int N,
                  int ldx, int ldw, int ldy, int ldadd, int relu, nkb_stream_t stream);

@@ -891,6 +891,72 @@ extern "C" int nkb_fp8_quantize(int dtype, int kind, const void* src, long long 
     else hipLaunchKernelGGL(fp8_quantize_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, n, state, (unsigned char*)dst, kind);
     return nkb_check_launch("fp8_quantize");
 }
+// Quantisation of a [rows][C] bf16 matrix that also leaves its COLUMN SUMS (a Linear layer's bias gradient when the matrix is
+// dY: the fp8 weight-gradient kernel does not produce it, and this pass reads the unquantised values anyway).  Thread = 8
+// consecutive columns, block = up to 2048 columns x one row block; per-block partial sums go to the workspace and are added to
+// colsum in block order (deterministic), the amax as in nkb_fp8_quantize.
+namespace {
+__global__ void fp8_quantize_colsum_kernel(const bf16_t* __restrict__ src, long long rows, int C, long long ld, float* __restrict__ state,
+                                           unsigned char* __restrict__ dst, float* __restrict__ part, int rpb, int kind) {
+    const int c8 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const float scale = state[0];
+    const float lim = kind == 0 ? 448.f : 57344.f;
+    const long long r0 = (long long)blockIdx.y * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float amax = 0.f;
+    if (c8 < C) {
+        for (long long r = r0; r < r1; ++r) {
+            float f[8], q[8];
+            unpack8(*(const u32x4*)(src + (size_t)r * ld + c8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sum[e] += f[e];
+                amax = fmaxf(amax, fabsf(f[e]));
+                q[e] = fminf(fmaxf(f[e] * scale, -lim), lim);
+            }
+            unsigned w0 = 0u, w1 = 0u;
+            if (kind == 0) {
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+            } else {
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], w1, true);
+            }
+            *(u32x2*)(dst + (size_t)r * C + c8) = (u32x2){w0, w1};
+        }
+        float* pp = part + (size_t)blockIdx.y * C + c8;
+        *(f32x4*)pp = (f32x4){sum[0], sum[1], sum[2], sum[3]};
+        *(f32x4*)(pp + 4) = (f32x4){sum[4], sum[5], sum[6], sum[7]};
+    }
+    fp8_block_amax(amax, state);
+}
+}  // namespace
+extern "C" long long nkb_fp8_quantize_colsum_workspace_floats(long long rows, int C) {
+    long long ry = (rows + 127) / 128;
+    if (ry > 256) ry = 256;
+    return ry * C;
+}
+// dst[rows][C] bytes = fp8(src * state[0]) (+ amax into state[2]), colsum[C] += column sums of src.  bf16 only; C % 512 == 0
+// (whole waves of 8-column threads), ld % 8 == 0; workspace >= nkb_fp8_quantize_colsum_workspace_floats(rows, C) floats.
+extern "C" int nkb_fp8_quantize_colsum(int kind, const void* src, long long rows, int C, long long ld, float* state, void* dst,
+                                       float* colsum, float* workspace, hipStream_t stream) {
+    if ((kind != 0 && kind != 1) || rows <= 0 || C <= 0 || C % 512 != 0 || ld % 8 != 0 || ld < C || !colsum || !workspace) {
+        nkb_set_error("fp8_quantize_colsum: kind %d rows %lld C %d ld %lld (C %% 512 == 0, workspace and colsum required)", kind, rows, C, ld);
+        return 1;
+    }
+    const int threads = 256;                      // (fp8_block_amax reduces over four waves; columns past C idle)
+    const int gx = (C / 8 + threads - 1) / threads;
+    long long ry = (rows + 127) / 128;
+    if (ry > 256) ry = 256;
+    const int rpb = (int)((rows + ry - 1) / ry);
+    ry = (rows + rpb - 1) / rpb;
+    NkbProfScope prof(NKB_K_MISC, stream, 0, (double)rows * C * 3.0);
+    hipLaunchKernelGGL(fp8_quantize_colsum_kernel, dim3((unsigned)gx, (unsigned)ry), dim3(threads), 0, stream, (const bf16_t*)src, rows, C, ld,
+                       state, (unsigned char*)dst, workspace, rpb, kind);
+    const int rc = nkb_check_launch("fp8_quantize_colsum");
+    if (rc) return rc;
+    return nkb_launch_wgrad_reduce(workspace, C, (int)ry, colsum, C, stream);
+}
 extern "C" int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, hipStream_t stream) {
     if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || n <= 0) { nkb_set_error("fp8_amax: dtype %d n %lld", dtype, n); return 1; }
     long long g = (n + 255) / 256;

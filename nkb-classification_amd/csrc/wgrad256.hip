@@ -407,6 +407,186 @@ __global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
 }
 
 
+
+// ---- fp8 weight gradient (BASELINE configs[4]): dW[cout][n] = deq * sum_m gq[m][cout] * xq[m][n] ------------------------------
+// The eight-phase schedule of wgrad8p_kernel on one-byte operands: gq = the e5m2 copy of dY that the fp8 data gradient consumed,
+// xq = the e4m3 copy of X that the fp8 forward GEMM consumed (no extra quantisation pass), 128 tokens per stage (the same 64 KB
+// of LDS-DMA as the bf16 stage, for twice the tokens) and ONE v_mfma_f32_16x16x128_f8f6f4 per accumulator tile and stage
+// (twice the bf16 rate).  Fragments come from LDS through ds_read_b64_tr_b8 (scripts/ubench/tr8_probe.hip: within a 16-lane
+// group, lane l supplying the address of (row l >> 1, byte 8 (l & 1)) of an 8-row x 16-byte block receives column l of that
+// block, rows 0-7).  A lane's 32 operand bytes are tokens 64 (g >> 1) + 16 n + 8 (g & 1) + e (g = lane group, n = read 0-3,
+// e = byte) for BOTH operands, so the two halves of the wave read 16 consecutive rows per instruction; with rows of 128 bytes
+// the 16-byte chunk index is XORed with (row >> 1) & 7 on the DMA source address, which makes those reads conflict-free.
+typedef int w8_i32x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512, 1) void wgrad8f_kernel(const W256Params p, const float* __restrict__ deq_g, const float* __restrict__ deq_x) {
+    constexpr int SUB = 128 * 128;                // one [128 tokens][128 channels] half-tile of bytes
+    constexpr int STG = 4 * SUB;                  // X lo | X hi | dY lo | dY hi
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wn = wave & 3;      // wave tile: cout [128 wr, +128) x n [64 wn, +64)
+
+    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
+    const int tile_c = tile % p.tilesC, tile_n = tile / p.tilesC;
+    const int c0 = tile_c * 256, n0 = tile_n * 256;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int KT = (m_end - m_begin) / 128;       // host guarantees whole stages, at least one
+    const int NH = 4 * KT;
+    if (KT <= 0) return;
+    const unsigned char* xq = (const unsigned char*)p.x;
+    const unsigned char* gq = (const unsigned char*)p.dy;
+
+    // DMA: a half-tile = 16 pieces of 1 KiB (8 token rows x 128 B); this thread moves pieces (wave, wave + 8)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    unsigned xs[2], ys[2];                        // byte offsets of this lane's 16 bytes in channel half 0 (half 1: + 128)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave + 8 * q) * 8 + lrow;                 // row inside the half-tile
+        const int ch = lslot ^ ((row >> 1) & 7);
+        xs[q] = (unsigned)(m_begin + row) * (unsigned)p.ldx + n0 + ch * 16;       // < 2^32 bytes (checked by the host)
+        ys[q] = (unsigned)(m_begin + row) * (unsigned)p.lddy + c0 + ch * 16;
+    }
+    const unsigned xstep = 128u * (unsigned)p.ldx, ystep = 128u * (unsigned)p.lddy;
+#define WF_ISSUE(tt, hh)                                                                                              \
+    do {                                                                                                              \
+        unsigned char* d_ = smem + ((tt) & 1) * STG + (hh) * SUB + wave * 1024;                                      \
+        const unsigned char* s_ = ((hh) < 2 ? xq : gq) + ((hh) & 1) * 128;                                           \
+        const unsigned o_ = (unsigned)(tt) * ((hh) < 2 ? xstep : ystep);                                             \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + (((hh) < 2 ? xs[0] : ys[0]) + o_)), \
+                                         (__attribute__((address_space(3))) void*)d_, 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + (((hh) < 2 ? xs[1] : ys[1]) + o_)), \
+                                         (__attribute__((address_space(3))) void*)(d_ + 8192), 16, 0, 0);            \
+    } while (0)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment of channel block blk (16 channels = one 16-byte chunk): read n covers rows 64 (g >> 1) + 16 n + 8 (g & 1) + 0..7,
+    // lane li of the group points at (row + (li >> 1), byte 8 (li & 1)); the chunk's swizzle key (row >> 1) & 7 = 4 (g & 1) + (li >> 2)
+    const int g = lane >> 4, li = lane & 15;
+    const int fbase = (64 * (g >> 1) + 8 * (g & 1) + (li >> 1)) * 128 + 8 * (li & 1);
+    const int kx16 = (4 * (g & 1) + (li >> 2)) << 4;
+    const int bblk0 = (wn & 1) * 4;
+    auto frag = [&](const unsigned char* tile_, int kx, int blk16) -> w8_i32x8 {
+        const unsigned o = (unsigned)(size_t)(tile_) + (unsigned)(fbase + (blk16 ^ kx));
+        u32x2 r0, r1, r2, r3;
+        asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(r0) : "v"(o));
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:2048" : "=v"(r1) : "v"(o));
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:4096" : "=v"(r2) : "v"(o));
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:6144" : "=v"(r3) : "v"(o));
+        return (w8_i32x8){(int)r0[0], (int)r0[1], (int)r1[0], (int)r1[1], (int)r2[0], (int)r2[1], (int)r3[0], (int)r3[1]};
+    };
+
+    if (0 < NH) WF_ISSUE(0, 0);
+    if (1 < NH) WF_ISSUE(0, 1);
+    if (2 < NH) WF_ISSUE(0, 2);
+    if (3 < NH) WF_ISSUE(0, 3);
+    if (4 < NH) WF_ISSUE(1, 0);
+    if (5 < NH) WF_ISSUE(1, 1);
+    if (6 < NH) WF_ISSUE(1, 2);
+    if (NH > 4) W8_VMCNT(6); else W8_VMCNT(0);
+    W8_BARRIER();
+    if (wr == 1) W8_BARRIER();
+
+    w8_i32x8 a[4], b[4];
+    // A = dY (e5m2: cbsz 1), B = X (e4m3: blgp 0); scale operands zero = the unscaled instruction
+#define WF_MMA(slot, ii)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                     \
+        acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[slot], b[j], acc[ii][j], 1, 0, 0, 0, 0, 0)
+
+    for (int t = 0; t < KT; ++t) {
+        const unsigned char* base = smem + (t & 1) * STG;
+        const unsigned char* A = base + (2 + wr) * SUB;
+        const unsigned char* B = base + (wn >> 1) * SUB;
+        int kxa = kx16, kxb = kx16 ^ (bblk0 << 4);
+        asm volatile("" : "+v"(kxa), "+v"(kxb));   // opaque per stage: the per-block offsets are recomputed, not kept live
+        // ---------------- phase 1: all X fragments + dY blocks 0-3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = frag(B, kxb, 16 * j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = frag(A, kxa, 16 * i);
+        if (4 * t + 7 < NH) WF_ISSUE(t + 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        W8_LGKM(15);                               // 32 reads issued, X first: at most 15 outstanding = every X read retired
+        W8_BARRIER();
+        W8_LGKM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        WF_MMA(0, 0); WF_MMA(1, 1);
+        __builtin_amdgcn_s_setprio(0);
+        W8_BARRIER();
+        // ---------------- phase 2
+        a[0] = frag(A, kxa, 16 * 4);
+        a[1] = frag(A, kxa, 16 * 5);
+        if (4 * t + 8 < NH) WF_ISSUE(t + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        W8_BARRIER();
+        W8_LGKM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        WF_MMA(2, 2); WF_MMA(3, 3);
+        __builtin_amdgcn_s_setprio(0);
+        W8_BARRIER();
+        // ---------------- phase 3
+        a[2] = frag(A, kxa, 16 * 6);
+        a[3] = frag(A, kxa, 16 * 7);
+        if (4 * t + 9 < NH) WF_ISSUE(t + 2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        W8_LGKM(0);
+        W8_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        WF_MMA(0, 4); WF_MMA(1, 5);
+        __builtin_amdgcn_s_setprio(0);
+        W8_BARRIER();
+        // ---------------- phase 4
+        if (4 * t + 10 < NH) WF_ISSUE(t + 2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < KT) W8_VMCNT(6);
+        else if (t + 1 < KT) W8_VMCNT(0);
+        W8_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        WF_MMA(2, 6); WF_MMA(3, 7);
+        __builtin_amdgcn_s_setprio(0);
+        W8_BARRIER();
+    }
+    if (wr == 0) W8_BARRIER();
+    __syncthreads();
+
+    const float deq = *deq_g * *deq_x;
+    const int q4g = lane >> 4;
+    constexpr int EROW = 256 * 4 + 16;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        if (wr == (pass >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = 4 * (pass & 1) + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rbase = 16 * ii + 4 * q4g, col = wn * 64 + 16 * j + li;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *(float*)(smem + (rbase + e) * EROW + col * 4) = acc[i][j][e] * deq;
+                }
+            }
+        }
+        __syncthreads();
+        for (int row = wave; row < 64; row += 8) {
+            float* dst = p.part + (size_t)split * p.slab + (size_t)(c0 + pass * 64 + row) * p.Ntot + n0;
+            *(f32x4*)(dst + 4 * lane) = *(const f32x4*)(smem + row * EROW + 16 * lane);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 static int wgrad256_target_wgs() {
@@ -473,4 +653,57 @@ int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, 
     rc = nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
     if (!rc && dbias) rc = nkb_launch_wgrad_reduce(p.bpart, Cout, p.splits, dbias, Cout, stream);
     return rc;
+}
+
+
+// ---- fp8 weight gradient: host side ------------------------------------------------------------------------------------------
+// dw[Cout][Cin] += (*deq_g * *deq_x) * sum_m gq[m][cout] * xq[m][cin]; gq: e5m2 bytes [M][ldg], xq: e4m3 bytes [M][ldx].
+// M % 128 == 0, Cin % 256 == 0, Cout % 256 == 0; workspace: nkb_wgrad_fp8_workspace_floats() floats (per-split slabs, reduced
+// in split order: deterministic).  The bias gradient is not part of this launch (it needs the unquantised dY column sums).
+static int wgrad8f_stages_per_split(int M, int tiles, int* splits_out) {
+    int splits = (wgrad256_target_wgs() + tiles / 2) / tiles;
+    if (splits < 1) splits = 1;
+    const int stages = M / 128;
+    if (splits > stages) splits = stages;
+    const int sps = (stages + splits - 1) / splits;
+    if (splits_out) *splits_out = (stages + sps - 1) / sps;
+    return sps;
+}
+extern "C" long long nkb_wgrad_fp8_workspace_floats(int M, int Cin, int Cout) {
+    if (M < 128 || M % 128 || Cin % 256 || Cout % 256 || Cin < 256 || Cout < 256) return -1;
+    int splits = 1;
+    wgrad8f_stages_per_split(M, (Cout / 256) * (Cin / 256), &splits);
+    return (long long)splits * Cout * Cin;
+}
+extern "C" int nkb_wgrad_fp8(const void* gq, const void* xq, float* dw, const float* deq_g, const float* deq_x, int M, int Cin,
+                             int ldx, int Cout, int ldg, float* workspace, long long workspace_floats, hipStream_t stream) {
+    const long long need = nkb_wgrad_fp8_workspace_floats(M, Cin, Cout);
+    if (need < 0 || ldx % 16 || ldg % 16 || ldx < Cin || ldg < Cout || !deq_g || !deq_x || !workspace || workspace_floats < need) {
+        nkb_set_error("wgrad_fp8: M=%d Cin=%d Cout=%d (M %% 128, Cin / Cout %% 256, 16-byte rows) with a workspace of %lld floats (got %lld)",
+                      M, Cin, Cout, need, workspace_floats);
+        return 1;
+    }
+    if ((long long)M * ldx >= 0xFFFFFFFFll || (long long)M * ldg >= 0xFFFFFFFFll) { nkb_set_error("wgrad_fp8: operand too large"); return 1; }
+    W256Params p;
+    p.dy = (const bf16_t*)gq; p.x = (const bf16_t*)xq; p.dw = dw; p.dbias = nullptr;
+    p.M = M; p.lddy = ldg; p.ldx = ldx; p.Ntot = Cin;
+    p.tilesC = Cout / 256; p.tilesN = Cin / 256;
+    const int tiles = p.tilesC * p.tilesN;
+    const int sps = wgrad8f_stages_per_split(M, tiles, &p.splits);
+    p.rows_per_split = sps * 128;
+    p.Cout = Cout;
+    p.slab = (long long)Cout * Cin;
+    p.part = workspace;
+    p.bpart = nullptr;
+    constexpr int lds = 2 * 4 * 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad8f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * M * (double)Cin * Cout);
+    hipLaunchKernelGGL(wgrad8f_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p, deq_g, deq_x);
+    int rc = nkb_check_launch("wgrad_fp8");
+    if (rc) return rc;
+    return nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
 }

@@ -86,6 +86,10 @@ _SIGS = {
     "nkb_fp8_scale_update": (i32, [vp, i32, vp]),
     "nkb_fp8_job_blocks": (i64, [i64]),
     "nkb_fp8_multi": (i32, [i32, vp, i32, i64, vp]),
+    "nkb_fp8_quantize_colsum_workspace_floats": (i64, [i64, i32]),
+    "nkb_fp8_quantize_colsum": (i32, [i32, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
+    "nkb_wgrad_fp8_workspace_floats": (i64, [i32, i32, i32]),
+    "nkb_wgrad_fp8": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
     "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp] + [i32] * 8 + [vp]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
@@ -138,7 +142,8 @@ _PURE = frozenset({"nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", 
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
                    "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config",
-                   "nkb_fp8_job_blocks"})
+                   "nkb_fp8_job_blocks", "nkb_wgrad_fp8_workspace_floats",
+                   "nkb_fp8_quantize_colsum_workspace_floats"})
 
 
 class Seed(int):
@@ -489,6 +494,27 @@ def gemm_fp8(mode, xq, wq, y, M, K, N, *, deq_x, deq_w, bias=None, add=None, aux
                               int(q_kind), ptr(deq_x), ptr(deq_w), M, K, N,
                               K if ldx is None else ldx, K if ldw is None else ldw, N if ldy is None else ldy, ldadd,
                               int(relu), stream()), "gemm_fp8")
+
+
+def fp8_quantize_colsum_workspace(rows, C) -> int:
+    return int(load().nkb_fp8_quantize_colsum_workspace_floats(rows, C))
+
+
+def fp8_quantize_colsum(kind, src, rows, C, ld, state, dst, colsum, workspace):
+    """fp8_quantize of a [rows][C] bf16 matrix + colsum[C] += its column sums (a Linear's bias gradient when src = dY)."""
+    check(load().nkb_fp8_quantize_colsum(kind, ptr(src), rows, C, ld, ptr(state), ptr(dst), ptr(colsum), ptr(workspace), stream()),
+          "fp8_quantize_colsum")
+
+
+def wgrad_fp8_workspace(M, Cin, Cout) -> int:
+    """Floats of workspace nkb_wgrad_fp8 needs, -1 when the shape is outside its envelope."""
+    return int(load().nkb_wgrad_fp8_workspace_floats(M, Cin, Cout))
+
+
+def wgrad_fp8(gq, xq, dw, M, Cin, Cout, *, deq_g, deq_x, workspace, ldx=None, ldg=None):
+    """dw += deq_g * deq_x * gq^T xq (gq e5m2 [M][Cout], xq e4m3 [M][Cin], fp32 accumulation, deterministic)."""
+    check(load().nkb_wgrad_fp8(ptr(gq), ptr(xq), ptr(dw), ptr(deq_g), ptr(deq_x), M, Cin, Cin if ldx is None else ldx, Cout,
+                               Cout if ldg is None else ldg, ptr(workspace), workspace.numel(), stream()), "wgrad_fp8")
 
 
 def prof_enable(on: bool):

@@ -34,6 +34,10 @@ _SPLITK = os.environ.get("NKB_SPLITK", "1") != "0"              # split-K for sk
 _EVAL_FOLD = os.environ.get("NKB_EVAL_FOLD", "1") != "0"     # eval mode: BatchNorm folded into the conv (one launch per stage)
 # weight / bias gradients through per-split slabs + an ordered second stage instead of fp32 atomics: bit-identical across runs
 _FP8_FUSED_QUANT = os.environ.get("NKB_FP8_FUSED_QUANT", "1") != "0"   # fp8 operands written by the producing kernel's epilogue
+_FP8_WGRAD = os.environ.get("NKB_FP8_WGRAD", "1") != "0"   # fp8 mode: weight gradients of the fp8 Linear layers on the fp8 kernel too
+# bias gradients summed inside the e5m2 quantisation pass of dY (main stream) instead of a column-sum pass on the side stream:
+# measured slower on unicom ViT-L/14 (65.0 vs 63.9 ms/step: the side stream has the slack, the main stream does not) — off
+_FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 _DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
 
 
@@ -191,12 +195,13 @@ class HipEngine:
         hip.fp8_multi(2, jfwd, nfwd, 0)            # scale <- 448 / amax
         hip.fp8_multi(1, jall, nall, ball)         # quantise both layouts
 
-    def _fp8_operand(self, key: str, x: torch.Tensor, kind: int):
+    def _fp8_operand(self, key: str, x: torch.Tensor, kind: int, colsum: Optional[torch.Tensor] = None):
         """fp8 copy of an activation (e4m3) or gradient (e5m2) with delayed per-tensor scaling: the scale comes from the amax
-        the previous step's pass over this site accumulated (the first call measures it just in time)."""
+        the previous step's pass over this site accumulated (the first call measures it just in time).  colsum: a [C] fp32
+        vector that receives (+=) the column sums of x in the same pass — returns (q, state, colsum_done)."""
         q = self._f8ready.pop(key, None)
         if q is not None:                           # the producing kernel wrote it (and accumulated the amax) in its epilogue
-            return q, self._f8act[key]
+            return q, self._f8act[key], False
         st = self._f8act.get(key)
         n = x.numel()
         if st is None:
@@ -204,8 +209,13 @@ class HipEngine:
             hip.fp8_amax(self.d, x, n, st)
         hip.fp8_scale_update(st, kind)
         q = self.ws.get(key + ".q", tuple(x.shape), torch.uint8)
+        if _FP8_COLSUM and colsum is not None and x.dim() == 2 and x.shape[1] % 512 == 0 and x.is_contiguous() and self.T == torch.bfloat16:
+            rows, C = x.shape
+            work = self.ws.at_least("f8.colsum." + self._stream_tag(), hip.fp8_quantize_colsum_workspace(rows, C), torch.float32)
+            hip.fp8_quantize_colsum(kind, x, rows, C, C, st, q, colsum, work)
+            return q, st, True
         hip.fp8_quantize(self.d, kind, x, n, st, q)
-        return q, st
+        return q, st, False
 
     def _fp8_produce(self, key: Optional[str], shape, kind: int):
         """Second output of an fp8 GEMM: (buffer, state, kind) for the site `key` that will consume this tensor as its fp8
@@ -702,32 +712,62 @@ class HipEngine:
         y = self.ws.get(key + ".y", (M, N), self.T)
         bias = self.arena.param_flat(lin.bias) if lin.bias is not None else None
         if self._fp8_linear_ok(lin, M):
-            xq, sx = self._fp8_operand(key + ".f8x", x, hip.E4M3)
+            xq, sx, _ = self._fp8_operand(key + ".f8x", x, hip.E4M3)
             wq, _, sw = self._f8w[id(lin.weight)]
             hip.gemm_fp8(0, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, add=add,
                          ldadd=N if add is not None else 0)
-        else:
-            hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
-                          bias=bias, add=add, ldadd=N if add is not None else 0)
+            if train:
+                self.saved[key] = dict(x=x, lin=lin, xq=xq, sx=sx)
+            return y
+        hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
+                      bias=bias, add=add, ldadd=N if add is not None else 0)
         if train:
             self.saved[key] = dict(x=x, lin=lin)
         return y
+
+    @staticmethod
+    def _fp8_wgrad_ok(sv, M: int, K: int, N: int) -> bool:
+        return _FP8_WGRAD and sv.get("xq") is not None and hip.wgrad_fp8_workspace(M, K, N) > 0
+
+    def _linear_wgrad(self, sv, g: torch.Tensor, gq=None, sg=None, bias_done: bool = False):
+        """Weight / bias gradient of a Linear on the side stream.  With both fp8 copies at hand (the forward operand xq and the
+        data gradient's operand gq) the contraction runs on the fp8 kernel (NKB_FP8_WGRAD=0: bf16); the bias gradient is then
+        the column sum of the unquantised g."""
+        x, lin = sv["x"], sv["lin"]
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        a = self.arena
+        dbias = a.grad_flat(lin.bias) if lin.bias is not None else None
+        if gq is not None and self._fp8_wgrad_ok(sv, M, K, N):
+            xq, sx = sv["xq"], sv["sx"]
+
+            def run():
+                work = self.ws.at_least("wgrad.slabs." + self._stream_tag(), hip.wgrad_fp8_workspace(M, K, N), torch.float32)
+                hip.wgrad_fp8(gq, xq, a.grad_flat(lin.weight), M, K, N, deq_g=sg[1:2], deq_x=sx[1:2], workspace=work)
+                if dbias is not None and not bias_done:
+                    self.colsum2d(g, dbias, M, N, N)
+            self.on_side(run)
+            return
+        self.on_side(lambda: self.wgrad(g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
+                                        dbias=dbias))
 
     def linear_backward(self, key: str, g: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None):
         sv = self.saved[key]
         x, lin = sv["x"], sv["lin"]
         M, K = x.shape
         N = lin.weight.shape[0]
-        a = self.arena
-
-        self.on_side(lambda: self.wgrad(
-            g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
-            dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
+        fp8 = self._fp8_linear_ok(lin, M)
+        gq = sg = None
+        bias_done = False
+        if fp8 and (slot is not None or (_FP8_WGRAD and sv.get("xq") is not None)):
+            # one e5m2 copy serves the data and the weight gradient; the pass that makes it also sums the columns (bias gradient)
+            want = self.arena.grad_flat(lin.bias) if (lin.bias is not None and self._fp8_wgrad_ok(sv, M, K, N)) else None
+            gq, sg, bias_done = self._fp8_operand(key + ".f8g", g, hip.E5M2, colsum=want)
+        self._linear_wgrad(sv, g, gq, sg, bias_done)
         if slot is None:
             return None
         dx = self.scratch(slot, (M, K))
-        if self._fp8_linear_ok(lin, M):
-            gq, sg = self._fp8_operand(key + ".f8g", g, hip.E5M2)
+        if fp8:
             _, wdq, sw = self._f8w[id(lin.weight)]
             hip.gemm_fp8(1, gq, wdq, dx, M, N, K, deq_x=sg[1:2], deq_w=sw[1:2], add=add, ldadd=K if add is not None else 0)
         else:
@@ -743,11 +783,14 @@ class HipEngine:
         u = self.ws.get(key + ".y", (M, N), self.T)
         bias = self.arena.param_flat(lin.bias) if lin.bias is not None else None
         if self._fp8_linear_ok(lin, M):
-            xq, sx = self._fp8_operand(key + ".f8x", x, hip.E4M3)
+            xq, sx, _ = self._fp8_operand(key + ".f8x", x, hip.E4M3)
             wq, _, sw = self._f8w[id(lin.weight)]
             out = self._fp8_produce(q_for, (M, N), hip.E4M3) if train else None
             hip.gemm_fp8(0, xq, wq, u, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, relu=2,
                          yq=out[0] if out else None, q_state=out[1] if out else None, q_kind=out[2] if out else 0)
+            if train:
+                self.saved[key] = dict(x=x, lin=lin, u=u, xq=xq, sx=sx)
+            return u
         else:
             hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), u, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
                           bias=bias, relu=2)
@@ -763,13 +806,15 @@ class HipEngine:
         x, lin = sv["x"], sv["lin"]          # x = u (ReLU6 output), lin = fc2
         M, K = x.shape
         N = lin.weight.shape[0]
-        a = self.arena
-        self.on_side(lambda: self.wgrad(
-            g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
-            dbias=a.grad_flat(lin.bias) if lin.bias is not None else None))
+        fp8 = self._fp8_linear_ok(lin, M)
+        gq = sg = None
+        bias_done = False
+        if fp8:
+            want = self.arena.grad_flat(lin.bias) if (lin.bias is not None and self._fp8_wgrad_ok(sv, M, K, N)) else None
+            gq, sg, bias_done = self._fp8_operand(key_next + ".f8g", g, hip.E5M2, colsum=want)
+        self._linear_wgrad(sv, g, gq, sg, bias_done)
         d_pre = self.scratch(slot, (M, K))
-        if self._fp8_linear_ok(lin, M):
-            gq, sg = self._fp8_operand(key_next + ".f8g", g, hip.E5M2)
+        if fp8:
             _, wdq, sw = self._f8w[id(lin.weight)]
             out = self._fp8_produce(q_for, (M, K), hip.E5M2)
             hip.gemm_fp8(1, gq, wdq, d_pre, M, N, K, deq_x=sg[1:2], deq_w=sw[1:2], aux=self.saved[key_act]["u"], aux_mode=1,

@@ -1239,3 +1239,70 @@ def test_gemm_fp8_matches_product_of_rounded_operands(shape, mode):
     full = x.double() @ w.double().t()
     rel = ((ref - full).norm() / full.norm()).item()
     assert rel < (0.04 if mode == 0 else 0.1), rel
+
+
+@pytest.mark.parametrize("shape", [(1024, 256, 256), (128 * 37, 512, 768), (32768, 1024, 256)], ids=lambda s: "M%d_Cin%d_Cout%d" % s)
+def test_wgrad_fp8_matches_product_of_rounded_operands(shape):
+    """configs[4]'s fp8 weight gradient: dW = deq_g deq_x gq^T xq against the fp64 product of the fp8-ROUNDED operands (torch
+    float8 casts of the same scaled values), accumulation into a non-zero dW, bit-identical on a second run (slabs + ordered
+    reduce), and at the fp8 level against the unquantised product."""
+    M, Cin, Cout = shape
+    torch.manual_seed(31)
+    x = (torch.randn(M, Cin) * 0.8).to(torch.bfloat16)
+    g = (torch.randn(M, Cout) * 0.02).to(torch.bfloat16)
+    sx, sg = torch.zeros(3, device=DEV), torch.zeros(3, device=DEV)
+    sx[0] = sx[1] = sg[0] = sg[1] = 1.0
+    xd, gd = x.to(DEV), g.to(DEV)
+    hip.fp8_amax(hip.BF16, xd, x.numel(), sx); hip.fp8_scale_update(sx, hip.E4M3)
+    hip.fp8_amax(hip.BF16, gd, g.numel(), sg); hip.fp8_scale_update(sg, hip.E5M2)
+    xq = torch.empty(M, Cin, device=DEV, dtype=torch.uint8); gq = torch.empty(M, Cout, device=DEV, dtype=torch.uint8)
+    hip.fp8_quantize(hip.BF16, hip.E4M3, xd, x.numel(), sx, xq)
+    hip.fp8_quantize(hip.BF16, hip.E5M2, gd, g.numel(), sg, gq)
+    torch.cuda.synchronize()
+    xr = xq.cpu().view(torch.float8_e4m3fn).double()
+    gr = gq.cpu().view(torch.float8_e5m2).double()
+    ref = (gr.t() @ xr) * (sx[1].item() * sg[1].item())
+    need = hip.wgrad_fp8_workspace(M, Cin, Cout)
+    assert need > 0
+    work = torch.empty(need, device=DEV)
+    outs = []
+    base = torch.randn(Cout, Cin)
+    for _ in range(2):
+        dw = base.clone().to(DEV)
+        hip.wgrad_fp8(gq, xq, dw, M, Cin, Cout, deq_g=sg[1:2], deq_x=sx[1:2], workspace=work)
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    got = (outs[0].cpu().double() - base.double())
+    assert ((got - ref).norm() / ref.norm()).item() < 2e-5
+    full = g.double().t() @ x.double()
+    assert ((ref - full).norm() / full.norm()).item() < 0.08
+    assert hip.wgrad_fp8_workspace(M + 64, Cin, Cout) == -1 and hip.wgrad_fp8_workspace(M, Cin + 64, Cout) == -1
+
+
+@pytest.mark.parametrize("shape", [(1000, 512), (4096 + 3, 1024), (32768, 4096)], ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("kind", ["e4m3", "e5m2"])
+def test_fp8_quantize_colsum_matches_the_two_separate_passes(shape, kind):
+    """The fused pass of the fp8 backward: same bytes and amax as nkb_fp8_quantize, column sums (added to a non-zero vector) equal
+    to the fp64 sums of the bf16 values, identical on a second run (per-row-block partials + ordered reduce)."""
+    rows, C = shape
+    k = hip.E4M3 if kind == "e4m3" else hip.E5M2
+    torch.manual_seed(41)
+    x = (torch.randn(rows, C) * 0.3).to(torch.bfloat16).to(DEV)
+    outs = []
+    for _ in range(2):
+        st = torch.tensor([7.0, 1.0 / 7.0, 0.0], device=DEV)
+        q = torch.empty(rows, C, device=DEV, dtype=torch.uint8)
+        col = torch.full((C,), 2.5, device=DEV)
+        work = torch.empty(hip.fp8_quantize_colsum_workspace(rows, C), device=DEV)
+        hip.fp8_quantize_colsum(k, x, rows, C, C, st, q, col, work)
+        torch.cuda.synchronize()
+        outs.append((q, col, st))
+    st2 = torch.tensor([7.0, 1.0 / 7.0, 0.0], device=DEV)
+    q2 = torch.empty(rows, C, device=DEV, dtype=torch.uint8)
+    hip.fp8_quantize(hip.BF16, k, x, x.numel(), st2, q2)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], q2) and outs[0][2][2].item() == st2[2].item()
+    want = x.double().sum(0) + 2.5
+    torch.testing.assert_close(outs[0][1].double().cpu(), want.cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(rows))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
