@@ -2,18 +2,18 @@
 # Runs on the GPU box (through gpurun): rocprofv3 kernel-trace + stats of the default bench command, the PMC passes the
 # roofline's `traffic` and MFMA-utilisation figures come from, and the bench lines themselves; results under gpurun_out/prof_$TAG,
 # summaries are copied to profiles/ by hand afterwards (profiles/ is tracked, gpurun_out/ is scratch).
-# Usage: bash scripts/collect_profiles.sh <tag> [model]
+# Usage: bash scripts/collect_profiles.sh <tag> [model] [extra bench.py arguments, e.g. --batch 128 --dtype fp8]
 set -o pipefail
-TAG=${1:-r02}; MODEL=${2:-resnet50}
+TAG=${1:-r02}; MODEL=${2:-resnet50}; shift; shift; EXTRA="$*"; SUFFIX=$(echo "$EXTRA" | tr -c 'a-zA-Z0-9' '_' | sed 's/__*/_/g; s/_$//')
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_${TAG}_${MODEL//[^a-zA-Z0-9]/_}
+OUT=$ROOT/gpurun_out/prof_${TAG}_${MODEL//[^a-zA-Z0-9]/_}${SUFFIX:+_$SUFFIX}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --model $MODEL --no-cpu-baseline --no-host-work"
-python3 $B --steps 30 --warmup 8 > $OUT/line.json 2> $OUT/line.err && echo "line ok"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $B --steps 20 --warmup 8 > $OUT/line_under_rocprofv3.json 2> $OUT/trace.err && echo "trace ok"
+B="$ROOT/bench.py --no-cpu-baseline --no-host-work $EXTRA --model"
+python3 $B "$MODEL" --steps 30 --warmup 8 > $OUT/line.json 2> $OUT/line.err && echo "line ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $B "$MODEL" --steps 20 --warmup 8 > $OUT/line_under_rocprofv3.json 2> $OUT/trace.err && echo "trace ok"
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python3 $B --steps 2 --warmup 1 --no-roofline > /dev/null 2> $OUT/pmc_$C.err && echo "pmc $C ok"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python3 $B "$MODEL" --steps 2 --warmup 1 --no-roofline > /dev/null 2> $OUT/pmc_$C.err && echo "pmc $C ok"
 done
 cd $ROOT
 T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
