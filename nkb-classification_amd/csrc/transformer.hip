@@ -154,19 +154,33 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
 }
 
-__global__ void ln_param_grad_kernel(const float* __restrict__ part, int blocks, int D, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
+// Second stage of the deterministic LayerNorm parameter gradients, itself in two launches: with one block per 64 columns (16 blocks
+// for D = 1024) the 1024 partial rows were read by 16 CUs and the launch took 21 us — longer than a third of the backward kernel
+// it follows.  Now LN_SLICES blocks per column group each sum a contiguous slice of the partial rows (fixed order), and a tiny
+// launch adds the slice sums in slice order.
+constexpr int LN_SLICES = 16;
+__global__ void ln_param_grad_kernel(const float* __restrict__ part, int blocks, int D, float* __restrict__ inter) {
     __shared__ float red[2][16][64];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
+    const int per = (blocks + LN_SLICES - 1) / LN_SLICES;
+    const int t0 = blockIdx.y * per, t1 = min(blocks, t0 + per);
     float a = 0.f, b = 0.f;
     if (c < D)
-        for (int t = py; t < blocks; t += 16) { a += part[((size_t)t * 2) * D + c]; b += part[((size_t)t * 2 + 1) * D + c]; }
+        for (int t = t0 + py; t < t1; t += 16) { a += part[((size_t)t * 2) * D + c]; b += part[((size_t)t * 2 + 1) * D + c]; }
     red[0][py][cx] = a; red[1][py][cx] = b;
     __syncthreads();
     if (py != 0 || c >= D) return;
     a = 0.f; b = 0.f;
     for (int k = 0; k < 16; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
+    inter[((size_t)blockIdx.y * 2) * D + c] = a;
+    inter[((size_t)blockIdx.y * 2 + 1) * D + c] = b;
+}
+__global__ void ln_param_grad_final_kernel(const float* __restrict__ inter, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < LN_SLICES; ++s) { a += inter[((size_t)s * 2) * D + c]; b += inter[((size_t)s * 2 + 1) * D + c]; }
     dgamma[c] += a; dbeta[c] += b;
 }
 
@@ -204,7 +218,14 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
     NkbProfScope prof(NKB_K_LN, stream, 0);
     int grid = (rows + 3) / 4;
     if (!backward) { if (grid > 256 * 16) grid = 256 * 16; }
-    else if (workspace) { if (grid > 1024) grid = 1024; }   // partials [grid][2][D] in the workspace
+    else if (workspace) {                                    // partials [grid][2][D] in the workspace
+        // ~44 rows per block (11 per wave): fewer and the per-block column-sum epilogue dominates (32768 x 1024: 1024 blocks 78 us,
+        // 768 blocks 62 us), more and the chip is under-filled (50432 x 768: 512 blocks 93 us, 1024 blocks 66 us)
+        static const int cap = [] { const char* e = getenv("NKB_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
+        const int want = cap > 0 ? cap : (rows + 43) / 44;
+        if (grid > want) grid = want;
+        if (grid > 1024) grid = 1024;
+    }
     else if (grid > 512) grid = 512;                         // atomics path: keep same-address contention low
     int rc;
     if (dtype == NKB_DT_BF16)
@@ -215,7 +236,11 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
                      : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace);
     if (rc) { nkb_set_error("layernorm: unsupported D=%d", D); return 1; }
     if (backward && workspace)
-        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, workspace, grid, D, dgamma, dbeta);
+    {
+        float* inter = workspace + (size_t)1024 * 2 * D;      // behind the (<= 1024) per-block partial rows
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
+        hipLaunchKernelGGL(ln_param_grad_final_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta);
+    }
     return nkb_check_launch("layernorm");
 }
 
