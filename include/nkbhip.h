@@ -271,15 +271,18 @@ int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float*
  *                     yq / q_state / q_kind (optional): second output yq[M][N] bytes = fp8(y * q_state[0]) (kind as in
  *                     nkb_fp8_quantize) with q_state[2] = max(q_state[2], max |y|) — the operand of the next fp8 GEMM without a
  *                     separate quantisation pass over y.
+ *                     row_scale / rows_per_sample (optional, with add): y = add + row_scale[m / rows_per_sample] * (product + bias):
+ *                     per-sample stochastic depth of the residual branch (unicom blocks) inside the epilogue.
  * state: three device floats {scale, 1 / scale, running amax}. */
 int nkb_fp8_quantize(int dtype, int kind, const void* src, long long n, float* state, void* dst, nkb_stream_t stream);
 int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, nkb_stream_t stream);
 /* nkb_fp8_quantize of a [rows][C] bf16 matrix (row stride ld) that also adds the matrix's column sums to colsum[C] — the bias
  * gradient of a Linear layer when src = dY, in the one pass that reads the unquantised values.  C % 512 == 0; workspace of
- * nkb_fp8_quantize_colsum_workspace_floats(rows, C) floats (partial sums per row block, added in block order). */
+ * nkb_fp8_quantize_colsum_workspace_floats(rows, C) floats (partial sums per row block, added in block order).  With row_scale
+ * (per sample, rows_per_sample rows each) the matrix quantised and summed is row_scale[row / rows_per_sample] * src. */
 long long nkb_fp8_quantize_colsum_workspace_floats(long long rows, int C);
 int nkb_fp8_quantize_colsum(int kind, const void* src, long long rows, int C, long long ld, float* state, void* dst, float* colsum,
-                            float* workspace, nkb_stream_t stream);
+                            float* workspace, const float* row_scale, int rows_per_sample, nkb_stream_t stream);
 int nkb_fp8_scale_update(float* state, int kind, nkb_stream_t stream);
 /* Many tensors in one launch (a model's weight matrices): jobs = device array of njobs x 6 int64 {src (bf16), dst (bytes),
  * n (multiple of 8), state (3 floats), kind, first block}; blocks per job from nkb_fp8_job_blocks(n).  pass 0: amax only;
@@ -295,8 +298,9 @@ long long nkb_wgrad_fp8_workspace_floats(int M, int Cin, int Cout);
 int nkb_wgrad_fp8(const void* gq, const void* xq, float* dw, const float* deq_g, const float* deq_x, int M, int Cin, int ldx,
                   int Cout, int ldg, float* workspace, long long workspace_floats, nkb_stream_t stream);
 int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add, const void* aux,
-                 int aux_mode, void* yq, float* q_state, int q_kind, const float* deq_x, const float* deq_w, int M, int K, int N,
-                 int ldx, int ldw, int ldy, int ldadd, int relu, nkb_stream_t stream);
+                 int aux_mode, void* yq, float* q_state, int q_kind, const float* row_scale, int rows_per_sample,
+                 const float* deq_x, const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd, int relu,
+                 nkb_stream_t stream);
 
 /* Envelope of the 256 x 256 eight-phase GEMM core that nkb_conv_gemm / nkb_linear_gelu use for wide plain 1x1 / Linear launches
  * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 768).  Tests and A/B timing. */

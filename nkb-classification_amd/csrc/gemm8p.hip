@@ -52,6 +52,9 @@ struct G8Params {
     unsigned char* yq;
     float* q_state;
     int q_kind, ldq;
+    // optional per-sample scale of the GEMM result in front of the residual add (stochastic depth: y = add + s[m / rows_per_sample] * (x w^T + b))
+    const float* row_scale;
+    FastDiv div_rows;
     int aux_mode;         // 0: the result is multiplied by aux; 1: the result is kept where 0 < aux < 6 (ReLU6 backward mask)
     int align_epi;        // DIRECT: both wave groups run the epilogue side by side (NKB_G8_ALIGN, default 1)
 };
@@ -308,6 +311,11 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             if (has_add) {
                 float af[8];
                 unpack8(araw, af);
+                if (p.row_scale) {                     // (uniform) stochastic depth: scale the branch, then add the trunk
+                    const float rs = p.row_scale[fdiv((unsigned)(em0 + lrow + 16 * j), p.div_rows)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= rs;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += af[e];
             }
@@ -686,6 +694,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     p.add = (const bf16_t*)cp.add; p.aux = (cp.act == 4 || cp.act == 3) ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
     p.aux_mode = cp.act == 3 ? 1 : 0; p.align_epi = g8_align();
     p.yq = nullptr; p.q_state = nullptr; p.q_kind = 0; p.ldq = 0;
+    p.row_scale = nullptr; p.div_rows = make_fastdiv(1);
     p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
     p.relu = cp.relu;
     p.deq_x = p.deq_w = nullptr;
@@ -712,10 +721,12 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
 // derivative), mode 1 keeps the result where 0 < aux < 6 (ReLU6 backward: aux = the clamped forward output).
 // yq / q_state / q_kind: optional fp8 copy of the result for the next fp8 GEMM — yq[M][N] bytes = fp8(y * q_state[0]) in e4m3
 // (q_kind 0) or e5m2 (1), and q_state[2] accumulates max |y| (what nkb_fp8_quantize would do in a second pass over y).
+// row_scale / rows_per_sample (optional, with add): y = add + row_scale[m / rows_per_sample] * (product + bias) — stochastic depth
+// on the residual branch inside the epilogue.
 extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add,
-                            const void* aux, int aux_mode, void* yq, float* q_state, int q_kind, const float* deq_x,
-                            const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd, int relu,
-                            hipStream_t stream) {
+                            const void* aux, int aux_mode, void* yq, float* q_state, int q_kind, const float* row_scale,
+                            int rows_per_sample, const float* deq_x, const float* deq_w, int M, int K, int N, int ldx, int ldw,
+                            int ldy, int ldadd, int relu, hipStream_t stream) {
     if ((mode != 0 && mode != 1) || (aux_mode != 0 && aux_mode != 1) || K % 128 != 0 || K < 256 || N % 256 != 0 || ldx % 16 || ldw % 16 || ldy % 8 || (add && ldadd % 8) ||
         M < 1 || deq_x == nullptr || deq_w == nullptr) {
         nkb_set_error("gemm_fp8: unsupported mode %d / shape M=%d K=%d N=%d (K %% 128, N %% 256, 16-byte rows, dequant scales)", mode, M, K, N);
@@ -726,6 +737,8 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     p.x = (const bf16_t*)xq; p.w = (const bf16_t*)wq; p.y = (bf16_t*)y; p.bias = bias; p.add = (const bf16_t*)add; p.aux = (const bf16_t*)aux;
     p.aux_mode = aux_mode; p.align_epi = g8_align();
     p.yq = (unsigned char*)yq; p.q_state = q_state; p.q_kind = q_kind; p.ldq = N;
+    p.row_scale = row_scale; p.div_rows = make_fastdiv(rows_per_sample > 0 ? (unsigned)rows_per_sample : 1u);
+    if (row_scale && (!add || rows_per_sample < 1)) { nkb_set_error("gemm_fp8: row_scale goes with a residual operand and rows_per_sample >= 1"); return 1; }
     if (yq && (q_state == nullptr || (q_kind != 0 && q_kind != 1))) { nkb_set_error("gemm_fp8: quantised output needs its scaling state and kind 0 / 1"); return 1; }
     p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu;
     p.deq_x = deq_x; p.deq_w = deq_w;
@@ -896,21 +909,35 @@ extern "C" int nkb_fp8_quantize(int dtype, int kind, const void* src, long long 
 // consecutive columns, block = up to 2048 columns x one row block; per-block partial sums go to the workspace and are added to
 // colsum in block order (deterministic), the amax as in nkb_fp8_quantize.
 namespace {
-__global__ void fp8_quantize_colsum_kernel(const bf16_t* __restrict__ src, long long rows, int C, long long ld, float* __restrict__ state,
-                                           unsigned char* __restrict__ dst, float* __restrict__ part, int rpb, int kind) {
-    const int c8 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
-    const float scale = state[0];
+// block = 64 column groups (8 columns each: one 16-byte load per thread and row, 1 KB per wave) x 4 row lanes; grid = (C / 512,
+// row blocks of `rpb` rows).  QUANT = false: column sums only (the bias gradient of a Linear whose fp8 dY came out of a GEMM epilogue).
+template <bool QUANT>
+__global__ __launch_bounds__(256) void fp8_quantize_colsum_kernel(const bf16_t* __restrict__ src, long long rows, int C, long long ld,
+                                                                  float* __restrict__ state, unsigned char* __restrict__ dst,
+                                                                  float* __restrict__ part, int rpb, int kind,
+                                                                  const float* __restrict__ row_scale, int rows_per_sample) {
+    __shared__ float red[4][64][9];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c8 = (blockIdx.x * 64 + tx) * 8;
+    const float scale = QUANT ? state[0] : 1.f;
     const float lim = kind == 0 ? 448.f : 57344.f;
     const long long r0 = (long long)blockIdx.y * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
     float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float amax = 0.f;
-    if (c8 < C) {
-        for (long long r = r0; r < r1; ++r) {
-            float f[8], q[8];
-            unpack8(*(const u32x4*)(src + (size_t)r * ld + c8), f);
+    for (long long r = r0 + ty; r < r1; r += 4) {
+        float f[8];
+        unpack8(*(const u32x4*)(src + (size_t)r * ld + c8), f);
+        if (row_scale) {                           // the matrix that is quantised and summed is row_scale[row / rows_per_sample] * src
+            const float rs = row_scale[r / rows_per_sample];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= rs;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] += f[e];
+        if constexpr (QUANT) {
+            float q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                sum[e] += f[e];
                 amax = fmaxf(amax, fabsf(f[e]));
                 q[e] = fminf(fmaxf(f[e] * scale, -lim), lim);
             }
@@ -924,38 +951,56 @@ __global__ void fp8_quantize_colsum_kernel(const bf16_t* __restrict__ src, long 
             }
             *(u32x2*)(dst + (size_t)r * C + c8) = (u32x2){w0, w1};
         }
-        float* pp = part + (size_t)blockIdx.y * C + c8;
-        *(f32x4*)pp = (f32x4){sum[0], sum[1], sum[2], sum[3]};
-        *(f32x4*)(pp + 4) = (f32x4){sum[4], sum[5], sum[6], sum[7]};
     }
-    fp8_block_amax(amax, state);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx][e] = sum[e];
+    __syncthreads();
+    if (ty == 0) {                                 // row lanes in a fixed order
+        float* pp = part + (size_t)blockIdx.y * C + c8;
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = ((red[0][tx][e] + red[1][tx][e]) + red[2][tx][e]) + red[3][tx][e];
+        *(f32x4*)pp = (f32x4){t[0], t[1], t[2], t[3]};
+        *(f32x4*)(pp + 4) = (f32x4){t[4], t[5], t[6], t[7]};
+    }
+    if constexpr (QUANT) fp8_block_amax(amax, state);
+}
+static void colsum_geometry(long long rows, int* ry, int* rpb) {
+    long long n = (rows + 63) / 64;
+    if (n > 512) n = 512;
+    *rpb = (int)((rows + n - 1) / n);
+    *ry = (int)((rows + *rpb - 1) / *rpb);
 }
 }  // namespace
 extern "C" long long nkb_fp8_quantize_colsum_workspace_floats(long long rows, int C) {
-    long long ry = (rows + 127) / 128;
-    if (ry > 256) ry = 256;
-    return ry * C;
+    int ry, rpb;
+    colsum_geometry(rows, &ry, &rpb);
+    return (long long)ry * C;
 }
-// dst[rows][C] bytes = fp8(src * state[0]) (+ amax into state[2]), colsum[C] += column sums of src.  bf16 only; C % 512 == 0
-// (whole waves of 8-column threads), ld % 8 == 0; workspace >= nkb_fp8_quantize_colsum_workspace_floats(rows, C) floats.
+// dst[rows][C] bytes = fp8(src * state[0]) (+ amax into state[2]), colsum[C] += column sums of src.  bf16 only; C % 512 == 0,
+// ld % 8 == 0; workspace >= nkb_fp8_quantize_colsum_workspace_floats(rows, C) floats.  dst == NULL (with state NULL): column sums only.
+// row_scale / rows_per_sample (optional): the matrix is row_scale[row / rows_per_sample] * src (the stochastic-depth branch
+// gradient, never materialised in bf16).
 extern "C" int nkb_fp8_quantize_colsum(int kind, const void* src, long long rows, int C, long long ld, float* state, void* dst,
-                                       float* colsum, float* workspace, hipStream_t stream) {
-    if ((kind != 0 && kind != 1) || rows <= 0 || C <= 0 || C % 512 != 0 || ld % 8 != 0 || ld < C || !colsum || !workspace) {
+                                       float* colsum, float* workspace, const float* row_scale, int rows_per_sample,
+                                       hipStream_t stream) {
+    if ((kind != 0 && kind != 1) || rows <= 0 || C <= 0 || C % 512 != 0 || ld % 8 != 0 || ld < C || !colsum || !workspace ||
+        ((dst == nullptr) != (state == nullptr))) {
         nkb_set_error("fp8_quantize_colsum: kind %d rows %lld C %d ld %lld (C %% 512 == 0, workspace and colsum required)", kind, rows, C, ld);
         return 1;
     }
-    const int threads = 256;                      // (fp8_block_amax reduces over four waves; columns past C idle)
-    const int gx = (C / 8 + threads - 1) / threads;
-    long long ry = (rows + 127) / 128;
-    if (ry > 256) ry = 256;
-    const int rpb = (int)((rows + ry - 1) / ry);
-    ry = (rows + rpb - 1) / rpb;
-    NkbProfScope prof(NKB_K_MISC, stream, 0, (double)rows * C * 3.0);
-    hipLaunchKernelGGL(fp8_quantize_colsum_kernel, dim3((unsigned)gx, (unsigned)ry), dim3(threads), 0, stream, (const bf16_t*)src, rows, C, ld,
-                       state, (unsigned char*)dst, workspace, rpb, kind);
+    int ry, rpb;
+    colsum_geometry(rows, &ry, &rpb);
+    const dim3 grid((unsigned)(C / 512), (unsigned)ry);
+    NkbProfScope prof(NKB_K_MISC, stream, 0, (double)rows * C * (dst ? 3.0 : 2.0));
+    const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
+    if (dst) hipLaunchKernelGGL(fp8_quantize_colsum_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)src, rows, C, ld, state,
+                                (unsigned char*)dst, workspace, rpb, kind, row_scale, rps);
+    else hipLaunchKernelGGL(fp8_quantize_colsum_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)src, rows, C, ld, state,
+                            (unsigned char*)nullptr, workspace, rpb, kind, row_scale, rps);
     const int rc = nkb_check_launch("fp8_quantize_colsum");
     if (rc) return rc;
-    return nkb_launch_wgrad_reduce(workspace, C, (int)ry, colsum, C, stream);
+    return nkb_launch_wgrad_reduce(workspace, C, ry, colsum, C, stream);
 }
 extern "C" int nkb_fp8_amax(int dtype, const void* src, long long n, float* state, hipStream_t stream) {
     if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || n <= 0) { nkb_set_error("fp8_amax: dtype %d n %lld", dtype, n); return 1; }

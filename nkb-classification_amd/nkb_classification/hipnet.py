@@ -195,7 +195,7 @@ class HipEngine:
         hip.fp8_multi(2, jfwd, nfwd, 0)            # scale <- 448 / amax
         hip.fp8_multi(1, jall, nall, ball)         # quantise both layouts
 
-    def _fp8_operand(self, key: str, x: torch.Tensor, kind: int, colsum: Optional[torch.Tensor] = None):
+    def _fp8_operand(self, key: str, x: torch.Tensor, kind: int, colsum: Optional[torch.Tensor] = None, row_scale=None):
         """fp8 copy of an activation (e4m3) or gradient (e5m2) with delayed per-tensor scaling: the scale comes from the amax
         the previous step's pass over this site accumulated (the first call measures it just in time).  colsum: a [C] fp32
         vector that receives (+=) the column sums of x in the same pass — returns (q, state, colsum_done)."""
@@ -209,13 +209,18 @@ class HipEngine:
             hip.fp8_amax(self.d, x, n, st)
         hip.fp8_scale_update(st, kind)
         q = self.ws.get(key + ".q", tuple(x.shape), torch.uint8)
-        if _FP8_COLSUM and colsum is not None and x.dim() == 2 and x.shape[1] % 512 == 0 and x.is_contiguous() and self.T == torch.bfloat16:
+        if (_FP8_COLSUM or row_scale is not None) and colsum is not None and self._fp8_colsum_ok(x):
             rows, C = x.shape
             work = self.ws.at_least("f8.colsum." + self._stream_tag(), hip.fp8_quantize_colsum_workspace(rows, C), torch.float32)
-            hip.fp8_quantize_colsum(kind, x, rows, C, C, st, q, colsum, work)
+            hip.fp8_quantize_colsum(kind, x, rows, C, C, st, q, colsum, work,
+                                    row_scale=row_scale[0] if row_scale else None, rows_per_sample=row_scale[1] if row_scale else 0)
             return q, st, True
+        assert row_scale is None, "a row-scaled operand needs the fused pass (checked by the caller)"
         hip.fp8_quantize(self.d, kind, x, n, st, q)
         return q, st, False
+
+    def _fp8_colsum_ok(self, x: torch.Tensor) -> bool:
+        return x.dim() == 2 and x.shape[1] % 512 == 0 and x.is_contiguous() and self.T == torch.bfloat16
 
     def _fp8_produce(self, key: Optional[str], shape, kind: int):
         """Second output of an fp8 GEMM: (buffer, state, kind) for the site `key` that will consume this tensor as its fp8
@@ -424,6 +429,11 @@ class HipEngine:
 
     def colsum2d(self, x, out, rows, C_, ld):
         """Column sums over many rows (bias / position-embedding gradients), ordered two-stage sum when rows span blocks."""
+        if _DET_WGRAD and self.T == torch.bfloat16 and C_ % 512 == 0 and ld % 8 == 0 and rows >= 1024:
+            # wide bf16 matrices: the 16-bytes-per-thread column-sum pass (the fp8 path's kernel without its quantisation)
+            work = self.ws.at_least("colsum.part." + self._stream_tag(), hip.fp8_quantize_colsum_workspace(rows, C_), torch.float32)
+            hip.fp8_quantize_colsum(0, x, rows, C_, ld, None, None, out, work)
+            return
         work = None
         if _DET_WGRAD and rows > 256:
             work = self.ws.at_least("colsum.part." + self._stream_tag(), 256 * C_, torch.float32)
@@ -705,8 +715,10 @@ class HipEngine:
         return dx
 
     # ------------------------------------------------------------------ transformer ops ----
-    def linear(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool, add: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """y = x @ W^T + b (+ add); x: [M, K] in the compute dtype."""
+    def linear(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool, add: Optional[torch.Tensor] = None,
+               row_scale=None) -> torch.Tensor:
+        """y = x @ W^T + b (+ add); x: [M, K] in the compute dtype.  row_scale = (per-sample scale [B], rows per sample), with
+        add: y = add + scale[m // rows] * (x @ W^T + b) — in the fp8 GEMM's epilogue, a second pass otherwise."""
         M, K = x.shape
         N = lin.weight.shape[0]
         y = self.ws.get(key + ".y", (M, N), self.T)
@@ -715,12 +727,19 @@ class HipEngine:
             xq, sx, _ = self._fp8_operand(key + ".f8x", x, hip.E4M3)
             wq, _, sw = self._f8w[id(lin.weight)]
             hip.gemm_fp8(0, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, add=add,
-                         ldadd=N if add is not None else 0)
+                         ldadd=N if add is not None else 0, row_scale=row_scale[0] if row_scale else None,
+                         rows_per_sample=row_scale[1] if row_scale else 0)
             if train:
                 self.saved[key] = dict(x=x, lin=lin, xq=xq, sx=sx)
             return y
-        hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
-                      bias=bias, add=add, ldadd=N if add is not None else 0)
+        if row_scale is not None:
+            hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N, bias=bias)
+            out = self.ws.get(key + ".ys", (M, N), self.T)
+            hip.scale_rows(self.d, y, add, out, row_scale[0], M // row_scale[1], row_scale[1] * N)
+            y = out
+        else:
+            hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
+                          bias=bias, add=add, ldadd=N if add is not None else 0)
         if train:
             self.saved[key] = dict(x=x, lin=lin)
         return y
@@ -751,18 +770,32 @@ class HipEngine:
         self.on_side(lambda: self.wgrad(g, x, a.grad_flat(lin.weight), N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, lddy=N,
                                         dbias=dbias))
 
-    def linear_backward(self, key: str, g: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None):
+    def _branch_gradient(self, sv, lin, g: torch.Tensor, g_scale, M: int, K: int, N: int, slot: str):
+        """g_scale = (per-sample scale, rows per sample) of a stochastic-depth branch: the gradient that enters the Linear is
+        scale[m // rows] * g.  Returns (g, row_scale): either the scaled tensor materialised in bf16 (row_scale None), or g itself
+        with the scale handed on to the fused fp8 quantise + column-sum pass (no bf16 copy of the branch gradient at all)."""
+        if g_scale is None:
+            return g, None
+        if (self._fp8_linear_ok(lin, M) and lin.bias is not None and self._fp8_wgrad_ok(sv, M, K, N) and self._fp8_colsum_ok(g)
+                and _FP8_FUSED_QUANT):
+            return g, g_scale
+        dx = self.scratch(slot, g.shape)
+        hip.scale_rows(self.d, g, None, dx, g_scale[0], M // g_scale[1], g_scale[1] * g.shape[1])
+        return dx, None
+
+    def linear_backward(self, key: str, g: torch.Tensor, slot: Optional[str], add: Optional[torch.Tensor] = None, g_scale=None):
         sv = self.saved[key]
         x, lin = sv["x"], sv["lin"]
         M, K = x.shape
         N = lin.weight.shape[0]
         fp8 = self._fp8_linear_ok(lin, M)
+        g, rsc = self._branch_gradient(sv, lin, g, g_scale, M, K, N, "gs_" + key.rsplit(".", 1)[-1])   # (read later by the side stream)
         gq = sg = None
         bias_done = False
         if fp8 and (slot is not None or (_FP8_WGRAD and sv.get("xq") is not None)):
             # one e5m2 copy serves the data and the weight gradient; the pass that makes it also sums the columns (bias gradient)
             want = self.arena.grad_flat(lin.bias) if (lin.bias is not None and self._fp8_wgrad_ok(sv, M, K, N)) else None
-            gq, sg, bias_done = self._fp8_operand(key + ".f8g", g, hip.E5M2, colsum=want)
+            gq, sg, bias_done = self._fp8_operand(key + ".f8g", g, hip.E5M2, colsum=want, row_scale=rsc)
         self._linear_wgrad(sv, g, gq, sg, bias_done)
         if slot is None:
             return None
@@ -799,7 +832,7 @@ class HipEngine:
         return u
 
     def linear_backward_through_relu6(self, key_next: str, key_act: str, g: torch.Tensor, slot: str,
-                                      q_for: Optional[str] = None) -> torch.Tensor:
+                                      q_for: Optional[str] = None, g_scale=None) -> torch.Tensor:
         """For u = relu6(pre), y = u @ W2^T + b2: weight/bias gradient of W2 (side stream) and d_pre = (g @ W2) masked by
         0 < u < 6 in one GEMM epilogue."""
         sv = self.saved[key_next]
@@ -807,11 +840,12 @@ class HipEngine:
         M, K = x.shape
         N = lin.weight.shape[0]
         fp8 = self._fp8_linear_ok(lin, M)
+        g, rsc = self._branch_gradient(sv, lin, g, g_scale, M, K, N, "gs_" + key_next.rsplit(".", 1)[-1])
         gq = sg = None
         bias_done = False
         if fp8:
             want = self.arena.grad_flat(lin.bias) if (lin.bias is not None and self._fp8_wgrad_ok(sv, M, K, N)) else None
-            gq, sg, bias_done = self._fp8_operand(key_next + ".f8g", g, hip.E5M2, colsum=want)
+            gq, sg, bias_done = self._fp8_operand(key_next + ".f8g", g, hip.E5M2, colsum=want, row_scale=rsc)
         self._linear_wgrad(sv, g, gq, sg, bias_done)
         d_pre = self.scratch(slot, (M, K))
         if fp8:
@@ -920,6 +954,22 @@ class HipEngine:
         dx = self.scratch(slot, x.shape)
         hip.relu6(self.d, x, g, dx, x.numel())
         return dx
+
+    def drop_path_scale(self, key: str, p: float, samples: int) -> torch.Tensor:
+        """The per-sample factor keep[b] / (1 - p) of one stochastic-depth site (kept for the backward pass)."""
+        ones = self.ws.get("droppath.ones", (samples,), torch.float32)
+        hip.host_op(lambda: ones.fill_(1.0))
+        scale = self.ws.get(key + ".scale", (samples,), torch.float32)
+        mask = self.ws.get(key + ".mask", (samples,), torch.uint8)
+        seed = hip.fresh_seed()
+        hip.dropout(hip.F32, False, ones, None, scale, mask, samples, p, seed)       # scale[b] = keep / (1 - p)
+        self.saved[key] = dict(scale=scale, samples=samples)
+        return scale
+
+    def drop_path_gscale(self, key: str, rows: int):
+        """(scale, rows per sample) of the stochastic-depth site `key` for the backward pass; None when it was inactive."""
+        sv = self.saved.get(key)
+        return None if sv is None else (sv["scale"], rows // sv["samples"])
 
     def drop_path(self, key: str, x: torch.Tensor, p: float, train: bool, samples: int, add: torch.Tensor) -> torch.Tensor:
         """Stochastic depth on a residual branch: y = add + x * keep[b] / (1 - p), one Bernoulli(1 - p) draw per sample

@@ -137,8 +137,8 @@ class HipUnicomViT(_ParamOnly):
             h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train)
             qkv = eng.linear(f"b{i}.qkv", h, at.qkv, train)
             o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train)
-            if dp > 0:
-                x = eng.drop_path(f"b{i}.dp1", eng.linear(f"b{i}.proj", o, at.proj, train), dp, train, B, add=x)
+            if dp > 0:     # y = x + keep[b] / (1 - p) * proj(o): the per-sample scale rides in the GEMM call
+                x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x, row_scale=(eng.drop_path_scale(f"b{i}.dp1", dp, B), T))
             else:
                 x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x)
             h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train)
@@ -147,7 +147,7 @@ class HipUnicomViT(_ParamOnly):
             else:
                 u = eng.relu6(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train)
             if dp > 0:
-                x = eng.drop_path(f"b{i}.dp2", eng.linear(f"b{i}.fc2", u, mlp.fc2, train), dp, train, B, add=x)
+                x = eng.linear(f"b{i}.fc2", u, mlp.fc2, train, add=x, row_scale=(eng.drop_path_scale(f"b{i}.dp2", dp, B), T))
             else:
                 x = eng.linear(f"b{i}.fc2", u, mlp.fc2, train, add=x)
         y = eng.layernorm("norm", x, self.norm, train)                      # every token feeds the feature head
@@ -177,15 +177,15 @@ class HipUnicomViT(_ParamOnly):
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
             eng.begin_block(i)
-            g2 = eng.drop_path_backward(f"b{i}.dp2", gx, "g2")              # branch gradient; the residual path keeps gx
+            gs2 = eng.drop_path_gscale(f"b{i}.dp2", M)                       # branch gradient = scale * gx; the residual path keeps gx
             if _FUSED_RELU6:
-                d_a = eng.linear_backward_through_relu6(f"b{i}.fc2", f"b{i}.fc1", g2, "da", q_for=f"b{i}.fc1.f8g")
+                d_a = eng.linear_backward_through_relu6(f"b{i}.fc2", f"b{i}.fc1", gx, "da", q_for=f"b{i}.fc1.f8g", g_scale=gs2)
             else:
-                d_u = eng.linear_backward(f"b{i}.fc2", g2, "du")
+                d_u = eng.linear_backward(f"b{i}.fc2", gx, "du", g_scale=gs2)
                 d_a = eng.relu6_backward(f"b{i}.act", d_u, "da")
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
             gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
-            d_o = eng.linear_backward(f"b{i}.proj", eng.drop_path_backward(f"b{i}.dp1", gmid, "g1"), "do")
+            d_o = eng.linear_backward(f"b{i}.proj", gmid, "do", g_scale=eng.drop_path_gscale(f"b{i}.dp1", M))
             d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv")
             d_h = eng.linear_backward(f"b{i}.qkv", d_qkv, "dh")
             gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid)

@@ -1223,6 +1223,15 @@ def test_gemm_fp8_matches_product_of_rounded_operands(shape, mode):
         hip.gemm_fp8(mode, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], **kw)
         torch.cuda.synchronize()
         torch.testing.assert_close(y.float().cpu(), fn(ref).float(), rtol=1e-2, atol=1e-2)
+    # stochastic depth in the epilogue: y = add + scale[m // rows_per_sample] * (product + bias)
+    rps = 50 if M % 50 == 0 else (64 if M % 64 == 0 else 1)
+    rsc = (torch.rand(M // rps) > 0.3).float() / 0.7
+    y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    hip.gemm_fp8(mode, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias.to(DEV), add=add.to(DEV), ldadd=N,
+                 row_scale=rsc.to(DEV), rows_per_sample=rps)
+    torch.cuda.synchronize()
+    want = ((ref + bias.double()) * rsc.double().repeat_interleave(rps)[:, None] + add.double()).float()
+    torch.testing.assert_close(y.float().cpu(), want, rtol=1e-2, atol=1e-2)
     # the fused second output: the fp8 copy of y (and its amax) that a separate nkb_fp8_quantize pass over y would produce
     for qk, kw in [(hip.E4M3, dict(relu=2, bias=bias.to(DEV))), (hip.E5M2, dict(aux=u6.to(DEV), aux_mode=1)), (hip.E4M3, dict(add=add.to(DEV), ldadd=N))]:
         y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
@@ -1306,3 +1315,22 @@ def test_fp8_quantize_colsum_matches_the_two_separate_passes(shape, kind):
     want = x.double().sum(0) + 2.5
     torch.testing.assert_close(outs[0][1].double().cpu(), want.cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(rows))
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    # column sums only (no fp8 output)
+    col = torch.zeros(C, device=DEV)
+    hip.fp8_quantize_colsum(k, x, rows, C, C, None, None, col, work)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(col.double().cpu(), x.double().sum(0).cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(rows))
+    # with a per-sample row scale: the matrix quantised and summed is scale[row // rows_per_sample] * x
+    rps = 8 if rows % 8 == 0 else 1
+    sc = (torch.rand(rows // rps, device=DEV) > 0.25).float() / 0.75
+    xs = x.float() * sc.repeat_interleave(rps)[:, None]
+    st = torch.tensor([7.0, 1.0 / 7.0, 0.0], device=DEV)
+    q = torch.empty(rows, C, device=DEV, dtype=torch.uint8)
+    col = torch.zeros(C, device=DEV)
+    hip.fp8_quantize_colsum(k, x, rows, C, C, st, q, col, work, row_scale=sc, rows_per_sample=rps)
+    st3 = torch.tensor([7.0, 1.0 / 7.0, 0.0], device=DEV)
+    q3 = torch.empty_like(q)
+    hip.fp8_quantize(hip.F32, k, xs.contiguous(), xs.numel(), st3, q3)
+    torch.cuda.synchronize()
+    assert torch.equal(q, q3) and st[2].item() == st3[2].item()
+    torch.testing.assert_close(col.double().cpu(), xs.double().sum(0).cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(rows))
