@@ -177,7 +177,9 @@ int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const floa
 int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
                   const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
                   long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps, float* workspace,
-                  nkb_stream_t stream);
+                  void* yq, float* q_state, int q_kind, nkb_stream_t stream);
+/* (yq / q_state / q_kind, forward only, optional: an fp8 copy of the output rows — packed [rows][D] bytes, scale q_state[0], amax
+ * into q_state[2], kind as in nkb_fp8_quantize — for the fp8 GEMM that consumes the normalised rows; D % 256 == 0, out_stride == D.) */
 size_t nkb_layernorm_workspace_floats(int D); /* backward: optional scratch for the deterministic dgamma/dbeta reduction */
 /* exact-erf GELU: dy == NULL -> out = gelu(x); else out = dy * gelu'(x) */
 /* forward that also stores gelu'(x) (timm Mlp.act, backward then is the act-4 epilogue of nkb_linear_gelu) */
@@ -286,7 +288,8 @@ int nkb_fp8_quantize_colsum(int kind, const void* src, long long rows, int C, lo
 int nkb_fp8_scale_update(float* state, int kind, nkb_stream_t stream);
 /* Many tensors in one launch (a model's weight matrices): jobs = device array of njobs x 6 int64 {src (bf16), dst (bytes),
  * n (multiple of 8), state (3 floats), kind, first block}; blocks per job from nkb_fp8_job_blocks(n).  pass 0: amax only;
- * 1: quantise with state[0] (+ amax); 2: scale from amax; 3: amax <- 0. */
+ * 1: quantise with state[0] (+ amax); 2: scale from amax; 3: amax <- 0; 4: scale from amax, then amax <- 0 (the per-step update
+ * of delayed-scaling sites, all of them in one launch). */
 long long nkb_fp8_job_blocks(long long n);
 int nkb_fp8_multi(int pass, const long long* jobs, int njobs, long long total_blocks, nkb_stream_t stream);
 /* fp8 weight gradient: dw[Cout][Cin] += (*deq_g * *deq_x) * sum_m gq[m][cout] * xq[m][cin] with gq = the e5m2 bytes [M][ldg] the

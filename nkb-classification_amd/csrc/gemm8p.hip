@@ -871,6 +871,18 @@ __global__ void fp8_scale_update_multi_kernel(const Fp8Job* __restrict__ jobs, i
         st[0] = sc; st[1] = 1.f / sc;
     }
 }
+// delayed scaling of activation / gradient sites (one state each): scale from the amax of the previous step, amax <- 0
+__global__ void fp8_scale_step_multi_kernel(const Fp8Job* __restrict__ jobs, int njobs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= njobs) return;
+    float* st = jobs[j].state;
+    const float amax = st[2];
+    if (amax > 0.f && amax < 3.0e38f) {
+        const float sc = (jobs[j].kind == 0 ? 448.f : 57344.f) / amax;
+        st[0] = sc; st[1] = 1.f / sc;
+    }
+    st[2] = 0.f;
+}
 __global__ void fp8_amax_clear_multi_kernel(const Fp8Job* __restrict__ jobs, int njobs) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < njobs) jobs[j].state[2] = 0.f;
@@ -887,6 +899,8 @@ extern "C" int nkb_fp8_multi(int pass, const long long* jobs, int njobs, long lo
         hipLaunchKernelGGL(fp8_quantize_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, (const Fp8Job*)jobs, njobs, pass == 0);
     else if (pass == 2)
         hipLaunchKernelGGL(fp8_scale_update_multi_kernel, dim3((njobs + 255) / 256), dim3(256), 0, stream, (const Fp8Job*)jobs, njobs);
+    else if (pass == 4)
+        hipLaunchKernelGGL(fp8_scale_step_multi_kernel, dim3((njobs + 255) / 256), dim3(256), 0, stream, (const Fp8Job*)jobs, njobs);
     else
         hipLaunchKernelGGL(fp8_amax_clear_multi_kernel, dim3((njobs + 255) / 256), dim3(256), 0, stream, (const Fp8Job*)jobs, njobs);
     return nkb_check_launch("fp8_multi");

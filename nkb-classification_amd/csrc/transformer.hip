@@ -42,10 +42,16 @@ template <typename T, int VW, int NP>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long long xs, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y, long long ys,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                            float eps) {
+                                                            float eps, unsigned char* __restrict__ yq, float* __restrict__ q_state,
+                                                            int q_kind) {
     constexpr int D = 64 * VW * NP;
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
+    // optional fp8 copy of the output for the fp8 GEMM that consumes it (delayed scale q_state[0], amax into q_state[2]): the
+    // arithmetic of nkb_fp8_quantize on the stored (rounded) row, four bytes per lane and pass (VW == 4 only)
+    const float qscale = yq ? q_state[0] : 1.f;
+    const float qlim = q_kind == 0 ? 448.f : 57344.f;
+    float amax = 0.f;
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
         const T* xr = x + (size_t)row * xs;
         float v[NP][VW];
@@ -71,8 +77,33 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < VW; ++e) o[e] = (v[k][e] - mu) * rs * gamma[e0 + e] + beta[e0 + e];
             VecIO<T, VW>::st(yr + e0, o);
+            if constexpr (VW == 4) {
+                if (yq) {
+                    float q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = DT<T>::rnd(o[e]);
+                        amax = fmaxf(amax, fabsf(r));
+                        q[e] = fminf(fmaxf(r * qscale, -qlim), qlim);
+                    }
+                    unsigned w = 0u;
+                    if (q_kind == 0) { w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true); }
+                    else { w = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w, true); }
+                    *(unsigned*)(yq + (size_t)row * D + e0) = w;
+                }
+            }
         }
         if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    }
+    if (yq) {                                      // one atomic per block (non-negative floats order as unsigned integers)
+        __shared__ float red[4];
+        amax = wave_max(amax);
+        if (lane == 0) red[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            if (m > 0.f) atomicMax((unsigned*)(q_state + 2), __float_as_uint(m));
+        }
     }
 }
 
@@ -187,17 +218,18 @@ __global__ void ln_param_grad_final_kernel(const float* __restrict__ inter, int 
 template <typename T, int VW, int NP>
 static void ln_launch(int backward, int grid, hipStream_t stream, const void* in, long long in_stride, const void* x,
                       long long x_stride, const float* gamma, const float* beta, float* mean, float* rstd, const void* add,
-                      void* out, long long out_stride, float* dgamma, float* dbeta, int rows, float eps, float* part) {
+                      void* out, long long out_stride, float* dgamma, float* dbeta, int rows, float eps, float* part,
+                      unsigned char* yq, float* q_state, int q_kind) {
     if (!backward)
-        hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps);
+        hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps, yq, q_state, q_kind);
     else
         hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part);
 }
 template <typename T, int VW>
 static int ln_dispatch(int np, int backward, int grid, hipStream_t stream, const void* in, long long is, const void* x, long long xs,
                        const float* g, const float* b, float* mean, float* rstd, const void* add, void* out, long long os,
-                       float* dg, float* db, int rows, float eps, float* part) {
-#define LN_CASE(N) case N: ln_launch<T, VW, N>(backward, grid, stream, in, is, x, xs, g, b, mean, rstd, add, out, os, dg, db, rows, eps, part); return 0;
+                       float* dg, float* db, int rows, float eps, float* part, unsigned char* yq, float* qs, int qk) {
+#define LN_CASE(N) case N: ln_launch<T, VW, N>(backward, grid, stream, in, is, x, xs, g, b, mean, rstd, add, out, os, dg, db, rows, eps, part, yq, qs, qk); return 0;
     switch (np) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
 #undef LN_CASE
     return 1;
@@ -205,19 +237,25 @@ static int ln_dispatch(int np, int backward, int grid, hipStream_t stream, const
 
 extern "C" size_t nkb_layernorm_workspace_floats(int D) { return (size_t)2048 * 2 * D; }
 
+// yq / q_state / q_kind (forward, optional): fp8 copy of the output rows ([rows][D] bytes, packed) for the fp8 GEMM that
+// consumes them — see nkb_fp8_quantize; needs D % 256 == 0 and out_stride == D.
 extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
                              const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
                              long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps,
-                             float* workspace, hipStream_t stream) {
+                             float* workspace, void* yq, float* q_state, int q_kind, hipStream_t stream) {
     const int vw = (D % 256 == 0) ? 4 : 2;
     const int np = D / (64 * vw);
     if (D % 128 != 0 || np < 1 || np > 8 || in_stride % vw || x_stride % vw || out_stride % vw) {
         nkb_set_error("layernorm: D=%d must be a multiple of 128 (<= 2048) with vector-aligned strides", D);
         return 1;
     }
+    if (yq && (backward || vw != 4 || out_stride != D || !q_state || (q_kind != 0 && q_kind != 1))) {
+        nkb_set_error("layernorm: the fp8 output goes with the forward pass, D %% 256 == 0, packed rows and a scaling state");
+        return 1;
+    }
     NkbProfScope prof(NKB_K_LN, stream, 0);
     int grid = (rows + 3) / 4;
-    if (!backward) { if (grid > 256 * 16) grid = 256 * 16; }
+    if (!backward) { if (grid > (yq ? 1024 : 256 * 16)) grid = yq ? 1024 : 256 * 16; }   // (fp8 copy: one amax atomic per block)
     else if (workspace) {                                    // partials [grid][2][D] in the workspace
         // ~44 rows per block (11 per wave): fewer and the per-block column-sum epilogue dominates (32768 x 1024: 1024 blocks 78 us,
         // 768 blocks 62 us), more and the chip is under-filled (50432 x 768: 512 blocks 93 us, 1024 blocks 66 us)
@@ -229,11 +267,11 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
     else if (grid > 512) grid = 512;                         // atomics path: keep same-address contention low
     int rc;
     if (dtype == NKB_DT_BF16)
-        rc = vw == 4 ? ln_dispatch<bf16_t, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace)
-                     : ln_dispatch<bf16_t, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace);
+        rc = vw == 4 ? ln_dispatch<bf16_t, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind)
+                     : ln_dispatch<bf16_t, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind);
     else
-        rc = vw == 4 ? ln_dispatch<float, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace)
-                     : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace);
+        rc = vw == 4 ? ln_dispatch<float, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind)
+                     : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind);
     if (rc) { nkb_set_error("layernorm: unsupported D=%d", D); return 1; }
     if (backward && workspace)
     {

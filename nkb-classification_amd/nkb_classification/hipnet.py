@@ -76,6 +76,8 @@ class HipEngine:
         self._f8w: Dict[int, tuple] = {}           # id(weight) -> (e4m3 [N][K], e4m3 dgrad layout [K][N], state)
         self._f8jobs = None                        # (all jobs, forward-layout jobs only) device tables for nkb_fp8_multi
         self._f8act: Dict[str, torch.Tensor] = {}  # activation / gradient site -> scaling state {scale, 1/scale, amax}
+        self._f8kind: Dict[str, int] = {}
+        self._f8table = None                       # device table of all site states for the one-launch scale update
         self._f8ready: Dict[str, torch.Tensor] = {}  # site -> fp8 copy already written by the kernel that produced the tensor
         # recorded launch plans of the train step (hip.Plan): key -> (plan, workspace generation, saved-activation table)
         self.plans: Dict[tuple, tuple] = {}
@@ -202,12 +204,8 @@ class HipEngine:
         q = self._f8ready.pop(key, None)
         if q is not None:                           # the producing kernel wrote it (and accumulated the amax) in its epilogue
             return q, self._f8act[key], False
-        st = self._f8act.get(key)
+        st = self._fp8_state(key, kind, x)
         n = x.numel()
-        if st is None:
-            st = self._f8act[key] = torch.tensor([1.0, 1.0, 0.0], device=self.device)
-            hip.fp8_amax(self.d, x, n, st)
-        hip.fp8_scale_update(st, kind)
         q = self.ws.get(key + ".q", tuple(x.shape), torch.uint8)
         if (_FP8_COLSUM or row_scale is not None) and colsum is not None and self._fp8_colsum_ok(x):
             rows, C = x.shape
@@ -218,6 +216,28 @@ class HipEngine:
         assert row_scale is None, "a row-scaled operand needs the fused pass (checked by the caller)"
         hip.fp8_quantize(self.d, kind, x, n, st, q)
         return q, st, False
+
+    def _fp8_state(self, key: str, kind: int, x: Optional[torch.Tensor] = None):
+        """Scaling state of a delayed-scaling site.  Existing sites are updated (scale from the previous step's amax, amax <- 0)
+        all at once by fp8_begin_step(); a new site measures x just in time (or is None when there is nothing to measure yet)."""
+        st = self._f8act.get(key)
+        if st is None and x is not None:
+            st = self._f8act[key] = torch.tensor([1.0, 1.0, 0.0], device=self.device)
+            self._f8kind[key] = kind
+            self._f8table = None
+            hip.fp8_amax(self.d, x, x.numel(), st)
+            hip.fp8_scale_update(st, kind)
+        return st
+
+    def fp8_begin_step(self):
+        """One launch at the start of a forward pass: every activation / gradient site's scale from the amax its tensor showed
+        in the previous step (192 single-thread launches per unicom ViT-L/14 step otherwise)."""
+        if not (self.fp8 and self._f8act):
+            return
+        if self._f8table is None:
+            rows = [[0, 0, 0, st.data_ptr(), self._f8kind[k], 0] for k, st in self._f8act.items()]
+            self._f8table = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows))
+        hip.fp8_multi(4, self._f8table[0], self._f8table[1], 0)
 
     def _fp8_colsum_ok(self, x: torch.Tensor) -> bool:
         return x.dim() == 2 and x.shape[1] % 512 == 0 and x.is_contiguous() and self.T == torch.bfloat16
@@ -230,7 +250,6 @@ class HipEngine:
         st = self._f8act.get(key)
         if st is None:
             return None
-        hip.fp8_scale_update(st, kind)
         q = self.ws.get(key + ".q", tuple(shape), torch.uint8)
         self._f8ready[key] = q
         return q, st, kind
@@ -884,14 +903,17 @@ class HipEngine:
         return d_pre
 
     def layernorm(self, key: str, x: torch.Tensor, ln: nn.LayerNorm, train: bool, rows: Optional[int] = None,
-                  x_stride: Optional[int] = None) -> torch.Tensor:
+                  x_stride: Optional[int] = None, q_for: Optional[str] = None) -> torch.Tensor:
         D = ln.weight.shape[0]
         rows = x.shape[0] if rows is None else rows
         xs = D if x_stride is None else x_stride
         y = self.ws.get(key + ".y", (rows, D), self.T)
         st = self.ws.get(key + ".stat", (2, rows), torch.float32)
         a = self.arena
-        hip.layernorm_fwd(self.d, x, xs, a.param_flat(ln.weight), a.param_flat(ln.bias), y, D, st[0], st[1], rows, D, ln.eps)
+        # q_for: the fp8 site (consuming Linear's key + ".f8x") whose operand this kernel writes next to y
+        out = self._fp8_produce(q_for, (rows, D), hip.E4M3) if (train and self.fp8 and self.T == torch.bfloat16 and D % 256 == 0) else None
+        hip.layernorm_fwd(self.d, x, xs, a.param_flat(ln.weight), a.param_flat(ln.bias), y, D, st[0], st[1], rows, D, ln.eps,
+                          yq=out[0] if out else None, q_state=out[1] if out else None, q_kind=out[2] if out else 0)
         if train:
             self.saved[key] = dict(x=x, xs=xs, rows=rows, ln=ln, mean=st[0], rstd=st[1])
         return y

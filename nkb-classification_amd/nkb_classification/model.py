@@ -169,6 +169,7 @@ class _HipClassifier(nn.Module):
             eng.fp8 = bool(self.fp8_linear and train)
             eng._wver = -1                          # the fp8 weight copies follow the switch
         eng.refresh_weights(need_dgrad=need_dgrad)
+        eng.fp8_begin_step()
         eng.fold_key = (self.arena.version, getattr(self, "_eval_phase", 0))
         drop_p = self._classifier_dropout_p() if train else 0.0
         ctot = sum(h.out_features for h in self._heads())

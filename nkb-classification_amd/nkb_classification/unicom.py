@@ -134,14 +134,14 @@ class HipUnicomViT(_ParamOnly):
         for i, blk in enumerate(self.blocks):
             at, mlp = blk.attn, blk.mlp
             dp = self._dp(blk) if train else 0.0
-            h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train)
+            h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train, q_for=f"b{i}.qkv.f8x")
             qkv = eng.linear(f"b{i}.qkv", h, at.qkv, train)
             o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train)
             if dp > 0:     # y = x + keep[b] / (1 - p) * proj(o): the per-sample scale rides in the GEMM call
                 x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x, row_scale=(eng.drop_path_scale(f"b{i}.dp1", dp, B), T))
             else:
                 x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x)
-            h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train)
+            h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train, q_for=f"b{i}.fc1.f8x")
             if _FUSED_RELU6:
                 u = eng.linear_relu6(f"b{i}.fc1", h, mlp.fc1, train, q_for=f"b{i}.fc2.f8x")
             else:

@@ -114,14 +114,14 @@ class HipViT(_ParamOnly):
         x = eng.dropout("pos_drop", x, self.pos_drop.p, train)
         for i, blk in enumerate(self.blocks):
             at, mlp = blk.attn, blk.mlp
-            h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train)
+            h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train, q_for=f"b{i}.qkv.f8x")
             qkv = eng.linear(f"b{i}.qkv", h, at.qkv, train)
             o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train, drop_p=at.attn_drop.p)
             if train and at.proj_drop.p > 0:
                 x = eng.dropout(f"b{i}.proj_drop", eng.linear(f"b{i}.proj", o, at.proj, train), at.proj_drop.p, train, add=x)
             else:
                 x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x)
-            h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train)
+            h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train, q_for=f"b{i}.fc1.f8x")
             if _FUSED_GELU:
                 u = eng.linear_gelu(f"b{i}.fc1", h, mlp.fc1, train)        # GELU fused into the fc1 epilogue
             else:

@@ -1334,3 +1334,23 @@ def test_fp8_quantize_colsum_matches_the_two_separate_passes(shape, kind):
     torch.cuda.synchronize()
     assert torch.equal(q, q3) and st[2].item() == st3[2].item()
     torch.testing.assert_close(col.double().cpu(), xs.double().sum(0).cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(rows))
+
+
+@pytest.mark.parametrize("shape", [(1000, 768), (4099, 1024)], ids=lambda s: "%dx%d" % s)
+def test_layernorm_forward_fp8_copy_equals_separate_quantisation(shape):
+    """nkb_layernorm's optional fp8 output: the same bytes and amax as nkb_fp8_quantize over the stored bf16 rows."""
+    rows, D = shape
+    torch.manual_seed(51)
+    x = (torch.randn(rows, D) * 2 + 0.3).to(torch.bfloat16).to(DEV)
+    gamma, beta = (torch.rand(D) + 0.5).to(DEV), (torch.randn(D) * 0.1).to(DEV)
+    y = torch.empty_like(x); y2 = torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    st = torch.tensor([20.0, 0.05, 0.0], device=DEV)
+    yq = torch.full((rows, D), 0x11, device=DEV, dtype=torch.uint8)
+    hip.layernorm_fwd(hip.BF16, x, D, gamma, beta, y, D, mean, rstd, rows, D, 1e-6, yq=yq, q_state=st, q_kind=hip.E4M3)
+    hip.layernorm_fwd(hip.BF16, x, D, gamma, beta, y2, D, mean, rstd, rows, D, 1e-6)
+    st2 = torch.tensor([20.0, 0.05, 0.0], device=DEV)
+    q2 = torch.empty_like(yq)
+    hip.fp8_quantize(hip.BF16, hip.E4M3, y2, y2.numel(), st2, q2)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and torch.equal(yq, q2) and st[2].item() == st2[2].item()
