@@ -191,7 +191,7 @@ int nkb_attn_softmax(int dtype, int backward, const float* s, int lds, const voi
 /* Fused attention (bf16, head dim 64, T <= 256): O = softmax(QK^T*scale)V with per-row log-sum-exp; the backward half
  * recomputes P from Q, K, LSE and writes P and dS = P o (dP - rowsum(P o dP)) * scale as [B*H][T][ldp] bf16. */
 int nkb_attn_forward(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int dh, float scale,
-                     nkb_stream_t stream);
+                     void* outq, float* q_state, nkb_stream_t stream);
 /* dq != NULL: the same pass also forms dQ = dS K and stores it at dq[(b*T + q) * ld_dq + h*64 ..] (e.g. the Q third of the
  * d_qkv matrix, ld_dq = 3*H*64), so that only dV = P^T dO and dK = dS^T Q remain as separate GEMMs. */
 int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout, const float* lse, void* P, void* dS, int ldp, int B,
@@ -200,7 +200,9 @@ int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout, const flo
  * ([B*T][3*H*64], same layout as qkv).  Reads qkv, dout, the forward output `out` (for delta = rowsum(dout o out)) and lse;
  * no score matrix reaches memory (bf16, head dim 64, T <= 256). */
 int nkb_attn_backward(int dtype, const void* qkv, const void* dout, const void* out, const float* lse, void* dqkv, int B, int T,
-                      int H, int dh, float scale, nkb_stream_t stream);
+                      int H, int dh, float scale, void* dqkv_q, float* q_state, nkb_stream_t stream);
+/* (outq / dqkv_q with q_state, optional: fp8 copies of the outputs — e4m3 of `out`, e5m2 of `dqkv`, packed rows, scale q_state[0],
+ * amax into q_state[2] as nkb_fp8_quantize would — for the fp8 projection / qkv-gradient GEMMs that consume them.) */
 int nkb_head_transpose(int dtype, const void* in, int ld_in, long long sio, long long sii, int outer, int inner, void* out,
                        int T, int dh, int ldt, nkb_stream_t stream);
 /* token assembly: forward x[b][t] = (t == 0 ? cls : tok[b][t-1]) + pos[t]; cls == NULL (unicom layout, no class token):

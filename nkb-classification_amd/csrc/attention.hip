@@ -69,10 +69,42 @@ __device__ __forceinline__ void score_tile(const unsigned char* rows_img, const 
 __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
 __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
 
+// Optional fp8 copy of an output row segment (the operand of the fp8 GEMM that consumes it: the projection after the forward
+// pass, the qkv data / weight gradient after the backward pass): the four stored bf16 values re-scaled with the consumer site's
+// delayed scale and converted — nkb_fp8_quantize's arithmetic; the running max of |bf16| bit patterns (they order as unsigned
+// integers) costs one register as a packed pair.
+typedef unsigned short attn_u16x2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__device__ __forceinline__ void store_q4(unsigned char* dst, u32x2 pk, float qscale, attn_u16x2& amax2) {
+    constexpr float lim = KIND == 0 ? 448.f : 57344.f;
+    float q[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        amax2 = __builtin_elementwise_max(amax2, __builtin_bit_cast(attn_u16x2, pk[e] & 0x7fff7fffu));
+        q[2 * e] = fminf(fmaxf(__uint_as_float(pk[e] << 16) * qscale, -lim), lim);
+        q[2 * e + 1] = fminf(fmaxf(__uint_as_float(pk[e] & 0xffff0000u) * qscale, -lim), lim);
+    }
+    unsigned w = 0u;
+    if constexpr (KIND == 0) { w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true); }
+    else { w = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w, true); }
+    *(unsigned*)dst = w;
+}
+// one atomicMax per workgroup into q_state[2] (called by every thread of the block)
+__device__ __forceinline__ void publish_amax(attn_u16x2 amax2, float* q_state) {
+    __shared__ unsigned amax_word;
+    if (threadIdx.x == 0) amax_word = 0u;
+    __syncthreads();
+    const float m = wave_max(__uint_as_float((unsigned)(amax2[0] > amax2[1] ? amax2[0] : amax2[1]) << 16));
+    if ((threadIdx.x & 63) == 0) atomicMax(&amax_word, __float_as_uint(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && amax_word) atomicMax((unsigned*)(q_state + 2), amax_word);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NKB>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                          float* __restrict__ lse, int T, int H, float scale) {
+                                                          float* __restrict__ lse, int T, int H, float scale,
+                                                          unsigned char* __restrict__ outq, float* __restrict__ q_state) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TK = NKB * 16, NKS = (NKB + 1) / 2;   // 32-key steps of the P*V product
     const int D = H * DH;
@@ -89,6 +121,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
     __syncthreads();
 
     const float sl2 = scale * 1.4426950408889634f;   // exp(x) = exp2(x log2 e): the hardware exponential is base 2
+    const float qscale = outq ? q_state[0] : 1.f;
+    attn_u16x2 amax2 = {0, 0};
     for (int qb = wave; qb * 16 < T; qb += 8) {            // 8 waves per workgroup, 2 workgroups per CU: 4 waves per SIMD
         const int q = qb * 16 + fr;
         f32x4 acc[NKB];
@@ -145,10 +179,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
         if (q < T) {
             bf16_t* orow = out + ((size_t)b * T + q) * D + h * DH;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *(u32x2*)(orow + 16 * i + 4 * g) = (u32x2){pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
+            for (int i = 0; i < 4; ++i) {
+                const u32x2 pk = {pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
+                *(u32x2*)(orow + 16 * i + 4 * g) = pk;
+                if (outq) store_q4<0>(outq + ((size_t)b * T + q) * D + h * DH + 16 * i + 4 * g, pk, qscale, amax2);
+            }
         }
     }
+    if (outq) publish_amax(amax2, q_state);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -267,9 +305,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(const bf16_t* __res
 template <int NKB>
 __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
-    const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+    const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int T, int H, float scale,
+    unsigned char* __restrict__ dqkv_q, float* __restrict__ q_state) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NKS = (NKB + 1) / 2, ROWS = NKS * 32, IMG = ROWS * 128;
+    const float qscale = dqkv_q ? q_state[0] : 1.f;
+    attn_u16x2 amax2 = {0, 0};
     constexpr int NT = NKB_ATTN_BWD_THREADS, NW = NT / 64;
     constexpr int IT = (ROWS * 8 + NT - 1) / NT;
     const int D = H * DH;
@@ -376,8 +417,11 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
         if (q < T) {
             bf16_t* orow = dqkv + ((size_t)b * T + q) * rs + h * DH;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *(u32x2*)(orow + 16 * i + 4 * g) = (u32x2){pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
+            for (int i = 0; i < 4; ++i) {
+                const u32x2 pk = {pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
+                *(u32x2*)(orow + 16 * i + 4 * g) = pk;
+                if (dqkv_q) store_q4<1>(dqkv_q + ((size_t)b * T + q) * rs + h * DH + 16 * i + 4 * g, pk, qscale, amax2);
+            }
         }
     }
 
@@ -423,17 +467,27 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
             bf16_t* krow = dqkv + ((size_t)b * T + key) * rs + D + h * DH;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *(u32x2*)(krow + 16 * i + 4 * g) = (u32x2){pack_bf2(ok[i][0], ok[i][1]), pack_bf2(ok[i][2], ok[i][3])};
-                *(u32x2*)(krow + D + 16 * i + 4 * g) = (u32x2){pack_bf2(ov[i][0], ov[i][1]), pack_bf2(ov[i][2], ov[i][3])};
+                const u32x2 pkk = {pack_bf2(ok[i][0], ok[i][1]), pack_bf2(ok[i][2], ok[i][3])};
+                const u32x2 pkv = {pack_bf2(ov[i][0], ov[i][1]), pack_bf2(ov[i][2], ov[i][3])};
+                *(u32x2*)(krow + 16 * i + 4 * g) = pkk;
+                *(u32x2*)(krow + D + 16 * i + 4 * g) = pkv;
+                if (dqkv_q) {
+                    unsigned char* kq = dqkv_q + ((size_t)b * T + key) * rs + D + h * DH + 16 * i + 4 * g;
+                    store_q4<1>(kq, pkk, qscale, amax2);
+                    store_q4<1>(kq + D, pkv, qscale, amax2);
+                }
             }
         }
     }
+    if (dqkv_q) publish_amax(amax2, q_state);
 }
 
 }  // namespace
 
+// outq / q_state (optional): e4m3 copy of out ([B*T][H*dh] bytes; scale q_state[0], amax into q_state[2]) for an fp8 projection
 extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int dh, float scale,
-                                hipStream_t stream) {
+                                void* outq, float* q_state, hipStream_t stream) {
+    if (outq && !q_state) { nkb_set_error("attn_forward: the fp8 output needs its scaling state"); return 1; }
     if (dtype != NKB_DT_BF16 || dh != DH || T > 16 * MAXKB || T < 1) {
         nkb_set_error("attn_forward: fused path needs bf16, head dim 64, T <= 256 (got dtype %d, dh %d, T %d)", dtype, dh, T);
         return 1;
@@ -445,7 +499,7 @@ extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* ls
     case N: {                                                                                                                \
         static bool attr = false;                                                                                            \
         if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024); attr = true; } \
-        hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * H), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale); \
+        hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * H), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale, (unsigned char*)outq, q_state); \
         break;                                                                                                               \
     }
     switch (nkb) {
@@ -483,8 +537,10 @@ extern "C" int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout
     return nkb_check_launch("attn_backward_ds");
 }
 
+// dqkv_q / q_state (optional): e5m2 copy of dqkv ([B*T][3*H*dh] bytes) for the fp8 data / weight gradient of the qkv projection
 extern "C" int nkb_attn_backward(int dtype, const void* qkv, const void* dout, const void* out, const float* lse, void* dqkv,
-                                 int B, int T, int H, int dh, float scale, hipStream_t stream) {
+                                 int B, int T, int H, int dh, float scale, void* dqkv_q, float* q_state, hipStream_t stream) {
+    if (dqkv_q && !q_state) { nkb_set_error("attn_backward: the fp8 output needs its scaling state"); return 1; }
     if (dtype != NKB_DT_BF16 || dh != DH || T > 16 * MAXKB || T < 1) {
         nkb_set_error("attn_backward: fused path needs bf16, head dim 64, T <= 256 (got dtype %d, dh %d, T %d)", dtype, dh, T);
         return 1;
@@ -497,7 +553,7 @@ extern "C" int nkb_attn_backward(int dtype, const void* qkv, const void* dout, c
         static bool attr = false;                                                                                            \
         if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024); attr = true; } \
         hipLaunchKernelGGL(attn_bwd_fused_kernel<N>, dim3(B * H), dim3(NKB_ATTN_BWD_THREADS), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)out, lse, \
-                           (bf16_t*)dqkv, T, H, scale);                                                                      \
+                           (bf16_t*)dqkv, T, H, scale, (unsigned char*)dqkv_q, q_state);                                     \
         break;                                                                                                               \
     }
     switch (nkb) {

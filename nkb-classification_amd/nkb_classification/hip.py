@@ -66,9 +66,9 @@ _SIGS = {
     "nkb_gelu_fwd_dgelu": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_scale_rows": (i32, [i32, vp, vp, vp, vp, i32, i64, vp]),
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
-    "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "nkb_attn_backward_ds": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, i64, vp]),
-    "nkb_attn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "nkb_attn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "nkb_head_transpose": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, i32, i32, i32, vp]),
     "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_dropout": (i32, [i32, i32, vp, vp, vp, vp, i64, f32, C.c_ulonglong, vp]),
@@ -628,13 +628,16 @@ def dropout(dtype, backward, src, add, out, mask, n, p, seed=0):
     check(load().nkb_dropout(dtype, int(backward), ptr(src), ptr(add), ptr(out), ptr(mask), n, p, seed, stream()), "dropout")
 
 
-def attn_forward(dtype, qkv, out, lse, B, T, H, dh, scale):
-    check(load().nkb_attn_forward(dtype, ptr(qkv), ptr(out), ptr(lse), B, T, H, dh, scale, stream()), "attn_forward")
+def attn_forward(dtype, qkv, out, lse, B, T, H, dh, scale, outq=None, q_state=None):
+    """outq / q_state: optional e4m3 copy of out for an fp8 projection (see fp8_quantize)."""
+    check(load().nkb_attn_forward(dtype, ptr(qkv), ptr(out), ptr(lse), B, T, H, dh, scale, ptr(outq), ptr(q_state), stream()),
+          "attn_forward")
 
 
-def attn_backward(dtype, qkv, dout, out, lse, dqkv, B, T, H, dh, scale):
-    check(load().nkb_attn_backward(dtype, ptr(qkv), ptr(dout), ptr(out), ptr(lse), ptr(dqkv), B, T, H, dh, scale, stream()),
-          "attn_backward")
+def attn_backward(dtype, qkv, dout, out, lse, dqkv, B, T, H, dh, scale, dqkv_q=None, q_state=None):
+    """dqkv_q / q_state: optional e5m2 copy of dqkv for the fp8 qkv gradients."""
+    check(load().nkb_attn_backward(dtype, ptr(qkv), ptr(dout), ptr(out), ptr(lse), ptr(dqkv), B, T, H, dh, scale, ptr(dqkv_q),
+                                   ptr(q_state), stream()), "attn_backward")
 
 
 def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale, dq=None, ld_dq=0):

@@ -1042,7 +1042,8 @@ class HipEngine:
         hip.dropout(hip.dt(g.dtype), True, g, None, dx, sv["mask"], g.numel(), sv["p"], 0)
         return dx
 
-    def attention(self, key: str, qkv: torch.Tensor, B: int, T: int, H: int, train: bool, drop_p: float = 0.0) -> torch.Tensor:
+    def attention(self, key: str, qkv: torch.Tensor, B: int, T: int, H: int, train: bool, drop_p: float = 0.0,
+                  q_for: Optional[str] = None) -> torch.Tensor:
         """softmax(q k^T / sqrt(dh)) v over all (image, head) pairs; qkv: [B*T, 3*D] laid out [which][head][dh].
         drop_p: attention-probability dropout (timm Attention.attn_drop); active dropout takes the materialised path."""
         D = qkv.shape[1] // 3
@@ -1053,7 +1054,9 @@ class HipEngine:
             # fused kernel: scores and probabilities never reach HBM; only the per-row log-sum-exp is kept
             o = self.ws.get(key + ".o", (B * T, D), self.T)
             lse = self.ws.get(key + ".lse", (B * H, T), torch.float32)
-            hip.attn_forward(self.d, qkv, o, lse, B, T, H, dh, dh ** -0.5)
+            out = self._fp8_produce(q_for, (B * T, D), hip.E4M3) if (train and self.fp8) else None    # the projection's fp8 operand
+            hip.attn_forward(self.d, qkv, o, lse, B, T, H, dh, dh ** -0.5, outq=out[0] if out else None,
+                             q_state=out[1] if out else None)
             if train:
                 self.saved[key] = dict(qkv=qkv, lse=lse, o=o, B=B, T=T, H=H, fused=True)
             return o
@@ -1073,7 +1076,7 @@ class HipEngine:
             self.saved[key] = dict(qkv=qkv, P=P, Pd=Pd, B=B, T=T, H=H, drop=attn_drop)
         return o
 
-    def attention_backward(self, key: str, d_o: torch.Tensor, slot: str) -> torch.Tensor:
+    def attention_backward(self, key: str, d_o: torch.Tensor, slot: str, q_for: Optional[str] = None) -> torch.Tensor:
         sv = self.saved[key]
         qkv, B, T, H = sv["qkv"], sv["B"], sv["T"], sv["H"]
         D = qkv.shape[1] // 3
@@ -1085,7 +1088,9 @@ class HipEngine:
         sq, sp, so = (T * 3 * D, dh), (H * T * Tp, T * Tp), (T * D, dh)
         if sv.get("fused") and _ATTN_FUSED_BWD:
             # dQ, dK, dV in one kernel per layer: P and dS never reach HBM
-            hip.attn_backward(self.d, qkv, d_o, sv["o"], sv["lse"], dqkv, B, T, H, dh, dh ** -0.5)
+            out = self._fp8_produce(q_for, tuple(qkv.shape), hip.E5M2) if self.fp8 else None       # the qkv gradients' fp8 operand
+            hip.attn_backward(self.d, qkv, d_o, sv["o"], sv["lse"], dqkv, B, T, H, dh, dh ** -0.5,
+                              dqkv_q=out[0] if out else None, q_state=out[1] if out else None)
             return dqkv
         if sv.get("fused"):
             # P and dS are recomputed in one pass (pad columns beyond roundup(T,16) stay zero from allocation)

@@ -136,7 +136,7 @@ class HipUnicomViT(_ParamOnly):
             dp = self._dp(blk) if train else 0.0
             h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train, q_for=f"b{i}.qkv.f8x")
             qkv = eng.linear(f"b{i}.qkv", h, at.qkv, train)
-            o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train)
+            o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train, q_for=f"b{i}.proj.f8x")
             if dp > 0:     # y = x + keep[b] / (1 - p) * proj(o): the per-sample scale rides in the GEMM call
                 x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x, row_scale=(eng.drop_path_scale(f"b{i}.dp1", dp, B), T))
             else:
@@ -186,7 +186,7 @@ class HipUnicomViT(_ParamOnly):
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
             gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
             d_o = eng.linear_backward(f"b{i}.proj", gmid, "do", g_scale=eng.drop_path_gscale(f"b{i}.dp1", M))
-            d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv")
+            d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv", q_for=f"b{i}.qkv.f8g")
             d_h = eng.linear_backward(f"b{i}.qkv", d_qkv, "dh")
             gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid)
             flip ^= 1

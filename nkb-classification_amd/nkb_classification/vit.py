@@ -116,7 +116,7 @@ class HipViT(_ParamOnly):
             at, mlp = blk.attn, blk.mlp
             h = eng.layernorm(f"b{i}.ln1", x, blk.norm1, train, q_for=f"b{i}.qkv.f8x")
             qkv = eng.linear(f"b{i}.qkv", h, at.qkv, train)
-            o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train, drop_p=at.attn_drop.p)
+            o = eng.attention(f"b{i}.attn", qkv, B, T, self.heads, train, drop_p=at.attn_drop.p, q_for=f"b{i}.proj.f8x")
             if train and at.proj_drop.p > 0:
                 x = eng.dropout(f"b{i}.proj_drop", eng.linear(f"b{i}.proj", o, at.proj, train), at.proj_drop.p, train, add=x)
             else:
@@ -164,7 +164,7 @@ class HipViT(_ParamOnly):
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
             gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
             d_o = eng.linear_backward(f"b{i}.proj", eng.dropout_backward(f"b{i}.proj_drop", gmid, "g1"), "do")
-            d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv")
+            d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv", q_for=f"b{i}.qkv.f8g")
             d_h = eng.linear_backward(f"b{i}.qkv", d_qkv, "dh")
             gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid)
             flip ^= 1

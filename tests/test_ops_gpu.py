@@ -1354,3 +1354,33 @@ def test_layernorm_forward_fp8_copy_equals_separate_quantisation(shape):
     hip.fp8_quantize(hip.BF16, hip.E4M3, y2, y2.numel(), st2, q2)
     torch.cuda.synchronize()
     assert torch.equal(y, y2) and torch.equal(yq, q2) and st[2].item() == st2[2].item()
+
+
+@pytest.mark.parametrize("T", [197, 256])
+def test_fused_attention_fp8_copies_equal_separate_quantisation(T):
+    """The optional fp8 outputs of the fused attention kernels (e4m3 of o, e5m2 of dqkv): identical bf16 results, and the same
+    bytes / amax as nkb_fp8_quantize over them."""
+    torch.manual_seed(61)
+    B, H, dh = 4, 3, 64
+    D = H * dh
+    qkv = torch.randn(B * T, 3 * D).to(torch.bfloat16).to(DEV)
+    do = torch.randn(B * T, D).to(torch.bfloat16).to(DEV)
+    o, o2 = torch.empty(B * T, D, device=DEV, dtype=torch.bfloat16), torch.empty(B * T, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B * H, T, device=DEV)
+    st = torch.tensor([30.0, 1 / 30.0, 0.0], device=DEV)
+    oq = torch.full((B * T, D), 0x22, device=DEV, dtype=torch.uint8)
+    hip.attn_forward(hip.BF16, qkv, o, lse, B, T, H, dh, dh ** -0.5, outq=oq, q_state=st)
+    hip.attn_forward(hip.BF16, qkv, o2, lse, B, T, H, dh, dh ** -0.5)
+    st2 = torch.tensor([30.0, 1 / 30.0, 0.0], device=DEV); q2 = torch.empty_like(oq)
+    hip.fp8_quantize(hip.BF16, hip.E4M3, o2, o2.numel(), st2, q2)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2) and torch.equal(oq, q2) and st[2].item() == st2[2].item()
+    dq, dq2 = torch.empty_like(qkv), torch.empty_like(qkv)
+    sg = torch.tensor([900.0, 1 / 900.0, 0.0], device=DEV)
+    dqq = torch.full((B * T, 3 * D), 0x33, device=DEV, dtype=torch.uint8)
+    hip.attn_backward(hip.BF16, qkv, do, o, lse, dq, B, T, H, dh, dh ** -0.5, dqkv_q=dqq, q_state=sg)
+    hip.attn_backward(hip.BF16, qkv, do, o, lse, dq2, B, T, H, dh, dh ** -0.5)
+    sg2 = torch.tensor([900.0, 1 / 900.0, 0.0], device=DEV); g2 = torch.empty_like(dqq)
+    hip.fp8_quantize(hip.BF16, hip.E5M2, dq2, dq2.numel(), sg2, g2)
+    torch.cuda.synchronize()
+    assert torch.equal(dq, dq2) and torch.equal(dqq, g2) and sg[2].item() == sg2[2].item()
