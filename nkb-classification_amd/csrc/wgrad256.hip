@@ -33,6 +33,15 @@ struct W256Params {
     long long slab;
     float* bpart;        // optional [splits][Cout] bias partial sums
     int Cout;
+    const float* deq_g = nullptr;   // fp8 kernel: dequantisation factors of dY / X (device floats)
+    const float* deq_x = nullptr;
+};
+// several problems over the same M tokens in ONE launch (the Linear layers of a transformer block): a workgroup's logical id is
+// (split, tile) over the concatenated tile lists; start[j] = first tile of problem j
+struct W256Group {
+    int njobs, total_tiles;
+    int start[5];
+    W256Params job[4];
 };
 
 __global__ __launch_bounds__(512, 1) void wgrad256_kernel(const W256Params p) {
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void wgrad256_kernel(const W256Params p) {
 #define W8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define W8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
-__global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
+__device__ __forceinline__ void wgrad8p_body(const W256Params& p, int tile, int split) {
     constexpr int SUB = 64 * 256;                 // one [64 tokens][128 channels] half-tile
     constexpr int STG = 4 * SUB;                  // X lo | X hi | dY lo | dY hi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -206,9 +215,6 @@ __global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wn = wave & 3;      // wave tile: cout [128 wr, +128) x n [64 wn, +64)
 
-    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
     const int tile_c = tile % p.tilesC, tile_n = tile / p.tilesC;
     const int c0 = tile_c * 256, n0 = tile_n * 256;
     const int m_begin = split * p.rows_per_split;
@@ -408,6 +414,20 @@ __global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
 
 
 
+__global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
+    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    wgrad8p_body(p, (int)(lid % ntile), (int)(lid / ntile));
+}
+// grouped form: consecutive logical ids = every tile of every problem for ONE token range (split), so the workgroups that share
+// dY / X rows still land on one XCD
+__global__ __launch_bounds__(512, 1) void wgrad8p_group_kernel(const W256Group g) {
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tt = (int)(lid % (unsigned)g.total_tiles), split = (int)(lid / (unsigned)g.total_tiles);
+    const int j = (tt >= g.start[1]) + (tt >= g.start[2]) + (tt >= g.start[3]);
+    wgrad8p_body(g.job[j], tt - g.start[j], split);
+}
+
 // ---- fp8 weight gradient (BASELINE configs[4]): dW[cout][n] = deq * sum_m gq[m][cout] * xq[m][n] ------------------------------
 // The eight-phase schedule of wgrad8p_kernel on one-byte operands: gq = the e5m2 copy of dY that the fp8 data gradient consumed,
 // xq = the e4m3 copy of X that the fp8 forward GEMM consumed (no extra quantisation pass), 128 tokens per stage (the same 64 KB
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
 // e = byte) for BOTH operands, so the two halves of the wave read 16 consecutive rows per instruction; with rows of 128 bytes
 // the 16-byte chunk index is XORed with (row >> 1) & 7 on the DMA source address, which makes those reads conflict-free.
 typedef int w8_i32x8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(512, 1) void wgrad8f_kernel(const W256Params p, const float* __restrict__ deq_g, const float* __restrict__ deq_x) {
+__device__ __forceinline__ void wgrad8f_body(const W256Params& p, int tile, int split) {
     constexpr int SUB = 128 * 128;                // one [128 tokens][128 channels] half-tile of bytes
     constexpr int STG = 4 * SUB;                  // X lo | X hi | dY lo | dY hi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -426,9 +446,6 @@ __global__ __launch_bounds__(512, 1) void wgrad8f_kernel(const W256Params p, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wn = wave & 3;      // wave tile: cout [128 wr, +128) x n [64 wn, +64)
 
-    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
     const int tile_c = tile % p.tilesC, tile_n = tile / p.tilesC;
     const int c0 = tile_c * 256, n0 = tile_n * 256;
     const int m_begin = split * p.rows_per_split;
@@ -561,7 +578,7 @@ __global__ __launch_bounds__(512, 1) void wgrad8f_kernel(const W256Params p, con
     if (wr == 0) W8_BARRIER();
     __syncthreads();
 
-    const float deq = *deq_g * *deq_x;
+    const float deq = *p.deq_g * *p.deq_x;
     const int q4g = lane >> 4;
     constexpr int EROW = 256 * 4 + 16;
 #pragma unroll
@@ -585,6 +602,18 @@ __global__ __launch_bounds__(512, 1) void wgrad8f_kernel(const W256Params p, con
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad8f_kernel(const W256Params p) {
+    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    wgrad8f_body(p, (int)(lid % ntile), (int)(lid / ntile));
+}
+__global__ __launch_bounds__(512, 1) void wgrad8f_group_kernel(const W256Group g) {
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tt = (int)(lid % (unsigned)g.total_tiles), split = (int)(lid / (unsigned)g.total_tiles);
+    const int j = (tt >= g.start[1]) + (tt >= g.start[2]) + (tt >= g.start[3]);
+    wgrad8f_body(g.job[j], tt - g.start[j], split);
 }
 
 }  // namespace
@@ -702,8 +731,122 @@ extern "C" int nkb_wgrad_fp8(const void* gq, const void* xq, float* dw, const fl
         attr_set = true;
     }
     NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * M * (double)Cin * Cout);
-    hipLaunchKernelGGL(wgrad8f_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p, deq_g, deq_x);
+    p.deq_g = deq_g; p.deq_x = deq_x;
+    hipLaunchKernelGGL(wgrad8f_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
     int rc = nkb_check_launch("wgrad_fp8");
     if (rc) return rc;
     return nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
+}
+
+
+// ---- grouped launch: up to four Linear weight gradients over the same M tokens in one kernel -----------------------------------
+// One launch per Linear pays its fixed costs four times per transformer block (prologue, ~450 barriers of an empty pipeline, the
+// per-split fp32 slabs: 53 us of a 210 us launch on ViT-B/16) and splits the token range 5-7 ways to fill 256 CUs with 9-36 tiles;
+// together the block's four problems have 99 (ViT-B/16) / 192 (ViT-L/14) tiles, so fewer, longer splits fill the chip.
+struct NkbWgradJob {
+    const void* dy; const void* x; float* dw; float* dbias;
+    const float* deq_g; const float* deq_x;       // fp8 form only
+    int Cin, ldx, Cout, lddy;
+};
+static int wgroup_check(int fp8, int njobs, const NkbWgradJob* jobs, int M, int* total_tiles) {
+    const int stage = fp8 ? 128 : 64, align = fp8 ? 16 : 8;
+    if (njobs < 1 || njobs > 4 || jobs == nullptr || M < 4096 || M % stage) return 1;
+    int tiles = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const NkbWgradJob& q = jobs[j];
+        if (q.Cin < 256 || q.Cout < 256 || q.Cin % 256 || q.Cout % 256 || q.ldx % align || q.lddy % align || q.ldx < q.Cin || q.lddy < q.Cout ||
+            !q.dy || !q.x || !q.dw || (fp8 && (!q.deq_g || !q.deq_x || q.dbias)))
+            return 1;
+        if ((long long)M * q.ldx >= (fp8 ? 0xFFFFFFFFll : (1ll << 31)) || (long long)M * q.lddy >= (fp8 ? 0xFFFFFFFFll : (1ll << 31))) return 1;
+        tiles += (q.Cout / 256) * (q.Cin / 256);
+    }
+    *total_tiles = tiles;
+    return 0;
+}
+// split count by a cost model: rounds of workgroups x (stages per split x time per stage + per-workgroup fixed time)
+static int wgroup_splits(int fp8, int M, int tiles) {
+    static const int forced = [] { const char* e = getenv("NKB_WGROUP_SPLITS"); return e ? atoi(e) : 0; }();
+    const int stages = M / (fp8 ? 128 : 64);
+    int cus = 256;
+    { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+    if (forced > 0) return forced < stages ? forced : stages;
+    const double per_stage = fp8 ? 1.0 : 2.1, fixed = 25.0;
+    int best = 1; double best_t = 1e30;
+    for (int s = 1; s <= 32 && s <= stages / 4; ++s) {
+        const int sps = (stages + s - 1) / s;
+        const int real = (stages + sps - 1) / sps;
+        const double rounds = (double)(((long long)tiles * real + cus - 1) / cus);
+        const double t = rounds * (sps * per_stage + fixed);
+        if (t < best_t) { best_t = t; best = real; }
+    }
+    return best;
+}
+static void wgroup_plan(int fp8, int M, int tiles, int* splits, int* rows_per_split) {
+    const int stage = fp8 ? 128 : 64, stages = M / stage;
+    const int s = wgroup_splits(fp8, M, tiles);
+    const int sps = (stages + s - 1) / s;
+    *splits = (stages + sps - 1) / sps;
+    *rows_per_split = sps * stage;
+}
+extern "C" long long nkb_wgrad_group_workspace_floats(int fp8, int njobs, const NkbWgradJob* jobs, int M) {
+    int tiles = 0;
+    if (wgroup_check(fp8, njobs, jobs, M, &tiles)) return -1;
+    int splits, rps;
+    wgroup_plan(fp8, M, tiles, &splits, &rps);
+    long long need = 0;
+    for (int j = 0; j < njobs; ++j) need += (long long)splits * ((long long)jobs[j].Cout * jobs[j].Cin + (jobs[j].dbias ? jobs[j].Cout : 0));
+    return need;
+}
+extern "C" int nkb_wgrad_group(int fp8, int njobs, const NkbWgradJob* jobs, int M, float* workspace, long long workspace_floats,
+                               hipStream_t stream) {
+    int tiles = 0;
+    if (wgroup_check(fp8, njobs, jobs, M, &tiles)) {
+        nkb_set_error("wgrad_group: 1-4 problems with Cin / Cout %% 256 == 0 over M %% %d == 0 tokens (M >= 4096), aligned rows%s", fp8 ? 128 : 64,
+                      fp8 ? ", dequantisation factors, no bias" : "");
+        return 1;
+    }
+    const long long need = nkb_wgrad_group_workspace_floats(fp8, njobs, jobs, M);
+    if (!workspace || workspace_floats < need) { nkb_set_error("wgrad_group: workspace of %lld floats needed, %lld given", need, workspace_floats); return 1; }
+    W256Group g;
+    g.njobs = njobs; g.total_tiles = tiles;
+    int splits, rps;
+    wgroup_plan(fp8, M, tiles, &splits, &rps);
+    float* wp = workspace;
+    int start = 0;
+    double flops = 0.0;
+    for (int j = 0; j < 4; ++j) {
+        g.start[j] = j < njobs ? start : 0x7fffffff;           // unused slots never match a tile id
+        if (j >= njobs) { g.job[j] = g.job[0]; continue; }
+        const NkbWgradJob& q = jobs[j];
+        W256Params& p = g.job[j];
+        p.dy = (const bf16_t*)q.dy; p.x = (const bf16_t*)q.x; p.dw = q.dw; p.dbias = q.dbias;
+        p.M = M; p.lddy = q.lddy; p.ldx = q.ldx; p.Ntot = q.Cin;
+        p.tilesC = q.Cout / 256; p.tilesN = q.Cin / 256;
+        p.splits = splits; p.rows_per_split = rps;
+        p.Cout = q.Cout; p.slab = (long long)q.Cout * q.Cin;
+        p.part = wp; wp += (size_t)splits * p.slab;
+        p.bpart = q.dbias ? wp : nullptr; if (q.dbias) wp += (size_t)splits * q.Cout;
+        p.deq_g = q.deq_g; p.deq_x = q.deq_x;
+        start += p.tilesC * p.tilesN;
+        flops += 2.0 * M * (double)q.Cout * q.Cin;
+    }
+    g.start[4] = 0x7fffffff;
+    constexpr int lds = 2 * 4 * 64 * 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad8p_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)wgrad8f_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, flops);
+    const dim3 grid((unsigned)tiles * (unsigned)splits);
+    if (fp8) hipLaunchKernelGGL(wgrad8f_group_kernel, grid, dim3(512), lds, stream, g);
+    else hipLaunchKernelGGL(wgrad8p_group_kernel, grid, dim3(512), lds, stream, g);
+    int rc = nkb_check_launch("wgrad_group");
+    for (int j = 0; j < njobs && !rc; ++j) {
+        const W256Params& p = g.job[j];
+        rc = nkb_launch_wgrad_reduce(p.part, p.slab, splits, p.dw, p.slab, stream);
+        if (!rc && p.dbias) rc = nkb_launch_wgrad_reduce(p.bpart, p.Cout, splits, p.dbias, p.Cout, stream);
+    }
+    return rc;
 }

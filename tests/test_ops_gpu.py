@@ -1384,3 +1384,56 @@ def test_fused_attention_fp8_copies_equal_separate_quantisation(T):
     hip.fp8_quantize(hip.BF16, hip.E5M2, dq2, dq2.numel(), sg2, g2)
     torch.cuda.synchronize()
     assert torch.equal(dq, dq2) and torch.equal(dqq, g2) and sg[2].item() == sg2[2].item()
+
+
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
+def test_wgrad_group_matches_the_products(fp8):
+    """nkb_wgrad_group: four Linear weight gradients (a ViT block's qkv / proj / fc1 / fc2 shapes, scaled down) over the same
+    tokens in one launch — every dW (and, in bf16, every bias gradient) against the fp64 product, accumulated into non-zero
+    gradients, identical on a second run; a group of one and the envelope errors."""
+    torch.manual_seed(71)
+    M = 4096 + 1024
+    shapes = [(256, 768), (256, 256), (256, 1024), (1024, 256)]          # (Cin, Cout)
+    jobs, refs, bases = [], [], []
+    for (K, N) in shapes:
+        x = (torch.randn(M, K) * 0.7).to(torch.bfloat16).to(DEV)
+        g = (torch.randn(M, N) * 0.05).to(torch.bfloat16).to(DEV)
+        dw0, db0 = torch.randn(N, K), torch.randn(N)
+        if fp8:
+            sx, sg = torch.tensor([1., 1., 0.], device=DEV), torch.tensor([1., 1., 0.], device=DEV)
+            hip.fp8_amax(hip.BF16, x, x.numel(), sx); hip.fp8_scale_update(sx, hip.E4M3)
+            hip.fp8_amax(hip.BF16, g, g.numel(), sg); hip.fp8_scale_update(sg, hip.E5M2)
+            xq = torch.empty(M, K, device=DEV, dtype=torch.uint8); gq = torch.empty(M, N, device=DEV, dtype=torch.uint8)
+            hip.fp8_quantize(hip.BF16, hip.E4M3, x, x.numel(), sx, xq); hip.fp8_quantize(hip.BF16, hip.E5M2, g, g.numel(), sg, gq)
+            torch.cuda.synchronize()
+            ref = (gq.cpu().view(torch.float8_e5m2).double().t() @ xq.cpu().view(torch.float8_e4m3fn).double()) * (sx[1].item() * sg[1].item())
+            jobs.append(dict(dy=gq, x=xq, dw=None, dbias=None, deq_g=sg[1:2], deq_x=sx[1:2], Cin=K, ldx=K, Cout=N, lddy=N))
+            refs.append((ref, None))
+        else:
+            jobs.append(dict(dy=g, x=x, dw=None, dbias=None, Cin=K, ldx=K, Cout=N, lddy=N))
+            refs.append((g.double().cpu().t() @ x.double().cpu(), g.double().cpu().sum(0)))
+        bases.append((dw0, db0))
+    outs = []
+    for _ in range(2):
+        dws = [b[0].clone().to(DEV) for b in bases]
+        dbs = [b[1].clone().to(DEV) for b in bases]
+        for j, dw, db in zip(jobs, dws, dbs):
+            j["dw"] = dw
+            j["dbias"] = None if fp8 else db
+        arr = hip.wgrad_jobs(jobs)
+        need = hip.wgrad_group_workspace(fp8, arr, M)
+        assert need > 0
+        work = torch.empty(need, device=DEV)
+        hip.wgrad_group(fp8, arr, M, work)
+        torch.cuda.synchronize()
+        outs.append((dws, dbs))
+    for k, ((ref, bref), (dw0, db0)) in enumerate(zip(refs, bases)):
+        assert torch.equal(outs[0][0][k], outs[1][0][k])
+        got = outs[0][0][k].double().cpu() - dw0.double()
+        assert ((got - ref).norm() / ref.norm()).item() < (2e-5 if fp8 else 2e-6), k
+        if not fp8:
+            assert torch.equal(outs[0][1][k], outs[1][1][k])
+            gb = outs[0][1][k].double().cpu() - db0.double()
+            assert ((gb - bref).norm() / bref.norm()).item() < 2e-6, k
+    one = hip.wgrad_jobs(jobs[:1])
+    assert hip.wgrad_group_workspace(fp8, one, M) > 0 and hip.wgrad_group_workspace(fp8, one, M + 32) == -1
