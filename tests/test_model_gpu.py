@@ -273,6 +273,21 @@ def test_train_py_end_to_end(tmp_path):
     assert len(lines) == 3 and "\t" in lines[0]
     sd = torch.load(exp / "weights" / "last.pth", map_location="cpu")
     assert "emb_model.layer4.1.bn2.running_var" in sd and "classifier.1.weight" in sd
+    # eval.py -cfg (the reference's eval.py:27-52): the checkpoint just written, one validation epoch, metrics.json
+    import json
+    ecfg = cfg.replace('"classifier_initialization": "kaiming_normal_"}',
+                       '"classifier_initialization": "kaiming_normal_", "checkpoint": %r}' % str(exp / "weights" / "last.pth"))
+    ecfg += "\nsave_path = %r\n" % str(tmp_path / "eval_out")
+    (tmp_path / "cfg_eval.py").write_text(ecfg)
+    r = subprocess.run([sys.executable, str(root / "eval.py"), "-cfg", str(tmp_path / "cfg_eval.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = json.loads((tmp_path / "eval_out" / "metrics.json").read_text())
+    assert "epoch_acc" in m and 0.0 <= m["epoch_acc"] <= 1.0
+    last = dict(zip(lines[0].split("\t"), lines[-1].split("\t")))          # the same validation set, the same weights
+    key = next((k for k in last if "val" in k.lower() and "acc" in k.lower() and "balanced" not in k.lower()), None)
+    if key is not None:
+        assert abs(float(last[key]) - m["epoch_acc"]) < 1e-6, (key, last[key], m["epoch_acc"])
 
 
 def _ddp_worker(rank, world, port, q, backbone="resnet_tiny_bottleneck"):
