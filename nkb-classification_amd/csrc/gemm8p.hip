@@ -55,6 +55,11 @@ struct G8Params {
     // optional per-sample scale of the GEMM result in front of the residual add (stochastic depth: y = add + s[m / rows_per_sample] * (x w^T + b))
     const float* row_scale;
     FastDiv div_rows;
+    // QOUT kernels only: ReLU6 as one bit per element instead of a bf16 tensor — mask_out[M][N / 8] (forward, relu == 2): bit e of
+    // byte (m, n / 8) = 0 < value < 6; mask_in (data gradient): the result is kept where the bit is set.  With mask_out and yq
+    // the bf16 output itself may be omitted (y == NULL): the fp8 step reads u only as fc2's fp8 operand and as this mask.
+    unsigned char* mask_out;
+    const unsigned char* mask_in;
     int aux_mode;         // 0: the result is multiplied by aux; 1: the result is kept where 0 < aux < 6 (ReLU6 backward mask)
     int align_epi;        // DIRECT: both wave groups run the epilogue side by side (NKB_G8_ALIGN, default 1)
 };
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         // reduced per wave and folded into one LDS word at the end of the epilogue, one global atomic per workgroup at the end
         [[maybe_unused]] g8_u16x2 amax2 = {0, 0};       // |bf16| bit patterns order as unsigned integers: two magnitudes per register
         const bool has_add = ADD < 0 ? p.add != nullptr : ADD != 0;
-        const int aux_kind = AUX < 0 ? (p.aux ? 1 + p.aux_mode : 0) : AUX;      // 0 none, 1 multiply, 2 ReLU6 mask (0 < aux < 6)
+        const int aux_kind = AUX < 0 ? (p.aux ? 1 + p.aux_mode : (QOUT && p.mask_in ? 3 : 0)) : AUX;   // 0 none, 1 multiply, 2 ReLU6 mask (0 < aux < 6), 3 mask bits
         const int relu = RELU < 0 ? p.relu : RELU;
         const int em0 = tile_m * 256, en0 = tile_n * 256;
         float deq = 1.f;
@@ -282,7 +287,11 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         // request half 1; only then store half 0; compute and store half 1.  No load is ever behind a store, and the plain
         // variant has no vector-memory load at all (the bias comes from LDS).  The run-time variant (edge tiles, rare
         // combinations) loads per row.
-        constexpr bool PRE = (ADD > 0) != (AUX > 0);
+        constexpr bool PRE = (ADD > 0) != (AUX > 0 && AUX < 3);
+        constexpr bool BITS = AUX == 3;                // ReLU6 mask as bits: 16 one-byte loads up front, nothing else to wait for
+        [[maybe_unused]] const unsigned mld = (unsigned)p.N >> 3;
+        [[maybe_unused]] const unsigned mo = (unsigned)lrow * mld + (unsigned)(lcol >> 3), mstep = 16u * mld;
+        [[maybe_unused]] const size_t morg = (size_t)em0 * mld + (en0 >> 3);
         // (the loads and their counted waits are inline assembly: with LDS-DMA in flight hipcc waits vmcnt(0) at the first use
         // of any load result, which for half 1 would be exactly the wait on half 0's stores this order exists to avoid)
         auto load_half = [&](int half, u32x4 (&raw)[2][4]) {
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                    "+v"(raw[1][2]), "+v"(raw[1][3])                                                                   \
                  :: "memory")
         // one (channel group, pixel block): accumulators -> the 8 packed outputs of this lane
-        auto value = [&](int pr, int j, const float (&bv)[8], u32x4 araw, u32x4 xraw) -> u32x4 {
+        auto value = [&](int pr, int j, const float (&bv)[8], u32x4 araw, u32x4 xraw, unsigned mbits = 0xffu) -> u32x4 {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -319,7 +328,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += af[e];
             }
-            if (aux_kind) {
+            if (aux_kind == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = ((mbits >> e) & 1u) ? v[e] : 0.f;
+            } else if (aux_kind) {
                 float af[8];
                 unpack8(xraw, af);
                 if (aux_kind == 1) {
@@ -336,7 +348,20 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             }
             acc[2 * pr][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[2 * pr + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            return pack8(v);
+            const u32x4 pkv = pack8(v);
+            if constexpr (QOUT) {
+                if (relu == 2 && p.mask_out) {         // ReLU6 mask of this row segment, from the STORED (bf16-rounded, clamped) values —
+                    unsigned bits = 0u;                // the same 0 < u < 6 a backward pass reading the bf16 tensor would test
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r0 = __uint_as_float(pkv[e] << 16), r1 = __uint_as_float(pkv[e] & 0xffff0000u);
+                        bits |= (r0 > 0.f && r0 < 6.f) ? (1u << (2 * e)) : 0u;
+                        bits |= (r1 > 0.f && r1 < 6.f) ? (2u << (2 * e)) : 0u;
+                    }
+                    if (FULL > 0 || em0 + lrow + 16 * j < p.M) p.mask_out[morg + (mo + j * mstep + 4 * pr)] = (unsigned char)bits;
+                }
+            }
+            return pkv;
         };
         // fp8 second output: the stored (bf16-rounded) row re-scaled and converted — the arithmetic of fp8_quantize_kernel
         [[maybe_unused]] auto quant_store = [&](u32x4 pk, int pr, int j, bool ok) {
@@ -413,6 +438,31 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     if (has_q) quant_store(out, 2 + q, j, true);
                 }
             }
+        } else if constexpr (BITS) {
+            unsigned mb[4][4];
+            const unsigned char* mb_base = p.mask_in + morg;
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("global_load_ubyte %0, %1, %2" : "=v"(mb[pr][j]) : "v"(mo + j * mstep + 4 * pr), "s"(mb_base) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(mb[0][0]), "+v"(mb[0][1]), "+v"(mb[0][2]), "+v"(mb[0][3]), "+v"(mb[1][0]), "+v"(mb[1][1]), "+v"(mb[1][2]),
+                           "+v"(mb[1][3]), "+v"(mb[2][0]), "+v"(mb[2][1]), "+v"(mb[2][2]), "+v"(mb[2][3]), "+v"(mb[3][0]), "+v"(mb[3][1]),
+                           "+v"(mb[3][2]), "+v"(mb[3][3])
+                         :: "memory");
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                float bv[8];
+                bias_of(pr, bv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
+                    const u32x4 out = value(pr, j, bv, z, z, mb[pr][j]);
+                    __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                    if (has_q) quant_store(out, pr, j, true);
+                }
+            }
         } else {
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
@@ -422,10 +472,12 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 for (int j = 0; j < 4; ++j) {
                     const bool ok = FULL > 0 || em0 + lrow + 16 * j < p.M;
                     u32x4 araw = (u32x4){0u, 0u, 0u, 0u}, xraw = (u32x4){0u, 0u, 0u, 0u};
+                    unsigned mbits = 0xffu;
                     if (has_add && ok) araw = *(const u32x4*)(abase + (ao + j * astep + 64 * pr));
-                    if (aux_kind && ok) xraw = *(const u32x4*)(xbase + (yo + j * ystep + 64 * pr));
-                    const u32x4 out = value(pr, j, bv, araw, xraw);
-                    if (ok) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                    if (aux_kind == 3) { if (ok) mbits = p.mask_in[morg + (mo + j * mstep + 4 * pr)]; }
+                    else if (aux_kind && ok) xraw = *(const u32x4*)(xbase + (yo + j * ystep + 64 * pr));
+                    const u32x4 out = value(pr, j, bv, araw, xraw, mbits);
+                    if (ok && p.y) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
                     if (has_q) quant_store(out, pr, j, ok);
                 }
             }
@@ -523,6 +575,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 if constexpr (QOUT) {             // the two producers of the fp8 train step; everything else takes the run-time form
                     if (fullt && !p.add && !p.aux && p.relu == 2) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<2>{});
                     else if (fullt && !p.add && p.aux && p.aux_mode == 1 && p.relu == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<2>{}, G8I<0>{});
+                    else if (fullt && !p.add && !p.aux && p.mask_in && p.relu == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<3>{}, G8I<0>{});
                     else epilogue(G8I<0>{}, G8I<-1>{}, G8I<-1>{}, G8I<-1>{});
                 } else
                 if (!fullt) epilogue(G8I<0>{}, G8I<-1>{}, G8I<-1>{}, G8I<-1>{});
@@ -694,7 +747,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     p.add = (const bf16_t*)cp.add; p.aux = (cp.act == 4 || cp.act == 3) ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
     p.aux_mode = cp.act == 3 ? 1 : 0; p.align_epi = g8_align();
     p.yq = nullptr; p.q_state = nullptr; p.q_kind = 0; p.ldq = 0;
-    p.row_scale = nullptr; p.div_rows = make_fastdiv(1);
+    p.row_scale = nullptr; p.div_rows = make_fastdiv(1); p.mask_out = nullptr; p.mask_in = nullptr;
     p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
     p.relu = cp.relu;
     p.deq_x = p.deq_w = nullptr;
@@ -723,10 +776,12 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
 // (q_kind 0) or e5m2 (1), and q_state[2] accumulates max |y| (what nkb_fp8_quantize would do in a second pass over y).
 // row_scale / rows_per_sample (optional, with add): y = add + row_scale[m / rows_per_sample] * (product + bias) — stochastic depth
 // on the residual branch inside the epilogue.
+// mask_out / mask_in (with yq): the ReLU6 mask as bits, [M][N / 8] bytes — written by a relu == 2 launch (bit = 0 < value < 6),
+// applied by a data-gradient launch instead of a bf16 aux tensor; with mask_out the bf16 output may be omitted (y == NULL).
 extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add,
                             const void* aux, int aux_mode, void* yq, float* q_state, int q_kind, const float* row_scale,
-                            int rows_per_sample, const float* deq_x, const float* deq_w, int M, int K, int N, int ldx, int ldw,
-                            int ldy, int ldadd, int relu, hipStream_t stream) {
+                            int rows_per_sample, void* mask_out, const void* mask_in, const float* deq_x, const float* deq_w,
+                            int M, int K, int N, int ldx, int ldw, int ldy, int ldadd, int relu, hipStream_t stream) {
     if ((mode != 0 && mode != 1) || (aux_mode != 0 && aux_mode != 1) || K % 128 != 0 || K < 256 || N % 256 != 0 || ldx % 16 || ldw % 16 || ldy % 8 || (add && ldadd % 8) ||
         M < 1 || deq_x == nullptr || deq_w == nullptr) {
         nkb_set_error("gemm_fp8: unsupported mode %d / shape M=%d K=%d N=%d (K %% 128, N %% 256, 16-byte rows, dequant scales)", mode, M, K, N);
@@ -738,6 +793,11 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     p.aux_mode = aux_mode; p.align_epi = g8_align();
     p.yq = (unsigned char*)yq; p.q_state = q_state; p.q_kind = q_kind; p.ldq = N;
     p.row_scale = row_scale; p.div_rows = make_fastdiv(rows_per_sample > 0 ? (unsigned)rows_per_sample : 1u);
+    p.mask_out = (unsigned char*)mask_out; p.mask_in = (const unsigned char*)mask_in;
+    if ((mask_out || mask_in) && (!yq || ldy != N)) { nkb_set_error("gemm_fp8: mask bits go with the quantised second output and packed rows"); return 1; }
+    if (mask_out && relu != 2) { nkb_set_error("gemm_fp8: mask_out is the ReLU6 mask (relu == 2)"); return 1; }
+    if (mask_in && (aux || add)) { nkb_set_error("gemm_fp8: mask_in replaces aux and excludes a residual operand"); return 1; }
+    if (!y && !(mask_out && yq)) { nkb_set_error("gemm_fp8: y may be omitted only with yq and mask_out"); return 1; }
     if (row_scale && (!add || rows_per_sample < 1)) { nkb_set_error("gemm_fp8: row_scale goes with a residual operand and rows_per_sample >= 1"); return 1; }
     if (yq && (q_state == nullptr || (q_kind != 0 && q_kind != 1))) { nkb_set_error("gemm_fp8: quantised output needs its scaling state and kind 0 / 1"); return 1; }
     p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu;

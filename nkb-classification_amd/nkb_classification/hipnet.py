@@ -43,6 +43,7 @@ _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 # four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
 # the block to end.  Off.
 _WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
+_FP8_MASK_BITS = os.environ.get("NKB_FP8_MASK_BITS", "1") != "0"   # fp8 step: ReLU6 output kept as fp8 operand + mask bits, no bf16 copy
 _DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
 
 
@@ -876,9 +877,13 @@ class HipEngine:
                           add=add, ldadd=K if add is not None else 0)
         return dx
 
-    def linear_relu6(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool, q_for: Optional[str] = None) -> torch.Tensor:
+    def linear_relu6(self, key: str, x: torch.Tensor, lin: nn.Linear, train: bool, q_for: Optional[str] = None,
+                     consumer: Optional[nn.Linear] = None) -> torch.Tensor:
         """u = relu6(x @ W^T + b) with the clamp in the GEMM epilogue (unicom Mlp: fc1 -> ReLU6); only u is kept.
-        q_for: the fp8 site (key of the Linear that consumes u + ".f8x") whose operand the epilogue writes as well."""
+        q_for: the fp8 site (key of the Linear that consumes u + ".f8x") whose operand the epilogue writes as well.
+        consumer: that Linear.  When its forward, data gradient AND weight gradient all run on the fp8 copy, nothing reads u in
+        bf16 any more except the ReLU6 mask of the backward pass: the epilogue then writes the mask as bits (1/16 of the bytes)
+        and does not store u at all — the returned tensor is a placeholder that only carries the shape."""
         M, K = x.shape
         N = lin.weight.shape[0]
         u = self.ws.get(key + ".y", (M, N), self.T)
@@ -887,10 +892,14 @@ class HipEngine:
             xq, sx, _ = self._fp8_operand(key + ".f8x", x, hip.E4M3)
             wq, _, sw = self._f8w[id(lin.weight)]
             out = self._fp8_produce(q_for, (M, N), hip.E4M3) if train else None
-            hip.gemm_fp8(0, xq, wq, u, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, relu=2,
-                         yq=out[0] if out else None, q_state=out[1] if out else None, q_kind=out[2] if out else 0)
+            bits = None
+            if (out and _FP8_MASK_BITS and consumer is not None and _FP8_WGRAD and M % 128 == 0 and N % 8 == 0
+                    and self._fp8_linear_ok(consumer, M) and hip.wgrad_fp8_workspace(M, N, consumer.weight.shape[0]) > 0):
+                bits = self.ws.get(key + ".bits", (M, N // 8), torch.uint8)
+            hip.gemm_fp8(0, xq, wq, None if bits is not None else u, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=bias, relu=2,
+                         yq=out[0] if out else None, q_state=out[1] if out else None, q_kind=out[2] if out else 0, mask_out=bits)
             if train:
-                self.saved[key] = dict(x=x, lin=lin, u=u, xq=xq, sx=sx)
+                self.saved[key] = dict(x=x, lin=lin, u=None if bits is not None else u, ubits=bits, xq=xq, sx=sx)
             return u
         else:
             hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), u, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N,
@@ -919,7 +928,11 @@ class HipEngine:
         if fp8:
             _, wdq, sw = self._f8w[id(lin.weight)]
             out = self._fp8_produce(q_for, (M, K), hip.E5M2)
-            hip.gemm_fp8(1, gq, wdq, d_pre, M, N, K, deq_x=sg[1:2], deq_w=sw[1:2], aux=self.saved[key_act]["u"], aux_mode=1,
+            ubits = self.saved[key_act].get("ubits") if out else None         # (the bit form needs the quantised second output)
+            if ubits is None and self.saved[key_act]["u"] is None:
+                raise RuntimeError("the ReLU6 output was kept as mask bits only, but this data gradient cannot consume them")
+            hip.gemm_fp8(1, gq, wdq, d_pre, M, N, K, deq_x=sg[1:2], deq_w=sw[1:2],
+                         aux=None if ubits is not None else self.saved[key_act]["u"], aux_mode=1, mask_in=ubits,
                          yq=out[0] if out else None, q_state=out[1] if out else None, q_kind=out[2] if out else 0)
         else:
             hip.linear_gelu(self.d, 3, g, self._wd[id(lin.weight)], None, self.saved[key_act]["u"], d_pre, None, M, N, K)

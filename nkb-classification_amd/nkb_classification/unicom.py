@@ -143,7 +143,7 @@ class HipUnicomViT(_ParamOnly):
                 x = eng.linear(f"b{i}.proj", o, at.proj, train, add=x)
             h = eng.layernorm(f"b{i}.ln2", x, blk.norm2, train, q_for=f"b{i}.fc1.f8x")
             if _FUSED_RELU6:
-                u = eng.linear_relu6(f"b{i}.fc1", h, mlp.fc1, train, q_for=f"b{i}.fc2.f8x")
+                u = eng.linear_relu6(f"b{i}.fc1", h, mlp.fc1, train, q_for=f"b{i}.fc2.f8x", consumer=mlp.fc2)
             else:
                 u = eng.relu6(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train)
             if dp > 0:

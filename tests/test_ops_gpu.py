@@ -1244,6 +1244,29 @@ def test_gemm_fp8_matches_product_of_rounded_operands(shape, mode):
         torch.cuda.synchronize()
         assert torch.equal(yq, yq2)
         assert st[2].item() == st2[2].item() == y.float().abs().max().item()
+    # ReLU6 as mask bits: a relu == 2 launch writes one bit per element (0 < value < 6) and may omit the bf16 output; a data-gradient
+    # launch keeps its result where the bit is set (instead of reading a bf16 aux tensor)
+    if M % 256 == 0 or True:
+        st = torch.tensor([3.0, 1.0 / 3.0, 0.0], device=DEV)
+        yq = torch.empty(M, N, device=DEV, dtype=torch.uint8); bits = torch.full((M, N // 8), 0xAA, device=DEV, dtype=torch.uint8)
+        yfull = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); yq0 = torch.empty_like(yq)
+        st0 = st.clone()
+        hip.gemm_fp8(mode, xq, wq, yfull, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=(bias * 3).to(DEV), relu=2, yq=yq0, q_state=st0, q_kind=hip.E4M3)
+        hip.gemm_fp8(mode, xq, wq, None, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], bias=(bias * 3).to(DEV), relu=2, yq=yq, q_state=st, q_kind=hip.E4M3,
+                     mask_out=bits)
+        torch.cuda.synchronize()
+        assert torch.equal(yq, yq0) and st[2].item() == st0[2].item()
+        uf = yfull.float().cpu()                                           # the bits are the 0 < u < 6 test on the STORED bf16 output
+        got_bits = ((bits.cpu()[:, :, None] >> torch.arange(8)) & 1).bool().reshape(M, N)
+        assert torch.equal(got_bits, (uf > 0) & (uf < 6))
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        y2 = torch.empty_like(y); q1 = torch.empty_like(yq); q2 = torch.empty_like(yq)
+        s1, s2 = torch.tensor([3.0, 1 / 3.0, 0.0], device=DEV), torch.tensor([3.0, 1 / 3.0, 0.0], device=DEV)
+        u_like = (got_bits.float() * 3.0).to(torch.bfloat16).to(DEV)      # any tensor that is in (0, 6) exactly where the bit is set
+        hip.gemm_fp8(mode, xq, wq, y, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], mask_in=bits, yq=q1, q_state=s1, q_kind=hip.E5M2)
+        hip.gemm_fp8(mode, xq, wq, y2, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], aux=u_like, aux_mode=1, yq=q2, q_state=s2, q_kind=hip.E5M2)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2) and torch.equal(q1, q2) and s1[2].item() == s2[2].item()
     # and the quantisation error itself stays at the fp8 level against the unquantised product
     full = x.double() @ w.double().t()
     rel = ((ref - full).norm() / full.norm()).item()
