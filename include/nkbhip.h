@@ -278,6 +278,10 @@ int nkb_segment_sumsq(const float* x, const long long* offsets, int nseg, float*
  *                     mask_out / mask_in (optional, with yq): the ReLU6 mask as one bit per element ([M][N / 8] bytes): a relu == 2
  *                     launch writes it (bit = 0 < value < 6) and may then omit the bf16 output (y == NULL); a data-gradient
  *                     launch keeps its result where the bit is set — 1/16 of the bytes of the bf16 `aux` form.
+ *                     colsum / colsum_work (optional, with mask_in and yq; M % 256 == 0): colsum[N] += the column sums of the
+ *                     (bf16-rounded) result — the bias gradient of the Linear this data gradient feeds — from per-tile partial
+ *                     sums in colsum_work ([M / 256][N] floats, added in tile order); y may then be NULL as well: the gradient
+ *                     exists only as the fp8 operand of the next GEMMs.
  *                     row_scale / rows_per_sample (optional, with add): y = add + row_scale[m / rows_per_sample] * (product + bias):
  *                     per-sample stochastic depth of the residual branch (unicom blocks) inside the epilogue.
  * state: three device floats {scale, 1 / scale, running amax}. */
@@ -321,8 +325,8 @@ int nkb_wgrad_group(int fp8, int njobs, const NkbWgradJob* jobs, int M, float* w
                     nkb_stream_t stream);
 int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add, const void* aux,
                  int aux_mode, void* yq, float* q_state, int q_kind, const float* row_scale, int rows_per_sample,
-                 void* mask_out, const void* mask_in, const float* deq_x, const float* deq_w, int M, int K, int N, int ldx,
-                 int ldw, int ldy, int ldadd, int relu, nkb_stream_t stream);
+                 void* mask_out, const void* mask_in, float* colsum, float* colsum_work, const float* deq_x, const float* deq_w,
+                 int M, int K, int N, int ldx, int ldw, int ldy, int ldadd, int relu, nkb_stream_t stream);
 
 /* Envelope of the 256 x 256 eight-phase GEMM core that nkb_conv_gemm / nkb_linear_gelu use for wide plain 1x1 / Linear launches
  * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 768).  Tests and A/B timing. */

@@ -60,6 +60,9 @@ struct G8Params {
     // the bf16 output itself may be omitted (y == NULL): the fp8 step reads u only as fc2's fp8 operand and as this mask.
     unsigned char* mask_out;
     const unsigned char* mask_in;
+    // QOUT data gradient: column sums of the stored result per 256-row tile, colpart[tilesM][N] (the bias gradient of the Linear that
+    // consumes this gradient; reduced over the tiles by the host wrapper) — with yq the bf16 output may then be omitted as well
+    float* colpart;
     int aux_mode;         // 0: the result is multiplied by aux; 1: the result is kept where 0 < aux < 6 (ReLU6 backward mask)
     int align_epi;        // DIRECT: both wave groups run the epilogue side by side (NKB_G8_ALIGN, default 1)
 };
@@ -105,6 +108,15 @@ __device__ __forceinline__ f32x4 g8_mma128(const bf16x8& a0, const bf16x8& a1, c
     const g8_i32x8 B = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
     // cbsz / blgp: operand formats (0 = e4m3, 1 = e5m2); F8 == 2 multiplies e4m3 weights (A) with e5m2 gradients (B)
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, F8 == 2 ? 1 : 0, 0, 0, 0, 0);
+}
+
+// sum over the 16 lanes of a DPP row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): every lane ends up with the total
+__device__ __forceinline__ float g8_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
 }
 
 // raw s_barrier (no vmcnt drain, unlike __syncthreads) between two compiler-level memory barriers
@@ -451,17 +463,35 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                            "+v"(mb[1][3]), "+v"(mb[2][0]), "+v"(mb[2][1]), "+v"(mb[2][2]), "+v"(mb[2][3]), "+v"(mb[3][0]), "+v"(mb[3][1]),
                            "+v"(mb[3][2]), "+v"(mb[3][3])
                          :: "memory");
+            float* cred = (float*)(smem + 2 * BUF + 4096 + 64);           // [4 pixel quarters][256 columns]
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
                 float bv[8];
                 bias_of(pr, bv);
+                float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
                     const u32x4 out = value(pr, j, bv, z, z, mb[pr][j]);
-                    __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                    if (p.y) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
                     if (has_q) quant_store(out, pr, j, true);
+                    if (p.colpart) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { cs[2 * e] += __uint_as_float(out[e] << 16); cs[2 * e + 1] += __uint_as_float(out[e] & 0xffff0000u); }
+                    }
                 }
+                if (p.colpart) {                       // the 16 pixel lanes of a column by DPP (fixed order), then this wave's 64-row sum to LDS
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t_ = g8_row16_sum(cs[e]);
+                        if (frow == 0) cred[wc * 256 + lcol + 32 * pr + e] = t_;
+                    }
+                }
+            }
+            if (p.colpart) {                           // (both wave groups are in the epilogue together: align_epi is forced on)
+                G8_BARRIER();
+                if (tid < 256) p.colpart[(size_t)tile_m * p.N + en0 + tid] = ((cred[tid] + cred[256 + tid]) + cred[512 + tid]) + cred[768 + tid];
+                G8_BARRIER();
             }
         } else {
 #pragma unroll
@@ -726,7 +756,7 @@ static int g8_align() {
 static int g8_cus() {
     static int cus = 0;
     if (!cus) {
-        constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64;
+        constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096;
         hipFuncSetAttribute((const void*)gemm8p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipFuncSetAttribute((const void*)gemm8p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipFuncSetAttribute((const void*)gemm8p_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -747,7 +777,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     p.add = (const bf16_t*)cp.add; p.aux = (cp.act == 4 || cp.act == 3) ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
     p.aux_mode = cp.act == 3 ? 1 : 0; p.align_epi = g8_align();
     p.yq = nullptr; p.q_state = nullptr; p.q_kind = 0; p.ldq = 0;
-    p.row_scale = nullptr; p.div_rows = make_fastdiv(1); p.mask_out = nullptr; p.mask_in = nullptr;
+    p.row_scale = nullptr; p.div_rows = make_fastdiv(1); p.mask_out = nullptr; p.mask_in = nullptr; p.colpart = nullptr;
     p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
     p.relu = cp.relu;
     p.deq_x = p.deq_w = nullptr;
@@ -755,7 +785,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
     const double wbytes = (double)p.N * p.K * 2.0;
     p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
-    constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64; // 128 KB (>= the 66.5 KB epilogue tile) + 512 B of bias per wave + the fp8 amax word
+    constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096; // 128 KB (>= the 66.5 KB epilogue tile) + 512 B of bias per wave + the fp8 amax word + 4 KB of column sums
     const int cus = g8_cus();
     const int tiles = p.tilesM * p.tilesN;
     // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
@@ -780,8 +810,9 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
 // applied by a data-gradient launch instead of a bf16 aux tensor; with mask_out the bf16 output may be omitted (y == NULL).
 extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add,
                             const void* aux, int aux_mode, void* yq, float* q_state, int q_kind, const float* row_scale,
-                            int rows_per_sample, void* mask_out, const void* mask_in, const float* deq_x, const float* deq_w,
-                            int M, int K, int N, int ldx, int ldw, int ldy, int ldadd, int relu, hipStream_t stream) {
+                            int rows_per_sample, void* mask_out, const void* mask_in, float* colsum, float* colsum_work,
+                            const float* deq_x, const float* deq_w, int M, int K, int N, int ldx, int ldw, int ldy, int ldadd,
+                            int relu, hipStream_t stream) {
     if ((mode != 0 && mode != 1) || (aux_mode != 0 && aux_mode != 1) || K % 128 != 0 || K < 256 || N % 256 != 0 || ldx % 16 || ldw % 16 || ldy % 8 || (add && ldadd % 8) ||
         M < 1 || deq_x == nullptr || deq_w == nullptr) {
         nkb_set_error("gemm_fp8: unsupported mode %d / shape M=%d K=%d N=%d (K %% 128, N %% 256, 16-byte rows, dequant scales)", mode, M, K, N);
@@ -797,7 +828,13 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     if ((mask_out || mask_in) && (!yq || ldy != N)) { nkb_set_error("gemm_fp8: mask bits go with the quantised second output and packed rows"); return 1; }
     if (mask_out && relu != 2) { nkb_set_error("gemm_fp8: mask_out is the ReLU6 mask (relu == 2)"); return 1; }
     if (mask_in && (aux || add)) { nkb_set_error("gemm_fp8: mask_in replaces aux and excludes a residual operand"); return 1; }
-    if (!y && !(mask_out && yq)) { nkb_set_error("gemm_fp8: y may be omitted only with yq and mask_out"); return 1; }
+    p.colpart = nullptr;
+    if (colsum) {
+        if (!mask_in || !colsum_work || M % 256 != 0) { nkb_set_error("gemm_fp8: colsum goes with mask_in, a [M / 256][N] workspace and M %% 256 == 0"); return 1; }
+        p.colpart = colsum_work;
+        p.align_epi = 1;                          // the column sums cross the wave groups through LDS inside the epilogue
+    }
+    if (!y && !(yq && (mask_out || colsum))) { nkb_set_error("gemm_fp8: y may be omitted only with yq and mask_out / colsum"); return 1; }
     if (row_scale && (!add || rows_per_sample < 1)) { nkb_set_error("gemm_fp8: row_scale goes with a residual operand and rows_per_sample >= 1"); return 1; }
     if (yq && (q_state == nullptr || (q_kind != 0 && q_kind != 1))) { nkb_set_error("gemm_fp8: quantised output needs its scaling state and kind 0 / 1"); return 1; }
     p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu;
@@ -806,7 +843,7 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
     p.group_m = (gm_env > 1 && (double)N * K > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     const int cus = g8_cus();
-    constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64;
+    constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096;
     const int tiles = p.tilesM * p.tilesN;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
@@ -817,7 +854,9 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
         if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<true, 1>), grid, dim3(512), lds, stream, p);
         else hipLaunchKernelGGL((gemm8p_kernel<true, 2>), grid, dim3(512), lds, stream, p);
     }
-    return nkb_check_launch("gemm_fp8");
+    int rc_ = nkb_check_launch("gemm_fp8");
+    if (!rc_ && colsum) rc_ = nkb_launch_wgrad_reduce(colsum_work, N, M / 256, colsum, N, stream);
+    return rc_;
 }
 
 // Per-tensor fp8 quantisation with delayed scaling.  state = {scale, 1 / scale, amax of the values seen since the last

@@ -15,39 +15,91 @@ struct OptimArgs {
     // radam: c0 = bias_correction1, c1 = sqrt(bias_correction2), c2 = rect (0 => unrectified branch)
 };
 
-__global__ void optim_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                  float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n, const OptimArgs a,
-                                  const float* __restrict__ skip) {
+// one element of the update (the arithmetic of torch's single-tensor Adam / NAdam / RAdam / SGD loops, op for op)
+__device__ __forceinline__ void optim_one(float& w, float grad, float& mi, float& vi, const OptimArgs& a) {
+    grad = grad * a.grad_scale;
+    if (a.kind == 3) {                                       // SGD, momentum 0
+        grad = grad + a.wd * w;
+        w = w - a.lr * grad;
+        return;
+    }
+    if (a.kind == 1) w = w * (1.f - a.lr * a.wd);            // NAdam: decoupled decay
+    else grad = grad + a.wd * w;                             // Adam / RAdam: L2 folded into the gradient
+    mi = mi + (grad - mi) * (1.f - a.beta1);                 // exp_avg.lerp_(grad, 1-beta1)
+    vi = vi * a.beta2 + (1.f - a.beta2) * grad * grad;
+    if (a.kind == 0) {
+        const float denom = sqrtf(vi) / a.c1 + a.eps;
+        w = w - a.c0 * (mi / denom);
+    } else if (a.kind == 1) {
+        const float denom = sqrtf(vi / a.c0) + a.eps;
+        w = w - a.c1 * (grad / denom);
+        w = w - a.c2 * (mi / denom);
+    } else {
+        const float bc = mi / a.c0;
+        if (a.c2 > 0.f) w = w - a.lr * bc * a.c2 * (a.c1 / (sqrtf(vi) + a.eps));
+        else w = w - a.lr * bc;
+    }
+}
+
+// HBM-bound: 30 bytes per parameter (master weight, both moments read + written, gradient read, bf16 shadow written).  Four
+// parameters per lane per access (16-byte loads / stores on every stream) and two such groups in flight per thread; the
+// one-element form this replaces moved 2.5 TB/s (3.6 ms for ViT-L/14's 304 M parameters), this one runs at the elementwise rate.
+__global__ void __launch_bounds__(256) optim_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n,
+                                                         const OptimArgs a, const float* __restrict__ skip) {
     // skipped step of the gradient scaler (engine.py:59, GradScaler.step): decided on the device, no host round trip
     if (skip && *skip != 0.f) return;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float w = p[i];
-        float grad = g[i] * a.grad_scale;
-        if (a.kind == 3) {                                   // SGD, momentum 0
-            grad = grad + a.wd * w;
-            w = w - a.lr * grad;
-        } else {
-            if (a.kind == 1) w = w * (1.f - a.lr * a.wd);    // NAdam: decoupled decay
-            else grad = grad + a.wd * w;                     // Adam / RAdam: L2 folded into the gradient
-            float mi = m[i], vi = v[i];
-            mi = mi + (grad - mi) * (1.f - a.beta1);         // exp_avg.lerp_(grad, 1-beta1)
-            vi = vi * a.beta2 + (1.f - a.beta2) * grad * grad;
-            m[i] = mi; v[i] = vi;
-            if (a.kind == 0) {
-                const float denom = sqrtf(vi) / a.c1 + a.eps;
-                w = w - a.c0 * (mi / denom);
-            } else if (a.kind == 1) {
-                const float denom = sqrtf(vi / a.c0) + a.eps;
-                w = w - a.c1 * (grad / denom);
-                w = w - a.c2 * (mi / denom);
-            } else {
-                const float bc = mi / a.c0;
-                if (a.c2 > 0.f) w = w - a.lr * bc * a.c2 * (a.c1 / (sqrtf(vi) + a.eps));
-                else w = w - a.lr * bc;
+    const bool moments = a.kind != 3;
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
+    f32x4* p4 = (f32x4*)p; const f32x4* g4 = (const f32x4*)g; f32x4* m4 = (f32x4*)m; f32x4* v4 = (f32x4*)v;
+    u32x2* s2 = (u32x2*)shadow;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+        const size_t i1 = i0 + stride;
+        const bool two = i1 < n4;
+        f32x4 w[2], gr[2], mi[2] = {}, vi[2] = {};
+        w[0] = p4[i0]; gr[0] = __builtin_nontemporal_load(g4 + i0);
+        if (two) { w[1] = p4[i1]; gr[1] = __builtin_nontemporal_load(g4 + i1); }
+        if (moments) {
+            mi[0] = __builtin_nontemporal_load(m4 + i0); vi[0] = __builtin_nontemporal_load(v4 + i0);
+            if (two) { mi[1] = __builtin_nontemporal_load(m4 + i1); vi[1] = __builtin_nontemporal_load(v4 + i1); }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const size_t i = u ? i1 : i0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float w_ = w[u][e], m_ = mi[u][e], v_ = vi[u][e]; optim_one(w_, gr[u][e], m_, v_, a); w[u][e] = w_; mi[u][e] = m_; vi[u][e] = v_; }
+            if (moments) { __builtin_nontemporal_store(mi[u], m4 + i); __builtin_nontemporal_store(vi[u], v4 + i); }
+            __builtin_nontemporal_store(w[u], p4 + i);
+            if (shadow) {
+                u32x2 o;
+                o[0] = (unsigned)f2bf(w[u][0]) | ((unsigned)f2bf(w[u][1]) << 16);
+                o[1] = (unsigned)f2bf(w[u][2]) | ((unsigned)f2bf(w[u][3]) << 16);
+                s2[i] = o;
             }
         }
-        p[i] = w;
-        if (shadow) shadow[i] = f2bf(w);
+    }
+    // (n % 4 tail)
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float w_ = p[i], m_ = moments ? m[i] : 0.f, v_ = moments ? v[i] : 0.f;
+        optim_one(w_, g[i], m_, v_, a);
+        if (moments) { m[i] = m_; v[i] = v_; }
+        p[i] = w_;
+        if (shadow) shadow[i] = f2bf(w_);
+    }
+}
+// the same, one parameter per thread: ranges that do not start on a 16-byte boundary
+__global__ void optim_step_scalar_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                         float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n, const OptimArgs a,
+                                         const float* __restrict__ skip) {
+    if (skip && *skip != 0.f) return;
+    const bool moments = a.kind != 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float w_ = p[i], m_ = moments ? m[i] : 0.f, v_ = moments ? v[i] : 0.f;
+        optim_one(w_, g[i], m_, v_, a);
+        if (moments) { m[i] = m_; v[i] = v_; }
+        p[i] = w_;
+        if (shadow) shadow[i] = f2bf(w_);
     }
 }
 
@@ -58,11 +110,20 @@ extern "C" int nkb_optim_step(int kind, float* p, const float* g, float* m, floa
     OptimArgs a;
     a.kind = kind; a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
     a.c0 = c0; a.c1 = c1; a.c2 = c2; a.c3 = c3;
-    size_t grid = ((size_t)n + 255) / 256;
-    if (grid > 256 * 16) grid = 256 * 16;
     NkbProfScope prof(NKB_K_OPTIM, stream, 0);
-    hipLaunchKernelGGL(optim_step_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16,
-                       (size_t)n, a, skip_flag);
+    const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)shadow_bf16 & 7) == 0;
+    if (aligned) {
+        size_t grid = ((size_t)n / 8 + 255) / 256;
+        if (grid > 256 * 8) grid = 256 * 8;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(optim_step_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16,
+                           (size_t)n, a, skip_flag);
+    } else {
+        size_t grid = ((size_t)n + 255) / 256;
+        if (grid > 256 * 16) grid = 256 * 16;
+        hipLaunchKernelGGL(optim_step_scalar_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16,
+                           (size_t)n, a, skip_flag);
+    }
     return nkb_check_launch("optim_step");
 }
 

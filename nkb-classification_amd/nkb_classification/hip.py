@@ -92,7 +92,7 @@ _SIGS = {
     "nkb_wgrad_group": (i32, [i32, i32, vp, i32, vp, i64, vp]),
     "nkb_wgrad_fp8_workspace_floats": (i64, [i32, i32, i32]),
     "nkb_wgrad_fp8": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
-    "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp] + [i32] * 8 + [vp]),
+    "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
     "nkb_prof_collect_raw": (i32, [vp, vp, vp, i32]),
@@ -489,12 +489,15 @@ def fp8_multi(pass_, jobs, njobs, total_blocks):
 
 
 def gemm_fp8(mode, xq, wq, y, M, K, N, *, deq_x, deq_w, bias=None, add=None, aux=None, aux_mode=0, yq=None, q_state=None, q_kind=0,
-             row_scale=None, rows_per_sample=0, mask_out=None, mask_in=None, ldx=None, ldw=None, ldy=None, ldadd=0, relu=0):
+             row_scale=None, rows_per_sample=0, mask_out=None, mask_in=None, colsum=None, colsum_work=None, ldx=None, ldw=None, ldy=None,
+             ldadd=0, relu=0):
     """aux ([M][ldy], bf16): aux_mode 0 multiplies the result by it, 1 keeps the result where 0 < aux < 6 (ReLU6 backward).
     yq / q_state / q_kind: optional fp8 copy of the result (scale q_state[0], amax into q_state[2]) for the next fp8 GEMM.
-    mask_out / mask_in: the ReLU6 mask as bits ([M][N / 8] bytes, with yq); y may be None when mask_out is given."""
+    mask_out / mask_in: the ReLU6 mask as bits ([M][N / 8] bytes, with yq); y may be None when mask_out is given.
+    colsum / colsum_work (with mask_in, yq): colsum[N] += column sums of the result, workspace [M / 256][N] fp32; y may be None."""
     check(load().nkb_gemm_fp8(mode, ptr(xq), ptr(wq), ptr(y), ptr(bias), ptr(add), ptr(aux), int(aux_mode), ptr(yq), ptr(q_state),
-                              int(q_kind), ptr(row_scale), int(rows_per_sample), ptr(mask_out), ptr(mask_in), ptr(deq_x), ptr(deq_w),
+                              int(q_kind), ptr(row_scale), int(rows_per_sample), ptr(mask_out), ptr(mask_in), ptr(colsum), ptr(colsum_work),
+                              ptr(deq_x), ptr(deq_w),
                               M, K, N,
                               K if ldx is None else ldx, K if ldw is None else ldw, N if ldy is None else ldy, ldadd,
                               int(relu), stream()), "gemm_fp8")

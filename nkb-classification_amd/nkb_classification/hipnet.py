@@ -43,6 +43,7 @@ _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 # four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
 # the block to end.  Off.
 _WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
+_FP8_EPI_COLSUM = os.environ.get("NKB_FP8_EPI_COLSUM", "1") != "0"   # fc1's bias gradient from the fc2 data gradient's epilogue
 _FP8_MASK_BITS = os.environ.get("NKB_FP8_MASK_BITS", "1") != "0"   # fp8 step: ReLU6 output kept as fp8 operand + mask bits, no bf16 copy
 _DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
 
@@ -85,6 +86,8 @@ class HipEngine:
         self._f8kind: Dict[str, int] = {}
         self._f8table = None                       # device table of all site states for the one-launch scale update
         self._f8ready: Dict[str, torch.Tensor] = {}
+        self._ones_cache: Dict[int, torch.Tensor] = {}
+        self._f8bias: Dict[str, bool] = {}          # ready sites whose producer also summed the columns (bias gradient done)
         self._wg_pending = []                      # Linear weight gradients of the current block, launched together by end_block
         self._wg_keep = {}                         # host job arrays of the grouped launches (kept alive for plan replay)  # site -> fp8 copy already written by the kernel that produced the tensor
         # recorded launch plans of the train step (hip.Plan): key -> (plan, workspace generation, saved-activation table)
@@ -211,7 +214,7 @@ class HipEngine:
         vector that receives (+=) the column sums of x in the same pass — returns (q, state, colsum_done)."""
         q = self._f8ready.pop(key, None)
         if q is not None:                           # the producing kernel wrote it (and accumulated the amax) in its epilogue
-            return q, self._f8act[key], False
+            return q, self._f8act[key], self._f8bias.pop(key, False)
         st = self._fp8_state(key, kind, x)
         n = x.numel()
         q = self.ws.get(key + ".q", tuple(x.shape), torch.uint8)
@@ -928,11 +931,21 @@ class HipEngine:
         if fp8:
             _, wdq, sw = self._f8w[id(lin.weight)]
             out = self._fp8_produce(q_for, (M, K), hip.E5M2)
-            ubits = self.saved[key_act].get("ubits") if out else None         # (the bit form needs the quantised second output)
-            if ubits is None and self.saved[key_act]["u"] is None:
+            sva = self.saved[key_act]
+            ubits = sva.get("ubits") if out else None         # (the bit form needs the quantised second output)
+            if ubits is None and sva["u"] is None:
                 raise RuntimeError("the ReLU6 output was kept as mask bits only, but this data gradient cannot consume them")
-            hip.gemm_fp8(1, gq, wdq, d_pre, M, N, K, deq_x=sg[1:2], deq_w=sw[1:2],
-                         aux=None if ubits is not None else self.saved[key_act]["u"], aux_mode=1, mask_in=ubits,
+            # When the Linear before the ReLU6 (fc1) takes its data AND weight gradient from the fp8 copy, the only other reader of
+            # d_pre is its bias gradient: the epilogue sums the columns too and d_pre is never stored in bf16.
+            lin1 = sva["lin"]
+            csum = work = None
+            if (_FP8_EPI_COLSUM and ubits is not None and lin1.bias is not None and M % 256 == 0
+                    and self._fp8_wgrad_ok(sva, M, lin1.weight.shape[1], K)):
+                csum = self.arena.grad_flat(lin1.bias)
+                work = self.ws.at_least("f8.epicolsum", (M // 256) * K, torch.float32)
+                self._f8bias[q_for] = True
+            hip.gemm_fp8(1, gq, wdq, None if csum is not None else d_pre, M, N, K, deq_x=sg[1:2], deq_w=sw[1:2],
+                         aux=None if ubits is not None else sva["u"], aux_mode=1, mask_in=ubits, colsum=csum, colsum_work=work,
                          yq=out[0] if out else None, q_state=out[1] if out else None, q_kind=out[2] if out else 0)
         else:
             hip.linear_gelu(self.d, 3, g, self._wd[id(lin.weight)], None, self.saved[key_act]["u"], d_pre, None, M, N, K)
@@ -1039,10 +1052,16 @@ class HipEngine:
         hip.relu6(self.d, x, g, dx, x.numel())
         return dx
 
+    def _ones(self, n: int) -> torch.Tensor:
+        """A persistent vector of ones (never written after its creation: one fill per engine, not one per drop-path site)."""
+        t = self._ones_cache.get(n)
+        if t is None:
+            t = self._ones_cache[n] = torch.ones(n, device=self.device, dtype=torch.float32)
+        return t
+
     def drop_path_scale(self, key: str, p: float, samples: int) -> torch.Tensor:
         """The per-sample factor keep[b] / (1 - p) of one stochastic-depth site (kept for the backward pass)."""
-        ones = self.ws.get("droppath.ones", (samples,), torch.float32)
-        hip.host_op(lambda: ones.fill_(1.0))
+        ones = self._ones(samples)
         scale = self.ws.get(key + ".scale", (samples,), torch.float32)
         mask = self.ws.get(key + ".mask", (samples,), torch.uint8)
         seed = hip.fresh_seed()
@@ -1059,8 +1078,7 @@ class HipEngine:
         """Stochastic depth on a residual branch: y = add + x * keep[b] / (1 - p), one Bernoulli(1 - p) draw per sample
         (timm-style DropPath as used by the unicom blocks).  Only called when active (train and p > 0)."""
         assert train and p > 0
-        ones = self.ws.get("droppath.ones", (samples,), torch.float32)
-        hip.host_op(lambda: ones.fill_(1.0))
+        ones = self._ones(samples)
         scale = self.ws.get(key + ".scale", (samples,), torch.float32)
         mask = self.ws.get(key + ".mask", (samples,), torch.uint8)
         seed = hip.fresh_seed()

@@ -700,8 +700,10 @@ def test_loss_kernels_match_golden(golden):
         assert am.cpu().tolist() == x.cpu().argmax(-1).tolist()
 
 
+@pytest.mark.parametrize("offset", [0, 1], ids=["aligned", "odd_start"])
 @pytest.mark.parametrize("kind", ["adam", "nadam", "radam", "sgd"])
-def test_optimizer_kernel_matches_torch(kind):
+def test_optimizer_kernel_matches_torch(kind, offset):
+    """offset 0: the 16-byte form (four parameters per lane, n % 4 tail); 1: a range that starts off a 16-byte boundary."""
     torch.manual_seed(8)
     n = 10007
     p0 = torch.randn(n)
@@ -716,16 +718,19 @@ def test_optimizer_kernel_matches_torch(kind):
     else:
         opt = torch.optim.SGD([ref_p], lr=lr, weight_decay=wd)
     from nkb_classification.utils import _step_scalars
-    p = p0.clone().to(DEV)
-    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    p = torch.zeros(n + 4, device=DEV)[offset:offset + n]
+    p.copy_(p0)
+    m, v = torch.zeros(n + 4, device=DEV)[offset:offset + n], torch.zeros(n + 4, device=DEV)[offset:offset + n]
+    shadow = torch.empty(n + 4, device=DEV, dtype=torch.bfloat16)[offset:offset + n]
+    gd = torch.empty(n + 4, device=DEV)[offset:offset + n]
     state = {}
     for step in range(1, 9):
         g = torch.randn(n)
         ref_p.grad = g.clone()
         opt.step()
         k, sc = _step_scalars(kind, state, lr=lr, beta1=0.9, beta2=0.999, eps=1e-8, momentum_decay=4e-3)
-        hip.optim_step(k, p, g.to(DEV), m, v, shadow, n, lr, wd, 0.9, 0.999, 1e-8, 1.0, *sc)
+        gd.copy_(g)
+        hip.optim_step(k, p, gd, m, v, shadow, n, lr, wd, 0.9, 0.999, 1e-8, 1.0, *sc)
         torch.cuda.synchronize()
         torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=1e-5, atol=2e-6, msg=f"{kind} step {step}")
     torch.testing.assert_close(shadow.float().cpu(), p.cpu().bfloat16().float())
@@ -1175,7 +1180,7 @@ def test_fp8_quantize_is_bit_exact_with_scaled_rne(kind):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("shape", [(1000, 256, 256), (4096 + 64, 1024, 768), (256 * 70, 4096, 256)], ids=lambda s: "M%d_K%d_N%d" % s)
+@pytest.mark.parametrize("shape", [(1000, 256, 256), (4096 + 64, 1024, 768), (256 * 70, 4096, 256), (256 * 5, 512, 768)], ids=lambda s: "M%d_K%d_N%d" % s)
 def test_gemm_fp8_matches_product_of_rounded_operands(shape, mode):
     """configs[4]'s fp8 contraction.  Oracle = the same product evaluated in fp64 on the fp8-ROUNDED operands (torch float8
     casts), times the two dequantisation factors — the only differences left are fp32 accumulation order and the bf16 result
@@ -1267,6 +1272,23 @@ def test_gemm_fp8_matches_product_of_rounded_operands(shape, mode):
         hip.gemm_fp8(mode, xq, wq, y2, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], aux=u_like, aux_mode=1, yq=q2, q_state=s2, q_kind=hip.E5M2)
         torch.cuda.synchronize()
         assert torch.equal(y, y2) and torch.equal(q1, q2) and s1[2].item() == s2[2].item()
+        if M % 256 == 0:
+            # + the column sums of the stored result (the next Linear's bias gradient) from the same epilogue, with and without
+            # the bf16 output: same fp8 bytes / amax, colsum += sums of the bf16-rounded values, identical on a second run
+            for keep_y in (True, False):
+                q3 = torch.empty_like(yq); s3 = torch.tensor([3.0, 1 / 3.0, 0.0], device=DEV)
+                y3 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+                cs = [torch.full((N,), 0.5, device=DEV) for _ in range(2)]
+                work = torch.empty(M // 256 * N, device=DEV)
+                for c in cs:
+                    s3[2] = 0.0
+                    hip.gemm_fp8(mode, xq, wq, y3 if keep_y else None, M, K, N, deq_x=sx[1:2], deq_w=sw[1:2], mask_in=bits, yq=q3,
+                                 q_state=s3, q_kind=hip.E5M2, colsum=c, colsum_work=work)
+                torch.cuda.synchronize()
+                assert torch.equal(q3, q1) and s3[2].item() == s1[2].item()
+                assert not keep_y or torch.equal(y3, y)
+                assert torch.equal(cs[0], cs[1])
+                torch.testing.assert_close(cs[0].cpu().double(), 0.5 + y.double().sum(0).cpu(), rtol=1e-5, atol=1e-4 * y.abs().max().item() * M ** 0.5)
     # and the quantisation error itself stays at the fp8 level against the unquantised product
     full = x.double() @ w.double().t()
     rel = ((ref - full).norm() / full.norm()).item()
