@@ -14,6 +14,13 @@
 
 namespace {
 
+// Waves per SIMD the forward kernel is compiled for (the second __launch_bounds__ argument is waves per execution unit, not
+// workgroups per CU).  With 2 the allocation drifted to 138 VGPRs = 3 waves per SIMD = ONE 8-wave workgroup per CU, so a
+// workgroup's K / V staging ran with nothing beside it; 4 holds it to 128 VGPRs (no spills) and two workgroups share a CU:
+// T = 256 forward 81-85 -> 69 us (rocprofv3 resource report + scripts/attn_microbench.py).
+#ifndef NKB_ATTN_FWD_WAVES
+#define NKB_ATTN_FWD_WAVES 4
+#endif
 #ifndef NKB_ATTN_BWD_THREADS
 #define NKB_ATTN_BWD_THREADS 1024
 #endif
@@ -101,8 +108,8 @@ __device__ __forceinline__ void publish_amax(attn_u16x2 amax2, float* q_state) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NKB>
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+template <int NKB, int WPS>
+__global__ __launch_bounds__(512, WPS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int T, int H, float scale,
                                                           unsigned char* __restrict__ outq, float* __restrict__ q_state) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -495,17 +502,19 @@ extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* ls
     const int nkb = (T + 15) / 16, nks = (T + 31) / 32;
     const int lds = nkb * 16 * 128 + nks * 32 * 128;
     NkbProfScope prof(NKB_K_ATTN, stream, 4.0 * B * H * (double)T * T * DH);
-#define NKB_ATTN_FWD(N)                                                                                                      \
-    case N: {                                                                                                                \
+#define NKB_ATTN_FWD1(N, W)                                                                                                  \
+    {                                                                                                                        \
         static bool attr = false;                                                                                            \
-        if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024); attr = true; } \
-        hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * H), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale, (unsigned char*)outq, q_state); \
-        break;                                                                                                               \
+        if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<N, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024); attr = true; } \
+        hipLaunchKernelGGL((attn_fwd_kernel<N, W>), dim3(B * H), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale, (unsigned char*)outq, q_state); \
     }
+#define NKB_ATTN_FWD(N) case N: if (waves == 2) NKB_ATTN_FWD1(N, 2) else NKB_ATTN_FWD1(N, 4) break;
+    static const int waves = getenv("NKB_ATTN_FWD_WAVES") ? atoi(getenv("NKB_ATTN_FWD_WAVES")) : NKB_ATTN_FWD_WAVES;
     switch (nkb) {
         NKB_ATTN_FWD(1) NKB_ATTN_FWD(2) NKB_ATTN_FWD(3) NKB_ATTN_FWD(4) NKB_ATTN_FWD(5) NKB_ATTN_FWD(6) NKB_ATTN_FWD(7) NKB_ATTN_FWD(8)
         NKB_ATTN_FWD(9) NKB_ATTN_FWD(10) NKB_ATTN_FWD(11) NKB_ATTN_FWD(12) NKB_ATTN_FWD(13) NKB_ATTN_FWD(14) NKB_ATTN_FWD(15) NKB_ATTN_FWD(16)
     }
+#undef NKB_ATTN_FWD1
 #undef NKB_ATTN_FWD
     return nkb_check_launch("attn_forward");
 }
