@@ -81,6 +81,7 @@ __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v,
 // delayed scale and converted — nkb_fp8_quantize's arithmetic; the running max of |bf16| bit patterns (they order as unsigned
 // integers) costs one register as a packed pair.
 typedef unsigned short attn_u16x2 __attribute__((ext_vector_type(2)));
+typedef float attn_f32x2 __attribute__((ext_vector_type(2)));
 template <int KIND>
 __device__ __forceinline__ void store_q4(unsigned char* dst, u32x2 pk, float qscale, attn_u16x2& amax2) {
     constexpr float lim = KIND == 0 ? 448.f : 57344.f;
@@ -138,22 +139,29 @@ __global__ __launch_bounds__(512, WPS) void attn_fwd_kernel(const bf16_t* __rest
             q0 = *(const bf16x8*)(qrow(qb + 8) + g * 8);
             q1 = *(const bf16x8*)(qrow(qb + 8) + (4 + g) * 8);
         }
+        // softmax over the raw scores: the row maximum first, then exp2(s * c - m * c) as ONE (packed) FMA per pair and the row
+        // sum as packed adds — 64 multiplies, 64 subtractions and 64 additions per lane become 32 + 32 packed instructions
         float m = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[kb][e] *= sl2;
                 if (kb == NKB - 1 && kb * 16 + 4 * g + e >= T) acc[kb][e] = -INFINITY;      // only the last block can run past T
                 m = fmaxf(m, acc[kb][e]);
             }
-        m = group_max(m);
-        float sum = 0.f;
+        m = group_max(m) * sl2;                          // (sl2 > 0: the maximum of the scaled scores)
+        const attn_f32x2 sl2v = {sl2, sl2}, mv = {-m, -m};
+        attn_f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[kb][e] = __builtin_amdgcn_exp2f(acc[kb][e] - m); sum += acc[kb][e]; }
-        sum = group_sum(sum);
+            for (int e = 0; e < 4; e += 2) {
+                const attn_f32x2 x = __builtin_elementwise_fma((attn_f32x2){acc[kb][e], acc[kb][e + 1]}, sl2v, mv);
+                const attn_f32x2 pe = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                acc[kb][e] = pe[0]; acc[kb][e + 1] = pe[1];
+                sum2 += pe;
+            }
+        const float sum = group_sum(sum2[0] + sum2[1]);
         const float inv = 1.f / sum;
         if (g == 0 && q < T) lse[((size_t)b * H + h) * T + q] = m * 0.6931471805599453f + __logf(sum);
         f32x4 o[4];
