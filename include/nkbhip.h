@@ -173,11 +173,17 @@ int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int 
 int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y, void* y2,
                     int M, int K, int N, nkb_stream_t stream);
 /* LayerNorm over the last dim (biased variance). backward=0: in = x -> out = y, writes mean/rstd.
- * backward=1: in = dy, x = saved input -> out = dx (+ add), dgamma/dbeta accumulated with atomics. Strides in elements. */
+ * backward=1: in = dy, x = saved input -> out = dx (+ add), dgamma/dbeta accumulated (workspace: per-block partials added in a
+ * fixed order; NULL: atomics). Strides in elements.
+ * yq / q_state / q_kind (optional, D % 256 == 0, out_stride == D): fp8 copy of the output rows for the fp8 GEMM that consumes
+ * them (see nkb_fp8_quantize).  Backward (workspace form only): the copy is of row_scale[row / rows_per_sample] * dx (row_scale
+ * optional: the stochastic-depth factor of the branch the gradient enters) and colsum[D] += its column sums — the operand and
+ * the bias gradient nkb_fp8_quantize_colsum would make of dx for the Linear backward that consumes it. */
 int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
                   const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
                   long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps, float* workspace,
-                  void* yq, float* q_state, int q_kind, nkb_stream_t stream);
+                  void* yq, float* q_state, int q_kind, const float* row_scale, int rows_per_sample, float* colsum,
+                  nkb_stream_t stream);
 /* (yq / q_state / q_kind, forward only, optional: an fp8 copy of the output rows — packed [rows][D] bytes, scale q_state[0], amax
  * into q_state[2], kind as in nkb_fp8_quantize — for the fp8 GEMM that consumes the normalised rows; D % 256 == 0, out_stride == D.) */
 size_t nkb_layernorm_workspace_floats(int D); /* backward: optional scratch for the deterministic dgamma/dbeta reduction */

@@ -108,22 +108,32 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // LayerNorm backward: dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ add);  dgamma += sum dy*xhat, dbeta += sum dy
-template <typename T, int VW, int NP>
+template <typename T, int VW, int NP, bool QOUT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, long long dys, const T* __restrict__ x,
                                                             long long xs, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const T* __restrict__ add, T* __restrict__ dx, long long dxs,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, unsigned char* __restrict__ yq,
+                                                            float* __restrict__ q_state, int q_kind,
+                                                            const float* __restrict__ row_scale, int rows_per_sample) {
     constexpr int D = 64 * VW * NP;
-    __shared__ float red[4][2][64 * VW];
+    constexpr int NV = QOUT ? 3 : 2;                // partial planes per block: dgamma, dbeta (, column sums of the fp8 operand)
+    __shared__ float red[4][NV][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
+    // QOUT: the Linear whose backward pass consumes dx (the gradient of a residual stream) takes it as an e5m2 / e4m3 operand,
+    // scaled per sample by its stochastic-depth factor, and needs the column sums of that scaled gradient for its bias: both
+    // are produced here, from the STORED (rounded) row — the bytes, the amax and the sums nkb_fp8_quantize_colsum would make of dx
+    const float qscale = QOUT ? q_state[0] : 1.f;
+    const float qlim = q_kind == 0 ? 448.f : 57344.f;
+    float amax = 0.f;
     float ag[NP][VW], ab[NP][VW], gam[NP][VW];
+    [[maybe_unused]] float cs[NP][VW];
 #pragma unroll
     for (int k = 0; k < NP; ++k)
 #pragma unroll
-        for (int e = 0; e < VW; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gam[k][e] = gamma[(k * 64 + lane) * VW + e]; }
+        for (int e = 0; e < VW; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gam[k][e] = gamma[(k * 64 + lane) * VW + e]; if constexpr (QOUT) cs[k][e] = 0.f; }
     for (int row = blockIdx.x * wpb + wave; row < rows; row += gridDim.x * wpb) {
         const T* xr = x + (size_t)row * xs;
         const T* gr = dy + (size_t)row * dys;
@@ -158,6 +168,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 if (add) o[e] += a[e];
             }
             VecIO<T, VW>::st(or_ + e0, o);
+            if constexpr (QOUT && VW == 4) {
+                const float rsc = row_scale ? row_scale[row / rows_per_sample] : 1.f;
+                float q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float r = DT<T>::rnd(o[e]);
+                    if (row_scale) r *= rsc;
+                    cs[k][e] += r;
+                    amax = fmaxf(amax, fabsf(r));
+                    q[e] = fminf(fmaxf(r * qscale, -qlim), qlim);
+                }
+                unsigned w = 0u;
+                if (q_kind == 0) { w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true); }
+                else { w = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w, true); }
+                *(unsigned*)(yq + (size_t)row * D + e0) = w;
+            }
         }
     }
     // block reduction of the per-lane column sums, then one atomic per column per block
@@ -165,22 +191,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int k = 0; k < NP; ++k) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < VW; ++e) { red[wave][0][lane * VW + e] = ag[k][e]; red[wave][1][lane * VW + e] = ab[k][e]; }
+        for (int e = 0; e < VW; ++e) {
+            red[wave][0][lane * VW + e] = ag[k][e]; red[wave][1][lane * VW + e] = ab[k][e];
+            if constexpr (QOUT) red[wave][2][lane * VW + e] = cs[k][e];
+        }
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
-                float s0 = 0.f, t0 = 0.f;
-                for (int w = 0; w < wpb; ++w) { s0 += red[w][0][lane * VW + e]; t0 += red[w][1][lane * VW + e]; }
+                float s0 = 0.f, t0 = 0.f, u0 = 0.f;
+                for (int w = 0; w < wpb; ++w) {
+                    s0 += red[w][0][lane * VW + e]; t0 += red[w][1][lane * VW + e];
+                    if constexpr (QOUT) u0 += red[w][2][lane * VW + e];
+                }
                 const int col = (k * 64 + lane) * VW + e;
                 if (part) {   // deterministic two-stage reduction: per-block partials, summed by ln_param_grad_kernel
-                    part[((size_t)blockIdx.x * 2) * D + col] = s0;
-                    part[((size_t)blockIdx.x * 2 + 1) * D + col] = t0;
+                    part[((size_t)blockIdx.x * NV) * D + col] = s0;
+                    part[((size_t)blockIdx.x * NV + 1) * D + col] = t0;
+                    if constexpr (QOUT) part[((size_t)blockIdx.x * NV + 2) * D + col] = u0;
                 } else {      // same-address float atomics: fine for a few hundred blocks, serialises beyond that
                     atomicAdd(dgamma + col, s0);
                     atomicAdd(dbeta + col, t0);
                 }
             }
+        }
+    }
+    if constexpr (QOUT) {                          // one atomic per block (non-negative floats order as unsigned integers)
+        __shared__ float redm[4];
+        amax = wave_max(amax);
+        if (lane == 0) redm[wave] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+            if (m > 0.f) atomicMax((unsigned*)(q_state + 2), __float_as_uint(m));
         }
     }
 }
@@ -190,46 +233,65 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // it follows.  Now LN_SLICES blocks per column group each sum a contiguous slice of the partial rows (fixed order), and a tiny
 // launch adds the slice sums in slice order.
 constexpr int LN_SLICES = 16;
+// (NV planes per partial row: dgamma, dbeta and, with the fp8 operand output, the column sums of that operand)
+template <int NV>
 __global__ void ln_param_grad_kernel(const float* __restrict__ part, int blocks, int D, float* __restrict__ inter) {
-    __shared__ float red[2][16][64];
+    __shared__ float red[NV][16][64];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     const int per = (blocks + LN_SLICES - 1) / LN_SLICES;
     const int t0 = blockIdx.y * per, t1 = min(blocks, t0 + per);
-    float a = 0.f, b = 0.f;
+    float a[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) a[v] = 0.f;
     if (c < D)
-        for (int t = t0 + py; t < t1; t += 16) { a += part[((size_t)t * 2) * D + c]; b += part[((size_t)t * 2 + 1) * D + c]; }
-    red[0][py][cx] = a; red[1][py][cx] = b;
+        for (int t = t0 + py; t < t1; t += 16)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) a[v] += part[((size_t)t * NV + v) * D + c];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[v][py][cx] = a[v];
     __syncthreads();
     if (py != 0 || c >= D) return;
-    a = 0.f; b = 0.f;
-    for (int k = 0; k < 16; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
-    inter[((size_t)blockIdx.y * 2) * D + c] = a;
-    inter[((size_t)blockIdx.y * 2 + 1) * D + c] = b;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[v][k][cx];
+        inter[((size_t)blockIdx.y * NV + v) * D + c] = t;
+    }
 }
-__global__ void ln_param_grad_final_kernel(const float* __restrict__ inter, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+template <int NV>
+__global__ void ln_param_grad_final_kernel(const float* __restrict__ inter, int D, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                           float* __restrict__ colsum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= D) return;
-    float a = 0.f, b = 0.f;
-    for (int s = 0; s < LN_SLICES; ++s) { a += inter[((size_t)s * 2) * D + c]; b += inter[((size_t)s * 2 + 1) * D + c]; }
-    dgamma[c] += a; dbeta[c] += b;
+    float a[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) a[v] = 0.f;
+    for (int s = 0; s < LN_SLICES; ++s)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) a[v] += inter[((size_t)s * NV + v) * D + c];
+    dgamma[c] += a[0]; dbeta[c] += a[1];
+    if constexpr (NV == 3) colsum[c] += a[2];
 }
 
 template <typename T, int VW, int NP>
 static void ln_launch(int backward, int grid, hipStream_t stream, const void* in, long long in_stride, const void* x,
                       long long x_stride, const float* gamma, const float* beta, float* mean, float* rstd, const void* add,
                       void* out, long long out_stride, float* dgamma, float* dbeta, int rows, float eps, float* part,
-                      unsigned char* yq, float* q_state, int q_kind) {
+                      unsigned char* yq, float* q_state, int q_kind, const float* row_scale, int rows_per_sample) {
     if (!backward)
         hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps, yq, q_state, q_kind);
+    else if (yq)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP, true>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part, yq, q_state, q_kind, row_scale, rows_per_sample);
     else
-        hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part);
+        hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP, false>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part, nullptr, nullptr, 0, nullptr, 1);
 }
 template <typename T, int VW>
 static int ln_dispatch(int np, int backward, int grid, hipStream_t stream, const void* in, long long is, const void* x, long long xs,
                        const float* g, const float* b, float* mean, float* rstd, const void* add, void* out, long long os,
-                       float* dg, float* db, int rows, float eps, float* part, unsigned char* yq, float* qs, int qk) {
-#define LN_CASE(N) case N: ln_launch<T, VW, N>(backward, grid, stream, in, is, x, xs, g, b, mean, rstd, add, out, os, dg, db, rows, eps, part, yq, qs, qk); return 0;
+                       float* dg, float* db, int rows, float eps, float* part, unsigned char* yq, float* qs, int qk,
+                       const float* rsc, int rps) {
+#define LN_CASE(N) case N: ln_launch<T, VW, N>(backward, grid, stream, in, is, x, xs, g, b, mean, rstd, add, out, os, dg, db, rows, eps, part, yq, qs, qk, rsc, rps); return 0;
     switch (np) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
 #undef LN_CASE
     return 1;
@@ -237,22 +299,30 @@ static int ln_dispatch(int np, int backward, int grid, hipStream_t stream, const
 
 extern "C" size_t nkb_layernorm_workspace_floats(int D) { return (size_t)2048 * 2 * D; }
 
-// yq / q_state / q_kind (forward, optional): fp8 copy of the output rows ([rows][D] bytes, packed) for the fp8 GEMM that
-// consumes them — see nkb_fp8_quantize; needs D % 256 == 0 and out_stride == D.
+// yq / q_state / q_kind (optional): fp8 copy of the output rows ([rows][D] bytes, packed) for the fp8 GEMM that consumes them —
+// see nkb_fp8_quantize; needs D % 256 == 0 and out_stride == D.  Backward (with the workspace): the copy is of
+// row_scale[row / rows_per_sample] * dx (row_scale optional) and colsum[D] += its column sums — what nkb_fp8_quantize_colsum
+// makes of dx for the Linear backward that consumes this gradient.
 extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
                              const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
                              long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps,
-                             float* workspace, void* yq, float* q_state, int q_kind, hipStream_t stream) {
+                             float* workspace, void* yq, float* q_state, int q_kind, const float* row_scale, int rows_per_sample,
+                             float* colsum, hipStream_t stream) {
     const int vw = (D % 256 == 0) ? 4 : 2;
     const int np = D / (64 * vw);
     if (D % 128 != 0 || np < 1 || np > 8 || in_stride % vw || x_stride % vw || out_stride % vw) {
         nkb_set_error("layernorm: D=%d must be a multiple of 128 (<= 2048) with vector-aligned strides", D);
         return 1;
     }
-    if (yq && (backward || vw != 4 || out_stride != D || !q_state || (q_kind != 0 && q_kind != 1))) {
-        nkb_set_error("layernorm: the fp8 output goes with the forward pass, D %% 256 == 0, packed rows and a scaling state");
+    if (yq && (vw != 4 || out_stride != D || !q_state || (q_kind != 0 && q_kind != 1))) {
+        nkb_set_error("layernorm: the fp8 output needs D %% 256 == 0, packed rows and a scaling state");
         return 1;
     }
+    if (yq && backward && (!workspace || !colsum || (row_scale && rows_per_sample < 1))) {
+        nkb_set_error("layernorm: the backward fp8 output goes with the workspace form, a column-sum vector and rows_per_sample >= 1");
+        return 1;
+    }
+    if (!yq && (row_scale || colsum)) { nkb_set_error("layernorm: row_scale / colsum belong to the fp8 output"); return 1; }
     NkbProfScope prof(NKB_K_LN, stream, 0);
     int grid = (rows + 3) / 4;
     if (!backward) { if (grid > (yq ? 1024 : 256 * 16)) grid = yq ? 1024 : 256 * 16; }   // (fp8 copy: one amax atomic per block)
@@ -267,17 +337,23 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
     else if (grid > 512) grid = 512;                         // atomics path: keep same-address contention low
     int rc;
     if (dtype == NKB_DT_BF16)
-        rc = vw == 4 ? ln_dispatch<bf16_t, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind)
-                     : ln_dispatch<bf16_t, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind);
+        rc = vw == 4 ? ln_dispatch<bf16_t, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind, row_scale, rows_per_sample)
+                     : ln_dispatch<bf16_t, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind, row_scale, rows_per_sample);
     else
-        rc = vw == 4 ? ln_dispatch<float, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind)
-                     : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind);
+        rc = vw == 4 ? ln_dispatch<float, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind, row_scale, rows_per_sample)
+                     : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind, row_scale, rows_per_sample);
     if (rc) { nkb_set_error("layernorm: unsupported D=%d", D); return 1; }
     if (backward && workspace)
     {
-        float* inter = workspace + (size_t)1024 * 2 * D;      // behind the (<= 1024) per-block partial rows
-        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
-        hipLaunchKernelGGL(ln_param_grad_final_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta);
+        if (yq) {                                             // three planes per partial row (3072 D + 48 D of the 4096 D floats)
+            float* inter = workspace + (size_t)1024 * 3 * D;
+            hipLaunchKernelGGL(ln_param_grad_kernel<3>, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
+            hipLaunchKernelGGL(ln_param_grad_final_kernel<3>, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta, colsum);
+        } else {
+            float* inter = workspace + (size_t)1024 * 2 * D;  // behind the (<= 1024) per-block partial rows
+            hipLaunchKernelGGL(ln_param_grad_kernel<2>, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
+            hipLaunchKernelGGL(ln_param_grad_final_kernel<2>, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta, nullptr);
+        }
     }
     return nkb_check_launch("layernorm");
 }

@@ -56,7 +56,7 @@ _SIGS = {
     "nkb_gemm_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [i32, vp]),
     "nkb_gemm_tn_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [vp]),
     "nkb_linear_gelu": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp]),
+    "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp, i32, vp, vp]),
     "nkb_layernorm_workspace_floats": (sz, [i32]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_splitk_reduce": (i32, [i32, vp, i32, i32, i32, vp, i32, vp, vp, vp]),
@@ -593,15 +593,18 @@ def gemm_tn_batched(dtype, a, b, out, M, Na, Nb, lda, ldb, ldo, outer, inner, sa
 def layernorm_fwd(dtype, x, x_stride, gamma, beta, y, y_stride, mean, rstd, rows, D, eps, yq=None, q_state=None, q_kind=0):
     """yq / q_state / q_kind: optional fp8 copy of y for the fp8 GEMM that consumes it (see fp8_quantize)."""
     check(load().nkb_layernorm(dtype, 0, ptr(x), x_stride, None, 0, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), None,
-                               ptr(y), y_stride, None, None, rows, D, eps, None, ptr(yq), ptr(q_state), int(q_kind), stream()),
-          "layernorm_fwd")
+                               ptr(y), y_stride, None, None, rows, D, eps, None, ptr(yq), ptr(q_state), int(q_kind), None, 0, None,
+                               stream()), "layernorm_fwd")
 
 
 def layernorm_bwd(dtype, dy, dy_stride, x, x_stride, gamma, mean, rstd, add, dx, dx_stride, dgamma, dbeta, rows, D,
-                  workspace=None):
+                  workspace=None, yq=None, q_state=None, q_kind=0, row_scale=None, rows_per_sample=0, colsum=None):
+    """yq / q_state / q_kind / row_scale / colsum: fp8 copy of (row_scale *) dx and its column sums (+= colsum) for the Linear
+    backward that consumes this gradient — what fp8_quantize_colsum would make of dx."""
     check(load().nkb_layernorm(dtype, 1, ptr(dy), dy_stride, ptr(x), x_stride, ptr(gamma), None, ptr(mean), ptr(rstd),
                                ptr(add), ptr(dx), dx_stride, ptr(dgamma), ptr(dbeta), rows, D, 0.0, ptr(workspace),
-                               None, None, 0, stream()), "layernorm_bwd")
+                               ptr(yq), ptr(q_state), int(q_kind), ptr(row_scale), int(rows_per_sample), ptr(colsum),
+                               stream()), "layernorm_bwd")
 
 
 def layernorm_ws(D):

@@ -43,6 +43,7 @@ _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 # four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
 # the block to end.  Off.
 _WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
+_FP8_LN_BWD_QUANT = os.environ.get("NKB_FP8_LN_BWD_QUANT", "1") != "0"   # LayerNorm backward writes the next Linear backward's fp8 operand
 _FP8_EPI_COLSUM = os.environ.get("NKB_FP8_EPI_COLSUM", "1") != "0"   # fc1's bias gradient from the fc2 data gradient's epilogue
 _FP8_MASK_BITS = os.environ.get("NKB_FP8_MASK_BITS", "1") != "0"   # fp8 step: ReLU6 output kept as fp8 operand + mask bits, no bf16 copy
 _DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
@@ -243,6 +244,8 @@ class HipEngine:
     def fp8_begin_step(self):
         """One launch at the start of a forward pass: every activation / gradient site's scale from the amax its tensor showed
         in the previous step (192 single-thread launches per unicom ViT-L/14 step otherwise)."""
+        self._f8ready.clear()                        # (an operand a producer wrote but nobody consumed does not outlive its step)
+        self._f8bias.clear()
         if not (self.fp8 and self._f8act):
             return
         if self._f8table is None:
@@ -994,15 +997,37 @@ class HipEngine:
         return y
 
     def layernorm_backward(self, key: str, g: torch.Tensor, out: torch.Tensor, out_stride: int,
-                           add: Optional[torch.Tensor] = None):
-        """dx (+ add) is written into `out` rows with stride out_stride (elements)."""
+                           add: Optional[torch.Tensor] = None, consumer: Optional[str] = None, consumer_dp: Optional[str] = None):
+        """dx (+ add) is written into `out` rows with stride out_stride (elements).
+        consumer: key of the Linear whose backward pass takes `out` as its incoming gradient (through the stochastic-depth site
+        consumer_dp, if any).  In the fp8 step that Linear consumes the gradient as an e5m2 operand scaled per sample, plus its
+        column sums for the bias: this kernel then writes both next to dx (no separate quantise + column-sum pass over dx)."""
         sv = self.saved[key]
         ln = sv["ln"]
         D = ln.weight.shape[0]
+        rows = sv["rows"]
         a = self.arena
         work = self.ws.at_least("ln.work", hip.layernorm_ws(D), torch.float32)
+        q = None
+        if consumer is not None and self.fp8 and _FP8_LN_BWD_QUANT and _FP8_FUSED_QUANT and self.T == torch.bfloat16:
+            svc = self.saved.get(consumer)
+            if svc is not None and out_stride == D and D % 256 == 0 and tuple(out.shape) == (rows, D):
+                lin = svc["lin"]
+                Mc, Kc = svc["x"].shape
+                Nc = lin.weight.shape[0]
+                if (Mc == rows and Nc == D and lin.bias is not None and self._fp8_linear_ok(lin, Mc)
+                        and self._fp8_wgrad_ok(svc, Mc, Kc, Nc) and self._fp8_colsum_ok(out)):
+                    q = self._fp8_produce(consumer + ".f8g", (rows, D), hip.E5M2)
+                    if q is not None:
+                        gs = self.drop_path_gscale(consumer_dp, rows) if consumer_dp else None
+                        self._f8bias[consumer + ".f8g"] = True
+                        hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
+                                          out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), rows, D, workspace=work,
+                                          yq=q[0], q_state=q[1], q_kind=q[2], row_scale=gs[0] if gs else None,
+                                          rows_per_sample=gs[1] if gs else 0, colsum=a.grad_flat(lin.bias))
+                        return out
         hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
-                          out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), sv["rows"], D, workspace=work)
+                          out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), rows, D, workspace=work)
         return out
 
     def gelu(self, key: str, x: torch.Tensor, train: bool, keep_derivative: bool = False) -> torch.Tensor:

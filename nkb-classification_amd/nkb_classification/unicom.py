@@ -168,7 +168,9 @@ class HipUnicomViT(_ParamOnly):
         g = eng.conv_backward("feat2", g, "gf2x")
         g = eng.bn_backward("feat1", g, "gf1")
         g = eng.conv_backward("feat1", g, "gf1x")                             # [B,1,1,T*D]
-        gx = eng.layernorm_backward("norm", g.view(M, D), eng.scratch("gx0", (M, D)), D)
+        nb = len(self.blocks)
+        gx = eng.layernorm_backward("norm", g.view(M, D), eng.scratch("gx0", (M, D)), D,
+                                    consumer=f"b{nb - 1}.fc2" if nb else None, consumer_dp=f"b{nb - 1}.dp2")
         eng.end_block(len(self.blocks))
         if on_done is not None:
             on_done(f)
@@ -184,11 +186,13 @@ class HipUnicomViT(_ParamOnly):
                 d_u = eng.linear_backward(f"b{i}.fc2", gx, "du", g_scale=gs2)
                 d_a = eng.relu6_backward(f"b{i}.act", d_u, "da")
             d_h = eng.linear_backward(f"b{i}.fc1", d_a, "dh")
-            gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx)
+            gmid = eng.layernorm_backward(f"b{i}.ln2", d_h, eng.scratch("gmid", (M, D)), D, add=gx,
+                                          consumer=f"b{i}.proj", consumer_dp=f"b{i}.dp1")
             d_o = eng.linear_backward(f"b{i}.proj", gmid, "do", g_scale=eng.drop_path_gscale(f"b{i}.dp1", M))
             d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv", q_for=f"b{i}.qkv.f8g")
             d_h = eng.linear_backward(f"b{i}.qkv", d_qkv, "dh")
-            gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid)
+            gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid,
+                                        consumer=f"b{i - 1}.fc2" if i > 0 else None, consumer_dp=f"b{i - 1}.dp2")
             flip ^= 1
             eng.end_block(i)
             if on_done is not None:

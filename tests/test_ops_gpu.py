@@ -1401,6 +1401,50 @@ def test_layernorm_forward_fp8_copy_equals_separate_quantisation(shape):
     assert torch.equal(y, y2) and torch.equal(yq, q2) and st[2].item() == st2[2].item()
 
 
+@pytest.mark.parametrize("scaled", [False, True], ids=["plain", "row_scaled"])
+@pytest.mark.parametrize("shape", [(1200, 1024), (4099, 512)], ids=lambda s: "%dx%d" % s)
+def test_layernorm_backward_fp8_copy_and_column_sums(shape, scaled):
+    """nkb_layernorm backward with the fp8 output: dx, dgamma, dbeta are those of the plain launch (bit for bit); the fp8 bytes
+    and the amax are what nkb_fp8_quantize_colsum makes of (row_scale *) dx, and colsum += the column sums of that operand
+    (against float64 sums of the rounded values; identical on a second run)."""
+    rows, D = shape
+    torch.manual_seed(52)
+    rps = 50 if scaled else 0
+    x = (torch.randn(rows, D) * 2 + 0.3).to(torch.bfloat16).to(DEV)
+    dy = (torch.randn(rows, D) * 0.05).to(torch.bfloat16).to(DEV)
+    add = (torch.randn(rows, D) * 0.05).to(torch.bfloat16).to(DEV)
+    gamma, beta = (torch.rand(D) + 0.5).to(DEV), (torch.randn(D) * 0.1).to(DEV)
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    hip.layernorm_fwd(hip.BF16, x, D, gamma, beta, y, D, mean, rstd, rows, D, 1e-6)
+    rsc = ((torch.rand((rows + rps - 1) // rps) > 0.3).float() / 0.7).to(DEV) if scaled else None
+    work = torch.empty(hip.layernorm_ws(D), device=DEV)
+    outs = []
+    for fp8 in (False, True, True):
+        dx = torch.full((rows, D), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dg, db, cs = torch.full((D,), 0.25, device=DEV), torch.full((D,), -0.5, device=DEV), torch.full((D,), 2.0, device=DEV)
+        st = torch.tensor([300.0, 1 / 300.0, 0.0], device=DEV)
+        q = torch.full((rows, D), 0x33, device=DEV, dtype=torch.uint8)
+        kw = dict(yq=q, q_state=st, q_kind=hip.E5M2, row_scale=rsc, rows_per_sample=rps, colsum=cs) if fp8 else {}
+        hip.layernorm_bwd(hip.BF16, dy, D, x, D, gamma, mean, rstd, add, dx, D, dg, db, rows, D, workspace=work, **kw)
+        torch.cuda.synchronize()
+        outs.append((dx, dg, db, cs, q, st))
+    (dx0, dg0, db0, _, _, _), (dx1, dg1, db1, cs1, q1, st1), (dx2, dg2, db2, cs2, q2, st2) = outs
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(q1, q2) and torch.equal(cs1, cs2) and torch.equal(dg1, dg2)
+    # the separate pass over the stored dx
+    stq = torch.tensor([300.0, 1 / 300.0, 0.0], device=DEV)
+    qq = torch.empty_like(q1); col = torch.zeros(D, device=DEV)
+    w2 = torch.empty(hip.fp8_quantize_colsum_workspace(rows, D), device=DEV)
+    hip.fp8_quantize_colsum(hip.E5M2, dx0, rows, D, D, stq, qq, col, w2, row_scale=rsc, rows_per_sample=rps)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, qq) and st1[2].item() == stq[2].item()
+    ref = dx0.double() * (rsc.double().repeat_interleave(rps)[:rows, None] if scaled else 1.0)
+    torch.testing.assert_close(cs1.double().cpu(), 2.0 + ref.sum(0).cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(rows) * dx0.abs().max().item())
+    with pytest.raises(RuntimeError, match="layernorm"):        # the fp8 output needs the deterministic (workspace) form
+        hip.layernorm_bwd(hip.BF16, dy, D, x, D, gamma, mean, rstd, add, dx0, D, dg0, db0, rows, D, yq=q1, q_state=st1, q_kind=hip.E5M2, colsum=cs1)
+
+
 @pytest.mark.parametrize("T", [197, 256])
 def test_fused_attention_fp8_copies_equal_separate_quantisation(T):
     """The optional fp8 outputs of the fused attention kernels (e4m3 of o, e5m2 of dqkv): identical bf16 results, and the same
