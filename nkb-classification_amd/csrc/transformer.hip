@@ -2,6 +2,7 @@
 // (forward / backward on materialised score rows), head-wise transposes, token assembly.
 // One wave64 per row with shuffle reductions; fp32 statistics; I/O in the compute dtype.
 #include "common.h"
+#include <type_traits>
 
 template <typename T> struct V2;
 template <> struct V2<bf16_t> {
@@ -19,10 +20,19 @@ template <> struct V2<float> {
 // VW-wide vector access (VW = 2: 4 B bf16 / 8 B fp32; VW = 4: 8 B bf16 / 16 B fp32)
 template <typename T, int VW> struct VecIO;
 template <typename T> struct VecIO<T, 2> {
+    struct Raw { float a, b; };
+    __device__ static __forceinline__ Raw ldr(const T* p) { Raw r; V2<T>::ld(p, r.a, r.b); return r; }
+    __device__ static __forceinline__ void cvt(Raw r, float* f) { f[0] = r.a; f[1] = r.b; }
     __device__ static __forceinline__ void ld(const T* p, float* f) { V2<T>::ld(p, f[0], f[1]); }
     __device__ static __forceinline__ void st(T* p, const float* f) { V2<T>::st(p, f[0], f[1]); }
 };
 template <> struct VecIO<bf16_t, 4> {
+    typedef u32x2 Raw;                               // (load and conversion apart: a row segment requested before it is needed)
+    __device__ static __forceinline__ Raw ldr(const bf16_t* p) { return *(const u32x2*)p; }
+    __device__ static __forceinline__ void cvt(Raw u, float* f) {
+        f[0] = __uint_as_float(u[0] << 16); f[1] = __uint_as_float(u[0] & 0xffff0000u);
+        f[2] = __uint_as_float(u[1] << 16); f[3] = __uint_as_float(u[1] & 0xffff0000u);
+    }
     __device__ static __forceinline__ void ld(const bf16_t* p, float* f) {
         const u32x2 u = *(const u32x2*)p;
         f[0] = __uint_as_float(u[0] << 16); f[1] = __uint_as_float(u[0] & 0xffff0000u);
@@ -31,6 +41,9 @@ template <> struct VecIO<bf16_t, 4> {
     __device__ static __forceinline__ void st(bf16_t* p, const float* f) { *(u32x2*)p = (u32x2){pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3])}; }
 };
 template <> struct VecIO<float, 4> {
+    typedef f32x4 Raw;
+    __device__ static __forceinline__ Raw ldr(const float* p) { return *(const f32x4*)p; }
+    __device__ static __forceinline__ void cvt(Raw v, float* f) { f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
     __device__ static __forceinline__ void ld(const float* p, float* f) { const f32x4 v = *(const f32x4*)p; f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
     __device__ static __forceinline__ void st(float* p, const float* f) { *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]}; }
 };
@@ -108,8 +121,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // LayerNorm backward: dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ add);  dgamma += sum dy*xhat, dbeta += sum dy
-template <typename T, int VW, int NP, bool QOUT>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, long long dys, const T* __restrict__ x,
+template <typename T, int VW, int NP, int QK>      // QK: -1 no fp8 output, 0 e4m3, 1 e5m2
+__global__ __launch_bounds__(256, NP <= 4 ? 3 : 1) void layernorm_bwd_kernel(const T* __restrict__ dy, long long dys, const T* __restrict__ x,
                                                             long long xs, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const T* __restrict__ add, T* __restrict__ dx, long long dxs,
@@ -118,6 +131,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             float* __restrict__ q_state, int q_kind,
                                                             const float* __restrict__ row_scale, int rows_per_sample) {
     constexpr int D = 64 * VW * NP;
+    constexpr bool QOUT = QK >= 0;
     constexpr int NV = QOUT ? 3 : 2;                // partial planes per block: dgamma, dbeta (, column sums of the fp8 operand)
     __shared__ float red[4][NV][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     // scaled per sample by its stochastic-depth factor, and needs the column sums of that scaled gradient for its bias: both
     // are produced here, from the STORED (rounded) row — the bytes, the amax and the sums nkb_fp8_quantize_colsum would make of dx
     const float qscale = QOUT ? q_state[0] : 1.f;
-    const float qlim = q_kind == 0 ? 448.f : 57344.f;
+    constexpr float qlim = QK == 0 ? 448.f : 57344.f;
     float amax = 0.f;
     float ag[NP][VW], ab[NP][VW], gam[NP][VW];
     [[maybe_unused]] float cs[NP][VW];
@@ -154,14 +168,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 c2 += g[k][e] * xh[k][e];
             }
         }
+        // (the residual rows are requested before the wave reductions, all at once: inside the output loop below every vector's
+        // load sat behind a branch of its own and the row paid NP exposed latencies)
+        typename VecIO<T, VW>::Raw araw[NP];
+        if (add) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) araw[k] = VecIO<T, VW>::ldr(add + (size_t)row * dxs + (k * 64 + lane) * VW);
+        }
         c1 = wave_sum(c1) / (float)D;
         c2 = wave_sum(c2) / (float)D;
         T* or_ = dx + (size_t)row * dxs;
+        [[maybe_unused]] float rsc = 1.f;              // (one scalar division per row, not one per vector)
+        if constexpr (QOUT) { if (row_scale) rsc = row_scale[__builtin_amdgcn_readfirstlane(row) / rows_per_sample]; }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int e0 = (k * 64 + lane) * VW;
             float o[VW], a[VW];
-            if (add) VecIO<T, VW>::ld(add + (size_t)row * dxs + e0, a);
+            if (add) VecIO<T, VW>::cvt(araw[k], a);
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
                 o[e] = rs * (g[k][e] - c1 - xh[k][e] * c2);
@@ -169,7 +192,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
             VecIO<T, VW>::st(or_ + e0, o);
             if constexpr (QOUT && VW == 4) {
-                const float rsc = row_scale ? row_scale[row / rows_per_sample] : 1.f;
                 float q[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     q[e] = fminf(fmaxf(r * qscale, -qlim), qlim);
                 }
                 unsigned w = 0u;
-                if (q_kind == 0) { w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true); }
+                if constexpr (QK == 0) { w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true); }
                 else { w = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w, true); }
                 *(unsigned*)(yq + (size_t)row * D + e0) = w;
             }
@@ -281,10 +303,15 @@ static void ln_launch(int backward, int grid, hipStream_t stream, const void* in
                       unsigned char* yq, float* q_state, int q_kind, const float* row_scale, int rows_per_sample) {
     if (!backward)
         hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps, yq, q_state, q_kind);
-    else if (yq)
-        hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP, true>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part, yq, q_state, q_kind, row_scale, rows_per_sample);
-    else
-        hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP, false>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part, nullptr, nullptr, 0, nullptr, 1);
+    else {
+#define LN_BWD(Q) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP, Q>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part, yq, q_state, q_kind, row_scale, yq ? rows_per_sample : 1)
+        if constexpr (VW == 4 && std::is_same<T, bf16_t>::value) {      // (the fp8 output: bf16 rows of 256-element multiples only)
+            if (yq && q_kind == 0) { LN_BWD(0); return; }
+            if (yq) { LN_BWD(1); return; }
+        }
+        LN_BWD(-1);
+#undef LN_BWD
+    }
 }
 template <typename T, int VW>
 static int ln_dispatch(int np, int backward, int grid, hipStream_t stream, const void* in, long long is, const void* x, long long xs,

@@ -14,7 +14,12 @@ for (M, D) in [(50432, 768), (32768, 1024)]:
     fwd = lambda: hip.layernorm_fwd(d, x, D, gamma, beta, y, D, mean, rstd, M, D, 1e-6)
     bwd = lambda: hip.layernorm_bwd(d, g, D, x, D, gamma, mean, rstd, add, dx, D, dg, db, M, D, workspace=work)
     fwd()
-    for fn, name in ((fwd, "fwd"), (bwd, "bwd+param")):
+    cs = torch.zeros(D, device=dev); st = torch.tensor([100.0, 0.01, 0.0], device=dev); yq = torch.empty(M, D, device=dev, dtype=torch.uint8)
+    rsc = torch.ones(M // 256 + 1, device=dev)
+    bwdq = lambda: hip.layernorm_bwd(d, g, D, x, D, gamma, mean, rstd, add, dx, D, dg, db, M, D, workspace=work, yq=yq, q_state=st,
+                                     q_kind=hip.E5M2, row_scale=rsc, rows_per_sample=256, colsum=cs)
+    cases = [(fwd, "fwd"), (bwd, "bwd+param")] + ([(bwdq, "bwd+param+fp8")] if D % 256 == 0 else [])
+    for fn, name in cases:
         for _ in range(3): fn()
         torch.cuda.synchronize()
         hip.prof_enable(True)
