@@ -744,6 +744,30 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const float* __restric
         ntaps = (ph ? 2 : 1) * Sc;
         sb = (((ph + 1) & 1) + 2 * (t / Sc)) * 3 + ((pw + 1) & 1) + 2 * (t % Sc);
     }
+    // 16-byte reads and 8 / 16-byte writes when the job's geometry allows (every Linear and 1x1 / 3x3 filter of the model
+    // zoo does): with one element per lane and access the pass moved 1.9 TB/s — 0.95 ms per unicom ViT-L/14 step
+    const bool vec = (C & 3) == 0 && (ld & 3) == 0 && (jb[0] & 3) == 0 && (((size_t)dst * 1) & 15) == 0 && a0 + 64 <= A && c0 + 64 <= C && a0 + 64 <= ld;
+    if (vec) {
+        const int tx4 = threadIdx.x & 15, ty = threadIdx.x >> 4;         // 16 x 4 columns, 16 rows per pass
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty + 16 * i;
+            const f32x4 v = *(const f32x4*)(src + ((size_t)(a0 + r) * B + sb) * C + c0 + 4 * tx4);
+            tile[r][4 * tx4] = v[0]; tile[r][4 * tx4 + 1] = v[1]; tile[r][4 * tx4 + 2] = v[2]; tile[r][4 * tx4 + 3] = v[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = ty + 16 * i;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = tile[4 * tx4 + j][cc];
+            T* d = dst + ((size_t)(c0 + cc) * ntaps + t) * ld + a0 + 4 * tx4;
+            if constexpr (sizeof(T) == 2) *(u32x2*)d = (u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            else *(f32x4*)d = (f32x4){o[0], o[1], o[2], o[3]};
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 columns x 4 rows per pass
     for (int r = ty; r < 64; r += 4) {
         const int a = a0 + r, c = c0 + tx;
