@@ -594,6 +594,35 @@ template <typename T>
 __global__ void vit_assemble_kernel(const T* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ pos,
                                     T* __restrict__ x, int B, int Tn, int D, int backward) {
     const size_t total = backward ? (size_t)B * (Tn - 1) * D : (size_t)B * Tn * D;
+    if constexpr (sizeof(T) == 2) {
+        if ((D & 7) == 0 && ((((size_t)tok) | ((size_t)x)) & 15) == 0) {   // 16-byte chunks of 8 bf16 (one element per lane and access ran at 1.6 TB/s)
+            const unsigned cpr = (unsigned)D >> 3, rows_out = backward ? (unsigned)B * (Tn - 1) : (unsigned)B * Tn;
+            const size_t chunks = (size_t)rows_out * cpr;
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+                const unsigned row = (unsigned)(i / cpr), d = ((unsigned)(i - (size_t)row * cpr)) << 3;
+                if (!backward) {
+                    const unsigned b = row / (unsigned)Tn, t = row - b * (unsigned)Tn;
+                    float v[8];
+                    if (cls == nullptr) unpack8(*(const u32x4*)(tok + (size_t)row * D + d), v);
+                    else if (t == 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = cls[d + e];
+                    } else unpack8(*(const u32x4*)(tok + ((size_t)b * (Tn - 1) + (t - 1)) * D + d), v);
+                    const float* pp = pos + (size_t)t * D + d;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += pp[e];
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                    *(u32x4*)(x + (size_t)row * D + d) = o;
+                } else {
+                    const unsigned b = row / (unsigned)(Tn - 1), pz = row - b * (unsigned)(Tn - 1);
+                    *(u32x4*)((T*)tok + (size_t)row * D + d) = *(const u32x4*)(x + ((size_t)b * Tn + 1 + pz) * D + d);
+                }
+            }
+            return;
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int d = (int)(i % D);
         if (!backward) {
