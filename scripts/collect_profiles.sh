@@ -24,3 +24,4 @@ M=$(find $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv" | hea
 python3 scripts/pmc_mfma.py $M $MT $OUT/pmc_mfma.json > $OUT/pmc_mfma.txt
 rm -rf $OUT/trace/*/*.db $OUT/pmc_*/*/*.db 2>/dev/null
 du -sh $OUT; cat $OUT/line.json | head -c 600; echo; cat $OUT/pmc_mfma.txt; head -30 $OUT/pmc_traffic.txt
+[ -s $OUT/line.json ] && [ -s $OUT/kernel_stats.csv ]
