@@ -169,9 +169,13 @@ int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int 
                         long long soo, long long soi, nkb_stream_t stream);
 /* Linear layer with a fused activation epilogue. act 1: y2 = xW^T+b, y = gelu(y2) (exact erf). act 2: y = (xW^T) * gelu'(aux).
  * act 3: y = (xW^T) where 0 < aux < 6, else 0 (ReLU6 backward; aux = the ReLU6 output, whose forward is nkb_conv_gemm(relu = 2)).
- * act 4: y = (xW^T) * aux (GELU backward with aux = gelu'(pre) kept by nkb_gelu_fwd_dgelu). */
+ * act 4: y = (xW^T) * aux (GELU backward with aux = gelu'(pre) kept by nkb_gelu_fwd_dgelu or by act 5).
+ * act 5: y = gelu(xW^T+b), y2 = gelu'(xW^T+b): fc1 forward that leaves exactly what act 4 needs and never stores the pre-activation
+ * (bf16 shapes of the 256 x 256 eight-phase core only: nkb_linear_gelu_fused_ok() == 1; erf by Abramowitz-Stegun 7.1.26,
+ * |error| <= 1.5e-7, below the bf16 rounding of both outputs). */
 int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y, void* y2,
                     int M, int K, int N, nkb_stream_t stream);
+int nkb_linear_gelu_fused_ok(int dtype, int M, int K, int N);
 /* LayerNorm over the last dim (biased variance). backward=0: in = x -> out = y, writes mean/rstd.
  * backward=1: in = dy, x = saved input -> out = dx (+ add), dgamma/dbeta accumulated (workspace: per-block partials added in a
  * fixed order; NULL: atomics). Strides in elements.

@@ -1203,19 +1203,10 @@ extern "C" int nkb_conv_dgrad_s2class(int dtype, const void* dy, const void* w_c
 //   act 3: y = (x W^T) where 0 < aux < 6, else 0              (unicom fc2 data-gradient, aux = fc1's ReLU6 output; the
 //          forward half is nkb_conv_gemm(relu = 2))
 //   act 4: y = (x W^T) * aux                                  (fc2 data-gradient, aux = gelu'(pre) from nkb_gelu_fwd_dgelu)
-extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y,
-                               void* y2, int M, int K, int N, hipStream_t stream) {
-    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
-    const int kte = 128 / esz;
-    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (act < 1 || act > 4) || K % kte != 0 || N % 8 != 0) {
-        nkb_set_error("linear_gelu: unsupported dtype/act/shape (K=%d N=%d)", K, N);
-        return 1;
-    }
-    if ((long long)M * K * esz >= 0xFFFFFF00ll || (long long)N * K * esz >= 0xFFFFFF00ll || (long long)M * N >= (1ll << 31)) {
-        nkb_set_error("linear_gelu: operand exceeds the 4 GiB buffer-addressing range");
-        return 1;
-    }
-    ConvParams p;
+//   act 5: pre = x W^T + b -> y = gelu(pre), y2 = gelu'(pre)  (fc1 forward when the backward pass is act 4: the pre-activation is
+//          never stored and the separate nkb_gelu_fwd_dgelu pass disappears; eight-phase core only — nkb_linear_gelu_fused_ok)
+static void linear_gelu_params(ConvParams& p, int act, const void* x, const void* w, const float* bias, const void* aux, void* y,
+                               void* y2, int M, int K, int N) {
     p.x = x; p.w = w; p.y = y; p.add = nullptr; p.bias = bias; p.stats = nullptr;
     p.M = M; p.H = M; p.W = 1; p.Cin = K; p.ldx = K; p.P = M; p.Q = 1; p.Cout = N; p.ldy = N; p.ldadd = 0;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 0; p.relu = 0; p.out_f32 = 0;
@@ -1223,7 +1214,32 @@ extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w,
     p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
     p.add_h = 0; p.add_w = 0; p.act = act; p.aux = aux; p.y2 = y2;
     p.ldw = K; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
-    NkbProfScope prof(act == 1 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
+}
+extern "C" int nkb_linear_gelu_fused_ok(int dtype, int M, int K, int N) {
+    if (dtype != NKB_DT_BF16 || (long long)M * K * 2 >= 0xFFFFFF00ll || (long long)N * K * 2 >= 0xFFFFFF00ll || (long long)M * N >= (1ll << 31)) return 0;
+    ConvParams p;
+    linear_gelu_params(p, 5, nullptr, nullptr, nullptr, nullptr, nullptr, (void*)16, M, K, N);
+    return nkb_gemm8p_eligible(p, dtype, 1) ? 1 : 0;
+}
+extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y,
+                               void* y2, int M, int K, int N, hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int kte = 128 / esz;
+    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || (act < 1 || act > 5) || K % kte != 0 || N % 8 != 0) {
+        nkb_set_error("linear_gelu: unsupported dtype/act/shape (K=%d N=%d)", K, N);
+        return 1;
+    }
+    if (act == 5 && (!y2 || !nkb_linear_gelu_fused_ok(dtype, M, K, N))) {
+        nkb_set_error("linear_gelu: act 5 needs y2 and a shape of the eight-phase core (nkb_linear_gelu_fused_ok)");
+        return 1;
+    }
+    if ((long long)M * K * esz >= 0xFFFFFF00ll || (long long)N * K * esz >= 0xFFFFFF00ll || (long long)M * N >= (1ll << 31)) {
+        nkb_set_error("linear_gelu: operand exceeds the 4 GiB buffer-addressing range");
+        return 1;
+    }
+    ConvParams p;
+    linear_gelu_params(p, act, x, w, bias, aux, y, y2, M, K, N);
+    NkbProfScope prof(act == 1 || act == 5 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
     if (nkb_gemm8p_eligible(p, dtype, 1)) return nkb_launch_gemm8p(p, stream);
     const bool narrow = N <= 64;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream) : launch_conv_auto<bf16_t, 128, 128>(p, stream);

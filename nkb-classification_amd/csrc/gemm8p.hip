@@ -41,7 +41,8 @@ struct G8Params {
     float* stats;         // optional [ceil(M/128)][2][N] sums of y and y^2 per 128 pixel rows (BatchNorm partials, same
                           // granularity as the 128 x 128 kernel so nkb_conv_gemm_stat_tiles stays a function of (M, Cout))
     int M, N, K, ldx, ldw, ldy, ldadd;
-    int relu;             // 0 none, 1 ReLU, 2 ReLU6
+    int relu;             // 0 none, 1 ReLU, 2 ReLU6, 3 GELU (exact form, see g8_gelu) with gelu'(pre) as a second bf16 output
+    bf16_t* y2;           // relu == 3: gelu'(product + bias), [M][ldy] — what the fc2 data gradient multiplies by (aux_mode 0)
     int tilesM, tilesN, group_m;
     // fp8 operands (F8 != 0): x and w hold one byte per element (K = bytes per row); the fp32 result is multiplied by
     // *deq_x * *deq_w (the per-tensor dequantisation factors, device floats) before bias / residual
@@ -117,6 +118,24 @@ __device__ __forceinline__ float g8_row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
     return v;
+}
+
+// GELU and its derivative for the epilogue: u = x Phi(x), u' = Phi(x) + x phi(x), Phi through erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, invisible behind the bf16 rounding of both outputs) — two quarter-rate instructions (rcp, exp2) and a
+// degree-5 Horner chain instead of libm's erff + expf, which cost more VALU time in a 256 x 256 epilogue than the separate
+// elementwise pass they would replace.
+__device__ __forceinline__ void g8_gelu(float x, float& u, float& du) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);            // exp(-x^2 / 2)
+    float pl = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    pl = __builtin_fmaf(pl, t, 1.421413741f);
+    pl = __builtin_fmaf(pl, t, -0.284496736f);
+    pl = __builtin_fmaf(pl, t, 0.254829592f);
+    const float erfa = __builtin_fmaf(-pl * t, e, 1.f);                               // erf(|x| / sqrt 2)
+    const float c = __builtin_fmaf(0.5f, __builtin_copysignf(erfa, x), 0.5f);         // Phi(x)
+    u = x * c;
+    du = __builtin_fmaf(x * 0.3989422804014327f, e, c);
 }
 
 // raw s_barrier (no vmcnt drain, unlike __syncthreads) between two compiler-level memory barriers
@@ -354,7 +373,13 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     for (int e = 0; e < 8; ++e) v[e] = (af[e] > 0.f && af[e] < 6.f) ? v[e] : 0.f;
                 }
             }
-            if (relu) {
+            if (relu == 3) {                           // GELU: u is the result, gelu'(pre) goes to the second output
+                float dv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g8_gelu(v[e], v[e], dv[e]);
+                if (FULL > 0 || em0 + lrow + 16 * j < p.M)
+                    __builtin_nontemporal_store(pack8(dv), (u32x4*)((unsigned char*)(p.y2 + ((size_t)em0 * p.ldy + en0)) + (yo + j * ystep + 64 * pr)));
+            } else if (relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
             }
@@ -612,6 +637,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 else if (!p.add && !p.aux) {
                     if (p.relu == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<0>{});
                     else if (p.relu == 2) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<2>{});
+                    else if (p.relu == 3) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<3>{});
                     else epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<1>{});
                 } else if (p.add && !p.aux && p.relu == 0) epilogue(G8I<1>{}, G8I<1>{}, G8I<0>{}, G8I<0>{});
                 else if (!p.add && p.aux && p.relu == 0) {
@@ -681,7 +707,12 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = p.aux_mode == 0 ? v[e] * af[e] : ((af[e] > 0.f && af[e] < 6.f) ? v[e] : 0.f);
                     }
-                    if (p.relu) {
+                    if (p.relu == 3) {
+                        float dv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) g8_gelu(v[e], v[e], dv[e]);
+                        *(u32x4*)(p.y2 + (size_t)m * p.ldy + co) = pack8(dv);
+                    } else if (p.relu) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
                     }
@@ -738,7 +769,9 @@ bool nkb_gemm8p_eligible(const ConvParams& p, int dtype, int batch) {
     if (!(p.R == 1 && p.S == 1 && p.stride == 1 && p.stride_w == 1 && p.pad == 0 && p.pad_w == 0 && p.stem_cprw == 0 &&
           p.sub_h == 0 && p.H == p.P && p.W == p.Q && p.mode == 0))
         return false;
-    if (p.out_f32 || p.add_h != 0 || p.add_bits != nullptr || p.y2 != nullptr || (p.act != 0 && p.act != 3 && p.act != 4)) return false;
+    if (p.out_f32 || p.add_h != 0 || p.add_bits != nullptr || (p.y2 != nullptr && p.act != 5) || (p.act != 0 && p.act != 3 && p.act != 4 && p.act != 5))
+        return false;
+    if (p.act == 5 && (p.y2 == nullptr || p.stats || p.add || p.relu)) return false;
     if (p.Cout % 256 != 0 || p.Cin % 64 != 0 || p.Cin < 128 || p.ldy % 8 != 0 || p.ldx % 8 != 0 || p.ldw % 8 != 0) return false;
     if (p.add && p.ldadd % 8 != 0) return false;
     if (p.add && p.stats) return false;
@@ -779,7 +812,12 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
     p.yq = nullptr; p.q_state = nullptr; p.q_kind = 0; p.ldq = 0;
     p.row_scale = nullptr; p.div_rows = make_fastdiv(1); p.mask_out = nullptr; p.mask_in = nullptr; p.colpart = nullptr;
     p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
-    p.relu = cp.relu;
+    p.relu = cp.act == 5 ? 3 : cp.relu;
+    p.y2 = cp.act == 5 ? (bf16_t*)cp.y2 : nullptr;
+    if (cp.act == 5) {
+        static const int ga = [] { const char* e = getenv("NKB_G8_GELU_ALIGN"); return e ? atoi(e) : 1; }();
+        p.align_epi = ga;
+    }
     p.deq_x = p.deq_w = nullptr;
     p.tilesM = (p.M + 255) / 256; p.tilesN = p.N / 256;
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
@@ -837,7 +875,7 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     if (!y && !(yq && (mask_out || colsum))) { nkb_set_error("gemm_fp8: y may be omitted only with yq and mask_out / colsum"); return 1; }
     if (row_scale && (!add || rows_per_sample < 1)) { nkb_set_error("gemm_fp8: row_scale goes with a residual operand and rows_per_sample >= 1"); return 1; }
     if (yq && (q_state == nullptr || (q_kind != 0 && q_kind != 1))) { nkb_set_error("gemm_fp8: quantised output needs its scaling state and kind 0 / 1"); return 1; }
-    p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu;
+    p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu; p.y2 = nullptr;
     p.deq_x = deq_x; p.deq_w = deq_w;
     p.tilesM = (M + 255) / 256; p.tilesN = N / 256;
     static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();

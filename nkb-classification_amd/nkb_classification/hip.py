@@ -56,6 +56,7 @@ _SIGS = {
     "nkb_gemm_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [i32, vp]),
     "nkb_gemm_tn_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [vp]),
     "nkb_linear_gelu": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "nkb_linear_gelu_fused_ok": (i32, [i32, i32, i32, i32]),
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp, i32, vp, vp]),
     "nkb_layernorm_workspace_floats": (sz, [i32]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
@@ -139,7 +140,7 @@ def exported_symbols():
 # (input images, logits, logits gradient) and dropout seeds.
 _REC = None            # list of plan entries while recording
 _REC_LIB = None
-_PURE = frozenset({"nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_bn_stats_floats",
+_PURE = frozenset({"nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_bn_stats_floats",
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
@@ -680,6 +681,11 @@ def attn_backward(dtype, qkv, dout, out, lse, dqkv, B, T, H, dh, scale, dqkv_q=N
 def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale, dq=None, ld_dq=0):
     check(load().nkb_attn_backward_ds(dtype, ptr(qkv), ptr(dout), ptr(lse), ptr(P), ptr(dS), ldp, B, T, H, dh, scale,
                                       ptr(dq), ld_dq, stream()), "attn_backward_ds")
+
+
+def linear_gelu_fused_ok(dtype, M, K, N) -> bool:
+    """act 5 of linear_gelu (y = gelu(pre), y2 = gelu'(pre) in the fc1 epilogue) is available for this shape."""
+    return bool(load().nkb_linear_gelu_fused_ok(dtype, M, K, N))
 
 
 def linear_gelu(dtype, act, x, w, bias, aux, y, y2, M, K, N):

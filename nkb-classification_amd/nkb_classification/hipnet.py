@@ -43,6 +43,7 @@ _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 # four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
 # the block to end.  Off.
 _WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
+_GELU_EPILOGUE = os.environ.get("NKB_GELU_EPILOGUE", "1") != "0"   # gelu + gelu' in the fc1 epilogue of the eight-phase core
 _FP8_LN_BWD_QUANT = os.environ.get("NKB_FP8_LN_BWD_QUANT", "1") != "0"   # LayerNorm backward writes the next Linear backward's fp8 operand
 _FP8_EPI_COLSUM = os.environ.get("NKB_FP8_EPI_COLSUM", "1") != "0"   # fc1's bias gradient from the fc2 data gradient's epilogue
 _FP8_MASK_BITS = os.environ.get("NKB_FP8_MASK_BITS", "1") != "0"   # fp8 step: ReLU6 output kept as fp8 operand + mask bits, no bf16 copy
@@ -963,6 +964,23 @@ class HipEngine:
         hip.linear_gelu(self.d, 1, x, self.w_fwd(lin.weight), self.arena.param_flat(lin.bias), None, u, pre, M, K, N)
         if train:
             self.saved[key] = dict(x=x, lin=lin, pre=pre)
+        return u
+
+    def linear_gelu_keep_derivative(self, key: str, key_act: str, x: torch.Tensor, lin: nn.Linear, train: bool):
+        """u = gelu(x @ W^T + b) AND gelu'(pre) from the fc1 GEMM's epilogue (the pre-activation is never stored; the separate
+        elementwise pass over it is gone); saved like linear() + gelu(keep_derivative=True), so the backward pass is
+        linear_backward_through_saved_derivative + linear_backward.  Returns None when the shape is not one of the eight-phase
+        core's (the caller then takes the two-kernel path)."""
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        if not (_GELU_EPILOGUE and train and self.T == torch.bfloat16 and lin.bias is not None and not self._fp8_linear_ok(lin, M)
+                and hip.linear_gelu_fused_ok(self.d, M, K, N)):
+            return None
+        u = self.ws.get(key_act + ".y", (M, N), self.T)
+        gp = self.ws.get(key + ".y", (M, N), self.T)            # (the buffer the plain path keeps the pre-activation / derivative in)
+        hip.linear_gelu(self.d, 5, x, self.w_fwd(lin.weight), self.arena.param_flat(lin.bias), None, u, gp, M, K, N)
+        self.saved[key] = dict(x=x, lin=lin)
+        self.saved[key_act] = dict(gp=gp)
         return u
 
     def linear_backward_through_gelu(self, key_next: str, key_act: str, g: torch.Tensor, slot: str) -> torch.Tensor:

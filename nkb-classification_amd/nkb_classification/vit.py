@@ -126,7 +126,9 @@ class HipViT(_ParamOnly):
                 u = eng.linear_gelu(f"b{i}.fc1", h, mlp.fc1, train)        # GELU fused into the fc1 epilogue
             else:
                 keep = _GELU_KEEP_DERIV and not (train and mlp.drop1.p > 0)
-                u = eng.gelu(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train, keep_derivative=keep)
+                u = eng.linear_gelu_keep_derivative(f"b{i}.fc1", f"b{i}.act", h, mlp.fc1, train) if keep else None
+                if u is None:
+                    u = eng.gelu(f"b{i}.act", eng.linear(f"b{i}.fc1", h, mlp.fc1, train), train, keep_derivative=keep)
             u = eng.dropout(f"b{i}.mlp_drop", u, mlp.drop1.p, train)
             if train and mlp.drop2.p > 0:
                 x = eng.dropout(f"b{i}.mlp2_drop", eng.linear(f"b{i}.fc2", u, mlp.fc2, train), mlp.drop2.p, train, add=x)
