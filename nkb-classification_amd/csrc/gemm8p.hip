@@ -122,20 +122,25 @@ __device__ __forceinline__ float g8_row16_sum(float v) {
 
 // GELU and its derivative for the epilogue: u = x Phi(x), u' = Phi(x) + x phi(x), Phi through erf by Abramowitz & Stegun 7.1.26
 // (|error| <= 1.5e-7, invisible behind the bf16 rounding of both outputs) — two quarter-rate instructions (rcp, exp2) and a
-// degree-5 Horner chain instead of libm's erff + expf, which cost more VALU time in a 256 x 256 epilogue than the separate
+// degree-5 Horner chain in packed FMAs (two elements per instruction) instead of libm's erff + expf, which cost more VALU time in a 256 x 256 epilogue than the separate
 // elementwise pass they would replace.
-__device__ __forceinline__ void g8_gelu(float x, float& u, float& du) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);            // exp(-x^2 / 2)
-    float pl = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    pl = __builtin_fmaf(pl, t, 1.421413741f);
-    pl = __builtin_fmaf(pl, t, -0.284496736f);
-    pl = __builtin_fmaf(pl, t, 0.254829592f);
-    const float erfa = __builtin_fmaf(-pl * t, e, 1.f);                               // erf(|x| / sqrt 2)
-    const float c = __builtin_fmaf(0.5f, __builtin_copysignf(erfa, x), 0.5f);         // Phi(x)
+typedef float g8_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void g8_gelu2(g8_f32x2 x, g8_f32x2& u, g8_f32x2& du) {          // two elements: packed FMAs / multiplies
+    const g8_f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const g8_f32x2 one = {1.f, 1.f}, half = {0.5f, 0.5f};
+    const g8_f32x2 den = __builtin_elementwise_fma(ax, (g8_f32x2){0.2316418882663604f, 0.2316418882663604f}, one);   // 0.3275911 / sqrt 2
+    const g8_f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const g8_f32x2 xx = x * x * (g8_f32x2){-0.72134752044448170f, -0.72134752044448170f};
+    const g8_f32x2 e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};       // exp(-x^2 / 2)
+    g8_f32x2 pl = __builtin_elementwise_fma((g8_f32x2){1.061405429f, 1.061405429f}, t, (g8_f32x2){-1.453152027f, -1.453152027f});
+    pl = __builtin_elementwise_fma(pl, t, (g8_f32x2){1.421413741f, 1.421413741f});
+    pl = __builtin_elementwise_fma(pl, t, (g8_f32x2){-0.284496736f, -0.284496736f});
+    pl = __builtin_elementwise_fma(pl, t, (g8_f32x2){0.254829592f, 0.254829592f});
+    const g8_f32x2 erfa = __builtin_elementwise_fma(-(pl * t), e, one);                     // erf(|x| / sqrt 2)
+    const g8_f32x2 se = {__builtin_copysignf(erfa[0], x[0]), __builtin_copysignf(erfa[1], x[1])};
+    const g8_f32x2 c = __builtin_elementwise_fma(half, se, half);                            // Phi(x)
     u = x * c;
-    du = __builtin_fmaf(x * 0.3989422804014327f, e, c);
+    du = __builtin_elementwise_fma(x * (g8_f32x2){0.3989422804014327f, 0.3989422804014327f}, e, c);
 }
 
 // raw s_barrier (no vmcnt drain, unlike __syncthreads) between two compiler-level memory barriers
@@ -376,7 +381,11 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             if (relu == 3) {                           // GELU: u is the result, gelu'(pre) goes to the second output
                 float dv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) g8_gelu(v[e], v[e], dv[e]);
+                for (int e = 0; e < 8; e += 2) {
+                    g8_f32x2 uu, dd;
+                    g8_gelu2((g8_f32x2){v[e], v[e + 1]}, uu, dd);
+                    v[e] = uu[0]; v[e + 1] = uu[1]; dv[e] = dd[0]; dv[e + 1] = dd[1];
+                }
                 if (FULL > 0 || em0 + lrow + 16 * j < p.M)
                     __builtin_nontemporal_store(pack8(dv), (u32x4*)((unsigned char*)(p.y2 + ((size_t)em0 * p.ldy + en0)) + (yo + j * ystep + 64 * pr)));
             } else if (relu) {
@@ -710,7 +719,11 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     if (p.relu == 3) {
                         float dv[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) g8_gelu(v[e], v[e], dv[e]);
+                        for (int e = 0; e < 8; e += 2) {
+                            g8_f32x2 uu, dd;
+                            g8_gelu2((g8_f32x2){v[e], v[e + 1]}, uu, dd);
+                            v[e] = uu[0]; v[e + 1] = uu[1]; dv[e] = dd[0]; dv[e + 1] = dd[1];
+                        }
                         *(u32x4*)(p.y2 + (size_t)m * p.ldy + co) = pack8(dv);
                     } else if (p.relu) {
 #pragma unroll
