@@ -176,6 +176,11 @@ int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int 
 int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y, void* y2,
                     int M, int K, int N, nkb_stream_t stream);
 int nkb_linear_gelu_fused_ok(int dtype, int M, int K, int N);
+/* y = add + row_scale[m / rows_per_sample] * (xW^T + b): a residual branch under per-sample stochastic depth (timm-style DropPath of
+ * the unicom blocks: the reference reaches it through unicom's Block.forward from /root/reference/nkb_classification/model.py:77-79)
+ * in one launch; bf16 shapes of the eight-phase core only (nkb_linear_gelu_fused_ok() == 1). */
+int nkb_linear_residual_scaled(int dtype, const void* x, const void* w, const float* bias, const void* add, const float* row_scale,
+                               int rows_per_sample, void* y, int M, int K, int N, nkb_stream_t stream);
 /* LayerNorm over the last dim (biased variance). backward=0: in = x -> out = y, writes mean/rstd.
  * backward=1: in = dy, x = saved input -> out = dx (+ add), dgamma/dbeta accumulated (workspace: per-block partials added in a
  * fixed order; NULL: atomics). Strides in elements.

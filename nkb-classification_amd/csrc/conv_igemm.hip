@@ -1221,6 +1221,22 @@ extern "C" int nkb_linear_gelu_fused_ok(int dtype, int M, int K, int N) {
     linear_gelu_params(p, 5, nullptr, nullptr, nullptr, nullptr, nullptr, (void*)16, M, K, N);
     return nkb_gemm8p_eligible(p, dtype, 1) ? 1 : 0;
 }
+// y = add + row_scale[m / rows_per_sample] * (x W^T + b): a residual branch under per-sample stochastic depth (the unicom blocks'
+// proj / fc2 forward in bf16) in ONE launch — the scale rides in the eight-phase core's residual epilogue instead of a second pass
+// over the branch output.  Shapes of that core only (nkb_linear_gelu_fused_ok(dtype, M, K, N) == 1).
+extern "C" int nkb_linear_residual_scaled(int dtype, const void* x, const void* w, const float* bias, const void* add,
+                                          const float* row_scale, int rows_per_sample, void* y, int M, int K, int N, hipStream_t stream) {
+    if (!add || !row_scale || rows_per_sample < 1 || !nkb_linear_gelu_fused_ok(dtype, M, K, N)) {
+        nkb_set_error("linear_residual_scaled: needs add, row_scale, rows_per_sample >= 1 and a bf16 shape of the eight-phase core");
+        return 1;
+    }
+    ConvParams p;
+    linear_gelu_params(p, 0, x, w, bias, nullptr, y, nullptr, M, K, N);
+    p.add = add; p.ldadd = N;
+    if (!nkb_gemm8p_eligible(p, dtype, 1)) { nkb_set_error("linear_residual_scaled: shape not eligible"); return 1; }
+    NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * M * (double)N * K);
+    return nkb_launch_gemm8p(p, stream, row_scale, rows_per_sample);
+}
 extern "C" int nkb_linear_gelu(int dtype, int act, const void* x, const void* w, const float* bias, const void* aux, void* y,
                                void* y2, int M, int K, int N, hipStream_t stream) {
     const int esz = dtype == NKB_DT_BF16 ? 2 : 4;

@@ -817,13 +817,15 @@ static int g8_cus() {
     return cus;
 }
 
-int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream) {
+int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream, const float* row_scale, int rows_per_sample) {
     G8Params p;
     p.x = (const bf16_t*)cp.x; p.w = (const bf16_t*)cp.w; p.y = (bf16_t*)cp.y; p.bias = cp.bias;
     p.add = (const bf16_t*)cp.add; p.aux = (cp.act == 4 || cp.act == 3) ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;
     p.aux_mode = cp.act == 3 ? 1 : 0; p.align_epi = g8_align();
     p.yq = nullptr; p.q_state = nullptr; p.q_kind = 0; p.ldq = 0;
-    p.row_scale = nullptr; p.div_rows = make_fastdiv(1); p.mask_out = nullptr; p.mask_in = nullptr; p.colpart = nullptr;
+    // row_scale (with add, DIRECT form only): y = add + row_scale[m / rows_per_sample] * (product + bias) — stochastic depth
+    p.row_scale = row_scale; p.div_rows = make_fastdiv(row_scale && rows_per_sample > 0 ? (unsigned)rows_per_sample : 1u);
+    p.mask_out = nullptr; p.mask_in = nullptr; p.colpart = nullptr;
     p.M = cp.M; p.N = cp.Cout; p.K = cp.Cin; p.ldx = cp.ldx; p.ldw = cp.ldw; p.ldy = cp.ldy; p.ldadd = cp.ldadd;
     p.relu = cp.act == 5 ? 3 : cp.relu;
     p.y2 = cp.act == 5 ? (bf16_t*)cp.y2 : nullptr;

@@ -57,6 +57,7 @@ _SIGS = {
     "nkb_gemm_tn_batched": (i32, [i32, vp, vp, vp] + [i32] * 8 + [i64] * 6 + [vp]),
     "nkb_linear_gelu": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_linear_gelu_fused_ok": (i32, [i32, i32, i32, i32]),
+    "nkb_linear_residual_scaled": (i32, [i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp, i32, vp, vp]),
     "nkb_layernorm_workspace_floats": (sz, [i32]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
@@ -686,6 +687,12 @@ def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale, dq=N
 def linear_gelu_fused_ok(dtype, M, K, N) -> bool:
     """act 5 of linear_gelu (y = gelu(pre), y2 = gelu'(pre) in the fc1 epilogue) is available for this shape."""
     return bool(load().nkb_linear_gelu_fused_ok(dtype, M, K, N))
+
+
+def linear_residual_scaled(dtype, x, w, bias, add, row_scale, rows_per_sample, y, M, K, N):
+    """y = add + row_scale[m // rows_per_sample] * (x @ w^T + bias) in one launch (shapes with linear_gelu_fused_ok)."""
+    check(load().nkb_linear_residual_scaled(dtype, ptr(x), ptr(w), ptr(bias), ptr(add), ptr(row_scale), int(rows_per_sample),
+                                            ptr(y), M, K, N, stream()), "linear_residual_scaled")
 
 
 def linear_gelu(dtype, act, x, w, bias, aux, y, y2, M, K, N):

@@ -43,6 +43,7 @@ _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 # four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
 # the block to end.  Off.
 _WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
+_ROWSCALE_EPILOGUE = os.environ.get("NKB_ROWSCALE_EPILOGUE", "1") != "0"   # bf16: drop-path scale in the residual GEMM epilogue
 _GELU_EPILOGUE = os.environ.get("NKB_GELU_EPILOGUE", "1") != "0"   # gelu + gelu' in the fc1 epilogue of the eight-phase core
 _FP8_LN_BWD_QUANT = os.environ.get("NKB_FP8_LN_BWD_QUANT", "1") != "0"   # LayerNorm backward writes the next Linear backward's fp8 operand
 _FP8_EPI_COLSUM = os.environ.get("NKB_FP8_EPI_COLSUM", "1") != "0"   # fc1's bias gradient from the fc2 data gradient's epilogue
@@ -770,7 +771,11 @@ class HipEngine:
             if train:
                 self.saved[key] = dict(x=x, lin=lin, xq=xq, sx=sx)
             return y
-        if row_scale is not None:
+        if row_scale is not None and add is not None and _ROWSCALE_EPILOGUE and self.T == torch.bfloat16 \
+                and hip.linear_gelu_fused_ok(self.d, M, K, N):
+            # stochastic depth in the residual epilogue of the eight-phase core (no second pass over the branch output)
+            hip.linear_residual_scaled(self.d, x, self.w_fwd(lin.weight), bias, add, row_scale[0], row_scale[1], y, M, K, N)
+        elif row_scale is not None:
             hip.conv_gemm(self.d, 0, x, self.w_fwd(lin.weight), y, N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N, bias=bias)
             out = self.ws.get(key + ".ys", (M, N), self.T)
             hip.scale_rows(self.d, y, add, out, row_scale[0], M // row_scale[1], row_scale[1] * N)

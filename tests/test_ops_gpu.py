@@ -1084,7 +1084,7 @@ def gemm8p_everywhere():
 @pytest.mark.parametrize("shape", [(1000, 256, 128), (2048 + 37, 768, 192), (4096, 512, 768), (777, 256, 1024), (256, 1024, 64 * 7),
                                    (256 * 300 + 100, 512, 256)],      # 602 tiles: every persistent workgroup walks 2-3 of them
                          ids=lambda s: "M%d_N%d_K%d" % s)
-@pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_add", "add", "relu6", "stats", "mul", "mask6", "gelu2"])
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_add", "add", "relu6", "stats", "mul", "mask6", "gelu2", "rowscale"])
 def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
     """y = x w^T through nkb_conv_gemm / nkb_linear_gelu with the eight-phase kernel forced on: ragged M (rows past M are
     loaded clamped and never stored), 2 to 16 k-tiles (the DMA stream's prologue / tail cases), every epilogue the kernel
@@ -1118,6 +1118,10 @@ def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
             hip.conv_gemm(d, 0, xd, wd, y, relu=2, **geom)
         elif epi == "mask6":
             hip.linear_gelu(d, 3, xd, wd, None, u6.to(DEV), y, None, M, K, N)
+        elif epi == "rowscale":       # residual branch under per-sample stochastic depth: y = add + s[m // rows] * (x w^T + b)
+            rps = 50
+            rsc = ((torch.arange((M + rps - 1) // rps) % 3 != 0).float() / 0.75)
+            hip.linear_residual_scaled(d, xd, wd, bias.to(DEV), add.to(DEV), rsc.to(DEV), rps, y, M, K, N)
         elif epi == "gelu2":          # fc1 forward of the timm MLP: gelu(pre) and gelu'(pre) from one epilogue, pre never stored
             assert hip.linear_gelu_fused_ok(d, M, K, N)
             stats = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)      # (second output: the derivative)
@@ -1138,6 +1142,10 @@ def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
         torch.testing.assert_close(outs[0][0].float().cpu(), (pre * cdf).float(), **tol(torch.bfloat16, K))
         torch.testing.assert_close(outs[0][1].float().cpu(), (cdf + pre * phi).float(), **tol(torch.bfloat16, K))
         assert torch.equal(outs[0][1], outs[1][1])
+        return
+    if epi == "rowscale":
+        rsc = ((torch.arange((M + 49) // 50) % 3 != 0).float() / 0.75).repeat_interleave(50)[:M, None]
+        torch.testing.assert_close(outs[0][0].float().cpu(), add.float() + rsc * (ref + bias), **tol(torch.bfloat16, K))
         return
     want = {"plain": ref, "bias_relu": (ref + bias).clamp_min(0), "bias_add": ref + bias + add.float(),
             "add": ref + add.float(), "relu6": ref.clamp(0, 6), "stats": ref, "mul": ref * aux.float(),
