@@ -187,7 +187,8 @@ int nkb_linear_residual_scaled(int dtype, const void* x, const void* w, const fl
  * yq / q_state / q_kind (optional, D % 256 == 0, out_stride == D): fp8 copy of the output rows for the fp8 GEMM that consumes
  * them (see nkb_fp8_quantize).  Backward (workspace form only): the copy is of row_scale[row / rows_per_sample] * dx (row_scale
  * optional: the stochastic-depth factor of the branch the gradient enters) and colsum[D] += its column sums — the operand and
- * the bias gradient nkb_fp8_quantize_colsum would make of dx for the Linear backward that consumes it. */
+ * the bias gradient nkb_fp8_quantize_colsum would make of dx for the Linear backward that consumes it.  q_kind 2 (backward, bf16):
+ * yq is a bf16 [rows][D] tensor that receives row_scale[row / rows_per_sample] * dx (nkb_scale_rows of the stored dx; no state, no colsum). */
 int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, const void* x, long long x_stride,
                   const float* gamma, const float* beta, float* mean, float* rstd, const void* add, void* out,
                   long long out_stride, float* dgamma, float* dbeta, int rows, int D, float eps, float* workspace,

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // LayerNorm backward: dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ add);  dgamma += sum dy*xhat, dbeta += sum dy
-template <typename T, int VW, int NP, int QK>      // QK: -1 no fp8 output, 0 e4m3, 1 e5m2
+template <typename T, int VW, int NP, int QK>      // QK: -1 no second output, 0 e4m3, 1 e5m2, 2 row-scaled copy in the compute dtype
 __global__ __launch_bounds__(256, NP <= 4 ? 3 : 1) void layernorm_bwd_kernel(const T* __restrict__ dy, long long dys, const T* __restrict__ x,
                                                             long long xs, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256, NP <= 4 ? 3 : 1) void layernorm_bwd_kernel(con
                                                             float* __restrict__ q_state, int q_kind,
                                                             const float* __restrict__ row_scale, int rows_per_sample) {
     constexpr int D = 64 * VW * NP;
-    constexpr bool QOUT = QK >= 0;
+    constexpr bool QOUT = QK == 0 || QK == 1;
+    constexpr bool SOUT = QK == 2;                  // second output = row_scale[row / rows_per_sample] * dx in T (bf16 step: the branch
+                                                    // gradient a stochastic-depth Linear backward consumes — nkb_scale_rows of dx)
     constexpr int NV = QOUT ? 3 : 2;                // partial planes per block: dgamma, dbeta (, column sums of the fp8 operand)
     __shared__ float red[4][NV][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256, NP <= 4 ? 3 : 1) void layernorm_bwd_kernel(con
         c2 = wave_sum(c2) / (float)D;
         T* or_ = dx + (size_t)row * dxs;
         [[maybe_unused]] float rsc = 1.f;              // (one scalar division per row, not one per vector)
-        if constexpr (QOUT) { if (row_scale) rsc = row_scale[__builtin_amdgcn_readfirstlane(row) / rows_per_sample]; }
+        if constexpr (QOUT || SOUT) { if (row_scale) rsc = row_scale[__builtin_amdgcn_readfirstlane(row) / rows_per_sample]; }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int e0 = (k * 64 + lane) * VW;
@@ -191,6 +193,12 @@ __global__ __launch_bounds__(256, NP <= 4 ? 3 : 1) void layernorm_bwd_kernel(con
                 if (add) o[e] += a[e];
             }
             VecIO<T, VW>::st(or_ + e0, o);
+            if constexpr (SOUT) {
+                float sc[VW];
+#pragma unroll
+                for (int e = 0; e < VW; ++e) sc[e] = DT<T>::rnd(o[e]) * rsc;
+                VecIO<T, VW>::st((T*)yq + (size_t)row * D + e0, sc);
+            }
             if constexpr (QOUT && VW == 4) {
                 float q[4];
 #pragma unroll
@@ -305,9 +313,10 @@ static void ln_launch(int backward, int grid, hipStream_t stream, const void* in
         hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps, yq, q_state, q_kind);
     else {
 #define LN_BWD(Q) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP, Q>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part, yq, q_state, q_kind, row_scale, yq ? rows_per_sample : 1)
-        if constexpr (VW == 4 && std::is_same<T, bf16_t>::value) {      // (the fp8 output: bf16 rows of 256-element multiples only)
+        if constexpr (VW == 4 && std::is_same<T, bf16_t>::value) {      // (the second outputs: bf16 rows of 256-element multiples only)
             if (yq && q_kind == 0) { LN_BWD(0); return; }
-            if (yq) { LN_BWD(1); return; }
+            if (yq && q_kind == 1) { LN_BWD(1); return; }
+            if (yq) { LN_BWD(2); return; }
         }
         LN_BWD(-1);
 #undef LN_BWD
@@ -341,15 +350,20 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
         nkb_set_error("layernorm: D=%d must be a multiple of 128 (<= 2048) with vector-aligned strides", D);
         return 1;
     }
-    if (yq && (vw != 4 || out_stride != D || !q_state || (q_kind != 0 && q_kind != 1))) {
+    const bool scaled_copy = yq && q_kind == 2;              // backward only: yq = row_scale * dx in the compute dtype (bf16)
+    if (scaled_copy && (!backward || dtype != NKB_DT_BF16 || vw != 4 || out_stride != D || !row_scale || rows_per_sample < 1 || q_state || colsum)) {
+        nkb_set_error("layernorm: the scaled copy (q_kind 2) goes with backward, bf16, D %% 256 == 0, packed rows, row_scale and nothing else");
+        return 1;
+    }
+    if (yq && !scaled_copy && (vw != 4 || out_stride != D || !q_state || (q_kind != 0 && q_kind != 1))) {
         nkb_set_error("layernorm: the fp8 output needs D %% 256 == 0, packed rows and a scaling state");
         return 1;
     }
-    if (yq && backward && (!workspace || !colsum || (row_scale && rows_per_sample < 1))) {
+    if (yq && !scaled_copy && backward && (!workspace || !colsum || (row_scale && rows_per_sample < 1))) {
         nkb_set_error("layernorm: the backward fp8 output goes with the workspace form, a column-sum vector and rows_per_sample >= 1");
         return 1;
     }
-    if (!yq && (row_scale || colsum)) { nkb_set_error("layernorm: row_scale / colsum belong to the fp8 output"); return 1; }
+    if (!yq && (row_scale || colsum)) { nkb_set_error("layernorm: row_scale / colsum belong to the second output"); return 1; }
     NkbProfScope prof(NKB_K_LN, stream, 0);
     int grid = (rows + 3) / 4;
     if (!backward) { if (grid > (yq ? 1024 : 256 * 16)) grid = yq ? 1024 : 256 * 16; }   // (fp8 copy: one amax atomic per block)
@@ -372,7 +386,7 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
     if (rc) { nkb_set_error("layernorm: unsupported D=%d", D); return 1; }
     if (backward && workspace)
     {
-        if (yq) {                                             // three planes per partial row (3072 D + 48 D of the 4096 D floats)
+        if (yq && !scaled_copy) {                             // three planes per partial row (3072 D + 48 D of the 4096 D floats)
             float* inter = workspace + (size_t)1024 * 3 * D;
             hipLaunchKernelGGL(ln_param_grad_kernel<3>, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
             hipLaunchKernelGGL(ln_param_grad_final_kernel<3>, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta, colsum);

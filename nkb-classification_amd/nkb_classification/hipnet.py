@@ -43,6 +43,7 @@ _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 # four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
 # the block to end.  Off.
 _WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
+_LN_BWD_SCALED_COPY = os.environ.get("NKB_LN_BWD_SCALED_COPY", "1") != "0"   # bf16: LayerNorm backward writes scale[b] * dx as well
 _ROWSCALE_EPILOGUE = os.environ.get("NKB_ROWSCALE_EPILOGUE", "1") != "0"   # bf16: drop-path scale in the residual GEMM epilogue
 _GELU_EPILOGUE = os.environ.get("NKB_GELU_EPILOGUE", "1") != "0"   # gelu + gelu' in the fc1 epilogue of the eight-phase core
 _FP8_LN_BWD_QUANT = os.environ.get("NKB_FP8_LN_BWD_QUANT", "1") != "0"   # LayerNorm backward writes the next Linear backward's fp8 operand
@@ -90,6 +91,7 @@ class HipEngine:
         self._f8table = None                       # device table of all site states for the one-launch scale update
         self._f8ready: Dict[str, torch.Tensor] = {}
         self._ones_cache: Dict[int, torch.Tensor] = {}
+        self._gs_ready: Dict[int, torch.Tensor] = {}      # data_ptr of a gradient -> its stochastic-depth-scaled copy
         self._f8bias: Dict[str, bool] = {}          # ready sites whose producer also summed the columns (bias gradient done)
         self._wg_pending = []                      # Linear weight gradients of the current block, launched together by end_block
         self._wg_keep = {}                         # host job arrays of the grouped launches (kept alive for plan replay)  # site -> fp8 copy already written by the kernel that produced the tensor
@@ -248,6 +250,7 @@ class HipEngine:
         in the previous step (192 single-thread launches per unicom ViT-L/14 step otherwise)."""
         self._f8ready.clear()                        # (an operand a producer wrote but nobody consumed does not outlive its step)
         self._f8bias.clear()
+        self._gs_ready.clear()
         if not (self.fp8 and self._f8act):
             return
         if self._f8table is None:
@@ -857,6 +860,9 @@ class HipEngine:
         with the scale handed on to the fused fp8 quantise + column-sum pass (no bf16 copy of the branch gradient at all)."""
         if g_scale is None:
             return g, None
+        ready = self._gs_ready.pop(g.data_ptr(), None)        # LayerNorm backward wrote the scaled copy next to g
+        if ready is not None:
+            return ready, None
         if (self._fp8_linear_ok(lin, M) and lin.bias is not None and self._fp8_wgrad_ok(sv, M, K, N) and self._fp8_colsum_ok(g)
                 and _FP8_FUSED_QUANT):
             return g, g_scale
@@ -1020,11 +1026,14 @@ class HipEngine:
         return y
 
     def layernorm_backward(self, key: str, g: torch.Tensor, out: torch.Tensor, out_stride: int,
-                           add: Optional[torch.Tensor] = None, consumer: Optional[str] = None, consumer_dp: Optional[str] = None):
+                           add: Optional[torch.Tensor] = None, consumer: Optional[str] = None, consumer_dp: Optional[str] = None,
+                           consumer_block: Optional[int] = None):
         """dx (+ add) is written into `out` rows with stride out_stride (elements).
         consumer: key of the Linear whose backward pass takes `out` as its incoming gradient (through the stochastic-depth site
         consumer_dp, if any).  In the fp8 step that Linear consumes the gradient as an e5m2 operand scaled per sample, plus its
-        column sums for the bias: this kernel then writes both next to dx (no separate quantise + column-sum pass over dx)."""
+        column sums for the bias: this kernel then writes both next to dx (no separate quantise + column-sum pass over dx).
+        In the bf16 step it writes the scaled branch gradient scale[b] * dx itself (consumer_block: the backward block index the
+        consumer runs in, when that is not the current one — its scratch set and the side-stream wait that guards it)."""
         sv = self.saved[key]
         ln = sv["ln"]
         D = ln.weight.shape[0]
@@ -1049,6 +1058,28 @@ class HipEngine:
                                           yq=q[0], q_state=q[1], q_kind=q[2], row_scale=gs[0] if gs else None,
                                           rows_per_sample=gs[1] if gs else 0, colsum=a.grad_flat(lin.bias))
                         return out
+        if (consumer is not None and consumer_dp and _LN_BWD_SCALED_COPY and self.T == torch.bfloat16 and out_stride == D
+                and D % 256 == 0 and tuple(out.shape) == (rows, D) and consumer in self.saved):
+            gs = self.drop_path_gscale(consumer_dp, rows)
+            svc = self.saved[consumer]
+            if gs is not None and not self._fp8_linear_ok(svc["lin"], rows) and svc["lin"].weight.shape[0] == D:
+                # bf16 step: the branch gradient scale[b] * dx that the consumer's data and weight gradient read is written here too
+                # (it was a scale_rows pass over dx: read + write of the whole tensor)
+                keep = self._suffix
+                if consumer_block is not None:
+                    # the consumer's scratch set (by block parity) is still read by the side-stream weight gradients issued two
+                    # blocks before it: the wait begin_block(consumer_block) would make, made now
+                    ev = self._side_done.pop(consumer_block + 2, None)
+                    if ev is not None:
+                        hip.host_op(lambda: torch.cuda.current_stream().wait_event(ev))
+                    self._suffix = ".p%d" % (consumer_block & 1)
+                scaled = self.scratch("gs_" + consumer.rsplit(".", 1)[-1], (rows, D))
+                self._suffix = keep
+                hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
+                                  out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), rows, D, workspace=work,
+                                  yq=scaled, q_kind=2, row_scale=gs[0], rows_per_sample=gs[1])
+                self._gs_ready[out.data_ptr()] = scaled
+                return out
         hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
                           out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), rows, D, workspace=work)
         return out

@@ -170,7 +170,7 @@ class HipUnicomViT(_ParamOnly):
         g = eng.conv_backward("feat1", g, "gf1x")                             # [B,1,1,T*D]
         nb = len(self.blocks)
         gx = eng.layernorm_backward("norm", g.view(M, D), eng.scratch("gx0", (M, D)), D,
-                                    consumer=f"b{nb - 1}.fc2" if nb else None, consumer_dp=f"b{nb - 1}.dp2")
+                                    consumer=f"b{nb - 1}.fc2" if nb else None, consumer_dp=f"b{nb - 1}.dp2", consumer_block=nb - 1)
         eng.end_block(len(self.blocks))
         if on_done is not None:
             on_done(f)
@@ -192,7 +192,7 @@ class HipUnicomViT(_ParamOnly):
             d_qkv = eng.attention_backward(f"b{i}.attn", d_o, "dqkv", q_for=f"b{i}.qkv.f8g")
             d_h = eng.linear_backward(f"b{i}.qkv", d_qkv, "dh")
             gx = eng.layernorm_backward(f"b{i}.ln1", d_h, eng.scratch(f"gx{flip}", (M, D)), D, add=gmid,
-                                        consumer=f"b{i - 1}.fc2" if i > 0 else None, consumer_dp=f"b{i - 1}.dp2")
+                                        consumer=f"b{i - 1}.fc2" if i > 0 else None, consumer_dp=f"b{i - 1}.dp2", consumer_block=i - 1)
             flip ^= 1
             eng.end_block(i)
             if on_done is not None:

@@ -1461,6 +1461,17 @@ def test_layernorm_backward_fp8_copy_and_column_sums(shape, scaled):
     assert torch.equal(q1, qq) and st1[2].item() == stq[2].item()
     ref = dx0.double() * (rsc.double().repeat_interleave(rps)[:rows, None] if scaled else 1.0)
     torch.testing.assert_close(cs1.double().cpu(), 2.0 + ref.sum(0).cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(rows) * dx0.abs().max().item())
+    if scaled:
+        # q_kind 2: the row-scaled copy in bf16 (the branch gradient of the bf16 step) = nkb_scale_rows over the stored dx
+        dx3 = torch.full((rows, D), float("nan"), device=DEV, dtype=torch.bfloat16)
+        sc3 = torch.full((rows, D), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dg3, db3 = torch.full((D,), 0.25, device=DEV), torch.full((D,), -0.5, device=DEV)
+        hip.layernorm_bwd(hip.BF16, dy, D, x, D, gamma, mean, rstd, add, dx3, D, dg3, db3, rows, D, workspace=work,
+                          yq=sc3, q_kind=2, row_scale=rsc, rows_per_sample=rps)
+        torch.cuda.synchronize()
+        assert torch.equal(dx3, dx0) and torch.equal(dg3, dg0) and torch.equal(db3, db0)
+        want3 = (dx0.float() * rsc.repeat_interleave(rps)[:rows, None]).to(torch.bfloat16)
+        assert torch.equal(sc3, want3)
     with pytest.raises(RuntimeError, match="layernorm"):        # the fp8 output needs the deterministic (workspace) form
         hip.layernorm_bwd(hip.BF16, dy, D, x, D, gamma, mean, rstd, add, dx0, D, dg0, db0, rows, D, yq=q1, q_state=st1, q_kind=hip.E5M2, colsum=cs1)
 
