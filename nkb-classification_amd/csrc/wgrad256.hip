@@ -618,14 +618,20 @@ __global__ __launch_bounds__(512, 1) void wgrad8f_group_kernel(const W256Group g
 
 }  // namespace
 
-static int wgrad256_target_wgs() {
-    static const int target = [] { const char* e = getenv("NKB_WGRAD256_WGS"); return e ? atoi(e) : 256; }();
-    return target;
+// Workgroups a weight-gradient launch aims for.  These kernels run on the side stream NEXT TO the main stream's GEMMs, so they
+// need not fill the chip by themselves, and every extra split costs a 4 bytes / weight slab written and read back.  Same-box
+// A/B of the whole step (scripts/ab_env.sh NKB_WGRAD256_WGS ...): 128 instead of 256 is -0.8 ms for the fp8 unicom step and
+// -0.25 ms for ResNet-50 (its eight-phase launches are small: <= 26 GFLOP), neutral for ViT-B/16, and +2.2 ms for the bf16 unicom
+// step, whose 200-280 GFLOP bf16 weight gradients are long enough to become the critical path when under-split (64: +40 ms).
+static int wgrad256_target_wgs(bool fp8, double flops) {
+    static const int forced = [] { const char* e = getenv("NKB_WGRAD256_WGS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    return (fp8 || flops < 5.0e10) ? 128 : 256;
 }
 
 // stages (64 tokens) per split for `tiles` output tiles: ~target workgroups in total
 static int wgrad256_stages_per_split(int M, int tiles, int* splits_out) {
-    int splits = (wgrad256_target_wgs() + tiles / 2) / tiles;
+    int splits = (wgrad256_target_wgs(false, 2.0 * M * 65536.0 * tiles) + tiles / 2) / tiles;
     if (splits < 1) splits = 1;
     const int stages = M / 64;
     if (splits > stages) splits = stages;
@@ -690,7 +696,7 @@ int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, 
 // M % 128 == 0, Cin % 256 == 0, Cout % 256 == 0; workspace: nkb_wgrad_fp8_workspace_floats() floats (per-split slabs, reduced
 // in split order: deterministic).  The bias gradient is not part of this launch (it needs the unquantised dY column sums).
 static int wgrad8f_stages_per_split(int M, int tiles, int* splits_out) {
-    int splits = (wgrad256_target_wgs() + tiles / 2) / tiles;
+    int splits = (wgrad256_target_wgs(true, 0.0) + tiles / 2) / tiles;
     if (splits < 1) splits = 1;
     const int stages = M / 128;
     if (splits > stages) splits = stages;
