@@ -22,9 +22,10 @@ _FUSED_BN_BWD = os.environ.get("NKB_FUSED_BNBWD", "1") != "0"
 # 3x3 stride-2 data gradients as four parity-class launches (9 taps instead of 36 multiplied, 27 of them by zero)
 _S2_CLASSES = os.environ.get("NKB_S2_CLASSES", "1") != "0"
 _FUSED_RES_BN_BWD = os.environ.get("NKB_FUSED_RES_BNBWD", "1") != "0"
-# stages with <= 64 channels use the 64x256 conv tile (2 workgroups per CU), whose fused epilogue costs more than the
-# separate reduction pass it replaces (A/B on ResNet-50: 23.75 vs 23.64 ms/step) -> fuse from 65 channels up
-_FUSE_MIN_C = int(os.environ.get("NKB_FUSE_MIN_C", "65"))
+# smallest channel count from which that fusion is taken.  Round 1 excluded the <= 64-channel stages (64x256 conv tile: the fused
+# epilogue cost more than the separate reduction pass, 23.75 vs 23.64 ms/step); with this round's kernels the same-box A/B
+# reads 20.43-20.49 ms fused everywhere against 20.63-20.67 (scripts/ab_env.sh NKB_FUSE_MIN_C "65 1 ..."): fuse always
+_FUSE_MIN_C = int(os.environ.get("NKB_FUSE_MIN_C", "1"))
 # residual-closing stages keep a 1-bit/element ReLU mask; backward reads it instead of the activation and the masked
 # block-output gradient is never materialised (consumers apply the bits on the fly)
 _RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
