@@ -799,6 +799,18 @@ static int g8_align() {
     return on;
 }
 
+// Persistent workgroups for `tiles` tiles on `cus` CUs: the tiles take ceil(tiles / cus) rounds whatever the grid, so the grid is
+// the SMALLEST one that still finishes in that many rounds — every workgroup then walks the same number of tiles (no idle tail),
+// and the CUs it leaves free run the side stream's weight gradients for the whole launch (ViT-B/16: 591 tiles -> 197 workgroups
+// x 3 tiles instead of 256 with a third round at 31 %; in-step A/B -0.3 ms; tile counts that are multiples of 256 are unchanged)
+static int g8_grid(int tiles, int cus) {
+    if (tiles <= cus) return tiles;
+    static const int balanced = [] { const char* e = getenv("NKB_G8_BALANCED"); return e ? atoi(e) : 1; }();
+    if (!balanced) return cus;
+    const int rounds = (tiles + cus - 1) / cus;
+    return (tiles + rounds - 1) / rounds;
+}
+
 static int g8_cus() {
     static int cus = 0;
     if (!cus) {
@@ -844,7 +856,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream, const float* row
     // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
     static const int direct_on = [] { const char* e = getenv("NKB_GEMM8P_DIRECT"); return e ? atoi(e) : 1; }();
     if (p.stats == nullptr && direct_on && p.K >= 128)
-        hipLaunchKernelGGL(gemm8p_kernel<true>, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(512), lds, stream, p);
+        hipLaunchKernelGGL(gemm8p_kernel<true>, dim3((unsigned)g8_grid(tiles, cus)), dim3(512), lds, stream, p);
     else
         hipLaunchKernelGGL(gemm8p_kernel<false>, dim3((unsigned)tiles), dim3(512), lds, stream, p);
     return nkb_check_launch("gemm8p");
@@ -899,7 +911,7 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096;
     const int tiles = p.tilesM * p.tilesN;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
-    const dim3 grid((unsigned)(tiles < cus ? tiles : cus));
+    const dim3 grid((unsigned)g8_grid(tiles, cus));
     if (yq) {
         if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<true, 1, true>), grid, dim3(512), lds, stream, p);
         else hipLaunchKernelGGL((gemm8p_kernel<true, 2, true>), grid, dim3(512), lds, stream, p);
