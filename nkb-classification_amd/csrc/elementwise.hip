@@ -40,14 +40,16 @@ __device__ __forceinline__ void ldvec(const float* __restrict__ p, float* o) {
 // bn_finalize: reduce the conv epilogue's per-tile partial sums -> batch mean / biased var,
 // fold gamma/beta into (scale, shift), update running stats (momentum, unbiased var).
 // eval mode (training == 0): scale/shift from the running statistics, nothing else touched.
-// stage A (only for many tiles): grid (C/64, 16) blocks of 64 channels x 16 partitions -> dpart[16][2][C] doubles
+// stage A (only for many tiles): grid (C/64, P) blocks of 64 channels x 16 tile lanes -> dpart[P][2][C] doubles; P partitions:
+// 16 for wide layers, more for narrow ones (C = 64: one block column — 16 blocks read the 3.2 MB of partials of a 56 x 56 layer)
+static inline int bn_partitions(int C) { return C <= 128 ? 64 : (C <= 256 ? 32 : 16); }
 __global__ void bn_partial_reduce_kernel(const float* __restrict__ partials, int tiles, int C, double* __restrict__ dpart) {
     __shared__ double red[2][16][64];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double s = 0.0, ss = 0.0;
     if (c < C) {
-        for (int t = blockIdx.y * 16 + py; t < tiles; t += 256) {
+        for (int t = blockIdx.y * 16 + py; t < tiles; t += 16 * (int)gridDim.y) {
             s += (double)partials[((size_t)t * 2) * C + c];
             ss += (double)partials[((size_t)t * 2 + 1) * C + c];
         }
@@ -106,7 +108,7 @@ __global__ void bn_finalize_kernel(const PT* __restrict__ partials, int tiles, i
     if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
 }
 
-// `partials` must have room for 64*C extra floats behind the [tiles][2][C] block when tiles > 128 (stage-A scratch).
+// `partials` must have the size nkb_bn_stats_floats(tiles, C): room for the stage-A scratch behind the [tiles][2][C] block when tiles > 128.
 extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                int training, float* scale, float* shift, float* save_mean, float* save_invstd,
@@ -114,8 +116,9 @@ extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long lon
     NkbProfScope prof(NKB_K_BN_FINALIZE, stream, 0);
     if (training && tiles > 128) {
         double* dpart = (double*)(partials + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, 16), dim3(1024), 0, stream, partials, tiles, C, dpart);
-        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream, (const double*)dpart, 16, C,
+        const int P = bn_partitions(C);
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, partials, tiles, C, dpart);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream, (const double*)dpart, P, C,
                            (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
                            save_mean, save_invstd);
     } else {
@@ -125,7 +128,9 @@ extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long lon
     }
     return nkb_check_launch("bn_finalize");
 }
-extern "C" size_t nkb_bn_stats_floats(int tiles, int C) { return (size_t)tiles * 2 * C + 2 + (tiles > 128 ? (size_t)64 * C : 0); }
+extern "C" size_t nkb_bn_stats_floats(int tiles, int C) {
+    return (size_t)tiles * 2 * C + 2 + (tiles > 128 ? (size_t)bn_partitions(C) * 4 * C : 0);     // + dpart[P][2][C] doubles
+}
 
 // ------------------------------------------------------------------------------------------
 // bn_apply: y = act(x*scale[c] + shift[c] (+ residual))
@@ -1308,9 +1313,10 @@ extern "C" int nkb_bn_backward_from_stats(int dtype, const void* g, const void* 
         NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0);
         if (tiles > 128) {
             double* dpart = (double*)(stats + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
-            hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, 16), dim3(1024), 0, stream, stats, tiles, C, dpart);
+            const int P = bn_partitions(C);
+            hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, stats, tiles, C, dpart);
             hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream,
-                               (const double*)dpart, 16, C, invstd, dgamma, dbeta, sums);
+                               (const double*)dpart, P, C, invstd, dgamma, dbeta, sums);
         } else {
             hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, stream,
                                (const float*)stats, tiles, C, invstd, dgamma, dbeta, sums);
