@@ -51,7 +51,7 @@ template <> struct VecIO<float, 4> {
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm forward: y = (x - mean) * rstd * gamma + beta, biased variance, two-pass in registers (torch numerics).
 // One wave per row; D = 64 * VW * NP, every lane holds NP vectors of VW elements.
-template <typename T, int VW, int NP>
+template <typename T, int VW, int NP, int QK>      // QK: -1 no fp8 copy, 0 e4m3, 1 e5m2 (compile time: no branch inside the row loop)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long long xs, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y, long long ys,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows,
@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const int wpb = blockDim.x >> 6;
     // optional fp8 copy of the output for the fp8 GEMM that consumes it (delayed scale q_state[0], amax into q_state[2]): the
     // arithmetic of nkb_fp8_quantize on the stored (rounded) row, four bytes per lane and pass (VW == 4 only)
-    const float qscale = yq ? q_state[0] : 1.f;
-    const float qlim = q_kind == 0 ? 448.f : 57344.f;
+    constexpr bool QOUT = QK >= 0;
+    const float qscale = QOUT ? q_state[0] : 1.f;
+    constexpr float qlim = QK == 0 ? 448.f : 57344.f;
     float amax = 0.f;
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
         const T* xr = x + (size_t)row * xs;
@@ -90,25 +91,23 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < VW; ++e) o[e] = (v[k][e] - mu) * rs * gamma[e0 + e] + beta[e0 + e];
             VecIO<T, VW>::st(yr + e0, o);
-            if constexpr (VW == 4) {
-                if (yq) {
-                    float q[4];
+            if constexpr (VW == 4 && QOUT) {
+                float q[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float r = DT<T>::rnd(o[e]);
-                        amax = fmaxf(amax, fabsf(r));
-                        q[e] = fminf(fmaxf(r * qscale, -qlim), qlim);
-                    }
-                    unsigned w = 0u;
-                    if (q_kind == 0) { w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true); }
-                    else { w = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w, true); }
-                    *(unsigned*)(yq + (size_t)row * D + e0) = w;
+                for (int e = 0; e < 4; ++e) {
+                    const float r = DT<T>::rnd(o[e]);
+                    amax = fmaxf(amax, fabsf(r));
+                    q[e] = fminf(fmaxf(r * qscale, -qlim), qlim);
                 }
+                unsigned w = 0u;
+                if constexpr (QK == 0) { w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true); }
+                else { w = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w, true); }
+                *(unsigned*)(yq + (size_t)row * D + e0) = w;
             }
         }
         if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
     }
-    if (yq) {                                      // one atomic per block (non-negative floats order as unsigned integers)
+    if constexpr (QOUT) {                          // one atomic per block (non-negative floats order as unsigned integers)
         __shared__ float red[4];
         amax = wave_max(amax);
         if (lane == 0) red[threadIdx.x >> 6] = amax;
@@ -309,8 +308,15 @@ static void ln_launch(int backward, int grid, hipStream_t stream, const void* in
                       long long x_stride, const float* gamma, const float* beta, float* mean, float* rstd, const void* add,
                       void* out, long long out_stride, float* dgamma, float* dbeta, int rows, float eps, float* part,
                       unsigned char* yq, float* q_state, int q_kind, const float* row_scale, int rows_per_sample) {
-    if (!backward)
-        hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps, yq, q_state, q_kind);
+    if (!backward) {
+#define LN_FWD(Q) hipLaunchKernelGGL((layernorm_fwd_kernel<T, VW, NP, Q>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, gamma, beta, (T*)out, out_stride, mean, rstd, rows, eps, yq, q_state, q_kind)
+        if constexpr (VW == 4 && std::is_same<T, bf16_t>::value) {
+            if (yq && q_kind == 0) { LN_FWD(0); return; }
+            if (yq) { LN_FWD(1); return; }
+        }
+        LN_FWD(-1);
+#undef LN_FWD
+    }
     else {
 #define LN_BWD(Q) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, NP, Q>), dim3(grid), dim3(256), 0, stream, (const T*)in, in_stride, (const T*)x, x_stride, mean, rstd, gamma, (const T*)add, (T*)out, out_stride, dgamma, dbeta, rows, part, yq, q_state, q_kind, row_scale, yq ? rows_per_sample : 1)
         if constexpr (VW == 4 && std::is_same<T, bf16_t>::value) {      // (the second outputs: bf16 rows of 256-element multiples only)
@@ -355,8 +361,8 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
         nkb_set_error("layernorm: the scaled copy (q_kind 2) goes with backward, bf16, D %% 256 == 0, packed rows, row_scale and nothing else");
         return 1;
     }
-    if (yq && !scaled_copy && (vw != 4 || out_stride != D || !q_state || (q_kind != 0 && q_kind != 1))) {
-        nkb_set_error("layernorm: the fp8 output needs D %% 256 == 0, packed rows and a scaling state");
+    if (yq && !scaled_copy && (dtype != NKB_DT_BF16 || vw != 4 || out_stride != D || !q_state || (q_kind != 0 && q_kind != 1))) {
+        nkb_set_error("layernorm: the fp8 output needs bf16 rows, D %% 256 == 0, packed rows and a scaling state");
         return 1;
     }
     if (yq && !scaled_copy && backward && (!workspace || !colsum || (row_scale && rows_per_sample < 1))) {
