@@ -197,6 +197,11 @@ int nkb_layernorm(int dtype, int backward, const void* in, long long in_stride, 
 /* (yq / q_state / q_kind, forward only, optional: an fp8 copy of the output rows — packed [rows][D] bytes, scale q_state[0], amax
  * into q_state[2], kind as in nkb_fp8_quantize — for the fp8 GEMM that consumes the normalised rows; D % 256 == 0, out_stride == D.) */
 size_t nkb_layernorm_workspace_floats(int D); /* backward: optional scratch for the deterministic dgamma/dbeta reduction */
+/* Workspace-form backward with dgamma = dbeta = NULL leaves only the per-block partial rows in `workspace`; this call then adds their
+ * ordered sums to dgamma / dbeta (and colsum when planes == 3: the launch wrote an fp8 copy) — on any stream ordered after that
+ * launch, so that the two small reduction launches need not sit in the backward chain.  rows, D as in that launch. */
+int nkb_layernorm_param_reduce(float* workspace, int rows, int D, int planes, float* dgamma, float* dbeta, float* colsum,
+                               nkb_stream_t stream);
 /* exact-erf GELU: dy == NULL -> out = gelu(x); else out = dy * gelu'(x) */
 /* forward that also stores gelu'(x) (timm Mlp.act, backward then is the act-4 epilogue of nkb_linear_gelu) */
 int nkb_gelu_fwd_dgelu(int dtype, const void* x, void* y, void* gp, long long n, nkb_stream_t stream);

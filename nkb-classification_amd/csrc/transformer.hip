@@ -341,6 +341,42 @@ static int ln_dispatch(int np, int backward, int grid, hipStream_t stream, const
 
 extern "C" size_t nkb_layernorm_workspace_floats(int D) { return (size_t)2048 * 2 * D; }
 
+// partial rows (= workgroups) of a workspace-form backward launch over `rows` rows
+static int ln_bwd_blocks(int rows) {
+    // ~44 rows per block (11 per wave): fewer and the per-block column-sum epilogue dominates (32768 x 1024: 1024 blocks 78 us,
+    // 768 blocks 62 us), more and the chip is under-filled (50432 x 768: 512 blocks 93 us, 1024 blocks 66 us)
+    static const int cap = [] { const char* e = getenv("NKB_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
+    int grid = (rows + 3) / 4;
+    const int want = cap > 0 ? cap : (rows + 43) / 44;
+    if (grid > want) grid = want;
+    if (grid > 1024) grid = 1024;
+    return grid;
+}
+static void ln_param_reduce(float* workspace, int grid, int D, int planes, float* dgamma, float* dbeta, float* colsum, hipStream_t stream) {
+    if (planes == 3) {                                        // three planes per partial row (3072 D + 48 D of the 4096 D floats)
+        float* inter = workspace + (size_t)1024 * 3 * D;
+        hipLaunchKernelGGL(ln_param_grad_kernel<3>, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
+        hipLaunchKernelGGL(ln_param_grad_final_kernel<3>, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta, colsum);
+    } else {
+        float* inter = workspace + (size_t)1024 * 2 * D;      // behind the (<= 1024) per-block partial rows
+        hipLaunchKernelGGL(ln_param_grad_kernel<2>, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
+        hipLaunchKernelGGL(ln_param_grad_final_kernel<2>, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta, nullptr);
+    }
+}
+// Second half of a workspace-form nkb_layernorm(backward = 1, ..., dgamma = dbeta = NULL) launch: dgamma / dbeta (/ colsum, planes
+// = 3 when that launch wrote an fp8 copy) += the ordered sums of its per-block partial rows.  A separate entry so that the caller
+// can put these two small launches on another stream than the backward chain (they only feed parameter gradients).
+extern "C" int nkb_layernorm_param_reduce(float* workspace, int rows, int D, int planes, float* dgamma, float* dbeta, float* colsum,
+                                          hipStream_t stream) {
+    if (!workspace || !dgamma || !dbeta || (planes != 2 && planes != 3) || (planes == 3 && !colsum) || D % 128 != 0 || rows < 1) {
+        nkb_set_error("layernorm_param_reduce: bad arguments (planes %d, D %d, rows %d)", planes, D, rows);
+        return 1;
+    }
+    NkbProfScope prof(NKB_K_LN, stream, 0);
+    ln_param_reduce(workspace, ln_bwd_blocks(rows), D, planes, dgamma, dbeta, colsum, stream);
+    return nkb_check_launch("layernorm_param_reduce");
+}
+
 // yq / q_state / q_kind (optional): fp8 copy of the output rows ([rows][D] bytes, packed) for the fp8 GEMM that consumes them —
 // see nkb_fp8_quantize; needs D % 256 == 0 and out_stride == D.  Backward (with the workspace): the copy is of
 // row_scale[row / rows_per_sample] * dx (row_scale optional) and colsum[D] += its column sums — what nkb_fp8_quantize_colsum
@@ -365,22 +401,17 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
         nkb_set_error("layernorm: the fp8 output needs bf16 rows, D %% 256 == 0, packed rows and a scaling state");
         return 1;
     }
-    if (yq && !scaled_copy && backward && (!workspace || !colsum || (row_scale && rows_per_sample < 1))) {
+    if (yq && !scaled_copy && backward && (!workspace || (dgamma && !colsum) || (row_scale && rows_per_sample < 1))) {
         nkb_set_error("layernorm: the backward fp8 output goes with the workspace form, a column-sum vector and rows_per_sample >= 1");
         return 1;
     }
     if (!yq && (row_scale || colsum)) { nkb_set_error("layernorm: row_scale / colsum belong to the second output"); return 1; }
+    if (backward && (dgamma == nullptr) != (dbeta == nullptr)) { nkb_set_error("layernorm: dgamma and dbeta go together"); return 1; }
+    if (backward && !dgamma && !workspace) { nkb_set_error("layernorm: partial-rows-only backward needs the workspace"); return 1; }
     NkbProfScope prof(NKB_K_LN, stream, 0);
     int grid = (rows + 3) / 4;
     if (!backward) { if (grid > (yq ? 1024 : 256 * 16)) grid = yq ? 1024 : 256 * 16; }   // (fp8 copy: one amax atomic per block)
-    else if (workspace) {                                    // partials [grid][2][D] in the workspace
-        // ~44 rows per block (11 per wave): fewer and the per-block column-sum epilogue dominates (32768 x 1024: 1024 blocks 78 us,
-        // 768 blocks 62 us), more and the chip is under-filled (50432 x 768: 512 blocks 93 us, 1024 blocks 66 us)
-        static const int cap = [] { const char* e = getenv("NKB_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
-        const int want = cap > 0 ? cap : (rows + 43) / 44;
-        if (grid > want) grid = want;
-        if (grid > 1024) grid = 1024;
-    }
+    else if (workspace) grid = ln_bwd_blocks(rows);           // partials [grid][2 or 3][D] in the workspace
     else if (grid > 512) grid = 512;                         // atomics path: keep same-address contention low
     int rc;
     if (dtype == NKB_DT_BF16)
@@ -390,18 +421,8 @@ extern "C" int nkb_layernorm(int dtype, int backward, const void* in, long long 
         rc = vw == 4 ? ln_dispatch<float, 4>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind, row_scale, rows_per_sample)
                      : ln_dispatch<float, 2>(np, backward, grid, stream, in, in_stride, x, x_stride, gamma, beta, mean, rstd, add, out, out_stride, dgamma, dbeta, rows, eps, workspace, (unsigned char*)yq, q_state, q_kind, row_scale, rows_per_sample);
     if (rc) { nkb_set_error("layernorm: unsupported D=%d", D); return 1; }
-    if (backward && workspace)
-    {
-        if (yq && !scaled_copy) {                             // three planes per partial row (3072 D + 48 D of the 4096 D floats)
-            float* inter = workspace + (size_t)1024 * 3 * D;
-            hipLaunchKernelGGL(ln_param_grad_kernel<3>, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
-            hipLaunchKernelGGL(ln_param_grad_final_kernel<3>, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta, colsum);
-        } else {
-            float* inter = workspace + (size_t)1024 * 2 * D;  // behind the (<= 1024) per-block partial rows
-            hipLaunchKernelGGL(ln_param_grad_kernel<2>, dim3((D + 63) / 64, LN_SLICES), dim3(1024), 0, stream, workspace, grid, D, inter);
-            hipLaunchKernelGGL(ln_param_grad_final_kernel<2>, dim3((D + 255) / 256), dim3(256), 0, stream, inter, D, dgamma, dbeta, nullptr);
-        }
-    }
+    // (dgamma == NULL with a workspace: partial rows only — the caller finishes with nkb_layernorm_param_reduce, possibly on another stream)
+    if (backward && workspace && dgamma) ln_param_reduce(workspace, grid, D, (yq && !scaled_copy) ? 3 : 2, dgamma, dbeta, colsum, stream);
     return nkb_check_launch("layernorm");
 }
 

@@ -60,6 +60,7 @@ _SIGS = {
     "nkb_linear_residual_scaled": (i32, [i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
     "nkb_layernorm": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp, i32, vp, vp]),
     "nkb_layernorm_workspace_floats": (sz, [i32]),
+    "nkb_layernorm_param_reduce": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "nkb_gelu": (i32, [i32, vp, vp, vp, i64, vp]),
     "nkb_splitk_reduce": (i32, [i32, vp, i32, i32, i32, vp, i32, vp, vp, vp]),
     "nkb_wfold": (i32, [i32, vp, vp, vp, i32, i32, vp]),
@@ -607,6 +608,12 @@ def layernorm_bwd(dtype, dy, dy_stride, x, x_stride, gamma, mean, rstd, add, dx,
                                ptr(add), ptr(dx), dx_stride, ptr(dgamma), ptr(dbeta), rows, D, 0.0, ptr(workspace),
                                ptr(yq), ptr(q_state), int(q_kind), ptr(row_scale), int(rows_per_sample), ptr(colsum),
                                stream()), "layernorm_bwd")
+
+
+def layernorm_param_reduce(workspace, rows, D, planes, dgamma, dbeta, colsum=None):
+    """Second half of layernorm_bwd(dgamma=None, dbeta=None, workspace=...): ordered sums of its partial rows into the gradients."""
+    check(load().nkb_layernorm_param_reduce(ptr(workspace), rows, D, planes, ptr(dgamma), ptr(dbeta), ptr(colsum), stream()),
+          "layernorm_param_reduce")
 
 
 def layernorm_ws(D):

@@ -44,6 +44,9 @@ _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 # four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
 # the block to end.  Off.
 _WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
+# LayerNorm dgamma / dbeta reduction (two small launches) on the side stream instead of in the backward chain: measured neutral
+# (unicom fp8 50.8-51.4 vs 50.9-51.3 ms, ViT-B/16 35.65-35.74 vs 35.74-35.78) — the other stream fills those gaps anyway.  Off.
+_LN_REDUCE_SIDE = os.environ.get("NKB_LN_REDUCE_SIDE", "0") != "0"
 _LN_BWD_SCALED_COPY = os.environ.get("NKB_LN_BWD_SCALED_COPY", "1") != "0"   # bf16: LayerNorm backward writes scale[b] * dx as well
 _ROWSCALE_EPILOGUE = os.environ.get("NKB_ROWSCALE_EPILOGUE", "1") != "0"   # bf16: drop-path scale in the residual GEMM epilogue
 _GELU_EPILOGUE = os.environ.get("NKB_GELU_EPILOGUE", "1") != "0"   # gelu + gelu' in the fc1 epilogue of the eight-phase core
@@ -1040,7 +1043,23 @@ class HipEngine:
         D = ln.weight.shape[0]
         rows = sv["rows"]
         a = self.arena
-        work = self.ws.at_least("ln.work", hip.layernorm_ws(D), torch.float32)
+        # The parameter-gradient half (two small launches that sum the per-block partial rows) only feeds dgamma / dbeta (/ a bias
+        # gradient): it goes to the side stream with the weight gradients instead of sitting in the backward chain.  Its partial
+        # rows then live in a workspace of this LayerNorm's own (per block parity, like the gradient scratch: begin_block waits
+        # for the side-stream readers before a set is reused).
+        split = _LN_REDUCE_SIDE and self.overlap_wgrad
+        work = self.ws.at_least("ln.work" + (self._suffix + "." + key.rsplit(".", 1)[-1] if split else ""), hip.layernorm_ws(D),
+                                torch.float32)
+        dg, db = a.grad_flat(ln.weight), a.grad_flat(ln.bias)
+
+        def launch(colsum=None, **kw):
+            if not split:
+                hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
+                                  out_stride, dg, db, rows, D, workspace=work, colsum=colsum, **kw)
+                return
+            hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
+                              out_stride, None, None, rows, D, workspace=work, **kw)
+            self.on_side(lambda: hip.layernorm_param_reduce(work, rows, D, 3 if colsum is not None else 2, dg, db, colsum))
         q = None
         if consumer is not None and self.fp8 and _FP8_LN_BWD_QUANT and _FP8_FUSED_QUANT and self.T == torch.bfloat16:
             svc = self.saved.get(consumer)
@@ -1054,10 +1073,8 @@ class HipEngine:
                     if q is not None:
                         gs = self.drop_path_gscale(consumer_dp, rows) if consumer_dp else None
                         self._f8bias[consumer + ".f8g"] = True
-                        hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
-                                          out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), rows, D, workspace=work,
-                                          yq=q[0], q_state=q[1], q_kind=q[2], row_scale=gs[0] if gs else None,
-                                          rows_per_sample=gs[1] if gs else 0, colsum=a.grad_flat(lin.bias))
+                        launch(colsum=a.grad_flat(lin.bias), yq=q[0], q_state=q[1], q_kind=q[2], row_scale=gs[0] if gs else None,
+                               rows_per_sample=gs[1] if gs else 0)
                         return out
         if (consumer is not None and consumer_dp and _LN_BWD_SCALED_COPY and self.T == torch.bfloat16 and out_stride == D
                 and D % 256 == 0 and tuple(out.shape) == (rows, D) and consumer in self.saved):
@@ -1076,13 +1093,10 @@ class HipEngine:
                     self._suffix = ".p%d" % (consumer_block & 1)
                 scaled = self.scratch("gs_" + consumer.rsplit(".", 1)[-1], (rows, D))
                 self._suffix = keep
-                hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
-                                  out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), rows, D, workspace=work,
-                                  yq=scaled, q_kind=2, row_scale=gs[0], rows_per_sample=gs[1])
+                launch(yq=scaled, q_kind=2, row_scale=gs[0], rows_per_sample=gs[1])
                 self._gs_ready[out.data_ptr()] = scaled
                 return out
-        hip.layernorm_bwd(self.d, g, D, sv["x"], sv["xs"], a.param_flat(ln.weight), sv["mean"], sv["rstd"], add, out,
-                          out_stride, a.grad_flat(ln.weight), a.grad_flat(ln.bias), rows, D, workspace=work)
+        launch()
         return out
 
     def gelu(self, key: str, x: torch.Tensor, train: bool, keep_derivative: bool = False) -> torch.Tensor:

@@ -1461,6 +1461,15 @@ def test_layernorm_backward_fp8_copy_and_column_sums(shape, scaled):
     assert torch.equal(q1, qq) and st1[2].item() == stq[2].item()
     ref = dx0.double() * (rsc.double().repeat_interleave(rps)[:rows, None] if scaled else 1.0)
     torch.testing.assert_close(cs1.double().cpu(), 2.0 + ref.sum(0).cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(rows) * dx0.abs().max().item())
+    # the two-call form: partial rows only, then nkb_layernorm_param_reduce (possibly on another stream) — same bits as the one-call form
+    dx4 = torch.empty_like(dx0); q4 = torch.empty_like(q1)
+    dg4, db4, cs4 = torch.full((D,), 0.25, device=DEV), torch.full((D,), -0.5, device=DEV), torch.full((D,), 2.0, device=DEV)
+    st4 = torch.tensor([300.0, 1 / 300.0, 0.0], device=DEV)
+    hip.layernorm_bwd(hip.BF16, dy, D, x, D, gamma, mean, rstd, add, dx4, D, None, None, rows, D, workspace=work,
+                      yq=q4, q_state=st4, q_kind=hip.E5M2, row_scale=rsc, rows_per_sample=rps)
+    hip.layernorm_param_reduce(work, rows, D, 3, dg4, db4, cs4)
+    torch.cuda.synchronize()
+    assert torch.equal(dx4, dx1) and torch.equal(q4, q1) and torch.equal(dg4, dg1) and torch.equal(db4, db1) and torch.equal(cs4, cs1)
     if scaled:
         # q_kind 2: the row-scaled copy in bf16 (the branch gradient of the bf16 step) = nkb_scale_rows over the stored dx
         dx3 = torch.full((rows, D), float("nan"), device=DEV, dtype=torch.bfloat16)
