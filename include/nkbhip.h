@@ -220,8 +220,10 @@ int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout, const flo
 /* Whole attention backward in one pass per (image, head): dQ, dK, dV written into the three thirds of dqkv
  * ([B*T][3*H*64], same layout as qkv).  Reads qkv, dout, the forward output `out` (for delta = rowsum(dout o out)) and lse;
  * no score matrix reaches memory (bf16, head dim 64, T <= 256). */
+/* (colsum / colsum_work, optional: colsum[3 H dh] += the column sums of the stored d_qkv rows = the qkv projection's bias gradient,
+ * from per-image sums in colsum_work[B][3 H dh] added in image order — no separate pass over d_qkv) */
 int nkb_attn_backward(int dtype, const void* qkv, const void* dout, const void* out, const float* lse, void* dqkv, int B, int T,
-                      int H, int dh, float scale, void* dqkv_q, float* q_state, nkb_stream_t stream);
+                      int H, int dh, float scale, void* dqkv_q, float* q_state, float* colsum, float* colsum_work, nkb_stream_t stream);
 /* (outq / dqkv_q with q_state, optional: fp8 copies of the outputs — e4m3 of `out`, e5m2 of `dqkv`, packed rows, scale q_state[0],
  * amax into q_state[2] as nkb_fp8_quantize would — for the fp8 projection / qkv-gradient GEMMs that consume them.) */
 int nkb_head_transpose(int dtype, const void* in, int ld_in, long long sio, long long sii, int outer, int inner, void* out,

@@ -73,6 +73,14 @@ __device__ __forceinline__ void score_tile(const unsigned char* rows_img, const 
     }
 }
 
+// sum over the 16 lanes of a DPP row (lanes with the same lane >> 4): every lane ends up with the total
+__device__ __forceinline__ float attn_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
 __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
 __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
 
@@ -321,7 +329,7 @@ template <int NKB>
 __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
     const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int T, int H, float scale,
-    unsigned char* __restrict__ dqkv_q, float* __restrict__ q_state) {
+    unsigned char* __restrict__ dqkv_q, float* __restrict__ q_state, float* __restrict__ colpart) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NKS = (NKB + 1) / 2, ROWS = NKS * 32, IMG = ROWS * 128;
     const float qscale = dqkv_q ? q_state[0] : 1.f;
@@ -336,6 +344,10 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
     unsigned char* Ds = smem + 3 * IMG;
     float* l2s = (float*)(smem + 4 * IMG);
     float* dls = l2s + ROWS;
+    // colpart (optional): column sums of the stored dQ / dK / dV rows of this (image, head) — the qkv projection's bias gradient,
+    // per image: colpart[b][3 D], summed over the images by the host wrapper.  Every wave adds the sums of its blocks into its
+    // own LDS slot cs[which][wave][64] (16 rows by DPP), the slots are added in wave order at the end: no pass over d_qkv for it.
+    float* cs = dls + ROWS;
     const long long rs = 3ll * D;
     const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
     const bf16_t* dbase = dout + (size_t)b * T * D + h * DH;
@@ -344,6 +356,8 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
         l2s[r] = r < T ? lse[((size_t)b * H + h) * T + r] * 1.4426950408889634f : INFINITY;
         dls[r] = 0.f;
     }
+    if (colpart)
+        for (int r = threadIdx.x; r < 3 * NW * 64; r += NT) cs[r] = 0.f;
     __syncthreads();
     {
         u32x4 rq[IT], rk[IT], rv[IT], rd[IT], ro[IT];
@@ -395,6 +409,21 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
         return __builtin_bit_cast(bf16x8, v);
     };
 
+    // adds the column sums of one stored 16-row block (pk = the packed bf16 values of this lane's row, zero for rows >= T) to
+    // this wave's slot of plane `which`
+    auto add_colsum = [&](int which, const u32x2 (&pk)[4], bool valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r[4] = {__uint_as_float(pk[i][0] << 16), __uint_as_float(pk[i][0] & 0xffff0000u),
+                          __uint_as_float(pk[i][1] << 16), __uint_as_float(pk[i][1] & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = attn_row16_sum(valid ? r[e] : 0.f);
+                if (fr == 0) cs[(which * NW + wave) * 64 + 16 * i + 4 * g + e] += t;
+            }
+        }
+    };
+
     // ---- pass A: dQ, one query block per wave at a time --------------------------------------------------------------
     for (int qb = wave; qb < NKB; qb += NW) {
         const int q = qb * 16 + fr;
@@ -429,15 +458,18 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ks, t, i), __builtin_bit_cast(bf16x8, pb), o[i], 0, 0, 0);
         }
+        u32x2 pkq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pkq[i] = (u32x2){pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
         if (q < T) {
             bf16_t* orow = dqkv + ((size_t)b * T + q) * rs + h * DH;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const u32x2 pk = {pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
-                *(u32x2*)(orow + 16 * i + 4 * g) = pk;
-                if (dqkv_q) store_q4<1>(dqkv_q + ((size_t)b * T + q) * rs + h * DH + 16 * i + 4 * g, pk, qscale, amax2);
+                *(u32x2*)(orow + 16 * i + 4 * g) = pkq[i];
+                if (dqkv_q) store_q4<1>(dqkv_q + ((size_t)b * T + q) * rs + h * DH + 16 * i + 4 * g, pkq[i], qscale, amax2);
             }
         }
+        if (colpart) add_colsum(0, pkq, q < T);
     }
 
     // ---- pass B: dK and dV, one key block per wave at a time ---------------------------------------------------------
@@ -478,20 +510,34 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
             }
         }
         const int key = kb * 16 + fr;
+        u32x2 pkk[4], pkv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pkk[i] = (u32x2){pack_bf2(ok[i][0], ok[i][1]), pack_bf2(ok[i][2], ok[i][3])};
+            pkv[i] = (u32x2){pack_bf2(ov[i][0], ov[i][1]), pack_bf2(ov[i][2], ov[i][3])};
+        }
         if (key < T) {
             bf16_t* krow = dqkv + ((size_t)b * T + key) * rs + D + h * DH;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const u32x2 pkk = {pack_bf2(ok[i][0], ok[i][1]), pack_bf2(ok[i][2], ok[i][3])};
-                const u32x2 pkv = {pack_bf2(ov[i][0], ov[i][1]), pack_bf2(ov[i][2], ov[i][3])};
-                *(u32x2*)(krow + 16 * i + 4 * g) = pkk;
-                *(u32x2*)(krow + D + 16 * i + 4 * g) = pkv;
+                *(u32x2*)(krow + 16 * i + 4 * g) = pkk[i];
+                *(u32x2*)(krow + D + 16 * i + 4 * g) = pkv[i];
                 if (dqkv_q) {
                     unsigned char* kq = dqkv_q + ((size_t)b * T + key) * rs + D + h * DH + 16 * i + 4 * g;
-                    store_q4<1>(kq, pkk, qscale, amax2);
-                    store_q4<1>(kq + D, pkv, qscale, amax2);
+                    store_q4<1>(kq, pkk[i], qscale, amax2);
+                    store_q4<1>(kq + D, pkv[i], qscale, amax2);
                 }
             }
+        }
+        if (colpart) { add_colsum(1, pkk, key < T); add_colsum(2, pkv, key < T); }
+    }
+    if (colpart) {
+        __syncthreads();
+        if (threadIdx.x < 192) {
+            const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += cs[(which * NW + w) * 64 + col];          // wave order: fixed
+            colpart[(size_t)b * 3 * D + (size_t)which * D + h * DH + col] = t;
         }
     }
     if (dqkv_q) publish_amax(amax2, q_state);
@@ -555,22 +601,26 @@ extern "C" int nkb_attn_backward_ds(int dtype, const void* qkv, const void* dout
 }
 
 // dqkv_q / q_state (optional): e5m2 copy of dqkv ([B*T][3*H*dh] bytes) for the fp8 data / weight gradient of the qkv projection
+// colsum / colsum_work (optional): colsum[3 H dh] += the column sums of the stored dqkv (the qkv projection's bias gradient);
+// colsum_work: [B][3 H dh] floats of scratch (per-image sums, added in image order)
 extern "C" int nkb_attn_backward(int dtype, const void* qkv, const void* dout, const void* out, const float* lse, void* dqkv,
-                                 int B, int T, int H, int dh, float scale, void* dqkv_q, float* q_state, hipStream_t stream) {
+                                 int B, int T, int H, int dh, float scale, void* dqkv_q, float* q_state, float* colsum,
+                                 float* colsum_work, hipStream_t stream) {
     if (dqkv_q && !q_state) { nkb_set_error("attn_backward: the fp8 output needs its scaling state"); return 1; }
+    if ((colsum == nullptr) != (colsum_work == nullptr)) { nkb_set_error("attn_backward: colsum and colsum_work go together"); return 1; }
     if (dtype != NKB_DT_BF16 || dh != DH || T > 16 * MAXKB || T < 1) {
         nkb_set_error("attn_backward: fused path needs bf16, head dim 64, T <= 256 (got dtype %d, dh %d, T %d)", dtype, dh, T);
         return 1;
     }
     const int nkb = (T + 15) / 16, rows = (nkb + 1) / 2 * 32;
-    const int lds = 4 * rows * 128 + 2 * rows * 4;
+    const int lds = 4 * rows * 128 + 2 * rows * 4 + (colsum ? 3 * (NKB_ATTN_BWD_THREADS / 64) * 64 * 4 : 0);
     NkbProfScope prof(NKB_K_ATTN, stream, 14.0 * B * H * (double)T * T * DH);     // S, dP twice; dQ, dK, dV once
 #define NKB_ATTN_BWDF(N)                                                                                                     \
     case N: {                                                                                                                \
         static bool attr = false;                                                                                            \
-        if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024); attr = true; } \
+        if (!attr) { hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; } \
         hipLaunchKernelGGL(attn_bwd_fused_kernel<N>, dim3(B * H), dim3(NKB_ATTN_BWD_THREADS), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)out, lse, \
-                           (bf16_t*)dqkv, T, H, scale, (unsigned char*)dqkv_q, q_state);                                     \
+                           (bf16_t*)dqkv, T, H, scale, (unsigned char*)dqkv_q, q_state, colsum_work);                        \
         break;                                                                                                               \
     }
     switch (nkb) {
@@ -578,5 +628,7 @@ extern "C" int nkb_attn_backward(int dtype, const void* qkv, const void* dout, c
         NKB_ATTN_BWDF(9) NKB_ATTN_BWDF(10) NKB_ATTN_BWDF(11) NKB_ATTN_BWDF(12) NKB_ATTN_BWDF(13) NKB_ATTN_BWDF(14) NKB_ATTN_BWDF(15) NKB_ATTN_BWDF(16)
     }
 #undef NKB_ATTN_BWDF
-    return nkb_check_launch("attn_backward");
+    int rc = nkb_check_launch("attn_backward");
+    if (!rc && colsum) rc = nkb_launch_wgrad_reduce(colsum_work, 3ll * H * DH, B, colsum, 3ll * H * DH, stream);
+    return rc;
 }

@@ -71,7 +71,7 @@ _SIGS = {
     "nkb_attn_softmax": (i32, [i32, i32, vp, i32, vp, vp, i32, i64, i32, f32, vp]),
     "nkb_attn_forward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "nkb_attn_backward_ds": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, i64, vp]),
-    "nkb_attn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "nkb_attn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "nkb_head_transpose": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, i32, i32, i32, vp]),
     "nkb_vit_assemble": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "nkb_dropout": (i32, [i32, i32, vp, vp, vp, vp, i64, f32, C.c_ulonglong, vp]),
@@ -680,10 +680,11 @@ def attn_forward(dtype, qkv, out, lse, B, T, H, dh, scale, outq=None, q_state=No
           "attn_forward")
 
 
-def attn_backward(dtype, qkv, dout, out, lse, dqkv, B, T, H, dh, scale, dqkv_q=None, q_state=None):
-    """dqkv_q / q_state: optional e5m2 copy of dqkv for the fp8 qkv gradients."""
+def attn_backward(dtype, qkv, dout, out, lse, dqkv, B, T, H, dh, scale, dqkv_q=None, q_state=None, colsum=None, colsum_work=None):
+    """dqkv_q / q_state: optional e5m2 copy of dqkv for the fp8 qkv gradients.  colsum / colsum_work ([B][3 H dh] scratch):
+    colsum += the column sums of dqkv (the qkv bias gradient)."""
     check(load().nkb_attn_backward(dtype, ptr(qkv), ptr(dout), ptr(out), ptr(lse), ptr(dqkv), B, T, H, dh, scale, ptr(dqkv_q),
-                                   ptr(q_state), stream()), "attn_backward")
+                                   ptr(q_state), ptr(colsum), ptr(colsum_work), stream()), "attn_backward")
 
 
 def attn_backward_ds(dtype, qkv, dout, lse, P, dS, ldp, B, T, H, dh, scale, dq=None, ld_dq=0):

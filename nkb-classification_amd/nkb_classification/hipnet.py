@@ -50,6 +50,7 @@ _LN_REDUCE_SIDE = os.environ.get("NKB_LN_REDUCE_SIDE", "0") != "0"
 _LN_BWD_SCALED_COPY = os.environ.get("NKB_LN_BWD_SCALED_COPY", "1") != "0"   # bf16: LayerNorm backward writes scale[b] * dx as well
 _ROWSCALE_EPILOGUE = os.environ.get("NKB_ROWSCALE_EPILOGUE", "1") != "0"   # bf16: drop-path scale in the residual GEMM epilogue
 _GELU_EPILOGUE = os.environ.get("NKB_GELU_EPILOGUE", "1") != "0"   # gelu + gelu' in the fc1 epilogue of the eight-phase core
+_FP8_ATTN_COLSUM = os.environ.get("NKB_FP8_ATTN_COLSUM", "1") != "0"   # qkv bias gradient from the attention backward kernel's stores
 _FP8_LN_BWD_QUANT = os.environ.get("NKB_FP8_LN_BWD_QUANT", "1") != "0"   # LayerNorm backward writes the next Linear backward's fp8 operand
 _FP8_EPI_COLSUM = os.environ.get("NKB_FP8_EPI_COLSUM", "1") != "0"   # fc1's bias gradient from the fc2 data gradient's epilogue
 _FP8_MASK_BITS = os.environ.get("NKB_FP8_MASK_BITS", "1") != "0"   # fp8 step: ReLU6 output kept as fp8 operand + mask bits, no bf16 copy
@@ -1263,8 +1264,20 @@ class HipEngine:
         if sv.get("fused") and _ATTN_FUSED_BWD:
             # dQ, dK, dV in one kernel per layer: P and dS never reach HBM
             out = self._fp8_produce(q_for, tuple(qkv.shape), hip.E5M2) if self.fp8 else None       # the qkv gradients' fp8 operand
+            csum = work = None
+            if out and _FP8_ATTN_COLSUM and q_for.endswith(".f8g") and q_for[:-4] in self.saved:
+                # the qkv projection takes both gradients from the fp8 copy: its bias gradient — the column sums of d_qkv — is the
+                # only other reader of the bf16 tensor, and comes out of this kernel's stores instead of a pass over d_qkv
+                svc = self.saved[q_for[:-4]]
+                lin = svc["lin"]
+                Mc, Kc = svc["x"].shape
+                if (lin.bias is not None and Mc == B * T and lin.weight.shape[0] == 3 * D and self._fp8_linear_ok(lin, Mc)
+                        and self._fp8_wgrad_ok(svc, Mc, Kc, 3 * D)):
+                    csum = self.arena.grad_flat(lin.bias)
+                    work = self.ws.at_least("attn.colsum", B * 3 * D, torch.float32)
+                    self._f8bias[q_for] = True
             hip.attn_backward(self.d, qkv, d_o, sv["o"], sv["lse"], dqkv, B, T, H, dh, dh ** -0.5,
-                              dqkv_q=out[0] if out else None, q_state=out[1] if out else None)
+                              dqkv_q=out[0] if out else None, q_state=out[1] if out else None, colsum=csum, colsum_work=work)
             return dqkv
         if sv.get("fused"):
             # P and dS are recomputed in one pass (pad columns beyond roundup(T,16) stay zero from allocation)

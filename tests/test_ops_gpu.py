@@ -1513,6 +1513,18 @@ def test_fused_attention_fp8_copies_equal_separate_quantisation(T):
     hip.fp8_quantize(hip.BF16, hip.E5M2, dq2, dq2.numel(), sg2, g2)
     torch.cuda.synchronize()
     assert torch.equal(dq, dq2) and torch.equal(dqq, g2) and sg[2].item() == sg2[2].item()
+    # + the column sums of the stored d_qkv (the qkv bias gradient) from the same kernel: same d_qkv / fp8 bytes, colsum += the sums
+    # of the bf16-rounded rows, identical on a second run
+    cs = [torch.full((3 * D,), 1.5, device=DEV) for _ in range(2)]
+    work = torch.empty(B * 3 * D, device=DEV)
+    for c in cs:
+        dq3 = torch.full_like(qkv, float("nan")); q3 = torch.empty_like(dqq)
+        s3 = torch.tensor([900.0, 1 / 900.0, 0.0], device=DEV)
+        hip.attn_backward(hip.BF16, qkv, do, o, lse, dq3, B, T, H, dh, dh ** -0.5, dqkv_q=q3, q_state=s3, colsum=c, colsum_work=work)
+        torch.cuda.synchronize()
+        assert torch.equal(dq3, dq2) and torch.equal(q3, g2) and s3[2].item() == sg2[2].item()
+    assert torch.equal(cs[0], cs[1])
+    torch.testing.assert_close(cs[0].double().cpu(), 1.5 + dq2.double().sum(0).cpu(), rtol=1e-5, atol=1e-4 * dq2.abs().max().item() * (B * T) ** 0.5)
 
 
 @pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
