@@ -202,6 +202,7 @@ _VITS = {
     "vit_small_patch16_224": dict(img=224, patch=16, dim=384, depth=12, heads=6),
     "vit_large_patch16_224": dict(img=224, patch=16, dim=1024, depth=24, heads=16),
     "vit_tiny_test": dict(img=64, patch=16, dim=128, depth=2, heads=2),   # reduced member for fast parity tests
+    "vit_small_test": dict(img=64, patch=16, dim=256, depth=2, heads=4),  # reduced member inside the fp8 GEMM envelope (dim 256)
 }
 
 

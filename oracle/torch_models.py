@@ -346,6 +346,7 @@ _BACKBONES = {
     "resnet_tiny_basic": lambda: ResNet(BasicBlock, (1, 1, 1, 1)),
     "resnet_tiny_bottleneck": lambda: ResNet(Bottleneck, (1, 1, 1, 1)),
     "vit_tiny_test": lambda: VisionTransformer(img=64, patch=16, dim=128, depth=2, heads=2),
+    "vit_small_test": lambda: VisionTransformer(img=64, patch=16, dim=256, depth=2, heads=4),
 }
 
 
