@@ -620,13 +620,16 @@ __global__ __launch_bounds__(512, 1) void wgrad8f_group_kernel(const W256Group g
 
 // Workgroups a weight-gradient launch aims for.  These kernels run on the side stream NEXT TO the main stream's GEMMs, so they
 // need not fill the chip by themselves, and every extra split costs a 4 bytes / weight slab written and read back.  Same-box
-// A/B of the whole step (scripts/ab_env.sh NKB_WGRAD256_WGS ...): 128 instead of 256 is -0.8 ms for the fp8 unicom step and
-// -0.25 ms for ResNet-50 (its eight-phase launches are small: <= 26 GFLOP), neutral for ViT-B/16, and +2.2 ms for the bf16 unicom
-// step, whose 200-280 GFLOP bf16 weight gradients are long enough to become the critical path when under-split (64: +40 ms).
+// A/B of the whole step (scripts/ab_env.sh): fp8 launches and bf16 launches below 220 GFLOP aim for 128 workgroups, the larger
+// bf16 ones (fc1 / fc2 of ViT-L/14 and ViT-B/16: 240-280 GFLOP) for 256 — ResNet-50 -0.25 ms, unicom fp8 -0.8 ms, unicom bf16
+// -0.55 ms, ViT-B/16 -0.1 ms against 256 everywhere; 128 everywhere costs the bf16 unicom step +2.2 ms (its longest weight
+// gradients become the critical path), 64 everywhere +40 ms.
 static int wgrad256_target_wgs(bool fp8, double flops) {
     static const int forced = [] { const char* e = getenv("NKB_WGRAD256_WGS"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced;
-    return (fp8 || flops < 5.0e10) ? 128 : 256;
+    static const double small = [] { const char* e = getenv("NKB_WGRAD_SMALL_GF"); return (e ? atof(e) : 220.0) * 1e9; }();
+    static const int big = [] { const char* e = getenv("NKB_WGRAD_BIG_WGS"); return e ? atoi(e) : 256; }();
+    return (fp8 || flops < small) ? 128 : big;
 }
 
 // stages (64 tokens) per split for `tiles` output tiles: ~target workgroups in total
