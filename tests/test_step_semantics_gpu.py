@@ -358,6 +358,49 @@ def test_unicom_fp8_train_step_tracks_bf16_and_oracle():
     assert c8 > 0.97 and c16 > 0.995
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_unicom_branch_gradient_from_layernorm_backward_equals_separate_pass(mode, monkeypatch):
+    """Stochastic depth active (rate 0.5) on the reduced unicom ViT (dim 256, two blocks): the branch gradient scale[b] * dx that
+    LayerNorm backward writes next to dx — bf16 copy in the bf16 step (into the CONSUMER block's scratch set, behind the side-stream
+    wait that guards it), e5m2 operand + bias column sums in the fp8 step — against the separate scale_rows / quantise + column-sum
+    passes, same drop masks (same host seed): the bf16 step must give bit-identical gradients, the fp8 step bit-identical weight
+    gradients (the operand bytes are the same) and bias gradients equal up to summation order."""
+    from nkb_classification import hipnet
+    cfg_model = dict(model="unicom ViT-small-test", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(32, 3, 56, 56, generator=g).to(DEV), torch.randint(0, 4, (32,), generator=g).to(DEV)
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(hipnet, "_LN_BWD_SCALED_COPY", fused)
+        monkeypatch.setattr(hipnet, "_FP8_LN_BWD_QUANT", fused)
+        torch.manual_seed(0)
+        model = get_model(dict(cfg_model), ["a", "b", "c", "d"], DEV)
+        for blk in model.emb_model.blocks:
+            blk.drop_path.drop_prob = 0.5
+        model.train()
+        model.fp8_linear = mode == "fp8"
+        torch.manual_seed(77)                       # the drop-path draws come from torch's host generator
+        for _ in range(3):                          # fp8: the producers write the operands from the second step on
+            for p in model.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = crit(model(x), y)
+            loss.backward()
+        torch.cuda.synchronize()
+        eng = model._engines[torch.bfloat16]
+        dropped = sum(int((eng.saved[f"b{i}.dp{j}"]["scale"] == 0).sum()) for i in range(2) for j in (1, 2))
+        assert 0 < dropped < 4 * 32
+        grads[fused] = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        if mode == "bf16" or not n.endswith("bias"):
+            assert torch.equal(a, b), n
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * max(1.0, b.abs().max().item()), msg=n)
+
+
 def test_timm_vit_fp8_train_step_tracks_bf16_and_oracle():
     """The fp8 mode on a reduced timm-layout ViT (dim 256, class token, GELU MLP, qkv WITH bias): 17 tokens x 128 images = 2176 rows
     inside the fp8 GEMM envelope.  Exercises what the unicom member does not: the qkv bias gradient from the attention backward
