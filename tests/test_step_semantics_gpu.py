@@ -14,6 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from nkb_classification import hip  # noqa: E402
 from nkb_classification.amp import HipGradScaler  # noqa: E402
 from nkb_classification.logging import BaseLogger  # noqa: E402
 from nkb_classification.losses import FocalLoss, get_loss  # noqa: E402
@@ -399,6 +400,98 @@ def test_unicom_branch_gradient_from_layernorm_backward_equals_separate_pass(mod
             assert torch.equal(a, b), n
         else:
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * max(1.0, b.abs().max().item()), msg=n)
+
+
+def test_unicom_bf16_fused_epilogues_against_oracle_with_replayed_drop_masks():
+    """The bf16 unicom step with every late-round-2 fusion in play on the reduced member (dim 256; the eight-phase core forced on
+    for its small GEMMs): stochastic-depth scale in the proj / fc2 residual epilogue, ReLU6 in the fc1 epilogue and its mask in
+    the fc2 data gradient, the scaled branch gradient from LayerNorm backward.  The engine's per-sample keep draws are replayed
+    in the fp32 CPU oracle; logits within bf16 rounding of it, whole-model gradient cosine >= 0.999."""
+    from oracle.torch_models import OracleClassifier
+    cfg_model = dict(model="unicom ViT-small-test", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    classes = ["a", "b", "c", "d"]
+    torch.manual_seed(0)
+    oracle = OracleClassifier(cfg_model, classes)
+    model = get_model(dict(cfg_model), classes, DEV)
+    model.load_state_dict(oracle.state_dict())
+    for net in (oracle, model):
+        for blk in net.emb_model.blocks:
+            blk.drop_path.drop_prob = 0.5
+    g = torch.Generator().manual_seed(6)
+    x, y = torch.randn(32, 3, 56, 56, generator=g), torch.randint(0, 4, (32,), generator=g)
+    oracle.train(); model.train()
+    hip.gemm8p_config(True, 1, 128)
+    try:
+        torch.manual_seed(31)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(x.to(DEV))
+            loss = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)(out, y.to(DEV))
+        eng = model._engines[torch.bfloat16]
+        dropped = 0
+        for i, blk in enumerate(oracle.emb_model.blocks):
+            s1, s2 = eng.saved[f"b{i}.dp1"]["scale"].cpu(), eng.saved[f"b{i}.dp2"]["scale"].cpu()
+            dropped += int((s1 == 0).sum() + (s2 == 0).sum())
+            keeps = iter([(s1 > 0).float(), (s2 > 0).float()])
+            blk.drop_path.forward = (lambda mod, it: (lambda t: t * next(it).reshape(-1, 1, 1) / (1.0 - mod.drop_prob)))(blk.drop_path, keeps)
+        assert 0 < dropped < 4 * 32
+        ref = oracle(x)
+        torch.nn.functional.cross_entropy(ref, y).backward()
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm8p_config(True, 192, 768)
+    scale = ref.detach().abs().max().item()
+    err = (out.detach().float().cpu() - ref.detach()).abs().max().item() / scale
+    ref_p = dict(oracle.named_parameters())
+    num = den_a = den_b = 0.0
+    for name, p in model.named_parameters():
+        a, b = p.grad.detach().cpu().double(), ref_p[name].grad.double()
+        num += (a * b).sum().item(); den_a += a.pow(2).sum().item(); den_b += b.pow(2).sum().item()
+    cos = num / (den_a * den_b) ** 0.5
+    print(f"\n[unicom small bf16, fused epilogues] logits relerr {err:.3e}, gradient cosine {cos:.6f}, dropped {dropped}")
+    assert err < 3e-2 and cos > 0.999
+
+
+def test_timm_vit_bf16_gelu_epilogue_against_oracle():
+    """timm-layout ViT (dim 256, GELU MLP) in bf16 with the eight-phase core forced on for its small GEMMs: fc1 then writes gelu(pre)
+    and gelu'(pre) from its epilogue (Abramowitz-Stegun erf) and the fc2 data gradient multiplies by the saved derivative — logits and
+    whole-model gradients against the fp32 CPU oracle (exact erf)."""
+    from oracle.torch_models import OracleClassifier
+    cfg_model = dict(model="vit_small_test", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    classes = ["a", "b", "c", "d"]
+    torch.manual_seed(0)
+    oracle = OracleClassifier(cfg_model, classes)
+    model = get_model(dict(cfg_model), classes, DEV)
+    model.load_state_dict(oracle.state_dict())
+    g = torch.Generator().manual_seed(8)
+    x, y = torch.randn(64, 3, 64, 64, generator=g), torch.randint(0, 4, (64,), generator=g)
+    oracle.train(); model.train()
+    ref = oracle(x)
+    torch.nn.functional.cross_entropy(ref, y).backward()
+    hip.gemm8p_config(True, 1, 128)
+    try:
+        assert hip.linear_gelu_fused_ok(hip.BF16, 64 * 17, 256, 1024)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(x.to(DEV))
+            loss = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)(out, y.to(DEV))
+        eng = model._engines[torch.bfloat16]
+        assert "gp" in eng.saved["b0.act"] and "x" not in eng.saved["b0.act"]      # the epilogue form ran: no pre-activation kept
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm8p_config(True, 192, 768)
+    scale = ref.detach().abs().max().item()
+    err = (out.detach().float().cpu() - ref.detach()).abs().max().item() / scale
+    ref_p = dict(oracle.named_parameters())
+    num = den_a = den_b = 0.0
+    for name, p in model.named_parameters():
+        a, b = p.grad.detach().cpu().double(), ref_p[name].grad.double()
+        num += (a * b).sum().item(); den_a += a.pow(2).sum().item(); den_b += b.pow(2).sum().item()
+    cos = num / (den_a * den_b) ** 0.5
+    print(f"\n[timm ViT small bf16, GELU epilogue] logits relerr {err:.3e}, gradient cosine {cos:.6f}")
+    assert err < 3e-2 and cos > 0.999
 
 
 def test_timm_vit_fp8_train_step_tracks_bf16_and_oracle():
