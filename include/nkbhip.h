@@ -150,7 +150,7 @@ int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int l
 /* All weight re-layouts of a step in one launch: jobs[j] = {src element offset from `base`, dst device pointer, A, B, C,
  * ld, mode (as nkb_wprep), index of the job's first block}, 8 x int64 per job on the device; a job occupies
  * nkb_wprep_job_blocks(...) consecutive blocks, total_blocks = sum over jobs. */
-int nkb_wprep_multi(int dtype, const float* base, const long long* jobs, int njobs, int total_blocks, nkb_stream_t stream);
+int nkb_wprep_multi(int dtype, const float* base, const long long* jobs, int njobs, int total_blocks, const void* shadow, nkb_stream_t stream);
 int nkb_wprep_block_elems(void);
 long long nkb_wprep_job_blocks(int A, int B, int C, int ld, int mode); /* blocks a job occupies in nkb_wprep_multi */
 int nkb_add2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, nkb_stream_t stream);

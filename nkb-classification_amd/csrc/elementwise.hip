@@ -720,7 +720,8 @@ static inline long long wprep_job_blocks(int A, int B, int C, int ld, int mode) 
 extern "C" long long nkb_wprep_job_blocks(int A, int B, int C, int ld, int mode) { return wprep_job_blocks(A, B, C, ld, mode); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void wprep_multi_kernel(const float* __restrict__ base, const long long* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void wprep_multi_kernel(const float* __restrict__ base, const long long* __restrict__ jobs, int njobs,
+                                                          const bf16_t* __restrict__ shadow) {
     __shared__ float tile[64][65];
     int lo = 0, hi = njobs - 1;                     // last job whose first block <= blockIdx.x
     while (lo < hi) {
@@ -754,10 +755,17 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const float* __restric
     const bool vec = (C & 3) == 0 && (ld & 3) == 0 && (jb[0] & 3) == 0 && (((size_t)dst * 1) & 15) == 0 && a0 + 64 <= A && c0 + 64 <= C && a0 + 64 <= ld;
     if (vec) {
         const int tx4 = threadIdx.x & 15, ty = threadIdx.x >> 4;         // 16 x 4 columns, 16 rows per pass
+        // (shadow: the bf16 mirror of `base` the optimizer keeps — the same values this pass would round to, half the bytes to read)
+        const bf16_t* src16 = (sizeof(T) == 2 && shadow) ? shadow + jb[0] : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = ty + 16 * i;
-            const f32x4 v = *(const f32x4*)(src + ((size_t)(a0 + r) * B + sb) * C + c0 + 4 * tx4);
+            const size_t off = ((size_t)(a0 + r) * B + sb) * C + c0 + 4 * tx4;
+            f32x4 v;
+            if (src16) {
+                const u32x2 u = *(const u32x2*)(src16 + off);
+                v = (f32x4){__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+            } else v = *(const f32x4*)(src + off);
             tile[r][4 * tx4] = v[0]; tile[r][4 * tx4 + 1] = v[1]; tile[r][4 * tx4 + 2] = v[2]; tile[r][4 * tx4 + 3] = v[3];
         }
         __syncthreads();
@@ -785,12 +793,14 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const float* __restric
     }
 }
 extern "C" int nkb_wprep_block_elems(void) { return NKB_WPREP_BLOCK_ELEMS; }
-extern "C" int nkb_wprep_multi(int dtype, const float* base, const long long* jobs, int njobs, int total_blocks,
+// shadow (optional, bf16 destinations): a bf16 mirror of `base` (same element offsets) to read from instead — same results, half the bytes
+extern "C" int nkb_wprep_multi(int dtype, const float* base, const long long* jobs, int njobs, int total_blocks, const void* shadow,
                                hipStream_t stream) {
     if (njobs <= 0 || total_blocks <= 0) return 0;
+    if (shadow && (dtype != NKB_DT_BF16 || ((uintptr_t)shadow & 15) != 0)) { nkb_set_error("wprep_multi: the shadow is a 16-byte-aligned bf16 mirror"); return 1; }
     NkbProfScope prof(NKB_K_WPREP, stream, 0);
-    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(wprep_multi_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, stream, base, jobs, njobs);
-    else hipLaunchKernelGGL(wprep_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, base, jobs, njobs);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(wprep_multi_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, stream, base, jobs, njobs, (const bf16_t*)shadow);
+    else hipLaunchKernelGGL(wprep_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, base, jobs, njobs, (const bf16_t*)nullptr);
     return nkb_check_launch("wprep_multi");
 }
 extern "C" int nkb_wprep(int dtype, const float* src, void* dst, int A, int B, int C, int ld, int mode, hipStream_t stream) {

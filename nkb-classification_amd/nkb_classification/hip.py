@@ -35,7 +35,7 @@ _SIGS = {
     "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32] + [i32] * 13 + [vp]),
     "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
-    "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp]),
+    "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp, vp]),
     "nkb_wprep_block_elems": (i32, []),
     "nkb_wprep_job_blocks": (i64, [i32, i32, i32, i32, i32]),
     "nkb_stem_pack": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
@@ -403,8 +403,9 @@ def im2row(dtype, x, col, N, Cin, H, W, R, S, stride, pad, Kp):
     check(load().nkb_im2row(dtype, ptr(x), ptr(col), N, Cin, H, W, R, S, stride, pad, Kp, stream()), "im2row")
 
 
-def wprep_multi(dtype, base, jobs, njobs, total_blocks):
-    check(load().nkb_wprep_multi(dtype, ptr(base), ptr(jobs), njobs, total_blocks, stream()), "wprep_multi")
+def wprep_multi(dtype, base, jobs, njobs, total_blocks, shadow=None):
+    """shadow: optional bf16 mirror of `base` (same element offsets) to read the transposing jobs' sources from."""
+    check(load().nkb_wprep_multi(dtype, ptr(base), ptr(jobs), njobs, total_blocks, ptr(shadow), stream()), "wprep_multi")
 
 
 def wprep_block_elems() -> int:

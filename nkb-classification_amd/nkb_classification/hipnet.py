@@ -44,6 +44,7 @@ _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
 # four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
 # the block to end.  Off.
 _WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
+_WPREP_FROM_SHADOW = os.environ.get("NKB_WPREP_FROM_SHADOW", "1") != "0"
 # LayerNorm dgamma / dbeta reduction (two small launches) on the side stream instead of in the backward chain: measured neutral
 # (unicom fp8 50.8-51.4 vs 50.9-51.3 ms, ViT-B/16 35.65-35.74 vs 35.74-35.78) — the other stream fills those gaps anyway.  Off.
 _LN_REDUCE_SIDE = os.environ.get("NKB_LN_REDUCE_SIDE", "0") != "0"
@@ -140,7 +141,9 @@ class HipEngine:
             if self._wjobs is None:
                 self._wjobs = self._build_dgrad_jobs()
             jobs, njobs, nblocks = self._wjobs
-            hip.wprep_multi(self.d, a.flat_param, jobs, njobs, nblocks)
+            # (bf16: the transposes read the optimizer's bf16 shadow of the masters — the values they would round to, half the bytes)
+            hip.wprep_multi(self.d, a.flat_param, jobs, njobs, nblocks,
+                            shadow=a.shadow if (self.T == torch.bfloat16 and _WPREP_FROM_SHADOW) else None)
         if self.fp8 and self.T == torch.bfloat16 and need_dgrad:
             self._refresh_fp8_weights()
         self._dgrad_ready = need_dgrad

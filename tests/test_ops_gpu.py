@@ -626,6 +626,13 @@ def test_wprep_multi_matches_single_jobs(dtype):
     torch.cuda.synchronize()
     for o, r, sh in zip(outs, refs, shapes):
         assert torch.equal(o, r), sh
+    if dtype == torch.bfloat16:      # the same jobs reading a bf16 mirror of `base`: identical results (the mirror holds what they round to)
+        for o in outs:
+            o.fill_(7.0)
+        hip.wprep_multi(d, base, jobs, len(rows), nblocks, shadow=base.to(torch.bfloat16))
+        torch.cuda.synchronize()
+        for o, r, sh in zip(outs, refs, shapes):
+            assert torch.equal(o, r), sh
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
