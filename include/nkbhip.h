@@ -90,7 +90,7 @@ int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, 
                       int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int R, int S, int stride, int pad,
                       nkb_stream_t stream);
 /* relu_bits != NULL: the stage closes a residual block — its mask comes from nkb_bn_apply's bit array (scale/shift
- * unused) and the residual operand `add` (optionally under add_bits, or on the sub-grid add_h x add_w) is still added
+ * unused; c and mean may then be NULL as well: only the sums of g' are produced, the Gram form takes sum g'c from R = g'^T a) and the residual operand `add` (optionally under add_bits, or on the sub-grid add_h x add_w) is still added
  * before masking, so the block-output gradient is produced, masked and reduced in the one epilogue. */
 /* One parity class (ph, pw) of the data gradient of a 3x3 / stride-2 / pad-1 convolution: output pixels (2h'+ph, 2w'+pw)
  * as a stride-1 gather over dY with (1|2) x (1|2) taps; w_class = [C][Rc][Sc][K] from nkb_wprep modes 2..5 (= 2 + 2*ph + pw).
@@ -105,6 +105,38 @@ int nkb_bn_backward_from_stats(int dtype, const void* g, const void* x, float* s
                                const float* invstd, const float* gamma, long long rows, int C, float* dgamma,
                                float* dbeta, void* dx, float* sums, nkb_stream_t stream);
 size_t nkb_bn_stats_floats(int tiles, int C); /* size of the `partials` buffer nkb_bn_finalize expects */
+
+/* ---- Gram form of a bottleneck's closing stage: conv3 (1x1) -> bn3 -> += shortcut -> ReLU ------------------------------
+ * (timm resnet.py Bottleneck.forward, built by timm.create_model at /root/reference/nkb_classification/model.py:82 and driven
+ * from engine.py:48 forward / engine.py:55-58 backward).  For c = a W^T every statistic BatchNorm needs of c follows from the
+ * Cin x Cin Gram matrix of a (nkb_conv_wgrad(dy = a, x = a, dbias = column sums)): mean = W mu, var = diag(W Cov W^T).  So
+ *   nkb_gram_bn_stats         scale / shift / mean / invstd / running statistics BEFORE the convolution runs (+ T = W Cov, mu kept),
+ *   nkb_conv_affine_residual  y = relu(conv(a, W) * scale + shift + res') with the ReLU bit mask; c is never written or re-read,
+ * and backward, with g = masked output gradient and R = g^T a (nkb_conv_wgrad into a zeroed scratch):
+ *   nkb_gram_bn_backward      sum g c = rowdot(W, R) -> dgamma, dbeta, dW = k1 R + M k2 T - gamma r dbeta mu^T, and the filter
+ *                             [k1 W ; W^T diag(k2) W] + bias k3 W of the concatenated data gradient,
+ *   nkb_conv_dgrad_bn_cat     da = [g | a] . wcat^T + cbias with nkb_conv_dgrad_bn's fused BN-backward epilogue for the stage before,
+ * so neither c nor dc = k1 g + k2 c + k3 exists in HBM (the 4x-wide tensor's bn_apply / bn_backward passes disappear).
+ * tests/test_gram_bn_math.py pins the algebra against autograd in float64. */
+int nkb_gram_bn_stats(int dtype, const void* w, const float* gram, const float* colsum, long long count, int Cin, int Cout,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                      float* cov, float* mu, float* T, float* scale, float* shift, float* mean, float* invstd, nkb_stream_t stream);
+/* w: [Cout][Cin] in the compute dtype (what the MFMA multiplies by); gram [Cin][Cin], colsum [Cin] fp32; cov: Cin*Cin floats of
+ * scratch; mu [Cin], T [Cout][Cin] are outputs kept for nkb_gram_bn_backward.  Cin <= 512. */
+int nkb_conv_affine_residual(int dtype, const void* x, const void* w, void* y, const float* scale, const float* shift,
+                             const void* res, int ldres, const float* res_scale, const float* res_shift,
+                             unsigned char* relu_bits, int N, int H, int W, int Cin, int ldx, int P, int Q, int Cout, int ldy,
+                             int R, int S, int stride, int pad, nkb_stream_t stream);
+/* bf16, Cout > 64.  res_scale / res_shift (optional): res is the raw output of a projection shortcut and enters as
+ * rnd(res * res_scale + res_shift), as in nkb_bn_apply.  relu_bits: layout of nkb_bn_apply's relu_bits. */
+int nkb_gram_bn_backward(int dtype, const void* w, const float* R, const float* T, const float* mu, float* gstats, int tiles,
+                         long long count, int Cin, int Cout, const float* gamma, const float* mean, const float* invstd,
+                         float* dgamma, float* dbeta, float* dw, void* wcat, float* cbias, float* coef, nkb_stream_t stream);
+/* gstats: per-row-tile sums of g as nkb_conv_dgrad_bn leaves them (first plane used; nkb_bn_stats_floats floats); dgamma, dbeta,
+ * dw accumulate (+=); wcat: [Cin][Cout + Cin] in the compute dtype, cbias [Cin]; coef: 5 * Cout floats of scratch. */
+int nkb_conv_dgrad_bn_cat(int dtype, const void* g, int ldg, int K1, const void* a, int lda, int K2, const void* wcat,
+                          const float* cbias, void* g_masked, const void* c_prev, const float* scale, const float* shift,
+                          const float* mean, float* stats, long long M, int Cout, int ldy, nkb_stream_t stream);
 size_t nkb_bn_backward_workspace_floats(long long rows, int C);
 
 /* MaxPool2d(3, 2, 1) and global average pool, forward (backward=0) / backward (backward=1), NHWC. */

@@ -164,6 +164,8 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, OOB, 0x00020000);
+    // K-concatenated launches: the activation rows of k-tiles >= kt2 come from a second tensor (plain 1x1 geometry only)
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(BNB == 1 ? p.x2 : nullptr), 0, OOB, 0x00020000);
 
     u32x4 sw[NWR], sx[NPX];
     int r = 0, s = 0, ck = 0;  // filter tap and channel-tile of the NEXT k-tile to load
@@ -187,6 +189,19 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 }
             }
             if (++s == 3) { s = 0; if (++ck == cpk) { ck = 0; ++r; } }
+            return;
+        }
+        if (BNB == 1 && p.x2 != nullptr && kt >= p.kt2) {
+            const int koff = (kt - p.kt2) * 128 + cc * 16;
+#pragma unroll
+            for (int i = 0; i < NWR; ++i)
+                sw[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)woff[i], kt * 128, 0);
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) {
+                const int m = m0 + srow + 32 * j;
+                const unsigned o = (m < p.M) ? (unsigned)(m * p.ldx2 * ESZ + koff) : OOB;
+                sx[j] = __builtin_amdgcn_raw_buffer_load_b128(rx2, (int)o, 0, 0);
+            }
             return;
         }
         // wave-uniform byte offsets of this k-tile
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
     float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = ((BNB == 0 || BNB == 3) && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bv[e] = ((BNB == 0 || BNB == 1 || BNB == 3) && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
     // BNB: the stage's scale / shift / mean for this tile's channels live in LDS behind the epilogue tile (keeping them
     // in registers next to the not-yet-stored accumulators cost a wave of occupancy)
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 bnl[tid] = ok ? p.bn_scale[c0 + tid] : 0.f;
                 bnl[TC + tid] = ok ? p.bn_shift[c0 + tid] : 0.f;
             }
-            bnl[2 * TC + tid] = ok ? p.bn_mean[c0 + tid] : 0.f;
+            bnl[2 * TC + tid] = (ok && p.bn_mean) ? p.bn_mean[c0 + tid] : 0.f;
         }
     }
 
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                     const unsigned ww = rem - hh * p.divQ.d;
                     crow = ((size_t)n * p.sub_h + 2 * hh + p.sub_ph) * p.sub_w + 2 * ww + p.sub_pw;
                 }
-                if (m < p.M && co + 8 <= p.Cout) cpre[i] = *(const u32x4*)((const bf16_t*)p.aux + crow * p.ldy + co);
+                if (m < p.M && co + 8 <= p.Cout && p.aux != nullptr) cpre[i] = *(const u32x4*)((const bf16_t*)p.aux + crow * p.ldy + co);
             }
         }
     };
@@ -444,6 +459,69 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 if (p.bias) rows(std::false_type{}, std::true_type{}, std::false_type{});
                 else rows(std::false_type{}, std::false_type{}, std::false_type{});
             }
+        }
+    } else if constexpr (BNB == 4) {
+        // closing stage of a residual block whose batch statistics are known BEFORE the launch (Gram form, grambn.hip):
+        // y = relu(acc * scale + shift + res) straight from the fp32 accumulators, + the ReLU bit mask of the stored values;
+        // the raw conv output is never written.  res enters as stored, or as rnd(res * add_scale + add_shift) when it is the
+        // raw output of a projection shortcut — the same expressions and roundings as bn_apply_kernel (elementwise.hip).
+        static_assert(sizeof(T) == 2, "the closing-stage epilogue exists for bf16 only");
+        const int mrow = m0 + half * (TP / 2) + er;
+        if (co < p.Cout) {
+            bf16_t* o = (bf16_t*)p.y + yoff + (size_t)mrow * p.ldy + co;
+            const size_t ostep = (size_t)RPP * p.ldy;
+            const unsigned char* lrow = smem + er * EROW + eg * 32;
+            const bf16_t* ad = (const bf16_t*)p.add + (size_t)mrow * p.ldadd + co;
+            const size_t astep = (size_t)RPP * p.ldadd;
+            unsigned char* ob = p.out_bits + (size_t)mrow * (size_t)(p.ldy >> 3) + (co >> 3);
+            const size_t bstep = (size_t)RPP * (size_t)(p.ldy >> 3);
+            u32x4 ar[RPH];                     // residual rows of this half, requested together
+#pragma unroll
+            for (int ri = 0; ri < RPH; ++ri) {
+                ar[ri] = (u32x4){0u, 0u, 0u, 0u};
+                if (mrow + RPP * ri < p.M) ar[ri] = *(const u32x4*)(ad + ri * astep);
+            }
+            float sc[8], sh[8];
+            {
+                const f32x4 a0 = *(const f32x4*)(p.oscale + co), a1 = *(const f32x4*)(p.oscale + co + 4);
+                const f32x4 b0 = *(const f32x4*)(p.bias + co), b1 = *(const f32x4*)(p.bias + co + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[e] = a0[e]; sc[4 + e] = a1[e]; sh[e] = b0[e]; sh[4 + e] = b1[e]; }
+            }
+            auto rows = [&](auto HRA) {
+                constexpr bool hra = decltype(HRA)::value;
+                float rsc[8], rsh[8];
+                if constexpr (hra) {
+                    const f32x4 a0 = *(const f32x4*)(p.add_scale + co), a1 = *(const f32x4*)(p.add_scale + co + 4);
+                    const f32x4 b0 = *(const f32x4*)(p.add_shift + co), b1 = *(const f32x4*)(p.add_shift + co + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { rsc[e] = a0[e]; rsc[4 + e] = a1[e]; rsh[e] = b0[e]; rsh[4 + e] = b1[e]; }
+                }
+#pragma unroll
+                for (int ri = 0; ri < RPH; ++ri) {
+                    if (mrow + RPP * ri >= p.M) break;
+                    const f32x4 lo = *(const f32x4*)(lrow + ri * RPP * EROW);
+                    const f32x4 hi = *(const f32x4*)(lrow + ri * RPP * EROW + 16);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    float af[8];
+                    unpack8(ar[ri], af);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if constexpr (hra) af[e] = bf2f(f2bf(af[e] * rsc[e] + rsh[e]));
+                        v[e] = fmaxf(v[e] * sc[e] + sh[e] + af[e], 0.f);
+                    }
+                    const u32x4 pk = pack8(v);
+                    *(u32x4*)(o + ri * ostep) = pk;
+                    unsigned b = 0u;           // after the clamp a stored value is > 0 exactly when its bf16 bits are non-zero
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        b |= ((pk[e] & 0x7fffu) ? 1u : 0u) << (2 * e);
+                        b |= ((pk[e] & 0x7fff0000u) ? 1u : 0u) << (2 * e + 1);
+                    }
+                    ob[ri * bstep] = (unsigned char)b;
+                }
+            };
+            if (p.add_scale) rows(std::true_type{}); else rows(std::false_type{});
         }
     } else {
     // residual-closing fused epilogue (BNB == 2, bf16, full-grid residual): the `add` rows of this half are requested up front,
@@ -532,7 +610,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             if (co + 8 <= p.Cout) {
                 if constexpr (sizeof(T) == 2) {
                     unpack8(cpre[ri], cv);
-                } else {
+                } else if (p.aux != nullptr) {
                     const float* ax = (const float*)p.aux + orow * p.ldy + co;
                     const f32x4 lo = *(const f32x4*)ax, hi = *(const f32x4*)(ax + 4);
 #pragma unroll
@@ -1135,13 +1213,84 @@ extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void*
     p.add_bits = add_bits; p.bn_bits = relu_bits;
     p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean;
     NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * p.M * (double)Cout * R * S * Cin,
-                      ((double)N * H * W * Cin + (double)Cout * R * S * Cin + (add ? 3.0 : 2.0) * p.M * Cout) * esz);
+                      ((double)N * H * W * Cin + (double)Cout * R * S * Cin + ((add ? 2.0 : 1.0) + (c ? 1.0 : 0.0)) * p.M * Cout) * esz);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
     if (relu_bits) {
         if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 2>(p, stream) : launch_conv<bf16_t, 128, 128, 2>(p, stream);
         return narrow ? launch_conv<float, 64, 256, 2>(p, stream) : launch_conv<float, 128, 128, 2>(p, stream);
     }
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
+    return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
+}
+
+// Closing stage of a residual block with the BatchNorm statistics known before the launch (Gram form, grambn.hip):
+//   y = relu(conv(x, w) * scale + shift + res'),   res' = res  or  rnd(res * res_scale + res_shift) (projection shortcut),
+// and the ReLU bit mask of the stored y (layout of nkb_bn_apply's relu_bits).  The raw conv output is never written and
+// no separate normalisation pass reads it back.  bf16, Cout > 64 and a multiple of 8.
+extern "C" int nkb_conv_affine_residual(int dtype, const void* x, const void* w, void* y, const float* scale, const float* shift,
+                                        const void* res, int ldres, const float* res_scale, const float* res_shift,
+                                        unsigned char* relu_bits, int N, int H, int W, int Cin, int ldx, int P, int Q, int Cout,
+                                        int ldy, int R, int S, int stride, int pad, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 || Cout <= 64 || Cout % 8 || ldy % 8 || ldres % 8 || Cin % 64 || ldx % 8 || !scale || !shift || !res || !relu_bits ||
+        (res_scale == nullptr) != (res_shift == nullptr)) {
+        nkb_set_error("conv_affine_residual: bf16 only, Cout=%d > 64 and %% 8, Cin=%d %% 64, scale/shift/res/relu_bits required", Cout, Cin);
+        return 1;
+    }
+    if (stride != 1 && stride != 2) { nkb_set_error("conv_affine_residual: stride %d unsupported", stride); return 1; }
+    if ((long long)N * H * W * ldx * 2 >= 0xFFFFFF00ll || (long long)Cout * R * S * Cin * 2 >= 0xFFFFFF00ll ||
+        (long long)N * P * Q * ldy >= (1ll << 31) || (long long)N * P * Q * ldres >= (1ll << 31)) {
+        nkb_set_error("conv_affine_residual: operand exceeds the addressing range");
+        return 1;
+    }
+    ConvParams p;
+    p.x = x; p.w = w; p.y = y; p.add = res; p.bias = shift; p.stats = nullptr;
+    p.M = N * P * Q; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.P = P; p.Q = Q; p.Cout = Cout; p.ldy = ldy;
+    p.ldadd = ldres; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.mode = 0; p.relu = 1;
+    p.stride_w = stride; p.pad_w = pad; p.stem_cprw = 0; p.out_f32 = 0;
+    p.divPQ = make_fastdiv((unsigned)(P * Q)); p.divQ = make_fastdiv((unsigned)Q);
+    p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
+    p.oscale = scale; p.add_scale = res_scale; p.add_shift = res_shift; p.out_bits = relu_bits;
+    NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * p.M * (double)Cout * R * S * Cin,
+                      ((double)N * H * W * Cin + (double)Cout * R * S * Cin + 2.0 * p.M * Cout) * 2 + (double)p.M * Cout / 8);
+    return launch_conv<bf16_t, 128, 128, 4>(p, stream);
+}
+
+// Data gradient of the Gram-form closing stage (grambn.hip): with dc = k1*g + k2*c + k3 and c = a W^T never materialised,
+//   da = dc W = [g | a] . wcat^T + cbias,   wcat[j] = [k1 .* W[:, j] | Q[:, j]],  Q = W^T diag(k2) W,  cbias = k3 W
+// i.e. ONE 1x1 contraction over the concatenated K range (K1 channels of g, K2 channels of a), followed by the fused
+// BN-backward epilogue of nkb_conv_dgrad_bn (mask recomputed from c_prev / scale / shift of the stage that produced a,
+// per-row-tile sums of g' and g'*(c_prev - mean) into stats).
+extern "C" int nkb_conv_dgrad_bn_cat(int dtype, const void* g, int ldg, int K1, const void* a, int lda, int K2, const void* wcat,
+                                     const float* cbias, void* g_masked, const void* c_prev, const float* scale, const float* shift,
+                                     const float* mean, float* stats, long long M, int Cout, int ldy, hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int kte = 128 / esz;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_dgrad_bn_cat: bad dtype %d", dtype); return 1; }
+    if (K1 % kte || K2 % kte || K2 <= 0 || ldg % (16 / esz) || lda % (16 / esz) || Cout % 8 || ldy % 8 || !c_prev || !scale || !shift || !mean || !stats) {
+        nkb_set_error("conv_dgrad_bn_cat: K1=%d / K2=%d must be multiples of %d, Cout=%d / ldy=%d of 8", K1, K2, kte, Cout, ldy);
+        return 1;
+    }
+    if (M * ldg * esz >= 0xFFFFFF00ll || M * lda * esz >= 0xFFFFFF00ll || (long long)Cout * (K1 + K2) * esz >= 0xFFFFFF00ll ||
+        M * ldy >= (1ll << 31)) {
+        nkb_set_error("conv_dgrad_bn_cat: operand exceeds the addressing range");
+        return 1;
+    }
+    ConvParams p;
+    p.x = g; p.w = wcat; p.y = g_masked; p.add = nullptr; p.bias = cbias; p.stats = stats;
+    p.M = (int)M; p.H = (int)M; p.W = 1; p.Cin = K1 + K2; p.ldx = ldg; p.P = (int)M; p.Q = 1; p.Cout = Cout; p.ldy = ldy;
+    p.ldadd = 0; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 1; p.relu = 0;
+    p.stride_w = 1; p.pad_w = 0; p.stem_cprw = 0; p.out_f32 = 0;
+    p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
+    p.ldw = K1 + K2; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = c_prev; p.y2 = nullptr;
+    p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean;
+    p.x2 = a; p.ldx2 = lda; p.kt2 = K1 / kte;
+    NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)Cout * (K1 + K2),
+                      ((double)M * (K1 + K2) + (double)Cout * (K1 + K2) + 2.0 * M * Cout) * esz);
+    static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
+    const bool narrow = Cout <= 64 && narrow_on;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
     return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
 }

@@ -41,6 +41,16 @@ struct ConvParams {
     // add[m][c] only counts where bit (c % chunk) of add_bits[m][c / chunk] is set, chunk = 8 (bf16) / 4 (fp32) channels
     const unsigned char* add_bits = nullptr;
     int ldw;            // row stride of w in elements (R*S*Cin unless batched)
+    // K-concatenated 1x1 contraction (Gram-form closing stage, grambn.hip): k-tiles kt >= kt2 read their activation rows from
+    // x2[m][ldx2] at column (kt - kt2) * KTE instead of x — y[m] = [x[m] | x2[m]] . w[co][:], w rows holding both K ranges
+    const void* x2 = nullptr;
+    int ldx2 = 0, kt2 = 0;
+    // BNB == 4 (closing stage forward with the batch statistics known up front): y = relu(acc * oscale + bias + add'), add' =
+    // add or rnd(add * add_scale + add_shift) (projection shortcut), plus the ReLU bit mask of the stored values
+    const float* oscale = nullptr;
+    const float* add_scale = nullptr;
+    const float* add_shift = nullptr;
+    unsigned char* out_bits = nullptr;
     int inner;
     long long sxo, sxi, swo, swi, syo, syi;
 };

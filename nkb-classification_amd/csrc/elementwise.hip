@@ -1312,11 +1312,27 @@ __global__ void bn_bwd_finalize_tiles_kernel(const PT* __restrict__ partials, in
     if (py != 0 || c >= C) return;
     a = 0.0; b = 0.0;
     for (int k = 0; k < 16; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
-    const float sg = (float)a, sgx = (float)(b * (double)invstd[c]);
+    const float sg = (float)a, sgx = (float)(b * (invstd ? (double)invstd[c] : 1.0));
     sums[c] = sg;
     sums[C + c] = sgx;
     if (dbeta) dbeta[c] += sg;
     if (dgamma) dgamma[c] += sgx;
+}
+
+// per-row-tile partial sums [tiles][2][C] (buffer sized by nkb_bn_stats_floats) -> sums[0][C], sums[1][C], fixed order, double
+// accumulation: the reduction half of nkb_bn_backward_from_stats on its own (grambn.hip)
+int nkb_launch_tile_sums(float* stats, int tiles, int C, float* sums, hipStream_t stream) {
+    if (tiles > 128) {
+        double* dpart = (double*)(stats + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
+        const int P = bn_partitions(C);
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, stats, tiles, C, dpart);
+        hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream,
+                           (const double*)dpart, P, C, (const float*)nullptr, (float*)nullptr, (float*)nullptr, sums);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, stream,
+                           (const float*)stats, tiles, C, (const float*)nullptr, (float*)nullptr, (float*)nullptr, sums);
+    }
+    return nkb_check_launch("tile_sums");
 }
 
 // `stats` must have the size nkb_bn_stats_floats(tiles, C) (room for the stage-A scratch); sums: 2*C floats of scratch.

@@ -133,7 +133,8 @@ class HipResNet(_ParamOnly):
             x = eng.conv_bn("stem", col, conv, self.bn1, True, None, train, col_input=True, pool=fused)
         if not fused:
             x = eng.maxpool("pool", x, train)
-        for name, blk in self.blocks():
+        nblocks = sum(1 for _ in self.blocks())
+        for bi, (name, blk) in enumerate(self.blocks()):
             inp = x
             stages = blk.stages()
             short, short_affine = inp, None
@@ -157,7 +158,11 @@ class HipResNet(_ParamOnly):
                 short, s_scale, s_shift = box["r"]
                 short_affine = (s_scale, s_shift) if s_scale is not None else None     # None: eval mode, already normalised
             cv, bn = stages[-1]
-            x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train, res_affine=short_affine)
+            # Gram form of the closing stage (hipnet._conv_bn_gram): every bottleneck but the last — its backward needs the masked
+            # output gradient + sums that the NEXT block's conv1 data gradient leaves (can_fuse_residual_bn_backward)
+            gram = (isinstance(blk, _Bottle) and bi + 1 < nblocks and train
+                    and eng.can_fuse_bn_backward(f"{name}.{len(stages) - 2}"))
+            x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train, res_affine=short_affine, gram=gram)
         return eng.avgpool("gap", x)
 
     def run_backward(self, eng: HipEngine, g_emb: torch.Tensor, on_done=None):
@@ -173,13 +178,24 @@ class HipResNet(_ParamOnly):
             n = len(blk.stages())
             # last stage: ReLU(bn(conv) + shortcut); the masked incoming gradient also feeds the shortcut
             last = f"{name}.{n - 1}"
-            if g_stats is not None:
+            top = n - 1
+            if eng.saved[last].get("gram") is not None:
+                # Gram-form closing stage: no BN-backward apply pass, no gradient of the raw conv output — R = g^T a, the small
+                # algebra, and one data gradient over [g | a] that lands directly on the stage before
+                if g_stats is None:
+                    raise RuntimeError(f"{last}: the Gram-form closing stage needs the fused residual BN-backward producer")
+                prev = f"{name}.{n - 2}"
+                ga, st = eng.gram_closing_backward(last, g, g_stats, prev, f"a{n - 1}")
+                gc = eng.bn_backward_fused(prev, ga, st, f"c{n - 1}")
+                bits = None
+                top = n - 2
+            elif g_stats is not None:
                 gc = eng.bn_backward_fused(last, g, g_stats, "t0")
                 bits = None                              # g is masked already
             else:
                 gc = eng.bn_backward(last, g, "t0", write_masked=True)
                 bits = eng.saved[last].get("bits")       # set: g was NOT masked in place, consumers apply the bits
-            for k in range(n - 1, 0, -1):
+            for k in range(top, 0, -1):
                 prev = f"{name}.{k - 1}"
                 if eng.can_fuse_bn_backward(prev):
                     ga, st = eng.conv_backward(f"{name}.{k}", gc, f"a{k}", fuse_bn=prev)

@@ -35,6 +35,10 @@ _SIGS = {
     "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32] + [i32] * 13 + [vp]),
     "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
+    "nkb_gram_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nkb_conv_affine_residual": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp] + [i32] * 13 + [vp]),
+    "nkb_gram_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nkb_conv_dgrad_bn_cat": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp, vp]),
     "nkb_wprep_block_elems": (i32, []),
     "nkb_wprep_job_blocks": (i64, [i32, i32, i32, i32, i32]),
@@ -350,6 +354,30 @@ def bn_backward_from_stats(dtype, g, x, stats, tiles, mean, invstd, gamma, rows,
     check(load().nkb_bn_backward_from_stats(dtype, ptr(g), ptr(x), ptr(stats), tiles, ptr(mean), ptr(invstd), ptr(gamma),
                                             rows, C_, ptr(dgamma), ptr(dbeta), ptr(dx), ptr(sums), stream()),
           "bn_backward_from_stats")
+
+
+def gram_bn_stats(dtype, w, gram, colsum, count, Cin, Cout, gamma, beta, rm, rv, momentum, eps, cov, mu, T, scale, shift, mean, invstd):
+    check(load().nkb_gram_bn_stats(dtype, ptr(w), ptr(gram), ptr(colsum), count, Cin, Cout, ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+                                   momentum, eps, ptr(cov), ptr(mu), ptr(T), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream()),
+          "gram_bn_stats")
+
+
+def conv_affine_residual(dtype, x, w, y, scale, shift, res, ldres, res_scale, res_shift, relu_bits, *, N, H, W, Cin, ldx, P, Q, Cout,
+                         ldy, R=1, S=1, stride=1, pad=0):
+    check(load().nkb_conv_affine_residual(dtype, ptr(x), ptr(w), ptr(y), ptr(scale), ptr(shift), ptr(res), ldres, ptr(res_scale),
+                                          ptr(res_shift), ptr(relu_bits), N, H, W, Cin, ldx, P, Q, Cout, ldy, R, S, stride, pad,
+                                          stream()), "conv_affine_residual")
+
+
+def gram_bn_backward(dtype, w, R, T, mu, gstats, tiles, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, coef):
+    check(load().nkb_gram_bn_backward(dtype, ptr(w), ptr(R), ptr(T), ptr(mu), ptr(gstats), tiles, count, Cin, Cout, ptr(gamma), ptr(mean),
+                                      ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dw), ptr(wcat), ptr(cbias), ptr(coef), stream()),
+          "gram_bn_backward")
+
+
+def conv_dgrad_bn_cat(dtype, g, ldg, K1, a, lda, K2, wcat, cbias, g_masked, c_prev, scale, shift, mean, stats, M, Cout, ldy):
+    check(load().nkb_conv_dgrad_bn_cat(dtype, ptr(g), ldg, K1, ptr(a), lda, K2, ptr(wcat), ptr(cbias), ptr(g_masked), ptr(c_prev),
+                                       ptr(scale), ptr(shift), ptr(mean), ptr(stats), M, Cout, ldy, stream()), "conv_dgrad_bn_cat")
 
 
 def bn_backward_ws(rows, C_):

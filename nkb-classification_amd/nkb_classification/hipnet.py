@@ -56,6 +56,10 @@ _FP8_LN_BWD_QUANT = os.environ.get("NKB_FP8_LN_BWD_QUANT", "1") != "0"   # Layer
 _FP8_EPI_COLSUM = os.environ.get("NKB_FP8_EPI_COLSUM", "1") != "0"   # fc1's bias gradient from the fc2 data gradient's epilogue
 _FP8_MASK_BITS = os.environ.get("NKB_FP8_MASK_BITS", "1") != "0"   # fp8 step: ReLU6 output kept as fp8 operand + mask bits, no bf16 copy
 _DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
+# Gram form of the bottleneck closing stage (csrc/grambn.hip): BatchNorm statistics of conv3's output from the Gram matrix of its
+# input, normalisation + shortcut + ReLU in conv3's epilogue, backward through R = g^T a and one K-concatenated data gradient — the
+# raw conv output c3 and its gradient never exist in HBM (0 = the separate bn_apply / bn_backward passes, for A/B runs)
+_GRAM_BN = os.environ.get("NKB_GRAM_BN", "1") != "0"
 
 
 class HipEngine:
@@ -104,6 +108,7 @@ class HipEngine:
         # recorded launch plans of the train step (hip.Plan): key -> (plan, workspace generation, saved-activation table)
         self.plans: Dict[tuple, tuple] = {}
         self.plan_seen: Dict[tuple, int] = {}      # key -> workspace generation after its last eager run
+        self.gram_bn = _GRAM_BN                    # Gram form of bottleneck closing stages (tests flip it per engine)
 
     # ------------------------------------------------------------------ weights ----
     def register(self, convs, stems, head_weights, head_biases):
@@ -304,7 +309,7 @@ class HipEngine:
     # ------------------------------------------------------------------ forward ops ----
     def conv_bn(self, key: str, x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool,
                 res: Optional[torch.Tensor], train: bool, col_input: bool = False, pool: bool = False,
-                stem_packed=None, defer_apply: bool = False, res_affine=None):
+                stem_packed=None, defer_apply: bool = False, res_affine=None, gram: bool = False):
         """y = act(bn(conv(x)) (+ res)).  x: [N,H,W,Cin] in the compute dtype (or the im2row matrix of the stem).
         stem_packed=(N, H, W): x is the packed image of nkb_stem_pack and conv the 7x7/2 stem.
         defer_apply=True: stop after the statistics and return (c, scale, shift) — for a projection shortcut, whose
@@ -356,6 +361,8 @@ class HipEngine:
             else:
                 hip.conv_gemm(self.d, 0, x, ent[1], y, bias=ent[2], relu=relu, add=res, ldadd=co if res is not None else 0, **geom)
             return (y, None, None) if defer_apply else y
+        if gram and train and self.gram_ok(conv, res, x):
+            return self._conv_bn_gram(key, x, conv, bn, res, res_affine, geom, rows)
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
         bits = None
         tiles = hip.stat_tiles(self.d, rows, co)
@@ -404,6 +411,66 @@ class HipEngine:
                                    rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None,
                                    pool_idx=idx, stem_packed=bool(packed), bits=bits)
         return y
+
+    def gram_ok(self, conv, res, x) -> bool:
+        """The Gram form exists for bf16 1x1 / stride-1 closing stages with 64 | Cin <= 512 and Cout > 64 (every timm Bottleneck conv3)."""
+        w = conv.weight
+        return (self.gram_bn and _RELU_BITS and _FUSED_BN_BWD and _FUSED_RES_BN_BWD and self.T == torch.bfloat16 and res is not None
+                and w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1 and conv.stride == (1, 1) and conv.padding == (0, 0)
+                and w.shape[1] % 64 == 0 and w.shape[1] <= 512 and w.shape[0] > 64 and w.shape[0] % 8 == 0 and x.dim() == 4)
+
+    def _conv_bn_gram(self, key, x, conv, bn, res, res_affine, geom, rows):
+        """Closing stage in the Gram form (train mode): G = x^T x and the column sums of x (one pass over the NARROW input), the
+        batch statistics of conv(x) from them (nkb_gram_bn_stats), then y = relu(conv(x) * scale + shift + res) in ONE launch."""
+        w = conv.weight
+        co, ci = w.shape[0], w.shape[1]
+        N, P, Q = geom["N"], geom["P"], geom["Q"]
+        gs = self.ws.get(key + ".gram", (ci * ci + ci,), torch.float32)
+        G, s = gs[:ci * ci], gs[ci * ci:]
+        hip.host_op(gs.zero_)
+        self.wgrad(x, x, G, dbias=s, N=N, H=P, W=Q, Cin=ci, ldx=ci, P=P, Q=Q, Cout=ci, lddy=ci)
+        sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
+        scale, shift, mean, invstd = sc[0], sc[1], sc[2], sc[3]
+        cov = self.ws.at_least("gram.cov", ci * ci, torch.float32)
+        mu = self.ws.get(key + ".gmu", (ci,), torch.float32)
+        T = self.ws.get(key + ".gT", (co, ci), torch.float32)
+        hip.gram_bn_stats(self.d, self.w_fwd(w), G, s, rows, ci, co, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                          bn.momentum if bn.momentum is not None else 0.1, bn.eps, cov, mu, T, scale, shift, mean, invstd)
+        y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
+        bits = self.ws.get(key + ".bits", (rows, co // 8), torch.uint8)
+        hip.conv_affine_residual(self.d, x, self.w_fwd(w), y, scale, shift, res, co, res_affine[0] if res_affine else None,
+                                 res_affine[1] if res_affine else None, bits, **geom)
+        self.saved[key] = dict(x=x, c=None, cshape=(N, P, Q, co), y=y, mean=mean, invstd=invstd, relu=True, geom=geom, conv=conv,
+                               bn=bn, rows=rows, col_input=False, scale=scale, shift=shift, has_res=True, pool_idx=None,
+                               stem_packed=False, bits=bits, gram=dict(T=T, mu=mu))
+        return y
+
+    def gram_closing_backward(self, key: str, g: torch.Tensor, g_stats, prev_key: str, slot: str):
+        """Backward of a Gram-form closing stage.  g: masked gradient of the block output with its per-tile sums (left by the next
+        block's conv1 data gradient, nkb_conv_dgrad_bn).  R = g^T a on the main stream (its row dots with W are sum g c, which the
+        coefficients need), then the small algebra (nkb_gram_bn_backward: dgamma, dbeta, dW, the concatenated filter) and ONE data
+        gradient over [g | a] with the fused BN-backward epilogue of the stage before.  Returns (masked gradient, (stats, tiles)) for
+        bn_backward_fused(prev_key, ...) exactly like conv_backward(..., fuse_bn=prev_key)."""
+        sv, svp = self.saved[key], self.saved[prev_key]
+        x, conv, bn, rows, geom = sv["x"], sv["conv"], sv["bn"], sv["rows"], sv["geom"]
+        w = conv.weight
+        co, ci = w.shape[0], w.shape[1]
+        a = self.arena
+        stats, tiles = g_stats
+        R = self.ws.get(key + ".gR", (co, ci), torch.float32)
+        hip.host_op(R.zero_)
+        self.wgrad(g, x, R, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
+        wcat = self.ws.get(key + ".gwcat", (ci, co + ci), self.T)
+        cbias = self.ws.get(key + ".gcbias", (ci,), torch.float32)
+        coef = self.ws.get(key + ".gcoef", (5 * co,), torch.float32)
+        hip.gram_bn_backward(self.d, self.w_fwd(w), R, sv["gram"]["T"], sv["gram"]["mu"], stats, tiles, rows, ci, co, bn.weight,
+                             sv["mean"], sv["invstd"], a.grad_flat(bn.weight), a.grad_flat(bn.bias), a.grad_flat(w), wcat, cbias, coef)
+        dx = self.scratch(slot, x.shape)
+        tiles2 = hip.stat_tiles(self.d, rows, ci)
+        stats2 = self.ws.get(prev_key + ".bstats", (hip.bn_stats_floats(tiles2, ci),), torch.float32)
+        hip.conv_dgrad_bn_cat(self.d, g, co, co, x, ci, ci, wcat, cbias, dx, svp["c"], svp["scale"], svp["shift"], svp["mean"],
+                              stats2, rows, ci, ci)
+        return dx, (stats2, tiles2)
 
     def _splitk_ok(self, rows: int, ci: int, co: int) -> bool:
         return _SPLITK and rows <= 256 and ci >= 32768 and co > 64 and ci % (self.kte * 32) == 0
@@ -660,7 +727,7 @@ class HipEngine:
         """The stage `bn_key` closes a residual block (kept ReLU bits) and `consumer_key` is the first conv of the next
         block, whose data gradient (+ shortcut gradient) IS the gradient of that stage's output."""
         sv, cv = self.saved[bn_key], self.saved[consumer_key]
-        return (_FUSED_BN_BWD and _FUSED_RES_BN_BWD and sv.get("bits") is not None and sv["c"].shape[-1] % 8 == 0
+        return (_FUSED_BN_BWD and _FUSED_RES_BN_BWD and sv.get("bits") is not None and sv["y"].shape[-1] % 8 == 0
                 and not self.s2_classes(cv["conv"]) and not cv["col_input"] and not cv["stem_packed"])
 
     def bn_backward_fused(self, key: str, g_masked: torch.Tensor, stats, slot: str) -> torch.Tensor:

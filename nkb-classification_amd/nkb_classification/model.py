@@ -186,7 +186,7 @@ class _HipClassifier(nn.Module):
         if not (_PLANS and train):
             run()
             return logits
-        key = ("fwd", tuple(img.shape), need_dgrad, drop_p, eng.overlap_wgrad, self.arena.total, eng.fp8)
+        key = ("fwd", tuple(img.shape), need_dgrad, drop_p, eng.overlap_wgrad, self.arena.total, eng.fp8, eng.gram_bn)
         self._fwd_key = key
         ent = eng.plans.get(key)
         if ent is not None and ent[1] == eng.ws.generation:
