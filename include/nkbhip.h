@@ -123,6 +123,12 @@ int nkb_gram_bn_stats(int dtype, const void* w, const float* gram, const float* 
                       float* cov, float* mu, float* T, float* scale, float* shift, float* mean, float* invstd, nkb_stream_t stream);
 /* w: [Cout][Cin] in the compute dtype (what the MFMA multiplies by); gram [Cin][Cin], colsum [Cin] fp32; cov: Cin*Cin floats of
  * scratch; mu [Cin], T [Cout][Cin] are outputs kept for nkb_gram_bn_backward.  Cin <= 512. */
+int nkb_bn_apply_gram(int dtype, const void* c, void* y, const float* scale, const float* shift, long long rows, int C, float* gram,
+                      float* work, size_t work_floats, nkb_stream_t stream);
+size_t nkb_bn_apply_gram_workspace_floats(long long rows, int C);
+/* nkb_bn_apply(relu) of the stage before the closing convolution fused with the Gram matrix of its output (bf16, C = 64 or 128):
+ * y is written once, bit-identical to nkb_bn_apply, and gram[0 .. C*C) = y^T y, gram[C*C .. C*C + C) = column sums of y come out of
+ * the same pass (per-workgroup fp32 slabs in `work`, added in a fixed order) — no second read of the activations. */
 int nkb_conv_affine_residual(int dtype, const void* x, const void* w, void* y, const float* scale, const float* shift,
                              const void* res, int ldres, const float* res_scale, const float* res_shift,
                              unsigned char* relu_bits, int N, int H, int W, int Cin, int ldx, int P, int Q, int Cout, int ldy,
@@ -131,9 +137,12 @@ int nkb_conv_affine_residual(int dtype, const void* x, const void* w, void* y, c
  * rnd(res * res_scale + res_shift), as in nkb_bn_apply.  relu_bits: layout of nkb_bn_apply's relu_bits. */
 int nkb_gram_bn_backward(int dtype, const void* w, const float* R, const float* T, const float* mu, float* gstats, int tiles,
                          long long count, int Cin, int Cout, const float* gamma, const float* mean, const float* invstd,
-                         float* dgamma, float* dbeta, float* dw, void* wcat, float* cbias, float* coef, nkb_stream_t stream);
+                         float* dgamma, float* dbeta, float* dw, void* wcat, float* cbias, float* work, nkb_stream_t stream);
+size_t nkb_gram_bn_backward_workspace_floats(int Cin, int Cout);
 /* gstats: per-row-tile sums of g as nkb_conv_dgrad_bn leaves them (first plane used; nkb_bn_stats_floats floats); dgamma, dbeta,
- * dw accumulate (+=); wcat: [Cin][Cout + Cin] in the compute dtype, cbias [Cin]; coef: 5 * Cout floats of scratch. */
+ * dw accumulate (+=); wcat: [Cin][Cout + Cin] in the compute dtype, cbias [Cin]; work: nkb_gram_bn_backward_workspace_floats floats
+ * of scratch (tile sums, the partial sums of cbias = k3 W, and V = k2 .* W whose product V^T W — Q — runs on the MFMA
+ * transposed-A GEMM of nkb_gemm_tn_batched).  64 | Cin <= 512. */
 int nkb_conv_dgrad_bn_cat(int dtype, const void* g, int ldg, int K1, const void* a, int lda, int K2, const void* wcat,
                           const float* cbias, void* g_masked, const void* c_prev, const float* scale, const float* shift,
                           const float* mean, float* stats, long long M, int Cout, int ldy, nkb_stream_t stream);

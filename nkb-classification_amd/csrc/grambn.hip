@@ -15,6 +15,7 @@
 // Everything here is O(Cout * Cin^2) fp32 work on L2-resident operands: tiny next to the launches it replaces, but on the
 // critical path, so each step is one launch with a fixed summation order (bit-reproducible).
 #include "common.h"
+#include <stdlib.h>
 
 template <typename WT> __device__ __forceinline__ float ldw(const WT* p);
 template <> __device__ __forceinline__ float ldw<float>(const float* p) { return *p; }
@@ -22,6 +23,180 @@ template <> __device__ __forceinline__ float ldw<bf16_t>(const bf16_t* p) { retu
 
 // tile partial sums -> per-channel sums (elementwise.hip)
 int nkb_launch_tile_sums(float* stats, int tiles, int C, float* sums, hipStream_t stream);
+
+// ---- bn_apply of the stage BEFORE the closing convolution, fused with the Gram matrix of its output ----------------------------
+// y = relu(c * scale + shift) is written to HBM once (bit-identical to nkb_bn_apply) and, still on chip, multiplied with itself:
+// every workgroup keeps a C x C fp32 block of G = y^T y in MFMA accumulators over its row stages (y staged through LDS in the
+// weight-gradient kernel's swizzled 256-byte-row image, fragments through ds_read_b64_tr_b16) plus the column sums, and leaves them
+// in its own slab; gram_reduce_kernel adds the slabs in a fixed order.  No second pass over y (a separate Gram launch re-read the
+// 103 MB of layer1's activations at < 1 TB/s: 120 us per block).  C = 64 or 128 (wider stages are small and use nkb_conv_wgrad).
+__device__ __forceinline__ int gswz(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <int C>
+__global__ __launch_bounds__(256, 3) void bn_apply_gram_kernel(const bf16_t* __restrict__ c, bf16_t* __restrict__ y,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               unsigned rows, float* __restrict__ part) {
+    constexpr int CPR = C / 8;                  // 16-byte chunks per row
+    constexpr int RPS = 256 / CPR;              // rows per pass of the workgroup
+    constexpr int SR = 8192 / C;                // rows per stage (16 KB of activations)
+    constexpr int NP = SR / RPS;                // chunks per thread per stage (4)
+    constexpr int NBLK = C / 16, NB = NBLK / 2; // 16-channel blocks; a wave owns NB x NB of them
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // SR rows of 256 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wn = wave & 1;
+    const int cc = tid % CPR, srow = tid / CPR;
+    float sc[8], sh[8], bsum[8];
+    {
+        const f32x4 a0 = *(const f32x4*)(scale + cc * 8), a1 = *(const f32x4*)(scale + cc * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(shift + cc * 8), b1 = *(const f32x4*)(shift + cc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[e] = a0[e]; sc[4 + e] = a1[e]; sh[e] = b0[e]; sh[4 + e] = b1[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    f32x4 acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned nstage = (rows + SR - 1) / SR;
+    u32x4 ld[NP];
+    auto load = [&](unsigned st) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const unsigned r = st * SR + srow + RPS * i;
+            ld[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (r < rows) ld[i] = *(const u32x4*)(c + (size_t)r * C + cc * 8);
+        }
+    };
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+    unsigned st = blockIdx.x;
+    if (st < nstage) load(st);
+    for (; st < nstage; st += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const unsigned r = st * SR + srow + RPS * i;
+            float v[8];
+            unpack8(ld[i], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);     // bn_apply_kernel's expression
+            u32x4 pk = pack8(v);
+            if (r < rows) *(u32x4*)(y + (size_t)r * C + cc * 8) = pk;
+            else pk = (u32x4){0u, 0u, 0u, 0u};
+            *(u32x4*)(smem + gswz(srow + RPS * i, cc)) = pk;
+            float f[8];
+            unpack8(pk, f);                        // the sums see the stored (rounded) values, as the convolution will
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+        }
+        __syncthreads();
+        if (st + gridDim.x < nstage) load(st + gridDim.x);      // in flight under the MFMAs and the second barrier
+#pragma unroll
+        for (int kk = 0; kk < SR / 32; ++kk) {
+            bf16x8 a[NB], b[NB];
+            const int row = 32 * kk + 8 * g + q4;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int blk = wr * NB + i;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4*)(smem + gswz(row, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4*)(smem + gswz(row + 4, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+                a[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int blk = wn * NB + j;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4*)(smem + gswz(row, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4*)(smem + gswz(row + 4, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
+                b[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                           // every wave is done reading the stage
+    }
+    float* slab = part + (size_t)blockIdx.x * (C * C + C);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int rbase = (wr * NB + i) * 16 + g * 4;
+            const int col = (wn * NB + j) * 16 + li;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slab[(size_t)(rbase + e) * C + col] = acc[i][j][e];
+        }
+    float* red = (float*)smem;                     // [RPS][CPR][8]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(srow * CPR + cc) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+        for (int rr = 0; rr < RPS; ++rr) t += red[(rr * CPR + (tid >> 3)) * 8 + (tid & 7)];
+        slab[C * C + tid] = t;
+    }
+}
+
+// dst[i] = sum over the slabs in a fixed order (SG threads share a 16-byte column and are combined through LDS)
+template <int SG>
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ part, long long slab, int splits,
+                                                          float* __restrict__ dst, long long n4) {
+    constexpr int COLS = 256 / SG;
+    __shared__ f32x4 red[256];
+    const int cx = threadIdx.x % COLS, sg = threadIdx.x / COLS;
+    const long long i = (long long)blockIdx.x * COLS + cx;
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int s = sg; s < splits; s += SG) a += *(const f32x4*)(part + (size_t)s * slab + 4 * i);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (sg == 0 && i < n4) {
+        for (int k = 1; k < SG; ++k) a += red[k * COLS + cx];
+        *(f32x4*)(dst + 4 * i) = a;
+    }
+}
+
+static int gram_grid(long long rows, int C) {
+    static const int t64 = [] { const char* e = getenv("NKB_GRAM_WGS64"); return e ? atoi(e) : 768; }();
+    static const int t128 = [] { const char* e = getenv("NKB_GRAM_WGS128"); return e ? atoi(e) : 384; }();
+    const long long nstage = (rows + (8192 / C) - 1) / (8192 / C);
+    const long long t = C == 64 ? t64 : t128;
+    return (int)(nstage < t ? (nstage < 1 ? 1 : nstage) : t);
+}
+extern "C" size_t nkb_bn_apply_gram_workspace_floats(long long rows, int C) {
+    return (C == 64 || C == 128) ? (size_t)gram_grid(rows, C) * ((size_t)C * C + C) : 0;
+}
+// y = relu(c * scale + shift) (bf16, [rows][C], C = 64 or 128) and gram[0 .. C*C) = y^T y, gram[C*C .. C*C + C) = column sums of y.
+extern "C" int nkb_bn_apply_gram(int dtype, const void* c, void* y, const float* scale, const float* shift, long long rows, int C,
+                                 float* gram, float* work, size_t work_floats, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 || (C != 64 && C != 128) || rows < 1 || rows >= (1ll << 31)) {
+        nkb_set_error("bn_apply_gram: bf16 with C = 64 or 128 only (C=%d)", C);
+        return 1;
+    }
+    const int G = gram_grid(rows, C);
+    const size_t slab = (size_t)C * C + C;
+    if (work_floats < (size_t)G * slab) { nkb_set_error("bn_apply_gram: workspace too small (nkb_bn_apply_gram_workspace_floats)"); return 1; }
+    {
+        NkbProfScope prof(NKB_K_BN_APPLY, stream, 2.0 * rows * (double)C * C, (double)rows * C * 2 * 2 + 2.0 * 4.0 * G * slab);
+        const int lds = (8192 / C) * 256;
+        if (C == 64) hipLaunchKernelGGL(bn_apply_gram_kernel<64>, dim3(G), dim3(256), lds, stream, (const bf16_t*)c, (bf16_t*)y, scale, shift, (unsigned)rows, work);
+        else hipLaunchKernelGGL(bn_apply_gram_kernel<128>, dim3(G), dim3(256), lds, stream, (const bf16_t*)c, (bf16_t*)y, scale, shift, (unsigned)rows, work);
+        if (int rc = nkb_check_launch("bn_apply_gram")) return rc;
+    }
+    NkbProfScope prof(NKB_K_WGRAD_REDUCE, stream, 0, 4.0 * ((double)G + 1.0) * slab);
+    const long long n4 = (long long)slab / 4;
+    const int sg = G >= 48 ? 16 : (G >= 6 ? 4 : 1);
+    const int cols = 256 / sg;
+    const unsigned grid = (unsigned)((n4 + cols - 1) / cols);
+    if (sg == 16) hipLaunchKernelGGL(gram_reduce_kernel<16>, dim3(grid), dim3(256), 0, stream, work, (long long)slab, G, gram, n4);
+    else if (sg == 4) hipLaunchKernelGGL(gram_reduce_kernel<4>, dim3(grid), dim3(256), 0, stream, work, (long long)slab, G, gram, n4);
+    else hipLaunchKernelGGL(gram_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, work, (long long)slab, G, gram, n4);
+    return nkb_check_launch("gram_reduce");
+}
 
 // ---- Cov = G / M - mu mu^T (double arithmetic on fp32 sums), mu = s / M ----------------------------------------------------
 __global__ void gram_cov_kernel(const float* __restrict__ G, const float* __restrict__ s, double inv_count, int Cin,
@@ -52,7 +227,9 @@ __device__ __forceinline__ void block_sums(float (&v)[KR], float* red /* [4][KR]
 }
 
 // ---- forward statistics: T = W Cov, mean, var -> scale / shift / running statistics ------------------------------------------
-// One block = KR output channels x all Cin columns (thread t owns columns t, t + 256, ...).
+// One block = KR output channels x all Cin columns (thread t owns columns t, t + 256, ...).  Cov is streamed through LDS in chunks
+// of IC rows, every thread issuing independent 16-byte loads (the first version read one Cov row per loop iteration straight
+// from L2: a dependent ~1 us round trip per row, 84 us for Cin = 512).
 template <typename WT, int NJ>
 __global__ __launch_bounds__(256) void gram_stats_kernel(const WT* __restrict__ W, const float* __restrict__ cov,
                                                          const float* __restrict__ mu, float count, int Cin, int Cout,
@@ -61,8 +238,10 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const WT* __restrict__ 
                                                          float momentum, float eps, float* __restrict__ T,
                                                          float* __restrict__ scale, float* __restrict__ shift,
                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    constexpr int KR = 8;
-    extern __shared__ float wl[];                 // [Cin][KR] fp32 copies of this block's weight rows
+    constexpr int KR = 4, IC = 16;
+    extern __shared__ float lds[];                // wl [Cin][KR] fp32 copies of this block's weight rows, then cl [IC][Cin]
+    float* wl = lds;
+    float* cl = lds + (size_t)KR * Cin;
     __shared__ float red[4 * KR];
     const int tid = threadIdx.x;
     const int k0 = blockIdx.x * KR;
@@ -70,26 +249,33 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const WT* __restrict__ 
         const int k = idx / Cin, i = idx - k * Cin;
         wl[i * KR + k] = (k0 + k < Cout) ? ldw<WT>(W + (size_t)(k0 + k) * Cin + i) : 0.f;
     }
-    __syncthreads();
     float acc[KR][NJ];
 #pragma unroll
     for (int k = 0; k < KR; ++k)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) acc[k][jj] = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < Cin; ++i) {
-        float cv[NJ];
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            const int j = tid + 256 * jj;
-            cv[jj] = j < Cin ? cov[(size_t)i * Cin + j] : 0.f;
+    const int c4 = Cin >> 2;                      // 16-byte groups per Cov row (Cin % 4 == 0)
+    for (int i0 = 0; i0 < Cin; i0 += IC) {
+        __syncthreads();                          // (first pass: wl complete; later: everyone done with the previous chunk)
+        for (int idx = tid; idx < IC * c4; idx += 256) {
+            const int ii = idx / c4, j4 = idx - ii * c4;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (i0 + ii < Cin) v = *(const f32x4*)(cov + (size_t)(i0 + ii) * Cin + 4 * j4);
+            *(f32x4*)(cl + (size_t)ii * Cin + 4 * j4) = v;
         }
-        const f32x4 w0 = *(const f32x4*)(wl + i * KR), w1 = *(const f32x4*)(wl + i * KR + 4);
-        const float w[KR] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < KR; ++k)
+        for (int ii = 0; ii < IC; ++ii) {
+            const f32x4 w4 = *(const f32x4*)(wl + (size_t)(i0 + ii < Cin ? i0 + ii : 0) * KR);
+            const float w[KR] = {w4[0], w4[1], w4[2], w4[3]};
 #pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) acc[k][jj] += w[k] * cv[jj];
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = tid + 256 * jj;
+                const float cv = j < Cin ? cl[(size_t)ii * Cin + j] : 0.f;      // rows past Cin were stored as zeros
+#pragma unroll
+                for (int k = 0; k < KR; ++k) acc[k][jj] += w[k] * cv;
+            }
+        }
     }
     float pv[KR], pm[KR];
 #pragma unroll
@@ -128,7 +314,8 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const WT* __restrict__ 
     }
 }
 
-// ---- backward coefficients, dW, dgamma, dbeta and the k1-scaled half of the concatenated data-gradient filter ------------------
+// ---- backward coefficients, dW, dgamma, dbeta, the k1-scaled half of the concatenated data-gradient filter, V = k2 .* W (left
+// operand of Q = V^T W) and this block's share of cbias = k3 W -----------------------------------------------------------------
 template <typename WT, typename CT, int NJ>
 __global__ __launch_bounds__(256) void gram_bwd_coef_kernel(const WT* __restrict__ W, const float* __restrict__ R,
                                                             const float* __restrict__ T, const float* __restrict__ mu,
@@ -136,10 +323,11 @@ __global__ __launch_bounds__(256) void gram_bwd_coef_kernel(const WT* __restrict
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dW,
-                                                            CT* __restrict__ wcat, int ldc, float* __restrict__ coef) {
+                                                            CT* __restrict__ wcat, int ldc, CT* __restrict__ V,
+                                                            float* __restrict__ cpart) {
     constexpr int KR = 8;
     __shared__ float red[4 * KR];
-    __shared__ float kc[4][KR];                   // k1, M*k2, gamma*r*dbeta, (unused)
+    __shared__ float kc[5][KR];                   // k1, M*k2, gamma*r*dbeta, k2, k3
     const int tid = threadIdx.x;
     const int k0 = blockIdx.x * KR;
     float w[KR][NJ], r[KR][NJ], p[KR];
@@ -162,19 +350,18 @@ __global__ __launch_bounds__(256) void gram_bwd_coef_kernel(const WT* __restrict
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < KR; ++k) if (k == tid) s = gc[k];
+        float k1 = 0.f, k2 = 0.f, k3 = 0.f, gb = 0.f;
         if (c < Cout) {
             const float g = gamma ? gamma[c] : 1.f, rs = invstd[c], m = mean[c], db = gsum[c];
             const float dg = rs * (s - m * db);
-            const float k1 = g * rs;
-            const float k2 = -g * rs * rs * dg / count;
-            const float k3 = -g * rs * db / count - k2 * m;
-            coef[c] = k1; coef[Cout + c] = k2; coef[2 * Cout + c] = k3;
+            k1 = g * rs;
+            k2 = -g * rs * rs * dg / count;
+            k3 = -g * rs * db / count - k2 * m;
+            gb = g * rs * db;
             if (dgamma) dgamma[c] += dg;
             if (dbeta) dbeta[c] += db;
-            kc[0][tid] = k1; kc[1][tid] = k2 * count; kc[2][tid] = g * rs * db;
-        } else {
-            kc[0][tid] = 0.f; kc[1][tid] = 0.f; kc[2][tid] = 0.f;
         }
+        kc[0][tid] = k1; kc[1][tid] = k2 * count; kc[2][tid] = gb; kc[3][tid] = k2; kc[4][tid] = k3;
     }
     __syncthreads();
 #pragma unroll
@@ -182,15 +369,19 @@ __global__ __launch_bounds__(256) void gram_bwd_coef_kernel(const WT* __restrict
         const int j = tid + 256 * jj;
         if (j >= Cin) continue;
         const float mj = mu[j];
-        float q[KR];
+        float q[KR], cb = 0.f;
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             q[k] = kc[0][k] * w[k][jj];
-            if (k0 + k < Cout && dW) {
+            cb += kc[4][k] * w[k][jj];
+            if (k0 + k < Cout) {
                 const size_t o = (size_t)(k0 + k) * Cin + j;
-                dW[o] += kc[0][k] * r[k][jj] + kc[1][k] * T[o] - kc[2][k] * mj;
+                if (dW) dW[o] += kc[0][k] * r[k][jj] + kc[1][k] * T[o] - kc[2][k] * mj;
+                const float v = kc[3][k] * w[k][jj];
+                if constexpr (sizeof(CT) == 2) V[o] = f2bf(v); else V[o] = v;
             }
         }
+        cpart[(size_t)blockIdx.x * Cin + j] = cb;
         // row j of the data-gradient filter: columns k0 .. k0+7 = k1_k W[k][j]
         CT* dst = wcat + (size_t)j * ldc + k0;
         if constexpr (sizeof(CT) == 2) {
@@ -202,61 +393,18 @@ __global__ __launch_bounds__(256) void gram_bwd_coef_kernel(const WT* __restrict
     }
 }
 
-// ---- Q = W^T diag(k2) W (columns Cout .. Cout+Cin of the concatenated filter) and cbias = k3 W -----------------------------
-// One block = IR rows i of Q x all columns j; wave w reduces over its quarter of the Cout range, lanes own columns j = lane + 64 m.
-template <typename WT, typename CT, int NJ64>
-__global__ __launch_bounds__(256) void gram_bwd_q_kernel(const WT* __restrict__ W, const float* __restrict__ coef, int Cin, int Cout,
-                                                         CT* __restrict__ wcat, int ldc, float* __restrict__ cbias) {
-    constexpr int IR = 4;
-    extern __shared__ float qred[];               // [4 waves][IR + 1][Cin]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * IR;
-    const float* k2 = coef + Cout;
-    const float* k3 = coef + 2 * Cout;
-    float acc[IR + 1][NJ64];
-#pragma unroll
-    for (int a = 0; a <= IR; ++a)
-#pragma unroll
-        for (int m = 0; m < NJ64; ++m) acc[a][m] = 0.f;
-    const int ks = (Cout + 3) / 4;
-    const int kb = wave * ks, ke = min(Cout, kb + ks);
-#pragma unroll 2
-    for (int k = kb; k < ke; ++k) {
-        const float c2 = k2[k], c3 = k3[k];
-        float wi[IR];
-#pragma unroll
-        for (int a = 0; a < IR; ++a) wi[a] = (i0 + a < Cin) ? c2 * ldw<WT>(W + (size_t)k * Cin + i0 + a) : 0.f;
-#pragma unroll
-        for (int m = 0; m < NJ64; ++m) {
-            const int j = lane + 64 * m;
-            const float wj = j < Cin ? ldw<WT>(W + (size_t)k * Cin + j) : 0.f;
-#pragma unroll
-            for (int a = 0; a < IR; ++a) acc[a][m] += wi[a] * wj;
-            acc[IR][m] += c3 * wj;
-        }
+// cbias[j] = sum over the coefficient kernel's blocks, in a fixed order
+__global__ void gram_cbias_kernel(const float* __restrict__ cpart, int nblk, int Cin, float* __restrict__ cbias) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Cin) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        a0 += cpart[(size_t)b * Cin + j]; a1 += cpart[(size_t)(b + 1) * Cin + j];
+        a2 += cpart[(size_t)(b + 2) * Cin + j]; a3 += cpart[(size_t)(b + 3) * Cin + j];
     }
-#pragma unroll
-    for (int a = 0; a <= IR; ++a)
-#pragma unroll
-        for (int m = 0; m < NJ64; ++m) {
-            const int j = lane + 64 * m;
-            if (j < Cin) qred[((size_t)wave * (IR + 1) + a) * Cin + j] = acc[a][m];
-        }
-    __syncthreads();
-    for (int j = tid; j < Cin; j += 256) {
-        float q[IR + 1];
-#pragma unroll
-        for (int a = 0; a <= IR; ++a) {
-            const float* b = qred + (size_t)a * Cin + j;
-            const size_t ws = (size_t)(IR + 1) * Cin;
-            q[a] = (b[0] + b[ws]) + (b[2 * ws] + b[3 * ws]);
-        }
-        CT* dst = wcat + (size_t)j * ldc + Cout + i0;       // Q is symmetric: Q[i][j] sits in row j, column Cout + i
-        for (int a = 0; a < IR && i0 + a < Cin; ++a) {
-            if constexpr (sizeof(CT) == 2) dst[a] = f2bf(q[a]); else dst[a] = q[a];
-        }
-        if (blockIdx.x == 0) cbias[j] = q[IR];
-    }
+    for (; b < nblk; ++b) a0 += cpart[(size_t)b * Cin + j];
+    cbias[j] = (a0 + a1) + (a2 + a3);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -264,8 +412,8 @@ template <typename WT>
 static int launch_stats(const void* w, const float* cov, const float* mu, long long count, int Cin, int Cout, const float* gamma,
                         const float* beta, float* rm, float* rv, float momentum, float eps, float* T, float* scale, float* shift,
                         float* mean, float* invstd, hipStream_t stream) {
-    const dim3 grid((Cout + 7) / 8), block(256);
-    const size_t lds = (size_t)8 * Cin * sizeof(float);
+    const dim3 grid((Cout + 3) / 4), block(256);
+    const size_t lds = (size_t)(4 + 16) * Cin * sizeof(float);
 #define NKB_GS(NJ) hipLaunchKernelGGL((gram_stats_kernel<WT, NJ>), grid, block, lds, stream, (const WT*)w, cov, mu, (float)count, Cin, Cout, \
                                       gamma, beta, rm, rv, momentum, eps, T, scale, shift, mean, invstd)
     if (Cin <= 256) NKB_GS(1); else NKB_GS(2);
@@ -294,43 +442,56 @@ extern "C" int nkb_gram_bn_stats(int dtype, const void* w, const float* gram, co
                                invstd, stream);
 }
 
+extern "C" int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void* out, int M, int Na, int Nb, int lda, int ldb, int ldo,
+                                   int outer, int inner, long long sao, long long sai, long long sbo, long long sbi, long long soo,
+                                   long long soi, hipStream_t stream);
+
 template <typename WT>
-static int launch_bwd(const void* w, const float* R, const float* T, const float* mu, const float* gsum, long long count, int Cin,
+static int launch_bwd(int dtype, const void* w, const float* R, const float* T, const float* mu, const float* gsum, long long count, int Cin,
                       int Cout, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw,
-                      void* wcat, float* cbias, float* coef, hipStream_t stream) {
+                      void* wcat, float* cbias, float* cpart, void* V, hipStream_t stream) {
     using CT = WT;
     const int ldc = Cout + Cin;
+    const int nblk = (Cout + 7) / 8;
     {
-        const dim3 grid((Cout + 7) / 8), block(256);
+        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0);
+        const dim3 grid(nblk), block(256);
 #define NKB_GC(NJ) hipLaunchKernelGGL((gram_bwd_coef_kernel<WT, CT, NJ>), grid, block, 0, stream, (const WT*)w, R, T, mu, gsum, (float)count, \
-                                      Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, (CT*)wcat, ldc, coef)
+                                      Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, (CT*)wcat, ldc, (CT*)V, cpart)
         if (Cin <= 256) NKB_GC(1); else NKB_GC(2);
 #undef NKB_GC
         if (int rc = nkb_check_launch("gram_bwd_coef")) return rc;
+        hipLaunchKernelGGL(gram_cbias_kernel, dim3((Cin + 63) / 64), dim3(64), 0, stream, cpart, nblk, Cin, cbias);
+        if (int rc = nkb_check_launch("gram_cbias")) return rc;
     }
-    const dim3 grid((Cin + 3) / 4), block(256);
-    const size_t lds = (size_t)4 * 5 * Cin * sizeof(float);
-#define NKB_GQ(NJ) hipLaunchKernelGGL((gram_bwd_q_kernel<WT, CT, NJ>), grid, block, lds, stream, (const WT*)w, coef, Cin, Cout, (CT*)wcat, ldc, cbias)
-    if (Cin <= 64) NKB_GQ(1); else if (Cin <= 128) NKB_GQ(2); else if (Cin <= 256) NKB_GQ(4); else NKB_GQ(8);
-#undef NKB_GQ
-    return nkb_check_launch("gram_bwd_q");
+    // Q = V^T W on the MFMA weight-gradient kernel (reduction over the Cout rows), stored in the compute dtype straight into columns
+    // Cout .. Cout+Cin of the concatenated filter (Q is symmetric, so row / column order does not matter)
+    return nkb_gemm_tn_batched(dtype, V, w, (CT*)wcat + Cout, Cout, Cin, Cin, Cin, Cin, ldc, 1, 1, 0, 0, 0, 0, 0, 0, stream);
 }
 
 // Backward of the same stage: R = g^T x (fp32 [Cout][Cin], e.g. from nkb_conv_wgrad into a zeroed scratch), gstats = the per-row-tile
 // partial sums of g left by nkb_conv_dgrad_bn (first plane used; buffer sized by nkb_bn_stats_floats) -> dgamma / dbeta / dw (all +=),
 // the concatenated data-gradient filter wcat [Cin][Cout + Cin] (compute dtype) + cbias [Cin] for nkb_conv_dgrad_bn_cat.
-// coef: 3*Cout + 2*Cout floats of scratch (k1, k2, k3, tile sums).
+// work: nkb_gram_bn_backward_workspace_floats(Cin, Cout) floats of scratch.
+extern "C" size_t nkb_gram_bn_backward_workspace_floats(int Cin, int Cout) {
+    // tile sums [2][Cout] | cbias partials [Cout/8][Cin] | V [Cout][Cin] (compute dtype, at most 4 bytes per element)
+    return (size_t)2 * Cout + (size_t)((Cout + 7) / 8) * Cin + (size_t)Cout * Cin + 64;
+}
 extern "C" int nkb_gram_bn_backward(int dtype, const void* w, const float* R, const float* T, const float* mu, float* gstats, int tiles,
                                     long long count, int Cin, int Cout, const float* gamma, const float* mean, const float* invstd,
-                                    float* dgamma, float* dbeta, float* dw, void* wcat, float* cbias, float* coef, hipStream_t stream) {
-    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || Cin < 1 || Cin > 512 || Cout % 8 || count < 1 || tiles < 1) {
-        nkb_set_error("gram_bn_backward: unsupported dtype %d / Cin=%d (<= 512) / Cout=%d (%% 8)", dtype, Cin, Cout);
+                                    float* dgamma, float* dbeta, float* dw, void* wcat, float* cbias, float* work, hipStream_t stream) {
+    if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || Cin < 1 || Cin > 512 || Cin % 64 || Cout % 8 || count < 1 || tiles < 1) {
+        nkb_set_error("gram_bn_backward: unsupported dtype %d / Cin=%d (<= 512, %% 64) / Cout=%d (%% 8)", dtype, Cin, Cout);
         return 1;
     }
-    NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 2.0 * Cout * (double)Cin * Cin);
-    float* gsum = coef + 3 * (size_t)Cout;
-    if (int rc = nkb_launch_tile_sums(gstats, tiles, Cout, gsum, stream)) return rc;
+    float* gsum = work;
+    float* cpart = work + (((size_t)2 * Cout + 15) & ~(size_t)15);
+    void* V = cpart + (((size_t)((Cout + 7) / 8) * Cin + 15) & ~(size_t)15);
+    {
+        NkbProfScope prof(NKB_K_BN_BWD_REDUCE, stream, 0);
+        if (int rc = nkb_launch_tile_sums(gstats, tiles, Cout, gsum, stream)) return rc;
+    }
     if (dtype == NKB_DT_BF16)
-        return launch_bwd<bf16_t>(w, R, T, mu, gsum, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, coef, stream);
-    return launch_bwd<float>(w, R, T, mu, gsum, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, coef, stream);
+        return launch_bwd<bf16_t>(dtype, w, R, T, mu, gsum, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, cpart, V, stream);
+    return launch_bwd<float>(dtype, w, R, T, mu, gsum, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, cpart, V, stream);
 }

@@ -150,18 +150,18 @@ class HipResNet(_ParamOnly):
                     eng.on_side(shortcut)
                 else:
                     shortcut()
+            # Gram form of the closing stage (hipnet._conv_bn_gram): every bottleneck but the last — its backward needs the masked
+            # output gradient + sums that the NEXT block's conv1 data gradient leaves (can_fuse_residual_bn_backward)
+            want_gram = isinstance(blk, _Bottle) and bi + 1 < nblocks and train
             for k, (cv, bn) in enumerate(stages[:-1]):
-                x = eng.conv_bn(f"{name}.{k}", x, cv, bn, True, None, train)
+                x = eng.conv_bn(f"{name}.{k}", x, cv, bn, True, None, train, gram_out=want_gram and k == len(stages) - 2)
             if blk.downsample is not None:
                 if _SIDE_SHORTCUT:
                     eng.join_side()
                 short, s_scale, s_shift = box["r"]
                 short_affine = (s_scale, s_shift) if s_scale is not None else None     # None: eval mode, already normalised
             cv, bn = stages[-1]
-            # Gram form of the closing stage (hipnet._conv_bn_gram): every bottleneck but the last — its backward needs the masked
-            # output gradient + sums that the NEXT block's conv1 data gradient leaves (can_fuse_residual_bn_backward)
-            gram = (isinstance(blk, _Bottle) and bi + 1 < nblocks and train
-                    and eng.can_fuse_bn_backward(f"{name}.{len(stages) - 2}"))
+            gram = want_gram and eng.can_fuse_bn_backward(f"{name}.{len(stages) - 2}")
             x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train, res_affine=short_affine, gram=gram)
         return eng.avgpool("gap", x)
 

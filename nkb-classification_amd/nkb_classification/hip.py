@@ -36,8 +36,11 @@ _SIGS = {
     "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
     "nkb_gram_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nkb_bn_apply_gram": (i32, [i32, vp, vp, vp, vp, i64, i32, vp, vp, sz, vp]),
+    "nkb_bn_apply_gram_workspace_floats": (sz, [i64, i32]),
     "nkb_conv_affine_residual": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp] + [i32] * 13 + [vp]),
     "nkb_gram_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nkb_gram_bn_backward_workspace_floats": (sz, [i32, i32]),
     "nkb_conv_dgrad_bn_cat": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp, vp]),
     "nkb_wprep_block_elems": (i32, []),
@@ -152,7 +155,8 @@ _PURE = frozenset({"nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", 
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
                    "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config",
                    "nkb_fp8_job_blocks", "nkb_wgrad_fp8_workspace_floats",
-                   "nkb_fp8_quantize_colsum_workspace_floats", "nkb_wgrad_group_workspace_floats"})
+                   "nkb_fp8_quantize_colsum_workspace_floats", "nkb_wgrad_group_workspace_floats",
+                   "nkb_gram_bn_backward_workspace_floats", "nkb_bn_apply_gram_workspace_floats"})
 
 
 class Seed(int):
@@ -362,11 +366,24 @@ def gram_bn_stats(dtype, w, gram, colsum, count, Cin, Cout, gamma, beta, rm, rv,
           "gram_bn_stats")
 
 
+def bn_apply_gram_ws(rows, C_) -> int:
+    return int(load().nkb_bn_apply_gram_workspace_floats(rows, C_))
+
+
+def bn_apply_gram(dtype, c, y, scale, shift, rows, C_, gram, work):
+    check(load().nkb_bn_apply_gram(dtype, ptr(c), ptr(y), ptr(scale), ptr(shift), rows, C_, ptr(gram), ptr(work), work.numel(), stream()),
+          "bn_apply_gram")
+
+
 def conv_affine_residual(dtype, x, w, y, scale, shift, res, ldres, res_scale, res_shift, relu_bits, *, N, H, W, Cin, ldx, P, Q, Cout,
                          ldy, R=1, S=1, stride=1, pad=0):
     check(load().nkb_conv_affine_residual(dtype, ptr(x), ptr(w), ptr(y), ptr(scale), ptr(shift), ptr(res), ldres, ptr(res_scale),
                                           ptr(res_shift), ptr(relu_bits), N, H, W, Cin, ldx, P, Q, Cout, ldy, R, S, stride, pad,
                                           stream()), "conv_affine_residual")
+
+
+def gram_bn_backward_ws(Cin, Cout) -> int:
+    return int(load().nkb_gram_bn_backward_workspace_floats(Cin, Cout))
 
 
 def gram_bn_backward(dtype, w, R, T, mu, gstats, tiles, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, coef):

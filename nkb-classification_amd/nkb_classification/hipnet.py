@@ -109,6 +109,7 @@ class HipEngine:
         self.plans: Dict[tuple, tuple] = {}
         self.plan_seen: Dict[tuple, int] = {}      # key -> workspace generation after its last eager run
         self.gram_bn = _GRAM_BN                    # Gram form of bottleneck closing stages (tests flip it per engine)
+        self._gram_of = None                       # (data_ptr of an activation, its Gram matrix + column sums) from nkb_bn_apply_gram
 
     # ------------------------------------------------------------------ weights ----
     def register(self, convs, stems, head_weights, head_biases):
@@ -309,7 +310,7 @@ class HipEngine:
     # ------------------------------------------------------------------ forward ops ----
     def conv_bn(self, key: str, x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool,
                 res: Optional[torch.Tensor], train: bool, col_input: bool = False, pool: bool = False,
-                stem_packed=None, defer_apply: bool = False, res_affine=None, gram: bool = False):
+                stem_packed=None, defer_apply: bool = False, res_affine=None, gram: bool = False, gram_out: bool = False):
         """y = act(bn(conv(x)) (+ res)).  x: [N,H,W,Cin] in the compute dtype (or the im2row matrix of the stem).
         stem_packed=(N, H, W): x is the packed image of nkb_stem_pack and conv the 7x7/2 stem.
         defer_apply=True: stop after the statistics and return (c, scale, shift) — for a projection shortcut, whose
@@ -404,8 +405,15 @@ class HipEngine:
             # cannot be recomputed from c alone there); y itself is then only read by the next block's convolutions
             if train and relu and res is not None and _RELU_BITS:
                 bits = self.ws.get(key + ".bits", (rows, co // (8 if self.T == torch.bfloat16 else 4)), torch.uint8)
-            hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu, bits,
-                         res_scale=res_affine[0] if res_affine else None, res_shift=res_affine[1] if res_affine else None)
+            if (gram_out and train and relu and res is None and co in (64, 128) and self.T == torch.bfloat16 and self.gram_bn):
+                # the stage before a Gram-form closing stage: the same normalisation pass also leaves y^T y and the column sums of y
+                gs = self.ws.get(key + ".gramout", (co * co + co,), torch.float32)
+                work = self.ws.at_least("gram.slabs", hip.bn_apply_gram_ws(rows, co), torch.float32)
+                hip.bn_apply_gram(self.d, c, y, scale, shift, rows, co, gs, work)
+                self._gram_of = (y.data_ptr(), gs)
+            else:
+                hip.bn_apply(self.d, c, res, y, scale, shift, rows, co, relu, bits,
+                             res_scale=res_affine[0] if res_affine else None, res_shift=res_affine[1] if res_affine else None)
         if train:
             self.saved[key] = dict(x=x, c=c, y=y, mean=mean, invstd=invstd, relu=relu, geom=geom, conv=conv, bn=bn,
                                    rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None,
@@ -425,10 +433,16 @@ class HipEngine:
         w = conv.weight
         co, ci = w.shape[0], w.shape[1]
         N, P, Q = geom["N"], geom["P"], geom["Q"]
-        gs = self.ws.get(key + ".gram", (ci * ci + ci,), torch.float32)
-        G, s = gs[:ci * ci], gs[ci * ci:]
-        hip.host_op(gs.zero_)
-        self.wgrad(x, x, G, dbias=s, N=N, H=P, W=Q, Cin=ci, ldx=ci, P=P, Q=Q, Cout=ci, lddy=ci)
+        ready = self._gram_of
+        self._gram_of = None
+        if ready is not None and ready[0] == x.data_ptr():
+            gs = ready[1]                           # left by the pass that produced x (nkb_bn_apply_gram)
+            G, s = gs[:ci * ci], gs[ci * ci:]
+        else:
+            gs = self.ws.get(key + ".gram", (ci * ci + ci,), torch.float32)
+            G, s = gs[:ci * ci], gs[ci * ci:]
+            hip.host_op(gs.zero_)
+            self.wgrad(x, x, G, dbias=s, N=N, H=P, W=Q, Cin=ci, ldx=ci, P=P, Q=Q, Cout=ci, lddy=ci)
         sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
         scale, shift, mean, invstd = sc[0], sc[1], sc[2], sc[3]
         cov = self.ws.at_least("gram.cov", ci * ci, torch.float32)
@@ -462,7 +476,7 @@ class HipEngine:
         self.wgrad(g, x, R, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
         wcat = self.ws.get(key + ".gwcat", (ci, co + ci), self.T)
         cbias = self.ws.get(key + ".gcbias", (ci,), torch.float32)
-        coef = self.ws.get(key + ".gcoef", (5 * co,), torch.float32)
+        coef = self.ws.at_least("gram.bwd", hip.gram_bn_backward_ws(ci, co), torch.float32)
         hip.gram_bn_backward(self.d, self.w_fwd(w), R, sv["gram"]["T"], sv["gram"]["mu"], stats, tiles, rows, ci, co, bn.weight,
                              sv["mean"], sv["invstd"], a.grad_flat(bn.weight), a.grad_flat(bn.bias), a.grad_flat(w), wcat, cbias, coef)
         dx = self.scratch(slot, x.shape)

@@ -93,7 +93,7 @@ def test_gram_closing_stage_forward_and_backward(N, H, w, proj, gamma_zero):
     hip.conv_wgrad(d, g, a, R, N=N, H=H, W=H, Cin=w, ldx=w, P=H, Q=H, Cout=co, lddy=co, workspace=work)
     dgamma, dbeta, dW = torch.zeros(co, device=DEV), torch.zeros(co, device=DEV), torch.zeros(co, w, device=DEV)
     wcat = torch.empty(w, co + w, device=DEV, dtype=BF)
-    cbias, coef = torch.empty(w, device=DEV), torch.empty(5 * co, device=DEV)
+    cbias, coef = torch.empty(w, device=DEV), torch.empty(hip.gram_bn_backward_ws(w, co), device=DEV)
     hip.gram_bn_backward(d, W, R, T, mu, gstats, tiles, M, w, co, gamma, bnv[2], bnv[3], dgamma, dbeta, dW, wcat, cbias, coef)
     torch.cuda.synchronize()
     scale_ref = max(dgamma64.norm().item(), 1e-6)
@@ -119,6 +119,31 @@ def test_gram_closing_stage_forward_and_backward(N, H, w, proj, gamma_zero):
     daf = da.double()
     assert _rel(part[0], daf.sum(0)) < 1e-3
     assert _rel(part[1], (daf * (c2.double() - mean2.double())).sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("rows,C", [(8 * 56 * 56, 64), (4 * 28 * 28 + 37, 128), (100, 64), (5000, 128)])
+def test_bn_apply_gram_matches_bn_apply_and_the_gram_matrix(rows, C):
+    """nkb_bn_apply_gram: y bit-identical to nkb_bn_apply(relu), Gram matrix / column sums of the STORED y to fp32 summation error,
+    bit-identical across repeats (ordered slab reduction)."""
+    torch.manual_seed(rows + C)
+    d = hip.BF16
+    c = torch.randn(rows, C, device=DEV).to(BF)
+    scale, shift = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+    y_ref = torch.empty_like(c)
+    hip.bn_apply(d, c, None, y_ref, scale, shift, rows, C, True)
+    outs = []
+    for _ in range(2):
+        y = torch.empty_like(c)
+        gs = torch.full((C * C + C,), float("nan"), device=DEV)
+        work = torch.empty(hip.bn_apply_gram_ws(rows, C), device=DEV)
+        hip.bn_apply_gram(d, c, y, scale, shift, rows, C, gs, work)
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+        outs.append(gs.clone())
+    assert torch.equal(outs[0], outs[1])
+    y64 = y_ref.double()
+    assert _rel(outs[0][:C * C].view(C, C), y64.t() @ y64) < 1e-5
+    assert _rel(outs[0][C * C:], y64.sum(0)) < 1e-5
 
 
 def test_gram_form_in_the_model_matches_separate_passes():
