@@ -137,12 +137,20 @@ int nkb_conv_affine_residual(int dtype, const void* x, const void* w, void* y, c
  * rnd(res * res_scale + res_shift), as in nkb_bn_apply.  relu_bits: layout of nkb_bn_apply's relu_bits. */
 int nkb_gram_bn_backward(int dtype, const void* w, const float* R, const float* T, const float* mu, float* gstats, int tiles,
                          long long count, int Cin, int Cout, const float* gamma, const float* mean, const float* invstd,
-                         float* dgamma, float* dbeta, float* dw, void* wcat, float* cbias, float* work, nkb_stream_t stream);
+                         float* dgamma, float* dbeta, float* dw, void* wcat, void* q, float* cbias, float* work, nkb_stream_t stream);
 size_t nkb_gram_bn_backward_workspace_floats(int Cin, int Cout);
 /* gstats: per-row-tile sums of g as nkb_conv_dgrad_bn leaves them (first plane used; nkb_bn_stats_floats floats); dgamma, dbeta,
  * dw accumulate (+=); wcat: [Cin][Cout + Cin] in the compute dtype, cbias [Cin]; work: nkb_gram_bn_backward_workspace_floats floats
  * of scratch (tile sums, the partial sums of cbias = k3 W, and V = k2 .* W whose product V^T W — Q — runs on the MFMA
  * transposed-A GEMM of nkb_gemm_tn_batched).  64 | Cin <= 512. */
+/* Two-launch form of that data gradient (exactly one of wcat / q is given to nkb_gram_bn_backward): nkb_gram_k1w builds
+ * wk1[j][k] = k1_k W[k][j] from the forward scale alone, t = g . wk1^T is a plain nkb_conv_gemm that can start before anything of the
+ * backward algebra exists (which then runs beside it on the weight-gradient stream, writing q = Q [Cin][Cin] and cbias), and
+ * nkb_conv_dgrad_bn_add finishes da = t + a . Q + cbias with the fused BN-backward epilogue. */
+int nkb_gram_k1w(int dtype, const void* w, const float* k1, int Cin, int Cout, void* out, nkb_stream_t stream);
+int nkb_conv_dgrad_bn_add(int dtype, const void* a, int lda, int K, const void* q, const float* cbias, const void* t, int ldt,
+                          void* g_masked, const void* c_prev, const float* scale, const float* shift, const float* mean, float* stats,
+                          long long M, int Cout, int ldy, nkb_stream_t stream);
 int nkb_conv_dgrad_bn_cat(int dtype, const void* g, int ldg, int K1, const void* a, int lda, int K2, const void* wcat,
                           const float* cbias, void* g_masked, const void* c_prev, const float* scale, const float* shift,
                           const float* mean, float* stats, long long M, int Cout, int ldy, nkb_stream_t stream);

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             const unsigned ww = rem - hh * p.divQ.d;
             orow = ((size_t)n * p.sub_h + 2 * hh + p.sub_ph) * p.sub_w + 2 * ww + p.sub_pw;
         }
-        bool do_add = BNB != 1 && p.add != nullptr;
+        bool do_add = p.add != nullptr;          // (BNB == 1: only nkb_conv_dgrad_bn_add passes one, full grid, no bits)
         size_t am = orow;                      // row of the add tensor
         if (do_add && p.add_h > 0 && p.sub_h > 0) {
             // sub-grid add on a parity-class launch: the even (h, w) grid IS class (0, 0), row for row
@@ -1289,6 +1289,40 @@ extern "C" int nkb_conv_dgrad_bn_cat(int dtype, const void* g, int ldg, int K1, 
     p.x2 = a; p.ldx2 = lda; p.kt2 = K1 / kte;
     NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)Cout * (K1 + K2),
                       ((double)M * (K1 + K2) + (double)Cout * (K1 + K2) + 2.0 * M * Cout) * esz);
+    static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
+    const bool narrow = Cout <= 64 && narrow_on;
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
+    return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
+}
+
+// The same closing-stage data gradient in two launches, so that everything that depends on the gradient statistics can run BESIDE
+// the bulk of it (weight-gradient stream): t = g . (k1 W) is a plain nkb_conv_gemm that needs nothing but the forward scale;
+// this entry then finishes da = t + a . Q + cbias with nkb_conv_dgrad_bn's fused BN-backward epilogue (mask recomputed from
+// c_prev / scale / shift, per-row-tile sums into stats).  q: [Cout][K] rows (Q is symmetric), t: [M][ldt] in the compute dtype.
+extern "C" int nkb_conv_dgrad_bn_add(int dtype, const void* a, int lda, int K, const void* q, const float* cbias, const void* t, int ldt,
+                                     void* g_masked, const void* c_prev, const float* scale, const float* shift, const float* mean,
+                                     float* stats, long long M, int Cout, int ldy, hipStream_t stream) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int kte = 128 / esz;
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("conv_dgrad_bn_add: bad dtype %d", dtype); return 1; }
+    if (K % kte || K <= 0 || lda % (16 / esz) || Cout % 8 || ldy % 8 || ldt % 8 || !t || !c_prev || !scale || !shift || !mean || !stats) {
+        nkb_set_error("conv_dgrad_bn_add: K=%d must be a multiple of %d, Cout=%d / ldy=%d / ldt=%d of 8", K, kte, Cout, ldy, ldt);
+        return 1;
+    }
+    if (M * lda * esz >= 0xFFFFFF00ll || (long long)Cout * K * esz >= 0xFFFFFF00ll || M * ldy >= (1ll << 31) || M * ldt >= (1ll << 31)) {
+        nkb_set_error("conv_dgrad_bn_add: operand exceeds the addressing range");
+        return 1;
+    }
+    ConvParams p;
+    p.x = a; p.w = q; p.y = g_masked; p.add = t; p.bias = cbias; p.stats = stats;
+    p.M = (int)M; p.H = (int)M; p.W = 1; p.Cin = K; p.ldx = lda; p.P = (int)M; p.Q = 1; p.Cout = Cout; p.ldy = ldy;
+    p.ldadd = ldt; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 1; p.relu = 0;
+    p.stride_w = 1; p.pad_w = 0; p.stem_cprw = 0; p.out_f32 = 0;
+    p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
+    p.ldw = K; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = c_prev; p.y2 = nullptr;
+    p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean;
+    NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)Cout * K, ((double)M * K + (double)Cout * K + 3.0 * M * Cout) * esz);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);

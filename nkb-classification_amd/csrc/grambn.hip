@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const WT* __restrict__ 
                                                          float momentum, float eps, float* __restrict__ T,
                                                          float* __restrict__ scale, float* __restrict__ shift,
                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    constexpr int KR = 4, IC = 16;
+    constexpr int KR = 4;
+    constexpr int IC = NJ == 1 ? 64 : 32;         // Cov rows per chunk: few, large chunks — each one is a dependent L2 round trip
     extern __shared__ float lds[];                // wl [Cin][KR] fp32 copies of this block's weight rows, then cl [IC][Cin]
     float* wl = lds;
     float* cl = lds + (size_t)KR * Cin;
@@ -255,13 +256,26 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const WT* __restrict__ 
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) acc[k][jj] = 0.f;
     const int c4 = Cin >> 2;                      // 16-byte groups per Cov row (Cin % 4 == 0)
-    for (int i0 = 0; i0 < Cin; i0 += IC) {
+    // every block needs all of Cov: start each one at a different chunk so that the 256 CUs do not all request the same 64 KB at the
+    // same moment (they did: 160 us for Cin = 512, i.e. 3 TB/s out of ONE hot L2 region)
+    const int nchunk = (Cin + IC - 1) / IC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int i0 = ((ch + (int)blockIdx.x) % nchunk) * IC;
         __syncthreads();                          // (first pass: wl complete; later: everyone done with the previous chunk)
-        for (int idx = tid; idx < IC * c4; idx += 256) {
-            const int ii = idx / c4, j4 = idx - ii * c4;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (i0 + ii < Cin) v = *(const f32x4*)(cov + (size_t)(i0 + ii) * Cin + 4 * j4);
-            *(f32x4*)(cl + (size_t)ii * Cin + 4 * j4) = v;
+        for (int base = 0; base < IC * c4; base += 256 * 8) {      // eight independent 16-byte loads in flight per thread
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + tid + 256 * u;
+                const int ii = idx / c4, j4 = idx - ii * c4;
+                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (idx < IC * c4 && i0 + ii < Cin) v[u] = *(const f32x4*)(cov + (size_t)(i0 + ii) * Cin + 4 * j4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + tid + 256 * u;
+                if (idx < IC * c4) *(f32x4*)(cl + 4 * (size_t)idx) = v[u];       // cl[ii][4 j4 ..] = cl + 4 idx (rows are c4 groups long)
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -382,7 +396,8 @@ __global__ __launch_bounds__(256) void gram_bwd_coef_kernel(const WT* __restrict
             }
         }
         cpart[(size_t)blockIdx.x * Cin + j] = cb;
-        // row j of the data-gradient filter: columns k0 .. k0+7 = k1_k W[k][j]
+        // row j of the data-gradient filter: columns k0 .. k0+7 = k1_k W[k][j]  (one-launch form only)
+        if (wcat == nullptr) continue;
         CT* dst = wcat + (size_t)j * ldc + k0;
         if constexpr (sizeof(CT) == 2) {
             if (k0 + KR <= Cout) *(u32x4*)dst = pack8(q);
@@ -393,18 +408,51 @@ __global__ __launch_bounds__(256) void gram_bwd_coef_kernel(const WT* __restrict
     }
 }
 
-// cbias[j] = sum over the coefficient kernel's blocks, in a fixed order
-__global__ void gram_cbias_kernel(const float* __restrict__ cpart, int nblk, int Cin, float* __restrict__ cbias) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= Cin) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblk; b += 4) {
-        a0 += cpart[(size_t)b * Cin + j]; a1 += cpart[(size_t)(b + 1) * Cin + j];
-        a2 += cpart[(size_t)(b + 2) * Cin + j]; a3 += cpart[(size_t)(b + 3) * Cin + j];
+// wk1[j][k] = k1_k W[k][j], k1 = the forward scale gamma * invstd: the filter of the bulk data gradient t = g . (k1 W), which depends
+// on nothing the backward pass computes (two-launch form, nkb_conv_dgrad_bn_add)
+template <typename WT>
+__global__ __launch_bounds__(256) void gram_k1w_kernel(const WT* __restrict__ W, const float* __restrict__ k1, int Cin, int Cout,
+                                                       WT* __restrict__ out) {
+    // tile of 64 k x 64 j through LDS so that both the read (rows of W) and the write (rows of out) are contiguous
+    __shared__ float tile[64][65];
+    const int k0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int k = idx >> 6, j = idx & 63;
+        tile[k][j] = (k0 + k < Cout && j0 + j < Cin) ? k1[k0 + k] * ldw<WT>(W + (size_t)(k0 + k) * Cin + j0 + j) : 0.f;
     }
-    for (; b < nblk; ++b) a0 += cpart[(size_t)b * Cin + j];
-    cbias[j] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int j = idx >> 6, k = idx & 63;
+        if (k0 + k < Cout && j0 + j < Cin) {
+            WT* d = out + (size_t)(j0 + j) * Cout + k0 + k;
+            if constexpr (sizeof(WT) == 2) *d = f2bf(tile[k][j]); else *d = tile[k][j];
+        }
+    }
+}
+extern "C" int nkb_gram_k1w(int dtype, const void* w, const float* k1, int Cin, int Cout, void* out, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("gram_k1w: bad dtype %d", dtype); return 1; }
+    NkbProfScope prof(NKB_K_WPREP, stream, 0);
+    const dim3 grid((Cout + 63) / 64, (Cin + 63) / 64);
+    if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(gram_k1w_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)w, k1, Cin, Cout, (bf16_t*)out);
+    else hipLaunchKernelGGL(gram_k1w_kernel<float>, grid, dim3(256), 0, stream, (const float*)w, k1, Cin, Cout, (float*)out);
+    return nkb_check_launch("gram_k1w");
+}
+
+// cbias[j] = sum over the coefficient kernel's blocks, in a fixed order: 16 row partitions per 64 columns, combined through LDS
+__global__ __launch_bounds__(1024) void gram_cbias_kernel(const float* __restrict__ cpart, int nblk, int Cin, float* __restrict__ cbias) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cx;
+    float a = 0.f;
+    if (j < Cin)
+        for (int b = py; b < nblk; b += 16) a += cpart[(size_t)b * Cin + j];
+    red[py][cx] = a;
+    __syncthreads();
+    if (py == 0 && j < Cin) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        cbias[j] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -413,7 +461,13 @@ static int launch_stats(const void* w, const float* cov, const float* mu, long l
                         const float* beta, float* rm, float* rv, float momentum, float eps, float* T, float* scale, float* shift,
                         float* mean, float* invstd, hipStream_t stream) {
     const dim3 grid((Cout + 3) / 4), block(256);
-    const size_t lds = (size_t)(4 + 16) * Cin * sizeof(float);
+    const size_t lds = (size_t)(4 + (Cin <= 256 ? 64 : 32)) * Cin * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gram_stats_kernel<WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipFuncSetAttribute((const void*)gram_stats_kernel<WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
 #define NKB_GS(NJ) hipLaunchKernelGGL((gram_stats_kernel<WT, NJ>), grid, block, lds, stream, (const WT*)w, cov, mu, (float)count, Cin, Cout, \
                                       gamma, beta, rm, rv, momentum, eps, T, scale, shift, mean, invstd)
     if (Cin <= 256) NKB_GS(1); else NKB_GS(2);
@@ -449,7 +503,7 @@ extern "C" int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void
 template <typename WT>
 static int launch_bwd(int dtype, const void* w, const float* R, const float* T, const float* mu, const float* gsum, long long count, int Cin,
                       int Cout, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw,
-                      void* wcat, float* cbias, float* cpart, void* V, hipStream_t stream) {
+                      void* wcat, void* qsep, float* cbias, float* cpart, void* V, hipStream_t stream) {
     using CT = WT;
     const int ldc = Cout + Cin;
     const int nblk = (Cout + 7) / 8;
@@ -461,11 +515,12 @@ static int launch_bwd(int dtype, const void* w, const float* R, const float* T, 
         if (Cin <= 256) NKB_GC(1); else NKB_GC(2);
 #undef NKB_GC
         if (int rc = nkb_check_launch("gram_bwd_coef")) return rc;
-        hipLaunchKernelGGL(gram_cbias_kernel, dim3((Cin + 63) / 64), dim3(64), 0, stream, cpart, nblk, Cin, cbias);
+        hipLaunchKernelGGL(gram_cbias_kernel, dim3((Cin + 63) / 64), dim3(1024), 0, stream, cpart, nblk, Cin, cbias);
         if (int rc = nkb_check_launch("gram_cbias")) return rc;
     }
     // Q = V^T W on the MFMA weight-gradient kernel (reduction over the Cout rows), stored in the compute dtype straight into columns
     // Cout .. Cout+Cin of the concatenated filter (Q is symmetric, so row / column order does not matter)
+    if (qsep) return nkb_gemm_tn_batched(dtype, V, w, qsep, Cout, Cin, Cin, Cin, Cin, Cin, 1, 1, 0, 0, 0, 0, 0, 0, stream);
     return nkb_gemm_tn_batched(dtype, V, w, (CT*)wcat + Cout, Cout, Cin, Cin, Cin, Cin, ldc, 1, 1, 0, 0, 0, 0, 0, 0, stream);
 }
 
@@ -479,7 +534,9 @@ extern "C" size_t nkb_gram_bn_backward_workspace_floats(int Cin, int Cout) {
 }
 extern "C" int nkb_gram_bn_backward(int dtype, const void* w, const float* R, const float* T, const float* mu, float* gstats, int tiles,
                                     long long count, int Cin, int Cout, const float* gamma, const float* mean, const float* invstd,
-                                    float* dgamma, float* dbeta, float* dw, void* wcat, float* cbias, float* work, hipStream_t stream) {
+                                    float* dgamma, float* dbeta, float* dw, void* wcat, void* q, float* cbias, float* work,
+                                    hipStream_t stream) {
+    if ((wcat == nullptr) == (q == nullptr)) { nkb_set_error("gram_bn_backward: exactly one of wcat / q"); return 1; }
     if ((dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) || Cin < 1 || Cin > 512 || Cin % 64 || Cout % 8 || count < 1 || tiles < 1) {
         nkb_set_error("gram_bn_backward: unsupported dtype %d / Cin=%d (<= 512, %% 64) / Cout=%d (%% 8)", dtype, Cin, Cout);
         return 1;
@@ -492,6 +549,6 @@ extern "C" int nkb_gram_bn_backward(int dtype, const void* w, const float* R, co
         if (int rc = nkb_launch_tile_sums(gstats, tiles, Cout, gsum, stream)) return rc;
     }
     if (dtype == NKB_DT_BF16)
-        return launch_bwd<bf16_t>(dtype, w, R, T, mu, gsum, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, cpart, V, stream);
-    return launch_bwd<float>(dtype, w, R, T, mu, gsum, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, cpart, V, stream);
+        return launch_bwd<bf16_t>(dtype, w, R, T, mu, gsum, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, q, cbias, cpart, V, stream);
+    return launch_bwd<float>(dtype, w, R, T, mu, gsum, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, q, cbias, cpart, V, stream);
 }

@@ -39,7 +39,9 @@ _SIGS = {
     "nkb_bn_apply_gram": (i32, [i32, vp, vp, vp, vp, i64, i32, vp, vp, sz, vp]),
     "nkb_bn_apply_gram_workspace_floats": (sz, [i64, i32]),
     "nkb_conv_affine_residual": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp] + [i32] * 13 + [vp]),
-    "nkb_gram_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nkb_gram_bn_backward": (i32, [i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nkb_gram_k1w": (i32, [i32, vp, vp, i32, i32, vp, vp]),
+    "nkb_conv_dgrad_bn_add": (i32, [i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "nkb_gram_bn_backward_workspace_floats": (sz, [i32, i32]),
     "nkb_conv_dgrad_bn_cat": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp, vp]),
@@ -386,10 +388,19 @@ def gram_bn_backward_ws(Cin, Cout) -> int:
     return int(load().nkb_gram_bn_backward_workspace_floats(Cin, Cout))
 
 
-def gram_bn_backward(dtype, w, R, T, mu, gstats, tiles, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, coef):
+def gram_bn_backward(dtype, w, R, T, mu, gstats, tiles, count, Cin, Cout, gamma, mean, invstd, dgamma, dbeta, dw, wcat, cbias, coef, q=None):
     check(load().nkb_gram_bn_backward(dtype, ptr(w), ptr(R), ptr(T), ptr(mu), ptr(gstats), tiles, count, Cin, Cout, ptr(gamma), ptr(mean),
-                                      ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dw), ptr(wcat), ptr(cbias), ptr(coef), stream()),
+                                      ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dw), ptr(wcat), ptr(q), ptr(cbias), ptr(coef), stream()),
           "gram_bn_backward")
+
+
+def gram_k1w(dtype, w, k1, Cin, Cout, out):
+    check(load().nkb_gram_k1w(dtype, ptr(w), ptr(k1), Cin, Cout, ptr(out), stream()), "gram_k1w")
+
+
+def conv_dgrad_bn_add(dtype, a, lda, K, q, cbias, t, ldt, g_masked, c_prev, scale, shift, mean, stats, M, Cout, ldy):
+    check(load().nkb_conv_dgrad_bn_add(dtype, ptr(a), lda, K, ptr(q), ptr(cbias), ptr(t), ldt, ptr(g_masked), ptr(c_prev), ptr(scale),
+                                       ptr(shift), ptr(mean), ptr(stats), M, Cout, ldy, stream()), "conv_dgrad_bn_add")
 
 
 def conv_dgrad_bn_cat(dtype, g, ldg, K1, a, lda, K2, wcat, cbias, g_masked, c_prev, scale, shift, mean, stats, M, Cout, ldy):

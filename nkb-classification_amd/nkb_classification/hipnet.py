@@ -60,6 +60,11 @@ _DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
 # input, normalisation + shortcut + ReLU in conv3's epilogue, backward through R = g^T a and one K-concatenated data gradient — the
 # raw conv output c3 and its gradient never exist in HBM (0 = the separate bn_apply / bn_backward passes, for A/B runs)
 _GRAM_BN = os.environ.get("NKB_GRAM_BN", "1") != "0"
+# its data gradient in two launches: the bulk t = g . (k1 W) starts at once on the main stream while R = g^T a and the algebra that
+# needs it run on the weight-gradient stream; da = t + a . Q + cbias finishes the job (0 = one K-concatenated launch after them).
+# Measured (same box, alternating): 20.65 ms split vs 19.72 ms one launch — the main stream's kernels shrink by 1.5 ms but it then
+# idles 0.4-3.4 ms per step at the joins (the side stream still holds the previous block's weight gradients in front of the chain).  Off.
+_GRAM_SPLIT = os.environ.get("NKB_GRAM_SPLIT", "0") != "0"
 
 
 class HipEngine:
@@ -472,16 +477,36 @@ class HipEngine:
         a = self.arena
         stats, tiles = g_stats
         R = self.ws.get(key + ".gR", (co, ci), torch.float32)
+        cbias = self.ws.get(key + ".gcbias", (ci,), torch.float32)
+        tiles2 = hip.stat_tiles(self.d, rows, ci)
+        stats2 = self.ws.get(prev_key + ".bstats", (hip.bn_stats_floats(tiles2, ci),), torch.float32)
+        if _GRAM_SPLIT and self.overlap_wgrad:
+            q = self.ws.get(key + ".gq", (ci, ci), self.T)
+
+            def algebra():
+                hip.host_op(R.zero_)
+                self.wgrad(g, x, R, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
+                work = self.ws.at_least("gram.bwd", hip.gram_bn_backward_ws(ci, co), torch.float32)
+                hip.gram_bn_backward(self.d, self.w_fwd(w), R, sv["gram"]["T"], sv["gram"]["mu"], stats, tiles, rows, ci, co,
+                                     bn.weight, sv["mean"], sv["invstd"], a.grad_flat(bn.weight), a.grad_flat(bn.bias),
+                                     a.grad_flat(w), None, cbias, work, q=q)
+            self.on_side(algebra)
+            wk1 = self.ws.get(key + ".gwk1", (ci, co), self.T)
+            hip.gram_k1w(self.d, self.w_fwd(w), sv["scale"], ci, co, wk1)
+            t = self.scratch(slot + "t", x.shape)
+            hip.conv_gemm(self.d, 0, g, wk1, t, N=rows, H=1, W=1, Cin=co, ldx=co, P=1, Q=1, Cout=ci, ldy=ci)
+            self.join_side()
+            dx = self.scratch(slot, x.shape)
+            hip.conv_dgrad_bn_add(self.d, x, ci, ci, q, cbias, t, ci, dx, svp["c"], svp["scale"], svp["shift"], svp["mean"], stats2,
+                                  rows, ci, ci)
+            return dx, (stats2, tiles2)
         hip.host_op(R.zero_)
         self.wgrad(g, x, R, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
         wcat = self.ws.get(key + ".gwcat", (ci, co + ci), self.T)
-        cbias = self.ws.get(key + ".gcbias", (ci,), torch.float32)
         coef = self.ws.at_least("gram.bwd", hip.gram_bn_backward_ws(ci, co), torch.float32)
         hip.gram_bn_backward(self.d, self.w_fwd(w), R, sv["gram"]["T"], sv["gram"]["mu"], stats, tiles, rows, ci, co, bn.weight,
                              sv["mean"], sv["invstd"], a.grad_flat(bn.weight), a.grad_flat(bn.bias), a.grad_flat(w), wcat, cbias, coef)
         dx = self.scratch(slot, x.shape)
-        tiles2 = hip.stat_tiles(self.d, rows, ci)
-        stats2 = self.ws.get(prev_key + ".bstats", (hip.bn_stats_floats(tiles2, ci),), torch.float32)
         hip.conv_dgrad_bn_cat(self.d, g, co, co, x, ci, ci, wcat, cbias, dx, svp["c"], svp["scale"], svp["shift"], svp["mean"],
                               stats2, rows, ci, ci)
         return dx, (stats2, tiles2)

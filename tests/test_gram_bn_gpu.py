@@ -120,6 +120,26 @@ def test_gram_closing_stage_forward_and_backward(N, H, w, proj, gamma_zero):
     assert _rel(part[0], daf.sum(0)) < 1e-3
     assert _rel(part[1], (daf * (c2.double() - mean2.double())).sum(0)) < 1e-3
 
+    # ---- the two-launch form: t = g . (k1 W) from the forward scale alone, then da = t + a . Q + cbias ----------------------------
+    wk1 = torch.empty(w, co, device=DEV, dtype=BF)
+    hip.gram_k1w(d, W, bnv[0], w, co, wk1)
+    assert torch.equal(wk1, wcat[:, :co].contiguous())
+    t = torch.empty(M, w, device=DEV, dtype=BF)
+    hip.conv_gemm(d, 0, g, wk1, t, N=M, H=1, W=1, Cin=co, ldx=co, P=1, Q=1, Cout=w, ldy=w)
+    q = torch.empty(w, w, device=DEV, dtype=BF)
+    cbias2 = torch.empty(w, device=DEV)
+    dg2, db2, dW2 = torch.zeros(co, device=DEV), torch.zeros(co, device=DEV), torch.zeros(co, w, device=DEV)
+    hip.gram_bn_backward(d, W, R, T, mu, gstats, tiles, M, w, co, gamma, bnv[2], bnv[3], dg2, db2, dW2, None, cbias2, coef, q=q)
+    torch.cuda.synchronize()
+    assert torch.equal(dW2, dW) and torch.equal(cbias2, cbias) and torch.equal(q, wcat[:, co:].contiguous())
+    stats3 = torch.zeros_like(stats2)
+    da2 = torch.empty(M, w, device=DEV, dtype=BF)
+    hip.conv_dgrad_bn_add(d, a, w, w, q, cbias2, t, w, da2, c2, sc2, sh2, mean2, stats3, M, w, w)
+    torch.cuda.synchronize()
+    assert _rel(da2, da64) < 1.2e-2
+    part3 = stats3[:st_tiles * 2 * w].view(st_tiles, 2, w).double().sum(0)
+    assert _rel(part3[0], da2.double().sum(0)) < 1e-3
+
 
 @pytest.mark.parametrize("rows,C", [(8 * 56 * 56, 64), (4 * 28 * 28 + 37, 128), (100, 64), (5000, 128)])
 def test_bn_apply_gram_matches_bn_apply_and_the_gram_matrix(rows, C):
