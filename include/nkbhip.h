@@ -56,6 +56,11 @@ int nkb_conv_gemm_stat_tiles(int dtype, int M, int Cout);
 int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin, int ldx,
                    int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad, float* workspace,
                    long long workspace_floats, nkb_stream_t stream);
+/* The same product with "=" instead of "+=" (dw / dbias overwritten; deterministic form only): scratch products such as the
+ * Gram-form R = g^T a need no memset in front of them. */
+int nkb_conv_wgrad_assign(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin, int ldx,
+                          int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad, float* workspace,
+                          long long workspace_floats, nkb_stream_t stream);
 /* Workspace that makes nkb_conv_wgrad deterministic (bit-identical across runs): every (tile, pixel-split) workgroup stores
  * its fp32 partial tile into its own slab and a second launch adds the slabs to dw (and the bias partials to dbias) in
  * split order.  workspace == NULL keeps the single-launch form that accumulates with fp32 atomics. */

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     constexpr int LDS_MAIN = (STAGE_BYTES * ((TC == 64 && !NKB_NARROW3) ? 2 : 1)) > ((TP / 2) * EROW) ? (STAGE_BYTES * ((TC == 64 && !NKB_NARROW3) ? 2 : 1))
                                                                                        : ((TP / 2) * EROW);
     float* bnl = (float*)(smem + LDS_MAIN);   // [3][TC]
-    if constexpr (BNB == 1 || BNB == 2) {
+    if constexpr (BNB == 1 || BNB == 2 || BNB == 6) {
         if (tid < TC) {
             const bool ok = c0 + tid < p.Cout;
             if constexpr (BNB == 1) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     // BNB (bf16): the c rows of a half are requested before that half's accumulators go through LDS, so their latency
     // hides behind the LDS round trip instead of stalling every row of the store loop
     constexpr int RPH = (TP / 2) / RPP;                      // rows per thread per half
-    constexpr bool CPRE = (BNB == 1 || BNB == 2) && sizeof(T) == 2;
+    constexpr bool CPRE = (BNB == 1 || BNB == 2 || BNB == 6) && sizeof(T) == 2;
     u32x4 cpre[CPRE ? RPH : 1];
     auto prefetch_c = [&](int half) {
         if constexpr (CPRE) {
@@ -384,8 +384,34 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
         }
     };
 
+    // BNB == 2, the common geometry (bf16, full-grid residual, no parity-class remap): a lean row loop.  Everything a row needs from
+    // HBM — the residual row, the c row, the two mask bytes — is requested for all rows of the half BEFORE the accumulators pass
+    // through LDS; inside the general loop the byte loads of the masks sat behind the previous row's store (the compiler cannot move
+    // a load above a store through an unrelated pointer) and every row exposed two memory latencies (3.9 TB/s on three large tensors
+    // where the closing-stage forward epilogue, same traffic shape, streams at 5+).
+    constexpr bool F2 = BNB == 6 && sizeof(T) == 2;    // (its own instantiation: compiled next to the general loop it spilled 70 VGPRs)
+    constexpr bool fast2 = F2;                       // (launch_conv_closing only picks BNB == 6 when the geometry qualifies)
+    u32x4 apre2[F2 ? RPH : 1];
+    unsigned abit2[F2 ? RPH : 1], obit2[F2 ? RPH : 1];
+    auto prefetch_fast = [&](int half) {
+        if constexpr (F2) {
+#pragma unroll
+            for (int i = 0; i < RPH; ++i) {
+                const int m = m0 + half * (TP / 2) + er + RPP * i;
+                apre2[i] = (u32x4){0u, 0u, 0u, 0u};
+                abit2[i] = 0xffu; obit2[i] = 0xffu;
+                if (m < p.M && co < p.Cout) {
+                    apre2[i] = *(const u32x4*)((const bf16_t*)p.add + (size_t)m * p.ldadd + co);
+                    if (p.add_bits) abit2[i] = p.add_bits[(size_t)m * (size_t)(p.ldadd >> 3) + (co >> 3)];
+                    obit2[i] = p.bn_bits[(size_t)m * (size_t)(p.ldy >> 3) + (co >> 3)];
+                }
+            }
+        }
+    };
+
   for (int half = 0; half < 2; ++half) {
     prefetch_c(half);
+    prefetch_fast(half);
     if (wp == half) {
 #pragma unroll
         for (int i = 0; i < MC; ++i)
@@ -523,7 +549,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             };
             if (p.add_scale) rows(std::true_type{}); else rows(std::false_type{});
         }
-    } else {
+    } else if constexpr (BNB != 6) {
     // residual-closing fused epilogue (BNB == 2, bf16, full-grid residual): the `add` rows of this half are requested up front,
     // like the c rows above — inside the row loop each of them was a dependent load in front of its row's arithmetic and the
     // kernel ran at ~3.5 TB/s on its three large tensors (profiles/r02a: 183 us average for 15 launches per step)
@@ -716,6 +742,41 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             ssum[e] += v[e];
             if constexpr (BNB == 1 || BNB == 2) ssq[e] += v[e] * cv[e];
             else ssq[e] += v[e] * v[e];
+        }
+    }
+    } else {
+        {
+            {
+            if (co < p.Cout) {
+                const int mrow = m0 + half * (TP / 2) + er;
+                bf16_t* o = (bf16_t*)p.y + yoff + (size_t)mrow * p.ldy + co;
+                const size_t ostep = (size_t)RPP * p.ldy;
+                const unsigned char* lrow = smem + er * EROW + eg * 32;
+                const f32x4 mu0 = *(const f32x4*)(bnl + 2 * TC + eg * 8), mu1 = *(const f32x4*)(bnl + 2 * TC + eg * 8 + 4);
+                const float mu[8] = {mu0[0], mu0[1], mu0[2], mu0[3], mu1[0], mu1[1], mu1[2], mu1[3]};
+#pragma unroll
+                for (int ri = 0; ri < RPH; ++ri) {
+                    if (mrow + RPP * ri >= p.M) break;
+                    const f32x4 lo = *(const f32x4*)(lrow + ri * RPP * EROW);
+                    const f32x4 hi = *(const f32x4*)(lrow + ri * RPP * EROW + 16);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    float fa[8], cv[8];
+                    unpack8(apre2[ri], fa);
+                    unpack8(cpre[ri], cv);
+                    const unsigned ab = abit2[ri], ob = obit2[ri];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] += ((ab >> e) & 1u) ? fa[e] : 0.f;
+                        if (!((ob >> e) & 1u)) v[e] = 0.f;
+                        cv[e] -= mu[e];
+                    }
+                    const u32x4 pk = pack8(v);
+                    *(u32x4*)(o + ri * ostep) = pk;
+                    unpack8(pk, v);                 // statistics see the stored value
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * cv[e]; }
+                }
+            }
         }
     }
     }
@@ -1008,7 +1069,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
 // consecutive elements; SG threads share a column and each sums the splits s = sg, sg + SG, ... in order, then the SG partial
 // sums are combined in a fixed order through LDS — the association is a function of (splits, SG) only, never of timing.
 // (With one thread per column a 256-split / 4 K-element gradient took 60 us of serial dependent loads.)
-template <int SG>
+template <int SG, bool ASSIGN = false>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long slab, int splits,
                                                            float* __restrict__ dst, long long n) {
     constexpr int COLS = 256 / SG;
@@ -1030,7 +1091,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         if (sg == 0 && i < n4) {
             f32x4* d = (f32x4*)(dst + 4 * i);
-            *d = *d + a;
+            if constexpr (ASSIGN) *d = a; else *d = *d + a;
         }
     }
     // tail (n not a multiple of 4): one thread per element, splits in order
@@ -1038,24 +1099,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const long long i = (n4 << 2) + threadIdx.x;
         float a = 0.f;
         for (int s = 0; s < splits; ++s) a += part[(size_t)s * slab + i];
-        dst[i] += a;
+        if constexpr (ASSIGN) dst[i] = a; else dst[i] += a;
     }
 }
 // unaligned slabs / destinations (a bias vector in the middle of a parameter block): one thread per element, splits in order
 __global__ void wgrad_reduce_scalar_kernel(const float* __restrict__ part, long long slab, int splits, float* __restrict__ dst,
-                                           long long n) {
+                                           long long n, int assign) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float a = 0.f;
         for (int s = 0; s < splits; ++s) a += part[(size_t)s * slab + i];
-        dst[i] += a;
+        dst[i] = assign ? a : dst[i] + a;
     }
 }
+// nkb_conv_wgrad_assign: the reductions launched inside it OVERWRITE their destination (a scratch product such as the Gram-form R =
+// g^T a needs no memset in front of it).  Host-side flag of the calling thread; launches are enqueued synchronously inside the call.
+static thread_local bool g_wgrad_assign = false;
 int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float* dst, long long n, hipStream_t stream) {
     if (n <= 0 || splits <= 0) return 0;
     if ((slab & 3) != 0 || (((uintptr_t)part | (uintptr_t)dst) & 15) != 0) {
         long long g = (n + 255) / 256;
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((unsigned)g), dim3(256), 0, stream, part, slab, splits, dst, n);
+        hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((unsigned)g), dim3(256), 0, stream, part, slab, splits, dst, n, g_wgrad_assign ? 1 : 0);
         return nkb_check_launch("wgrad_reduce");
     }
     const long long n4 = n >> 2;
@@ -1064,6 +1128,12 @@ int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float
     long long grid = (n4 + cols - 1) / cols;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
+    if (g_wgrad_assign) {
+        if (sg == 16) hipLaunchKernelGGL((wgrad_reduce_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
+        else if (sg == 4) hipLaunchKernelGGL((wgrad_reduce_kernel<4, true>), dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
+        return nkb_check_launch("wgrad_reduce");
+    }
     if (sg == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
     else if (sg == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
     else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
@@ -1090,7 +1160,7 @@ static int launch_conv_impl(ConvParams& p, hipStream_t stream, int batch) {
     constexpr int xrows = HALO ? 32 * ((TP + 2 + 31) / 32) : TP;
     constexpr int stage = (TC + xrows) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1);
     constexpr int epi = (TP / 2) * (TC * 4 + 16);
-    constexpr int lds = (stage > epi ? stage : epi) + ((BNB == 1 || BNB == 2) ? 3 * TC * 4 : 0);
+    constexpr int lds = (stage > epi ? stage : epi) + ((BNB == 1 || BNB == 2 || BNB == 6) ? 3 * TC * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TC, TP, BNB, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1217,6 +1287,10 @@ extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void*
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
     if (relu_bits) {
+        // lean epilogue instantiation for the common geometry (full-grid residual, 8-channel-aligned rows)
+        static const int lean2 = [] { const char* e = getenv("NKB_LEAN_RES_EPILOGUE"); return e ? atoi(e) : 1; }();
+        if (lean2 && dtype == NKB_DT_BF16 && add != nullptr && add_h == 0 && (ldy & 7) == 0 && (ldadd & 7) == 0 && (Cout & 7) == 0 && stats != nullptr)
+            return narrow ? launch_conv<bf16_t, 64, 256, 6>(p, stream) : launch_conv<bf16_t, 128, 128, 6>(p, stream);
         if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 2>(p, stream) : launch_conv<bf16_t, 128, 128, 2>(p, stream);
         return narrow ? launch_conv<float, 64, 256, 2>(p, stream) : launch_conv<float, 128, 128, 2>(p, stream);
     }
@@ -1591,6 +1665,17 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     NkbProfScope prof(NKB_K_WGRAD_REDUCE, stream, 0, 4.0 * ((double)splits + 2.0) * slab);
     int rc = nkb_launch_wgrad_reduce(workspace, slab, splits, dw, slab, stream);
     if (!rc && dbias) rc = nkb_launch_wgrad_reduce(p.bpart, Cout, splits * p.tilesN, dbias, Cout, stream);
+    return rc;
+}
+
+// nkb_conv_wgrad with "=" instead of "+=": dw (and dbias) are OVERWRITTEN by the product — needs the deterministic form (workspace).
+extern "C" int nkb_conv_wgrad_assign(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
+                                     int Cin, int ldx, int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad,
+                                     float* workspace, long long workspace_floats, hipStream_t stream) {
+    if (workspace == nullptr) { nkb_set_error("conv_wgrad_assign: needs the slab workspace (the atomic form can only accumulate)"); return 1; }
+    g_wgrad_assign = true;
+    const int rc = nkb_conv_wgrad(dtype, dy, x, dw, dbias, N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad, workspace, workspace_floats, stream);
+    g_wgrad_assign = false;
     return rc;
 }
 

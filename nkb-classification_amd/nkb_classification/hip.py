@@ -25,6 +25,7 @@ _SIGS = {
     "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 18 + [vp, vp]),
     "nkb_conv_gemm_stat_tiles": (i32, [i32, i32, i32]),
     "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp, i64, vp]),
+    "nkb_conv_wgrad_assign": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp, i64, vp]),
     "nkb_conv_wgrad_workspace_floats": (i64, [i32] * 11),
     "nkb_stem_wgrad_workspace_floats": (i64, [i32] * 5),
     "nkb_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
@@ -303,10 +304,11 @@ def stat_tiles(dtype, M, Cout):
 
 
 def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0, dbias=None,
-               workspace=None):
+               workspace=None, assign=False):
     """workspace: fp32 scratch of at least conv_wgrad_workspace(...) floats -> deterministic two-stage accumulation; None ->
-    fp32 atomics."""
-    check(load().nkb_conv_wgrad(dtype, ptr(dy), ptr(x), ptr(dw), ptr(dbias), N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad,
+    fp32 atomics.  assign: dw / dbias are overwritten instead of accumulated into (needs the workspace)."""
+    fn = load().nkb_conv_wgrad_assign if assign else load().nkb_conv_wgrad
+    check(fn(dtype, ptr(dy), ptr(x), ptr(dw), ptr(dbias), N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad,
                                 ptr(workspace), workspace.numel() if workspace is not None else 0, stream()), "conv_wgrad")
 
 

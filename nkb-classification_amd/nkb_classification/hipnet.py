@@ -446,8 +446,7 @@ class HipEngine:
         else:
             gs = self.ws.get(key + ".gram", (ci * ci + ci,), torch.float32)
             G, s = gs[:ci * ci], gs[ci * ci:]
-            hip.host_op(gs.zero_)
-            self.wgrad(x, x, G, dbias=s, N=N, H=P, W=Q, Cin=ci, ldx=ci, P=P, Q=Q, Cout=ci, lddy=ci)
+            self.wgrad(x, x, G, dbias=s, assign=True, N=N, H=P, W=Q, Cin=ci, ldx=ci, P=P, Q=Q, Cout=ci, lddy=ci)
         sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
         scale, shift, mean, invstd = sc[0], sc[1], sc[2], sc[3]
         cov = self.ws.at_least("gram.cov", ci * ci, torch.float32)
@@ -484,8 +483,8 @@ class HipEngine:
             q = self.ws.get(key + ".gq", (ci, ci), self.T)
 
             def algebra():
-                hip.host_op(R.zero_)
-                self.wgrad(g, x, R, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
+                self.wgrad(g, x, R, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co,
+                           lddy=co)
                 work = self.ws.at_least("gram.bwd", hip.gram_bn_backward_ws(ci, co), torch.float32)
                 hip.gram_bn_backward(self.d, self.w_fwd(w), R, sv["gram"]["T"], sv["gram"]["mu"], stats, tiles, rows, ci, co,
                                      bn.weight, sv["mean"], sv["invstd"], a.grad_flat(bn.weight), a.grad_flat(bn.bias),
@@ -500,8 +499,7 @@ class HipEngine:
             hip.conv_dgrad_bn_add(self.d, x, ci, ci, q, cbias, t, ci, dx, svp["c"], svp["scale"], svp["shift"], svp["mean"], stats2,
                                   rows, ci, ci)
             return dx, (stats2, tiles2)
-        hip.host_op(R.zero_)
-        self.wgrad(g, x, R, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
+        self.wgrad(g, x, R, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
         wcat = self.ws.get(key + ".gwcat", (ci, co + ci), self.T)
         coef = self.ws.at_least("gram.bwd", hip.gram_bn_backward_ws(ci, co), torch.float32)
         hip.gram_bn_backward(self.d, self.w_fwd(w), R, sv["gram"]["T"], sv["gram"]["mu"], stats, tiles, rows, ci, co, bn.weight,
@@ -569,15 +567,21 @@ class HipEngine:
         # launches of one stream run in order, so one scratch buffer per stream is race-free
         return "side" if self._side is not None and torch.cuda.current_stream() == self._side else "main"
 
-    def wgrad(self, dy, x, dw, *, dbias=None, **geom):
-        """nkb_conv_wgrad into the gradient arena, deterministic (slabs + ordered reduce) unless NKB_DET_WGRAD=0."""
+    def wgrad(self, dy, x, dw, *, dbias=None, assign=False, **geom):
+        """nkb_conv_wgrad into the gradient arena, deterministic (slabs + ordered reduce) unless NKB_DET_WGRAD=0.
+        assign: dw (a scratch product, not the arena) is overwritten — no memset in front of the launch."""
+        if assign and not _DET_WGRAD:
+            hip.host_op(dw.zero_)
+            if dbias is not None:
+                hip.host_op(dbias.zero_)
+            assign = False
         work = None
         if _DET_WGRAD:
             need = hip.conv_wgrad_workspace(self.d, N=geom["N"], P=geom["P"], Q=geom["Q"], Cin=geom["Cin"], Cout=geom["Cout"],
                                             R=geom.get("R", 1), S=geom.get("S", 1), stride=geom.get("stride", 1),
                                             pad=geom.get("pad", 0), has_bias=dbias is not None)
             work = self.ws.at_least("wgrad.slabs." + self._stream_tag(), need, torch.float32)
-        hip.conv_wgrad(self.d, dy, x, dw, dbias=dbias, workspace=work, **geom)
+        hip.conv_wgrad(self.d, dy, x, dw, dbias=dbias, workspace=work, assign=assign, **geom)
 
     def colsum2d(self, x, out, rows, C_, ld):
         """Column sums over many rows (bias / position-embedding gradients), ordered two-stage sum when rows span blocks."""
