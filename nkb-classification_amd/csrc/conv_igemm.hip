@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, OOB, 0x00020000);
     // K-concatenated launches: the activation rows of k-tiles >= kt2 come from a second tensor (plain 1x1 geometry only)
-    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(BNB == 1 ? p.x2 : nullptr), 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)((BNB == 1 || BNB == 7) ? p.x2 : nullptr), 0, OOB, 0x00020000);
 
     u32x4 sw[NWR], sx[NPX];
     int r = 0, s = 0, ck = 0;  // filter tap and channel-tile of the NEXT k-tile to load
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             if (++s == 3) { s = 0; if (++ck == cpk) { ck = 0; ++r; } }
             return;
         }
-        if (BNB == 1 && p.x2 != nullptr && kt >= p.kt2) {
+        if ((BNB == 1 || BNB == 7) && p.x2 != nullptr && kt >= p.kt2) {
             const int koff = (kt - p.kt2) * 128 + cc * 16;
 #pragma unroll
             for (int i = 0; i < NWR; ++i)
@@ -342,17 +342,17 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
     float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = ((BNB == 0 || BNB == 1 || BNB == 3) && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bv[e] = ((BNB == 0 || BNB == 1 || BNB == 3 || BNB == 7) && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
     // BNB: the stage's scale / shift / mean for this tile's channels live in LDS behind the epilogue tile (keeping them
     // in registers next to the not-yet-stored accumulators cost a wave of occupancy)
     constexpr int LDS_MAIN = (STAGE_BYTES * ((TC == 64 && !NKB_NARROW3) ? 2 : 1)) > ((TP / 2) * EROW) ? (STAGE_BYTES * ((TC == 64 && !NKB_NARROW3) ? 2 : 1))
                                                                                        : ((TP / 2) * EROW);
     float* bnl = (float*)(smem + LDS_MAIN);   // [3][TC]
-    if constexpr (BNB == 1 || BNB == 2 || BNB == 6) {
+    if constexpr (BNB == 1 || BNB == 2 || BNB == 6 || BNB == 7) {
         if (tid < TC) {
             const bool ok = c0 + tid < p.Cout;
-            if constexpr (BNB == 1) {
+            if constexpr (BNB == 1 || BNB == 7) {
                 bnl[tid] = ok ? p.bn_scale[c0 + tid] : 0.f;
                 bnl[TC + tid] = ok ? p.bn_shift[c0 + tid] : 0.f;
             }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     // BNB (bf16): the c rows of a half are requested before that half's accumulators go through LDS, so their latency
     // hides behind the LDS round trip instead of stalling every row of the store loop
     constexpr int RPH = (TP / 2) / RPP;                      // rows per thread per half
-    constexpr bool CPRE = (BNB == 1 || BNB == 2 || BNB == 6) && sizeof(T) == 2;
+    constexpr bool CPRE = (BNB == 1 || BNB == 2 || BNB == 6 || BNB == 7) && sizeof(T) == 2;
     u32x4 cpre[CPRE ? RPH : 1];
     auto prefetch_c = [&](int half) {
         if constexpr (CPRE) {
@@ -548,6 +548,43 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 }
             };
             if (p.add_scale) rows(std::true_type{}); else rows(std::false_type{});
+        }
+    } else if constexpr (BNB == 7) {
+        // lean form of the BNB == 1 epilogue (interior stage: mask recomputed from c, no residual, no parity-class remap, bf16):
+        // the c rows are already in flight (prefetch_c); no per-row geometry, no runtime flags inside the row loop
+        static_assert(sizeof(T) == 2, "bf16 only");
+        if (co < p.Cout) {
+            const int mrow = m0 + half * (TP / 2) + er;
+            bf16_t* o = (bf16_t*)p.y + yoff + (size_t)mrow * p.ldy + co;
+            const size_t ostep = (size_t)RPP * p.ldy;
+            const unsigned char* lrow = smem + er * EROW + eg * 32;
+            float sc[8], sh[8], mu[8];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f32x4 a = *(const f32x4*)(bnl + eg * 8 + 4 * h2), b = *(const f32x4*)(bnl + TC + eg * 8 + 4 * h2),
+                            c4 = *(const f32x4*)(bnl + 2 * TC + eg * 8 + 4 * h2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[4 * h2 + e] = a[e]; sh[4 * h2 + e] = b[e]; mu[4 * h2 + e] = c4[e]; }
+            }
+#pragma unroll
+            for (int ri = 0; ri < RPH; ++ri) {
+                if (mrow + RPP * ri >= p.M) break;
+                const f32x4 lo = *(const f32x4*)(lrow + ri * RPP * EROW);
+                const f32x4 hi = *(const f32x4*)(lrow + ri * RPP * EROW + 16);
+                float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3], hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
+                float cv[8];
+                unpack8(cpre[ri], cv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (!(bf2f(f2bf(cv[e] * sc[e] + sh[e])) > 0.f)) v[e] = 0.f;     // same expression / rounding as bn_apply
+                    cv[e] -= mu[e];
+                }
+                const u32x4 pk = pack8(v);
+                *(u32x4*)(o + ri * ostep) = pk;
+                unpack8(pk, v);                     // statistics see the stored value
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * cv[e]; }
+            }
         }
     } else if constexpr (BNB != 6) {
     // residual-closing fused epilogue (BNB == 2, bf16, full-grid residual): the `add` rows of this half are requested up front,
@@ -1160,7 +1197,7 @@ static int launch_conv_impl(ConvParams& p, hipStream_t stream, int batch) {
     constexpr int xrows = HALO ? 32 * ((TP + 2 + 31) / 32) : TP;
     constexpr int stage = (TC + xrows) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1);
     constexpr int epi = (TP / 2) * (TC * 4 + 16);
-    constexpr int lds = (stage > epi ? stage : epi) + ((BNB == 1 || BNB == 2 || BNB == 6) ? 3 * TC * 4 : 0);
+    constexpr int lds = (stage > epi ? stage : epi) + ((BNB == 1 || BNB == 2 || BNB == 6 || BNB == 7) ? 3 * TC * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TC, TP, BNB, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1172,7 +1209,19 @@ static int launch_conv_impl(ConvParams& p, hipStream_t stream, int batch) {
 }
 
 template <typename T, int TC, int TP, int BNB = 0>
-static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1) {
+static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1);
+// BNB == 1 launches: the lean instantiation (BNB == 7) when the geometry is the common one
+template <typename T, int TC, int TP>
+static int launch_conv_bn1(ConvParams& p, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2) {
+        static const int lean1 = [] { const char* e = getenv("NKB_LEAN_BN_EPILOGUE"); return e ? atoi(e) : 1; }();
+        if (lean1 && p.sub_h == 0 && p.add == nullptr && (p.ldy & 7) == 0 && (p.Cout & 7) == 0 && p.stats != nullptr && p.aux != nullptr)
+            return launch_conv<T, TC, TP, 7>(p, stream);
+    }
+    return launch_conv<T, TC, TP, 1>(p, stream);
+}
+template <typename T, int TC, int TP, int BNB>
+static int launch_conv(ConvParams& p, hipStream_t stream, int batch) {
     if constexpr (sizeof(T) == 2 && (NKB_NARROW3 || TC != 64)) {
         // 3x3 / stride 1 / pad 1 (forward and data gradient): the filter-row-sharing form, 3 activation tiles per
         // channel chunk instead of 9
@@ -1294,7 +1343,7 @@ extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void*
         if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 2>(p, stream) : launch_conv<bf16_t, 128, 128, 2>(p, stream);
         return narrow ? launch_conv<float, 64, 256, 2>(p, stream) : launch_conv<float, 128, 128, 2>(p, stream);
     }
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv_bn1<bf16_t, 64, 256>(p, stream) : launch_conv_bn1<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
 }
 
@@ -1365,7 +1414,7 @@ extern "C" int nkb_conv_dgrad_bn_cat(int dtype, const void* g, int ldg, int K1, 
                       ((double)M * (K1 + K2) + (double)Cout * (K1 + K2) + 2.0 * M * Cout) * esz);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv_bn1<bf16_t, 64, 256>(p, stream) : launch_conv_bn1<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
 }
 
@@ -1399,7 +1448,7 @@ extern "C" int nkb_conv_dgrad_bn_add(int dtype, const void* a, int lda, int K, c
     NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)Cout * K, ((double)M * K + (double)Cout * K + 3.0 * M * Cout) * esz);
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = Cout <= 64 && narrow_on;
-    if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
+    if (dtype == NKB_DT_BF16) return narrow ? launch_conv_bn1<bf16_t, 64, 256>(p, stream) : launch_conv_bn1<bf16_t, 128, 128>(p, stream);
     return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
 }
 
@@ -1447,7 +1496,7 @@ extern "C" int nkb_conv_dgrad_s2class(int dtype, const void* dy, const void* w_c
     static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
     const bool narrow = C <= 64 && narrow_on;
     if (c) {
-        if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 1>(p, stream) : launch_conv<bf16_t, 128, 128, 1>(p, stream);
+        if (dtype == NKB_DT_BF16) return narrow ? launch_conv_bn1<bf16_t, 64, 256>(p, stream) : launch_conv_bn1<bf16_t, 128, 128>(p, stream);
         return narrow ? launch_conv<float, 64, 256, 1>(p, stream) : launch_conv<float, 128, 128, 1>(p, stream);
     }
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream) : launch_conv_auto<bf16_t, 128, 128>(p, stream);

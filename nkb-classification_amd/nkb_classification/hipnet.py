@@ -65,6 +65,7 @@ _GRAM_BN = os.environ.get("NKB_GRAM_BN", "1") != "0"
 # Measured (same box, alternating): 20.65 ms split vs 19.72 ms one launch — the main stream's kernels shrink by 1.5 ms but it then
 # idles 0.4-3.4 ms per step at the joins (the side stream still holds the previous block's weight gradients in front of the chain).  Off.
 _GRAM_SPLIT = os.environ.get("NKB_GRAM_SPLIT", "0") != "0"
+_GRAM_MAX_C = int(os.environ.get("NKB_GRAM_MAX_C", "256"))
 
 
 class HipEngine:
@@ -426,11 +427,13 @@ class HipEngine:
         return y
 
     def gram_ok(self, conv, res, x) -> bool:
-        """The Gram form exists for bf16 1x1 / stride-1 closing stages with 64 | Cin <= 512 and Cout > 64 (every timm Bottleneck conv3)."""
+        """The Gram form exists for bf16 1x1 / stride-1 closing stages with 64 | Cin <= 512 and Cout > 64 (every timm Bottleneck conv3);
+        it is TAKEN up to Cin = 256 (_GRAM_MAX_C): the small algebra costs O(Cout * Cin^2) whatever the image count, and at Cin = 512
+        (layer4: 7 x 7 maps, 51 MB of conv output) it costs more than the two passes it removes (statistics kernel 156 us per block)."""
         w = conv.weight
         return (self.gram_bn and _RELU_BITS and _FUSED_BN_BWD and _FUSED_RES_BN_BWD and self.T == torch.bfloat16 and res is not None
                 and w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1 and conv.stride == (1, 1) and conv.padding == (0, 0)
-                and w.shape[1] % 64 == 0 and w.shape[1] <= 512 and w.shape[0] > 64 and w.shape[0] % 8 == 0 and x.dim() == 4)
+                and w.shape[1] % 64 == 0 and w.shape[1] <= _GRAM_MAX_C and w.shape[0] > 64 and w.shape[0] % 8 == 0 and x.dim() == 4)
 
     def _conv_bn_gram(self, key, x, conv, bn, res, res_affine, geom, rows):
         """Closing stage in the Gram form (train mode): G = x^T x and the column sums of x (one pass over the NARROW input), the
