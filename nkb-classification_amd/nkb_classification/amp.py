@@ -11,7 +11,9 @@ the enqueue loop from running ahead of the GPU.  Here
   * the host learns about a skipped step ONE STEP LATE, from a pinned copy of the flag that is normally complete by then, and
     only to keep the optimizer's step counters (bias corrections) exactly as torch would have them: a skipped step must not
     advance them, so the counters of the previous call are rolled back before the next one is evaluated.
-With a torch optimizer (or parameters outside the arena) the scaler defers to torch.amp.GradScaler.
+With a torch optimizer (e.g. sparse_adam), or parameters outside the arena, there is no fused launch to hand the flag to: the
+same HIP kernel then unscales every `p.grad` in place, ORing into the same device flag, and `step()` reads the flag once (the one
+host sync of this slow path) to decide whether `optimizer.step()` runs — same scale, same growth tracker, same `update()`.
 Under data parallelism the gradient exchange has finished before `step()` is called (model._backward_impl waits for the
 reducer), so every rank tests identical reduced gradients and takes the same decision.
 """
@@ -38,7 +40,6 @@ class HipGradScaler:
         self._host_event = None
         self._last_opt = None                           # optimizer whose previous step may have been skipped
         self._unscaled = set()
-        self._torch = None                              # fallback for non-fused optimizers
         self._init_growth_tracker = 0
 
     # ---- torch.amp.GradScaler surface ----------------------------------------------------------------------
@@ -62,18 +63,21 @@ class HipGradScaler:
     def get_scale(self) -> float:
         if not self._enabled:
             return 1.0
+        self._settle()
         return self._init_scale if self._state is None else float(self._state[0].item())
 
     def _fused(self, optimizer):
+        """One fused launch over the arena decides the skip on the device — only when EVERY parameter of the optimizer lives in
+        the packed arena (anything else would be stepped with gradients that were neither unscaled nor checked)."""
         from .utils import FusedOptimizer
-        return isinstance(optimizer, FusedOptimizer) and optimizer.arena is not None and optimizer.arena.packed
+        if not (isinstance(optimizer, FusedOptimizer) and optimizer.arena is not None and optimizer.arena.packed):
+            return False
+        a = optimizer.arena
+        return all(a.owns(p) for g in optimizer.param_groups for p in g["params"])
 
-    def _fallback(self):
-        if self._torch is None:
-            self._torch = torch.amp.GradScaler("cuda", init_scale=self.get_scale(), growth_factor=self._growth_factor,
-                                               backoff_factor=self._backoff_factor,
-                                               growth_interval=self._growth_interval, enabled=True)
-        return self._torch
+    def settle(self):
+        """Public flush: make the optimizer's step counters reflect a possibly skipped LAST step (call before checkpoints)."""
+        self._settle()
 
     def _settle(self):
         """Apply what the PREVIOUS step's flag says: a skipped step must not have advanced the optimizer's counters."""
@@ -88,10 +92,29 @@ class HipGradScaler:
     def unscale_(self, optimizer):
         if not self._enabled:
             return
-        if not self._fused(optimizer):
-            return self._fallback().unscale_(optimizer)
         if id(optimizer) in self._unscaled:
             raise RuntimeError("unscale_() has already been called on this optimizer since the last update().")
+        if not self._fused(optimizer):
+            # per-parameter form: the same kernel over every gradient tensor, one shared device flag
+            for group in optimizer.param_groups:
+                for p in group["params"]:
+                    g = p.grad
+                    if g is None:
+                        continue
+                    if g.is_sparse:
+                        g = g._values()
+                    if g.dtype != torch.float32 or not g.is_cuda:
+                        raise RuntimeError("HipGradScaler: gradients must be fp32 tensors on a cuda device")
+                    self._lazy_init(g.device)
+                    flat = g if g.is_contiguous() else None
+                    if flat is None:
+                        flat = g.contiguous()
+                    with torch.cuda.device(g.device):
+                        hip.grad_unscale_check(flat, flat.numel(), self._state[0:1], self._state[1:2])
+                    if flat is not g:
+                        g.copy_(flat)
+            self._unscaled.add(id(optimizer))
+            return
         a = optimizer.arena
         self._lazy_init(a.flat_grad.device)
         with torch.cuda.device(a.flat_grad.device):
@@ -101,11 +124,15 @@ class HipGradScaler:
     def step(self, optimizer, *args, **kwargs):
         if not self._enabled:
             return optimizer.step(*args, **kwargs)
-        if not self._fused(optimizer):
-            return self._fallback().step(optimizer, *args, **kwargs)
         self._settle()
         if id(optimizer) not in self._unscaled:
             self.unscale_(optimizer)
+        if not self._fused(optimizer):
+            if self._state is None:                     # nothing had a gradient
+                return optimizer.step(*args, **kwargs)
+            if float(self._state[1].item()) != 0.0:     # the slow path's one host read: skip, as torch's GradScaler.step does
+                return None
+            return optimizer.step(*args, **kwargs)
         out = optimizer.step(*args, skip_flag=self._state[1:2], **kwargs)
         self._last_opt = optimizer
         return out
@@ -113,8 +140,6 @@ class HipGradScaler:
     def update(self, new_scale=None):
         if not self._enabled:
             return
-        if self._torch is not None and self._state is None:
-            return self._torch.update(new_scale)
         if self._state is None:
             return
         if new_scale is not None:
@@ -130,6 +155,7 @@ class HipGradScaler:
     def state_dict(self):
         if not self._enabled:
             return {}
+        self._settle()
         tracker = self._init_growth_tracker if self._tracker is None else int(self._tracker.item())
         return {"scale": self.get_scale(), "growth_factor": self._growth_factor, "backoff_factor": self._backoff_factor,
                 "growth_interval": self._growth_interval, "_growth_tracker": tracker}

@@ -108,12 +108,17 @@ class ImbalancedDatasetSampler(Sampler):
 
 
 class ShardedSampler(Sampler):
-    """Data-parallel split: the same seeded permutation on every rank (re-drawn per epoch through set_epoch), padded to a
-    multiple of the world size, rank r taking positions r::world."""
+    """Data-parallel split: the same seeded permutation on every rank (re-drawn per epoch through set_epoch), rank r taking
+    positions r::world.  pad=True (training: every rank must run the same number of steps, the gradient exchange is a
+    collective) repeats the first indices up to a multiple of the world size — `real_len` tells how many of this rank's samples
+    are NOT such repeats, so that gathered epoch results can drop them; pad=False (validation: no collective runs inside
+    val_epoch) leaves the shards uneven and every sample is seen exactly once."""
 
-    def __init__(self, n, rank, world, shuffle=True, seed=0):
+    def __init__(self, n, rank, world, shuffle=True, seed=0, pad=True):
         self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
-        self.num_samples = (n + world - 1) // world
+        self.pad = pad
+        self.real_len = max(0, (n - rank + world - 1) // world)
+        self.num_samples = (n + world - 1) // world if pad else self.real_len
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -123,7 +128,8 @@ class ShardedSampler(Sampler):
             order = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist()
         else:
             order = list(range(self.n))
-        order += order[: self.num_samples * self.world - self.n]
+        if self.pad:
+            order += order[: self.num_samples * self.world - self.n]
         return iter(order[self.rank::self.world])
 
     def __len__(self):
@@ -229,7 +235,8 @@ def get_dataset(data, pipeline=None):
         sampler, shuffle = ImbalancedDatasetSampler(ds, seed=data.get("shard_seed", 0) if world > 1 else None, rank=rank,
                                                     world=world), False
     elif world > 1:
-        sampler, shuffle = ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=data.get("shard_seed", 0)), False
+        sampler, shuffle = ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=data.get("shard_seed", 0),
+                                          pad=bool(data.get("shard_pad", True))), False
     loader = DataLoader(ds, batch_size=data["batch_size"], shuffle=shuffle, sampler=sampler,
                         num_workers=data.get("num_workers", 0), drop_last=data.get("drop_last", False), pin_memory=True)
     if on_device:

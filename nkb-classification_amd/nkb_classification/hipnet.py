@@ -65,7 +65,7 @@ _GRAM_BN = os.environ.get("NKB_GRAM_BN", "1") != "0"
 # Measured (same box, alternating): 20.65 ms split vs 19.72 ms one launch — the main stream's kernels shrink by 1.5 ms but it then
 # idles 0.4-3.4 ms per step at the joins (the side stream still holds the previous block's weight gradients in front of the chain).  Off.
 _GRAM_SPLIT = os.environ.get("NKB_GRAM_SPLIT", "0") != "0"
-_GRAM_MAX_C = int(os.environ.get("NKB_GRAM_MAX_C", "256"))
+_GRAM_MAX_C = int(os.environ.get("NKB_GRAM_MAX_C", "128"))
 
 
 class HipEngine:
@@ -428,8 +428,9 @@ class HipEngine:
 
     def gram_ok(self, conv, res, x) -> bool:
         """The Gram form exists for bf16 1x1 / stride-1 closing stages with 64 | Cin <= 512 and Cout > 64 (every timm Bottleneck conv3);
-        it is TAKEN up to Cin = 256 (_GRAM_MAX_C): the small algebra costs O(Cout * Cin^2) whatever the image count, and at Cin = 512
-        (layer4: 7 x 7 maps, 51 MB of conv output) it costs more than the two passes it removes (statistics kernel 156 us per block)."""
+        it is TAKEN up to Cin = 128 (_GRAM_MAX_C; ResNet-50 layer1 / layer2, 7 of 16 blocks, 73 % of the closing-stage bytes): the small
+        algebra costs O(Cout * Cin^2) whatever the image count, and the launches around it are latency-bound — same box, alternating:
+        Cin <= 512 19.13 ms, <= 256 18.65 / 18.70, <= 128 18.40 (layer3: 14 x 14 maps, 103 MB of conv output per block; layer4: 51 MB)."""
         w = conv.weight
         return (self.gram_bn and _RELU_BITS and _FUSED_BN_BWD and _FUSED_RES_BN_BWD and self.T == torch.bfloat16 and res is not None
                 and w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1 and conv.stride == (1, 1) and conv.padding == (0, 0)

@@ -141,14 +141,22 @@ def attach(model, optimizer, device) -> GradReducer:
     return reducer
 
 
-def gather_epoch_results(results: dict) -> dict:
+def gather_epoch_results(results: dict, real_len=None) -> dict:
     """Concatenate the per-rank result lists of engine.train_epoch / val_epoch (logging.py:287-294) in rank order, so that
-    metrics.compute_metrics sees the whole epoch on every rank.  Single-process runs pass through."""
+    metrics.compute_metrics sees the whole epoch on every rank.  Single-process runs pass through.
+    real_len: how many of THIS rank's samples are real (ShardedSampler.real_len) — a padded training shard repeats the first
+    indices of the permutation at its tail, and those repeats must not be counted twice in the epoch metrics or in the choice
+    of best.pth; the per-sample lists (confidences, predictions, ground truth) are cut to it before the exchange."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return results
     keys = ("running_loss", "confidences", "predictions", "ground_truth")
+    mine = {k: results[k] for k in keys}
+    if real_len is not None:
+        for k in ("confidences", "predictions", "ground_truth"):
+            v = mine[k]
+            mine[k] = {t: vals[:real_len] for t, vals in v.items()} if isinstance(v, dict) else v[:real_len]
     parts = [None] * dist.get_world_size()
-    dist.all_gather_object(parts, {k: results[k] for k in keys})
+    dist.all_gather_object(parts, mine)
     out = dict(results)
     for k in keys:
         if isinstance(results[k], dict):

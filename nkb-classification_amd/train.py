@@ -51,6 +51,7 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, come
     train_logger = TrainLogger(cfg, comet_experiment, local_experiment, classes)
     train_logger.log_images_at_start(train_loader)
     scaler = HipGradScaler("cuda", enabled=cfg.enable_gradient_scaler)
+    train_results = val_results = None
 
     for epoch in tqdm(range(cfg.n_epochs), desc="Training epochs", disable=not rank0):
         if epoch in cfg.backbone_state_policy.keys():
@@ -60,8 +61,11 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, come
             if hasattr(sampler, "set_epoch"):
                 sampler.set_epoch(epoch)                 # data parallel: the shared permutation is re-drawn per epoch
         train_results = parallel.gather_epoch_results(
-            train_epoch(model, train_loader, optimizer, scheduler, scaler, criterion, device, cfg, train_logger))
-        val_results = parallel.gather_epoch_results(val_epoch(model, val_loader, criterion, device, cfg, train_logger))
+            train_epoch(model, train_loader, optimizer, scheduler, scaler, criterion, device, cfg, train_logger),
+            real_len=_real_len(train_loader))
+        scaler.settle()          # a skipped LAST step must not stay counted in the optimizer state the checkpoint sees
+        val_results = parallel.gather_epoch_results(val_epoch(model, val_loader, criterion, device, cfg, train_logger),
+                                                    real_len=_real_len(val_loader))
         train_results["metrics"] = compute_metrics(cfg, train_results)
         val_results["metrics"] = compute_metrics(cfg, val_results)
         epoch_val_acc = val_results["metrics"]["epoch_acc"]
@@ -74,15 +78,16 @@ def train(model, train_loader, val_loader, optimizer, scheduler, criterion, come
             save_scripted(model, Path(model_path, "scripted_best.pt"))
         torch.save(model.state_dict(), Path(model_path, "last.pth"))
         save_scripted(model, Path(model_path, "scripted_last.pt"))
-    dump = os.environ.get("NKB_DUMP_PARAMS")
-    if dump:         # test hook (tests/test_step_semantics_gpu.py): what THIS rank ended up with
-        sampler = getattr(getattr(train_loader, "loader", train_loader), "sampler", None)
-        gt = train_results["ground_truth"]
-        torch.save(dict(flat_param=model.arena.flat_param.cpu(), buffers={k: v.cpu() for k, v in model.named_buffers()},
-                        head_weight=model.state_dict()["classifier.1.weight"].cpu() if cfg.task == "single" else None,
-                        n_train=len(gt) if isinstance(gt, list) else len(next(iter(gt.values()))),
-                        dataset_len=len(train_loader.dataset), shard_len=len(sampler) if sampler is not None else -1),
-                   Path(dump, f"params_rank{parallel.rank()}.pt"))
+    return train_results, val_results
+
+
+def _real_len(loader):
+    """Samples of this rank's shard that are not padding repeats (None: not a sharded loader)."""
+    sampler = getattr(getattr(loader, "loader", loader), "sampler", None)
+    return getattr(sampler, "real_len", None)
+
+
+_after_train = None      # callable(model=, train_loader=, val_loader=, results=, cfg=): set by a wrapper that imports this module
 
 
 def main():
@@ -107,7 +112,8 @@ def main():
     train_loader = get_dataset({**cfg.train_data, **shard}, getattr(cfg, "train_pipeline", None))  # noqa: F821
     classes = train_loader.dataset.classes
     val_data = cfg.val_data if "classes" in cfg.val_data.keys() else {**cfg.val_data, "classes": classes}  # noqa: F821
-    val_loader = get_dataset({**val_data, **shard}, getattr(cfg, "val_pipeline", None))
+    # validation shards stay unpadded: no collective runs inside val_epoch, and every image must count exactly once
+    val_loader = get_dataset({**val_data, **shard, **({"shard_pad": False} if world > 1 else {})}, getattr(cfg, "val_pipeline", None))
     model = get_model(cfg.model, classes, device, compile=cfg.compile)  # noqa: F821
     optimizer = get_optimizer(model, cfg_optimizer=cfg.optimizer)  # noqa: F821
     scheduler = get_scheduler(optimizer, cfg.lr_policy)  # noqa: F821
@@ -117,7 +123,9 @@ def main():
         torch.manual_seed(seed + 1 + rank)     # dropout / stochastic-depth draws differ per rank from here on
     # train.py:104-108: only rank 0 owns the run directory (no exists()->mkdir race, one metrics.csv)
     local_experiment = get_local_experiment(cfg.experiment["local"]) if rank == 0 else None  # noqa: F821
-    train(model, train_loader, val_loader, optimizer, scheduler, criterion, None, local_experiment, device, cfg)  # noqa: F821
+    out = train(model, train_loader, val_loader, optimizer, scheduler, criterion, None, local_experiment, device, cfg)  # noqa: F821
+    if _after_train is not None:
+        _after_train(model=model, train_loader=train_loader, val_loader=val_loader, results=out, cfg=cfg)  # noqa: F821
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -52,6 +52,46 @@ def test_grad_reducer_world2_gloo():
     assert sorted(results) == [(0, True), (1, True)]
 
 
+def _gather_worker(rank, world, port, q):
+    """Odd dataset length: 7 samples over 2 ranks.  The padded training shards hold 4 + 4 samples, one of them a
+    repeat; the gathered epoch must hold each of the 7 exactly once.  Unpadded validation shards (4 + 3) pass through whole."""
+    from nkb_classification.dataset import ShardedSampler
+    from nkb_classification.parallel import gather_epoch_results
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 7
+        ok = True
+        for pad in (True, False):
+            smp = ShardedSampler(n, rank, world, shuffle=True, seed=3, pad=pad)
+            idx = list(iter(smp))
+            ok &= len(idx) == len(smp) == (4 if pad else (4 if rank == 0 else 3)) and smp.real_len == (4 if rank == 0 else 3)
+            res = dict(running_loss=[0.5] * 2, confidences=[[float(i)] for i in idx], predictions=list(idx), ground_truth=list(idx))
+            out = gather_epoch_results(res, real_len=smp.real_len)
+            ok &= sorted(out["ground_truth"]) == list(range(n)) and len(out["confidences"]) == n and len(out["running_loss"]) == 4
+            multi = dict(running_loss={"a": [0.5], "loss": [0.5]}, confidences={"a": [[float(i)] for i in idx]},
+                         predictions={"a": list(idx)}, ground_truth={"a": list(idx)})
+            outm = gather_epoch_results(multi, real_len=smp.real_len)
+            ok &= sorted(outm["ground_truth"]["a"]) == list(range(n))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gathered_epoch_counts_every_sample_once_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
 def test_reducer_requires_process_group():
     with pytest.raises(RuntimeError, match="process group"):
         GradReducer(types.SimpleNamespace(arena=None, grad_ready_hook=None))

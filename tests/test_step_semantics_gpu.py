@@ -109,6 +109,89 @@ def test_grad_scaler_unscale_exposes_true_gradients():
     assert HipGradScaler(enabled=False).scale(x) is x and HipGradScaler(enabled=False).get_scale() == 1.0
 
 
+def test_grad_scaler_tracks_torch_amp_gradscaler_step_by_step():
+    """A15 against the class the reference instantiates (/root/reference/train.py:37, used at engine.py:55-60): the SAME inf pattern is
+    driven through torch.amp.GradScaler on the oracle module (torch kernels, fp32) and through HipGradScaler on the HIP model; after
+    every step the scale, the growth tracker, the skip decision and the parameters must agree."""
+    from oracle.torch_models import OracleClassifier
+    cfg_model = dict(model="resnet_tiny_bottleneck", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_", task="single")
+    torch.manual_seed(0)
+    ref = OracleClassifier(cfg_model, ["a", "b", "c"]).to(DEV)
+    model = get_model(dict(cfg_model), ["a", "b", "c"], DEV)
+    model.load_state_dict(ref.state_dict())
+    cfg_opt = dict(type="sgd", lr=0.05, weight_decay=0.0)       # (updates linear in the gradients: parameters stay comparable)
+    o_hip = get_optimizer(model, cfg_opt)
+    o_ref = torch.optim.SGD(ref.parameters(), lr=0.05)
+    kw = dict(init_scale=256.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2)
+    s_hip, s_ref = HipGradScaler("cuda", **kw), torch.amp.GradScaler("cuda", **kw)
+    g = torch.Generator().manual_seed(3)
+    poison = [False, True, False, False, True, True, False, False, False]
+    ref.train(); model.train()
+    for i, bad in enumerate(poison):
+        x = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+        y = torch.randint(0, 3, (4,), generator=g).to(DEV)
+        o_ref.zero_grad()
+        s_ref.scale(torch.nn.functional.cross_entropy(ref(x), y)).backward()
+        if bad:
+            next(ref.parameters()).grad.view(-1)[0] = float("inf")
+        before_ref = [p.detach().clone() for p in ref.parameters()]
+        s_ref.step(o_ref)
+        s_ref.update()
+        skipped_ref = all(torch.equal(a, b.detach()) for a, b in zip(before_ref, ref.parameters()))
+        o_hip.zero_grad()
+        s_hip.scale(torch.nn.functional.cross_entropy(model(x), y)).backward()
+        if bad:
+            model.arena.flat_grad[0] = float("inf")
+        before_hip = model.arena.flat_param.clone()
+        s_hip.step(o_hip)
+        s_hip.update()
+        torch.cuda.synchronize()
+        skipped_hip = torch.equal(before_hip, model.arena.flat_param)
+        assert skipped_hip == skipped_ref == bad, (i, skipped_hip, skipped_ref)
+        assert s_hip.get_scale() == s_ref.get_scale(), (i, s_hip.get_scale(), s_ref.get_scale())
+        assert s_hip.state_dict()["_growth_tracker"] == s_ref.state_dict()["_growth_tracker"], i
+    sd = {k: v for k, v in model.state_dict().items()}
+    for name, p in ref.named_parameters():
+        torch.testing.assert_close(sd[name].float(), p.detach(), rtol=2e-3, atol=2e-4, msg=name)
+
+
+def test_grad_scaler_with_a_torch_optimizer_and_outside_parameters():
+    """an optimizer that is not the fused one (here torch's SGD over the model's parameters plus one parameter that lives
+    outside the arena) goes through the per-parameter unscale + one host read of the flag: finite step applied with UNSCALED
+    gradients, poisoned step skipped, scale backs off — with the same scale / tracker state as the fused path."""
+    a, b = _tiny(), _tiny()
+    b.load_state_dict(a.state_dict())
+    extra_a, extra_b = (torch.nn.Parameter(torch.ones(5, device=DEV)) for _ in range(2))
+    oa = torch.optim.SGD(list(a.parameters()) + [extra_a], lr=0.1)
+    ob = torch.optim.SGD(list(b.parameters()) + [extra_b], lr=0.1)
+    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), DEV)
+    x, y = torch.randn(4, 3, 64, 64).to(DEV), torch.tensor([0, 1, 2, 1]).to(DEV)
+    a.train(); b.train()
+    scaler = HipGradScaler("cuda", init_scale=2048.0, growth_interval=100)
+    assert not scaler._fused(oa)
+    ob.zero_grad()
+    (crit(b(x), y) + extra_b.pow(2).sum()).backward()
+    ob.step()
+    oa.zero_grad()
+    scaler.scale(crit(a(x), y) + extra_a.pow(2).sum()).backward()
+    scaler.step(oa)
+    scaler.update()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a.arena.flat_param, b.arena.flat_param, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(extra_a.detach(), extra_b.detach(), rtol=1e-5, atol=1e-7)
+    assert scaler.get_scale() == 2048.0
+    keep, keep_extra = a.arena.flat_param.clone(), extra_a.detach().clone()
+    oa.zero_grad()
+    scaler.scale(crit(a(x), y) + extra_a.pow(2).sum()).backward()
+    extra_a.grad[2] = float("nan")                                # the overflow sits in the parameter OUTSIDE the arena
+    scaler.step(oa)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert torch.equal(a.arena.flat_param, keep) and torch.equal(extra_a.detach(), keep_extra)
+    assert scaler.get_scale() == 1024.0 and scaler.state_dict()["_growth_tracker"] == 0
+
+
 # ------------------------------------------------------------------------------------------------------ logger ----
 def test_logger_lists_match_reference_golden(golden):
     """A16 / G5: the device-side logger returns the lists the reference's BaseLogger produced for the same inputs."""
@@ -183,16 +266,19 @@ def test_out_of_range_label_poisons_the_loss():
 
 
 # ------------------------------------------------------------------------------------- data-parallel entry point ----
-def _launch_train(tmp_path, nproc, extra_env=None):
+def _launch_train(tmp_path, nproc, extra_env=None, edits=()):
     root = ROOT / "nkb-classification_amd"
     cfg = (root / "configs" / "synthetic_singletask_config.py").read_text().replace(
         '"runs/synthetic_single"', repr(str(tmp_path / "exp"))).replace(
         "enable_gradient_scaler = False", "enable_gradient_scaler = True")
+    for a, b in edits:
+        assert a in cfg
+        cfg = cfg.replace(a, b)
     assert "enable_gradient_scaler = True" in cfg
     (tmp_path / "cfg_ddp.py").write_text(cfg)
     env = dict(os.environ, NKB_DDP_BACKEND="gloo", NKB_DDP_ONE_GPU="1", NKB_DUMP_PARAMS=str(tmp_path), **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
-           "127.0.0.1", "--master-port", str(29900 + os.getpid() % 500), str(root / "train.py"), "-cfg",
+           "127.0.0.1", "--master-port", str(29900 + os.getpid() % 500), str(ROOT / "tests" / "ddp_train_probe.py"), "-cfg",
            str(tmp_path / "cfg_ddp.py")]
     return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
 
@@ -220,6 +306,19 @@ def test_train_py_under_torchrun_two_ranks(tmp_path):
     assert d0["n_train"] == d1["n_train"] == d0["dataset_len"] > d0["shard_len"]     # gathered epoch covers every image
     sd = torch.load(exp / "weights" / "last.pth", map_location="cpu")
     torch.testing.assert_close(sd["classifier.1.weight"], d1["head_weight"])          # rank 1 agrees with rank 0's checkpoint
+
+
+def test_train_py_two_ranks_odd_dataset_counts_every_image_once(tmp_path):
+    """with len(dataset) % world != 0 the padded training shard repeats an index and a padded validation shard would
+    too — epoch metrics and the choice of best.pth must still be computed over each image exactly once (255 train / 127 val
+    images on 2 ranks: shards of 128 + 128 with one repeat, validation shards of 64 + 63 unpadded)."""
+    r = _launch_train(tmp_path, 2, edits=(('"n_images": 256', '"n_images": 255'), ('"n_images": 128', '"n_images": 127')))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d0, d1 = (torch.load(tmp_path / f"params_rank{k}.pt") for k in (0, 1))
+    assert d0["dataset_len"] == 255 and d0["val_len"] == 127
+    assert d0["n_train"] == d1["n_train"] == 255 and d0["n_val"] == d1["n_val"] == 127
+    assert d0["shard_len"] == d1["shard_len"] == 128
+    assert torch.equal(d0["flat_param"], d1["flat_param"])
 
 
 def _scaler_ddp_worker(rank, world, port, q):
