@@ -42,7 +42,16 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}   # dense MFMA peaks
 # v_mfma_f32_16x16x128_f8f6f4 (twice the bf16 rate, the ~5 PF dense figure), so the fp8 run's GEMM family and its step are priced
 # against 5 PFLOP/s although attention / the remaining bf16 work can only reach half of that
 HBM_PEAK_GBS = 8000.0                          # HBM3E, MI355X_MICROARCH.md
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"      # regenerate with scripts/pmc_traffic.py after any kernel change
+# HBM-side traffic ON FILE per benchmarked workload (scripts/collect_profiles.sh -> scripts/pmc_traffic.py; regenerate after any
+# kernel change).  key = (model, batch, dtype)
+PMC_TRAFFIC_FILES = {("resnet50", 256, "bf16"): "r03_resnet50_bf16_pmc_traffic.json",
+                     ("vit_base_patch16_224", 256, "bf16"): "r03_vit_b16_bf16_pmc_traffic.json",
+                     ("unicom ViT-L/14", 128, "bf16"): "r03_unicom_vit_l14_bf16_pmc_traffic.json",
+                     ("unicom ViT-L/14", 128, "fp8"): "r03_unicom_vit_l14_fp8_pmc_traffic.json"}
+# profiler tag (api.hip kernel ids) -> families of scripts/pmc_traffic.py that hold the same launches
+TRAFFIC_FAMILIES = {"conv_igemm": ("conv_igemm_fwd", "conv_igemm_bwd", "gemm8p_fwd", "gemm8p_bwd"),
+                    "conv_wgrad": ("conv_wgrad", "wgrad8p", "wgrad8f", "wgrad3x3"), "bn_apply": ("bn_apply",),
+                    "bn_bwd_apply": ("bn_bwd_apply",), "attn": ("attn_fwd", "attn_bwd", "attn_other"), "ln": ("layernorm",)}
 
 
 def log(*a):
@@ -50,22 +59,23 @@ def log(*a):
 
 
 def pmc_traffic(args, kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
-    (PMC_TRAFFIC_FILE, produced by scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).
-    A bench run cannot profile itself (counter collection needs its own rocprofv3 passes), so this is the measurement ON FILE
-    for the default workload — the line says so in roofline.traffic_source; any other workload reports null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
-    if not (args.model == "resnet50" and args.batch == 256 and args.dtype == "bf16" and os.path.exists(path)):
-        return None
+    """(HBM-side bytes per launch of `kernel`, HBM-side GB per step, file) from the committed rocprofv3 PMC passes over this same
+    command (scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  A bench run cannot profile
+    itself (counter collection needs its own rocprofv3 passes), so this is the measurement ON FILE for this workload — the line
+    says so in roofline.traffic_source; a workload without a file reports null."""
+    name = PMC_TRAFFIC_FILES.get((args.model, args.batch, args.dtype))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name) if name else None
+    if not (path and os.path.exists(path)):
+        return None, None, None
     try:
         with open(path) as f:
-            ks = json.load(f)["kernels"]
-        if kernel == "conv_igemm":      # launch-weighted mean over the forward and data-gradient launches
-            parts = [ks[k] for k in ("conv_igemm_fwd", "conv_igemm_dgrad")]
-            return round(sum(x["traffic_bytes_per_launch"] * x["launches"] for x in parts) / sum(x["launches"] for x in parts))
-        return ks[kernel]["traffic_bytes_per_launch"]
-    except (KeyError, ValueError):
-        return None
+            doc = json.load(f)
+        ks = doc["kernels"]
+        parts = [ks[k] for k in TRAFFIC_FAMILIES.get(kernel, (kernel,)) if k in ks]
+        per_launch = round(sum(x["traffic_bytes_per_launch"] * x["launches"] for x in parts) / sum(x["launches"] for x in parts)) if parts else None
+        return per_launch, round(doc["step_total_bytes"] / 1e9, 2), name
+    except (KeyError, ValueError, ZeroDivisionError):
+        return None, None, None
 
 
 def usable_cpus() -> int:
@@ -220,6 +230,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    dist_info = None
+    if dist.is_initialized():
+        # what the process group really is: every rank contributes a one, so `ranks_seen` is counted by the collective itself
+        ones = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        dist_info = {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "world": dist.get_world_size(),
+                     "ranks_seen": int(ones.item())}
 
     from nkb_classification import hip
     from nkb_classification.logging import softmax_argmax
@@ -385,9 +403,9 @@ def main():
             peak_tf, peak_gbs = PEAK_TFLOPS[args.dtype], HBM_PEAK_GBS
             t_mfma, t_hbm = v["work"] / (peak_tf * 1e12), v.get("bytes", 0.0) / (peak_gbs * 1e9)
             total_ms = sum(x["ms"] for x in prof.values())
-            traffic = pmc_traffic(args, name)
+            traffic, step_traffic_gb, tfile = pmc_traffic(args, name)
             common = dict(traffic=traffic,
-                          traffic_source=(f"profiles/{PMC_TRAFFIC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                          traffic_source=(f"profiles/{tfile}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                           "over this command, not this run") if traffic is not None else None,
                           kernel=name, launches_per_step=v["launches"] // nprof,
                           avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
@@ -440,6 +458,10 @@ def main():
             "step_tflops": round(ips * gflop / 1e3, 1) if gflop else None,
             "step_mfma_frac": round(ips * gflop / 1e3 / PEAK_TFLOPS[args.dtype], 4) if gflop else None,
             "final_loss": round(final_loss, 4),
+            # HBM-side GB per step from the same PMC passes the roofline's `traffic` comes from (null: no file for this workload)
+            "step_traffic_gb": pmc_traffic(args, "conv_igemm")[1],
+            # data parallel: what the process group really was (ranks counted by an all-reduce of ones)
+            "dist": dist_info,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: round(v["ms"] / max(min(args.steps, 5), 1), 3) for k, v in

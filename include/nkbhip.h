@@ -331,6 +331,10 @@ int nkb_loss_backward(const float* probs, int ldp, const long long* target, cons
 int nkb_optim_step(int kind, float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n, float lr,
                    float wd, float beta1, float beta2, float eps, float grad_scale, float c0, float c1, float c2,
                    float c3, const float* skip_flag, nkb_stream_t stream);
+/* Data-parallel gradient exchange in bf16 with fp32 accumulation (new functionality: the reference is single-device,
+ * /root/reference/train.py:98): out[i] = sum_{p < nparts} parts[p * stride + i] accumulated in fp32 in part order, optional bf16 copy of
+ * the sum; nparts = 1 widens a received bf16 bucket back into the fp32 gradient arena. */
+int nkb_bucket_sum_bf16(const void* parts, long long stride, int nparts, float* out, void* out_bf16, long long n, nkb_stream_t stream);
 /* Gradient scaler (train.py:37 torch.cuda.amp.GradScaler; engine.py:55-60): in-place g *= 1 / *scale with an inf/nan check
  * (*found_inf = 1 when any unscaled value is not finite), and the scale / growth-tracker update of GradScaler.update();
  * the update also copies found_inf to *last_found_inf and clears found_inf.  scale, found_inf: device floats. */

@@ -218,3 +218,47 @@ extern "C" int nkb_scaler_update(float* scale, int* growth_tracker, float* found
                        growth, backoff, interval);
     return nkb_check_launch("scaler_update");
 }
+
+// ---- data-parallel gradient exchange in bf16 with fp32 accumulation (parallel.GradReducer, bf16 bucket mode) -------------------
+// out[i] = sum over p < nparts of parts[p * stride + i], summed in fp32 in part order; optional bf16 copy of the sum (the payload
+// of the all-gather that follows).  nparts = 1 widens a received bf16 bucket back into the fp32 gradient arena.
+__global__ __launch_bounds__(256) void bucket_sum_kernel(const bf16_t* __restrict__ parts, long long stride, int nparts,
+                                                         float* __restrict__ out, bf16_t* __restrict__ out16, long long n) {
+    const long long n8 = n >> 3;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (long long)gridDim.x * blockDim.x) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < nparts; ++p) {
+            float f[8];
+            unpack8(*(const u32x4*)(parts + (size_t)p * stride + 8 * c), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+        if (out) {
+            *(f32x4*)(out + 8 * c) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+            *(f32x4*)(out + 8 * c + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+        }
+        if (out16) *(u32x4*)(out16 + 8 * c) = pack8(acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 7)) {
+        const long long i = (n8 << 3) + threadIdx.x;
+        float a = 0.f;
+        for (int p = 0; p < nparts; ++p) a += bf2f(parts[(size_t)p * stride + i]);
+        if (out) out[i] = a;
+        if (out16) out16[i] = f2bf(a);
+    }
+}
+extern "C" int nkb_bucket_sum_bf16(const void* parts, long long stride, int nparts, float* out, void* out_bf16, long long n,
+                                   hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (nparts < 1 || (!out && !out_bf16) || (stride & 7) || (((uintptr_t)parts | (uintptr_t)out | (uintptr_t)out_bf16) & 15)) {
+        nkb_set_error("bucket_sum_bf16: nparts >= 1, an output, stride %% 8 == 0 and 16-byte-aligned pointers required");
+        return 1;
+    }
+    NkbProfScope prof(NKB_K_MISC, stream, 0, (double)n * (2.0 * nparts + (out ? 4 : 0) + (out_bf16 ? 2 : 0)));
+    long long g = ((n >> 3) + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(bucket_sum_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)parts, stride, nparts, out,
+                       (bf16_t*)out_bf16, n);
+    return nkb_check_launch("bucket_sum_bf16");
+}

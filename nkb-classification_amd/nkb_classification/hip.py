@@ -92,6 +92,7 @@ _SIGS = {
     "nkb_optim_step": (i32, [i32, vp, vp, vp, vp, vp, i64] + [f32] * 10 + [vp, vp]),
     "nkb_grad_unscale_check": (i32, [vp, i64, vp, vp, vp]),
     "nkb_scaler_update": (i32, [vp, vp, vp, vp, f32, f32, i32, vp]),
+    "nkb_bucket_sum_bf16": (i32, [vp, i64, i32, vp, vp, i64, vp]),
     "nkb_segment_sumsq": (i32, [vp, vp, i32, vp, vp]),
     "nkb_gemm8p_config": (None, [i32, i32, i32]),
     "nkb_fp8_quantize": (i32, [i32, i32, vp, i64, vp, vp, vp]),
@@ -506,6 +507,10 @@ def optim_step(kind, p, g, m, v, shadow, n, lr, wd, beta1, beta2, eps, grad_scal
                skip_flag=None):
     check(load().nkb_optim_step(kind, ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), n, lr, wd, beta1, beta2, eps,
                                 grad_scale, c0, c1, c2, c3, ptr(skip_flag), stream()), "optim_step")
+
+
+def bucket_sum_bf16(parts, stride, nparts, out, out_bf16, n):
+    check(load().nkb_bucket_sum_bf16(ptr(parts), stride, nparts, ptr(out), ptr(out_bf16), n, stream()), "bucket_sum_bf16")
 
 
 def grad_unscale_check(g, n, scale, found_inf):

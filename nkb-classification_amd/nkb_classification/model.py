@@ -28,6 +28,11 @@ from .runtime import ParamArena
 _PLANS = os.environ.get("NKB_PLAN", "1") != "0"
 
 
+def _alloc_count(device) -> int:
+    """Number of device allocations torch has served so far (cache hits included)."""
+    return int(torch.cuda.memory_stats(device).get("allocation.all.allocated", 0))
+
+
 class _NetFn(torch.autograd.Function):
     """model(img) as a single autograd node.  Parameters are passed only so autograd schedules backward; their
     gradients are written straight into the arena (returned as None here) — see ParamArena.publish_grads."""
@@ -186,7 +191,10 @@ class _HipClassifier(nn.Module):
         if not (_PLANS and train):
             run()
             return logits
-        key = ("fwd", tuple(img.shape), need_dgrad, drop_p, eng.overlap_wgrad, self.arena.total, eng.fp8, eng.gram_bn)
+        # (the arena's base address and the requires_grad pattern are part of the key: a re-packed arena or a changed freeze
+        # pattern must never replay pointers / launch sequences recorded for the old one — ADVICE r2)
+        key = ("fwd", tuple(img.shape), need_dgrad, drop_p, eng.overlap_wgrad, self.arena.total, eng.fp8, eng.gram_bn,
+               self.arena.flat_param.data_ptr(), hash(tuple(p.requires_grad for p in self.parameters())))
         self._fwd_key = key
         ent = eng.plans.get(key)
         if ent is not None and ent[1] == eng.ws.generation:
@@ -197,6 +205,7 @@ class _HipClassifier(nn.Module):
         record = eng.plan_seen.get(key) == eng.ws.generation
         if record:
             hip.record_begin()
+        allocs = _alloc_count(img.device)
         try:
             run()
         except BaseException:
@@ -204,7 +213,9 @@ class _HipClassifier(nn.Module):
             raise
         if record:
             plan = hip.record_end({"img": img, "logits": logits})
-            if eng.plan_seen.get(key) == eng.ws.generation:
+            # a plan freezes raw addresses: it is only kept when the recorded run allocated NOTHING (every buffer it touched is a
+            # persistent workspace / arena / engine buffer) — a torch temporary created inside run() would be replayed after its free
+            if eng.plan_seen.get(key) == eng.ws.generation and _alloc_count(img.device) == allocs:
                 eng.plans[key] = (plan, eng.ws.generation, dict(eng.saved))
         eng.plan_seen[key] = eng.ws.generation
         return logits
@@ -252,6 +263,7 @@ class _HipClassifier(nn.Module):
                 record = eng.plan_seen.get(key) == eng.ws.generation
                 if record:
                     hip.record_begin()
+                allocs = _alloc_count(glogits.device)
                 try:
                     run()
                 except BaseException:
@@ -259,7 +271,7 @@ class _HipClassifier(nn.Module):
                     raise
                 if record:
                     plan = hip.record_end({"glogits": glogits})
-                    if eng.plan_seen.get(key) == eng.ws.generation:
+                    if eng.plan_seen.get(key) == eng.ws.generation and _alloc_count(glogits.device) == allocs:
                         eng.plans[key] = (plan, eng.ws.generation, None)
                 eng.plan_seen[key] = eng.ws.generation
         if self.grad_done_hook is not None:

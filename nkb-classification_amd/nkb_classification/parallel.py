@@ -10,6 +10,7 @@ BatchNorm statistics stay per-GPU (no SyncBN), as in standard DDP.
 """
 from __future__ import annotations
 
+import os
 from collections import defaultdict
 from typing import List, Optional
 
@@ -18,13 +19,25 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes: int = 25 << 20):
+    """bucket_dtype: "fp32" — ring all-reduce of fp32 arena slices (2 (W-1)/W x 4 B per parameter and rank); "bf16" — the mesh form
+    for large models: every rank casts its bucket to bf16 and sends slice j to rank j (all-to-all), rank j adds the W slices in
+    FP32, rounds the sum once and all ranks all-gather the bf16 sums (2 (W-1)/W x 2 B per parameter: half the bytes, and both
+    phases are direct point-to-point transfers on the xGMI mesh instead of a ring); "auto" (default) picks bf16 above 100 M
+    parameters — unicom ViT-L/14's 572 M parameters are 2.29 GB per step in fp32, which a ring over 153 GB/s links does not hide
+    under a ~50 ms step.  Every rank ends up with bit-identical gradients in either mode."""
+
+    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes: int = 25 << 20, bucket_dtype: str = "auto"):
         if not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        mode = os.environ.get("NKB_GRAD_BUCKET_DTYPE", bucket_dtype)
+        if mode not in ("auto", "fp32", "bf16"):
+            raise ValueError(f"bucket_dtype {mode!r}: expected auto, fp32 or bf16")
+        total = getattr(getattr(model, "arena", None), "total", 0) or 0
+        self.bf16_buckets = mode == "bf16" or (mode == "auto" and total > 100_000_000)
         self._pending: List = []
         self._ready: List[List[int]] = []          # finished, not yet sent arena intervals [lo, hi), merged and sorted
         self._side_event = None
@@ -98,8 +111,34 @@ class GradReducer:
         b = hi
         while b > lo:
             a = max(lo, b - self.bucket_elems)
-            self._pending.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.bf16_buckets:
+                self._exchange_bf16(flat[a:b])
+            else:
+                self._pending.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             b = a
+
+    def _exchange_bf16(self, g: torch.Tensor):
+        """In-place sum over ranks of the fp32 slice g, moved as bf16 and accumulated in fp32 (see the class docstring).  Runs in
+        stream order on the communication stream (cuda) or synchronously (cpu tensors: the gloo rehearsal)."""
+        W, n = self.world, g.numel()
+        chunk = -(-n // W)
+        chunk += (-chunk) % 8                                   # 16-byte-aligned slices for the sum kernel
+        send = torch.zeros(W * chunk, device=g.device, dtype=torch.bfloat16)
+        recv = torch.empty_like(send)
+        mine = torch.empty(chunk, device=g.device, dtype=torch.bfloat16)
+        if g.is_cuda:
+            from . import hip
+            hip.wprep(hip.BF16, g, send, 1, 1, n, n, 0)         # fp32 -> bf16 (round to nearest even)
+            dist.all_to_all_single(recv, send, group=self.group)
+            hip.bucket_sum_bf16(recv, chunk, W, None, mine, chunk)
+            dist.all_gather_into_tensor(send, mine, group=self.group)
+            hip.bucket_sum_bf16(send, 0, 1, g, None, n)          # widen the gathered sums back into the arena
+        else:
+            send[:n] = g.to(torch.bfloat16)
+            dist.all_to_all_single(recv, send, group=self.group)
+            mine.copy_(recv.view(W, chunk).float().sum(0).to(torch.bfloat16))
+            dist.all_gather_into_tensor(send, mine, group=self.group)
+            g.copy_(send[:n].float())
 
     def wait(self):
         """Send what is left, then make the compute stream wait for every outstanding bucket (no host block on GPU)."""

@@ -1,10 +1,38 @@
-"""HBM-side traffic per launch from two rocprofv3 PMC passes over bench.py (FETCH_SIZE and WRITE_SIZE, one pass each,
---kernel-trace only), corrected as MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB; on gfx950
-FETCH_SIZE tallies the 128-B requests of wide (16 B/lane) streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact
-for 16-B-per-lane streaming stores and float atomics.  Launches are classified forward / backward by their position
-relative to the loss kernel inside each step (steps are delimited by optim_step_kernel launches).
+"""HBM-side traffic per launch AND per step from two rocprofv3 PMC passes over bench.py (FETCH_SIZE and WRITE_SIZE, one pass each,
+--kernel-trace only), corrected as MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB; on gfx950 FETCH_SIZE
+tallies the 128-B requests of wide (16 B/lane) streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane
+streaming stores and float atomics.  Launches are classified forward / backward by their position relative to the loss kernel
+inside each step (steps are delimited by optim_step_kernel launches).
+
+Every kernel lands in exactly one family ("other" catches the rest), so sum(families) == step_total_bytes by construction —
+round 2's version dropped every kernel in an anonymous namespace (gemm8p, wgrad8p, wgrad3x3, attention): their names start with
+"void (anonymous namespace)::", which `split("(")[0]` cut down to "void ".
 Usage: python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [skip_steps]"""
-import csv, json, sys, collections
+import collections
+import csv
+import json
+import sys
+
+FAMILIES = (  # first match wins; (substring of the kernel name, family)
+    ("gemm8p_kernel", "gemm8p"), ("conv_igemm_kernel", "conv_igemm"),
+    ("wgrad_reduce_kernel", "wgrad_reduce"), ("gram_reduce_kernel", "wgrad_reduce"),
+    ("wgrad8p", "wgrad8p"), ("wgrad8f", "wgrad8f"), ("wgrad3x3_kernel", "wgrad3x3"), ("wgrad256_kernel", "wgrad8p"),
+    ("conv_wgrad_kernel", "conv_wgrad"),
+    ("bn_apply_gram_kernel", "bn_apply"), ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
+    ("bn_apply_kernel", "bn_apply"), ("bn_relu_maxpool", "stem_tail"), ("stem_", "stem"),
+    ("bn_partial_reduce", "bn_finalize"), ("bn_finalize", "bn_finalize"), ("bn_bwd_finalize", "bn_finalize"),
+    ("gram_", "gram_algebra"),
+    ("attn_fwd", "attn_fwd"), ("attn_bwd", "attn_bwd"), ("attn_", "attn_other"),
+    ("layernorm", "layernorm"), ("gelu", "gelu"), ("relu6", "relu6"), ("scale_rows", "scale_rows"),
+    ("fp8_", "fp8_quant"), ("splitk", "splitk_reduce"),
+    ("optim_step", "optim"), ("wprep", "wprep"), ("loss_", "loss"), ("avgpool", "avgpool"), ("maxpool", "maxpool"),
+    ("colsum", "colsum"), ("dropout", "dropout"), ("vit_assemble", "vit_assemble"), ("head_transpose", "head_transpose"),
+)
+PHASED = {"conv_igemm", "gemm8p"}     # reported separately for the forward and the backward pass
+
+
+def short(name: str) -> str:
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
 
 
 def load(path, counter):
@@ -12,66 +40,69 @@ def load(path, counter):
     with open(path) as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] == counter:
-                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0], float(r["Counter_Value"])))
+                rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), float(r["Counter_Value"])))
     rows.sort()
     return rows
 
 
 def family(name, phase):
-    if "conv_igemm_kernel" in name or "gemm8p_kernel" in name:
-        return "conv_igemm_fwd" if phase == "fwd" else "conv_igemm_dgrad"
-    for key, fam in (("conv_wgrad_kernel", "conv_wgrad"), ("wgrad3x3_kernel", "conv_wgrad"), ("wgrad8p_kernel", "conv_wgrad"),
-                     ("wgrad256_kernel", "conv_wgrad"), ("wgrad_reduce_kernel", "wgrad_reduce"), ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
-                     ("bn_apply_kernel", "bn_apply")):
+    for key, fam in FAMILIES:
         if key in name:
-            return fam
-    return None
+            return f"{fam}_{phase}" if fam in PHASED else fam
+    return "other"
 
 
 def per_family(rows, skip_steps):
+    """-> ({family: [launches, KiB]}, number of whole steps counted)"""
+    # a step is closed by its optimizer launches; whatever follows the last optimizer launch of the trace belongs to no step
+    closed = sum(1 for i, r in enumerate(rows) if "optim_step_kernel" in r[1] and (i + 1 == len(rows) or "optim_step_kernel" not in rows[i + 1][1]))
     out = collections.defaultdict(lambda: [0, 0.0])
-    step, phase = 0, "fwd"
+    step, phase, in_opt, counted = 0, "fwd", False, set()
     for _, name, val in rows:
-        if "optim_step_kernel" in name:
-            step_end = True
-        else:
-            step_end = False
-        if "loss_fwd" in name or "loss_forward" in name or name.startswith("void loss") or "loss_" in name and phase == "fwd":
+        is_opt = "optim_step_kernel" in name
+        if in_opt and not is_opt:          # first launch after the optimizer launches: a new step starts
+            step += 1
+            phase = "fwd"
+        in_opt = is_opt
+        if name.startswith("loss_"):
             phase = "bwd"
-        fam = family(name, phase)
-        if fam and step >= skip_steps:
+        if skip_steps <= step < closed:
+            fam = family(name, phase)
             out[fam][0] += 1
             out[fam][1] += val
-        if step_end:
-            phase = "fwd"
-            nxt = True
-        else:
-            nxt = False
-        if nxt:
-            step += 0.5 if False else 0   # (optimizer launches are consecutive per parameter group; count on transition below)
-        per_family.last_opt = step_end if not hasattr(per_family, "last_opt") else per_family.last_opt
-        if per_family.last_opt and not step_end:
-            step += 1
-        per_family.last_opt = step_end
-    return out
+            counted.add(step)
+    return out, counted
 
 
-fetch = load(sys.argv[1], "FETCH_SIZE")
-write = load(sys.argv[2], "WRITE_SIZE")
-skip = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-per_family.last_opt = False
-f = per_family(fetch, skip)
-per_family.last_opt = False
-w = per_family(write, skip)
-res = {}
-for fam in sorted(set(f) | set(w)):
-    nf, kf = f.get(fam, [0, 0.0])
-    nw, kw = w.get(fam, [0, 0.0])
-    n = max(nf, nw, 1)
-    rd, wr = 2.0 * kf * 1024.0 / max(nf, 1), kw * 1024.0 / max(nw, 1)
-    res[fam] = dict(launches=n, read_bytes_per_launch=round(rd), write_bytes_per_launch=round(wr), traffic_bytes_per_launch=round(rd + wr))
-json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1`",
-               correction="bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md, HBM section)", kernels=res),
-          open(sys.argv[3], "w"), indent=1)
-for k, v in res.items():
-    print(f"{k:18s} n={v['launches']:5d} read {v['read_bytes_per_launch']/1e6:8.1f} MB  write {v['write_bytes_per_launch']/1e6:8.1f} MB per launch")
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    skip = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    f, steps_f = per_family(fetch, skip)
+    w, steps_w = per_family(write, skip)
+    # the last "step" of a trace ends with the optimizer launches; a trailing partial step (none in bench.py) would only add to "other"
+    nsteps = max(len(steps_f), len(steps_w), 1)
+    res, total = {}, 0.0
+    for fam in sorted(set(f) | set(w)):
+        nf, kf = f.get(fam, [0, 0.0])
+        nw, kw = w.get(fam, [0, 0.0])
+        n = max(nf, nw, 1)
+        rd_tot, wr_tot = 2.0 * kf * 1024.0, kw * 1024.0
+        total += rd_tot + wr_tot
+        res[fam] = dict(launches=n, launches_per_step=round(n / nsteps, 2), read_bytes_per_launch=round(rd_tot / max(nf, 1)),
+                        write_bytes_per_launch=round(wr_tot / max(nw, 1)),
+                        traffic_bytes_per_launch=round(rd_tot / max(nf, 1) + wr_tot / max(nw, 1)),
+                        bytes_per_step=round((rd_tot + wr_tot) / nsteps))
+    out = dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --steps 2 --warmup 1`",
+               correction="bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md, HBM section)",
+               steps_counted=nsteps, step_total_bytes=round(total / nsteps),
+               families_sum_bytes=sum(v["bytes_per_step"] for v in res.values()), kernels=res)
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(f"steps counted {nsteps}; HBM-side bytes per step {total / nsteps / 1e9:.2f} GB")
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["bytes_per_step"]):
+        print(f"{k:18s} n/step={v['launches_per_step']:7.1f} read {v['read_bytes_per_launch'] / 1e6:8.1f} MB  write "
+              f"{v['write_bytes_per_launch'] / 1e6:8.1f} MB per launch   {v['bytes_per_step'] / 1e9:7.2f} GB per step")
+
+
+if __name__ == "__main__":
+    main()

@@ -166,10 +166,12 @@ def test_bn_apply_gram_matches_bn_apply_and_the_gram_matrix(rows, C):
     assert _rel(outs[0][C * C:], y64.sum(0)) < 1e-5
 
 
-def test_gram_form_in_the_model_matches_separate_passes():
+def test_gram_form_in_the_model_matches_separate_passes(monkeypatch):
     """The same reduced bottleneck ResNet, same weights, same batch, bf16: train step with the Gram-form closing stages against
     the separate bn_apply / bn_backward passes — logits and every gradient agree to bf16 noise, and the Gram path really ran."""
+    from nkb_classification import hipnet
     from nkb_classification.model import get_model
+    monkeypatch.setattr(hipnet, "_GRAM_MAX_C", 512)        # all three eligible widths (64, 128: fused Gram pass; 256: nkb_conv_wgrad)
 
     def run(gram):
         cfg_model = dict(model="resnet_tiny_bottleneck", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,

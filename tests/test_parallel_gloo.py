@@ -92,6 +92,51 @@ def test_gathered_epoch_counts_every_sample_once_world2_gloo():
     assert sorted(results) == [(0, True), (1, True)]
 
 
+def _bf16_worker(rank, world, port, q):
+    """bf16 bucket mode (all-to-all of bf16 slices, fp32 accumulation, all-gather of the sums) against the fp32 all-reduce on
+    gradients that are exactly representable in bf16 together with their sums: the two modes must agree bit for bit, and an arena
+    above 100 M parameters must select the bf16 mode by itself."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 10_007                                             # not a multiple of the world size or of the bucket
+        outs = {}
+        for mode in ("fp32", "bf16"):
+            arena = types.SimpleNamespace(flat_grad=torch.zeros(n), total=n)
+            model = types.SimpleNamespace(arena=arena, grad_ready_hook=None)
+            opt = types.SimpleNamespace(grad_scale=1.0, step=lambda: None)
+            red = GradReducer(model, opt, bucket_bytes=4 * 1500, bucket_dtype=mode)
+            assert red.bf16_buckets == (mode == "bf16")
+            arena.flat_grad[4000:] = (torch.arange(4000, n) % 61).float() * (rank + 1)
+            model.grad_ready_hook(4000, n)
+            arena.flat_grad[:4000] = (torch.arange(0, 4000) % 61).float() * (rank + 1)
+            model.grad_ready_hook(0, 4000)
+            opt.step()
+            outs[mode] = arena.flat_grad.clone()
+        expect = (torch.arange(n) % 61).float() * sum(r + 1 for r in range(world))
+        ok = torch.equal(outs["fp32"], expect) and torch.equal(outs["bf16"], expect)
+        big = types.SimpleNamespace(arena=types.SimpleNamespace(flat_grad=torch.zeros(8), total=572_328_448), grad_ready_hook=None)
+        ok &= GradReducer(big).bf16_buckets and not GradReducer(types.SimpleNamespace(
+            arena=types.SimpleNamespace(flat_grad=torch.zeros(8), total=25_557_032), grad_ready_hook=None)).bf16_buckets
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_bucket_mode_matches_fp32_on_representable_gradients_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
 def test_reducer_requires_process_group():
     with pytest.raises(RuntimeError, match="process group"):
         GradReducer(types.SimpleNamespace(arena=None, grad_ready_hook=None))
