@@ -33,6 +33,10 @@ typedef struct ihipStream_t* nkb_stream_t; /* hipStream_t */
 
 const char* nkb_last_error(void);
 int nkb_version(void);
+/* Launch counters of the specialised kernels since process start (or the last reset): which = 0 eight-phase GEMM (gemm8p), 1 eight-phase
+ * weight gradient (wgrad8p / wgrad256), 2 shared-strip 3x3 weight gradient, 3 fp8 weight gradient, 4 Gram-form closing convolution,
+ * 5 bn_apply fused with the Gram matrix.  Tests use them to prove that a benchmark configuration took the path it is priced on. */
+long long nkb_kernel_launches(int which, int reset);
 
 /* Implicit-GEMM convolution / linear layer on MFMA.
  * mode 0 (forward):  y[n,p,q,co] = sum_{r,s,ci} x[n, p*stride+r-pad, q*stride+s-pad, ci] * w[co,r,s,ci]

@@ -105,6 +105,11 @@ int nkb_check_launch(const char* what);
 // deterministic weight gradients
 int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float* dst, long long n, hipStream_t stream);
 
+// launch counters of the specialised kernels (api.hip: nkb_kernel_launches) — tests assert from them that the path a benchmark
+// configuration is supposed to take really ran (0 gemm8p, 1 wgrad8p / wgrad256, 2 wgrad3x3, 3 wgrad8f (fp8), 4 Gram-form closing
+// stage (nkb_conv_affine_residual), 5 bn_apply fused with the Gram matrix)
+void nkb_count_launch(int which);
+
 // per-launch HIP-event profiler (enabled from bench.py); see api.hip
 struct NkbProfScope {
     int slot;

@@ -1375,6 +1375,7 @@ extern "C" int nkb_conv_affine_residual(int dtype, const void* x, const void* w,
     p.ldw = R * S * Cin; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
     p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
     p.oscale = scale; p.add_scale = res_scale; p.add_shift = res_shift; p.out_bits = relu_bits;
+    nkb_count_launch(4);
     NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * p.M * (double)Cout * R * S * Cin,
                       ((double)N * H * W * Cin + (double)Cout * R * S * Cin + 2.0 * p.M * Cout) * 2 + (double)p.M * Cout / 8);
     return launch_conv<bf16_t, 128, 128, 4>(p, stream);

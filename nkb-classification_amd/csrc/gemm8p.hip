@@ -830,6 +830,7 @@ static int g8_cus() {
 }
 
 int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream, const float* row_scale, int rows_per_sample) {
+    nkb_count_launch(0);
     G8Params p;
     p.x = (const bf16_t*)cp.x; p.w = (const bf16_t*)cp.w; p.y = (bf16_t*)cp.y; p.bias = cp.bias;
     p.add = (const bf16_t*)cp.add; p.aux = (cp.act == 4 || cp.act == 3) ? (const bf16_t*)cp.aux : nullptr; p.stats = cp.stats;

@@ -179,6 +179,7 @@ extern "C" int nkb_bn_apply_gram(int dtype, const void* c, void* y, const float*
     }
     const int G = gram_grid(rows, C);
     const size_t slab = (size_t)C * C + C;
+    nkb_count_launch(5);
     if (work_floats < (size_t)G * slab) { nkb_set_error("bn_apply_gram: workspace too small (nkb_bn_apply_gram_workspace_floats)"); return 1; }
     {
         NkbProfScope prof(NKB_K_BN_APPLY, stream, 2.0 * rows * (double)C * C, (double)rows * C * 2 * 2 + 2.0 * 4.0 * G * slab);

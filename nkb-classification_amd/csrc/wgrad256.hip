@@ -684,6 +684,7 @@ int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, 
         attr_set = true;
     }
     static const int eight_phase = [] { const char* e = getenv("NKB_WGRAD8P"); return e ? atoi(e) : 1; }();
+    nkb_count_launch(1);
     if (eight_phase) hipLaunchKernelGGL(wgrad8p_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
     else hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
     int rc = nkb_check_launch("wgrad256");
@@ -715,6 +716,7 @@ extern "C" long long nkb_wgrad_fp8_workspace_floats(int M, int Cin, int Cout) {
 }
 extern "C" int nkb_wgrad_fp8(const void* gq, const void* xq, float* dw, const float* deq_g, const float* deq_x, int M, int Cin,
                              int ldx, int Cout, int ldg, float* workspace, long long workspace_floats, hipStream_t stream) {
+    nkb_count_launch(3);
     const long long need = nkb_wgrad_fp8_workspace_floats(M, Cin, Cout);
     if (need < 0 || ldx % 16 || ldg % 16 || ldx < Cin || ldg < Cout || !deq_g || !deq_x || !workspace || workspace_floats < need) {
         nkb_set_error("wgrad_fp8: M=%d Cin=%d Cout=%d (M %% 128, Cin / Cout %% 256, 16-byte rows) with a workspace of %lld floats (got %lld)",

@@ -225,6 +225,7 @@ long long nkb_wgrad3x3_workspace_floats(int N, int H, int W, int Cin, int Cout) 
 
 int nkb_launch_wgrad3x3(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int ldx, int Cout, int lddy,
                         float* workspace, hipStream_t stream) {
+    nkb_count_launch(2);
     W3Params p;
     p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw; p.part = workspace;
     p.slab = (long long)Cout * 9 * Cin;

@@ -22,6 +22,7 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 _SIGS = {
     "nkb_version": (i32, []),
     "nkb_last_error": (C.c_char_p, []),
+    "nkb_kernel_launches": (i64, [i32, i32]),
     "nkb_conv_gemm": (i32, [i32, i32, vp, vp, vp, vp, vp, vp] + [i32] * 18 + [vp, vp]),
     "nkb_conv_gemm_stat_tiles": (i32, [i32, i32, i32]),
     "nkb_conv_wgrad": (i32, [i32, vp, vp, vp, vp] + [i32] * 13 + [vp, i64, vp]),
@@ -153,7 +154,7 @@ def exported_symbols():
 # (input images, logits, logits gradient) and dropout seeds.
 _REC = None            # list of plan entries while recording
 _REC_LIB = None
-_PURE = frozenset({"nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_bn_stats_floats",
+_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_bn_stats_floats",
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
@@ -262,6 +263,12 @@ def host_op(fn):
                     fn()
             _REC.append(["py", on_stream])
     fn()
+
+
+def kernel_launches(which: str, reset: bool = False) -> int:
+    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply."""
+    idx = {"gemm8p": 0, "wgrad8p": 1, "wgrad3x3": 2, "wgrad8f": 3, "gram_conv": 4, "gram_bn_apply": 5}[which]
+    return int(load().nkb_kernel_launches(idx, int(reset)))
 
 
 def dt(t) -> int:

@@ -1,0 +1,158 @@
+"""Parity AT THE SIZE THE BENCH RUNS: the smaller-batch model tests never reach the kernels bench.py's numbers
+come from — the eight-phase GEMM (>= 192 tiles), wgrad8p's split targets, the multi-round XCD remap, recorded launch plans with the
+weight-gradient stream on, the Gram-form closing stages at layer1 / layer2 extents.  Here the model is built exactly as bench.py builds
+it (bench.build: same config, optimizer, batch, dtype, default eligibility, plans and side stream on) and trained for four steps next to
+TWO runs of the oracle module (oracle/torch_models.py) on the same GPU, from the same state_dict and batch, each with its own optimizer:
+  * truth     : torch's kernels in fp32 (no autocast) — the reference's CPU path moved to the GPU so that batch 256 takes seconds;
+  * yardstick : torch's kernels under torch.autocast(bfloat16), the reference's own mixed-precision mechanism (engine.py:43-47).
+At every step the whole gradient (every parameter, concatenated), the loss and the logits of the HIP engine and of the yardstick are
+measured against the truth.  Step 1 runs eager launches, step 4 replays the recorded launch plans.
+
+Bars (every bf16 configuration): the HIP engine's gradient may be at most 1.25x as far (relative L2) from the truth as the yardstick
+is, + 5e-3, with a cosine no more than 1e-3 (ViT-L/14, 24 blocks: 2e-3) below the yardstick's; loss within 1e-2 relative of the
+truth.  fp8 (e4m3 x e4m3 forward, e5m2 x e4m3 backward) has no torch yardstick: cosine >= 0.93, L2 <= 0.36 against the fp32 truth over six
+steps, loss within 2e-2.
+First measurement (MI355X, step 1; HIP / autocast, both against the fp32 truth): ResNet-50 L2 0.122 / 0.125, cosine 0.99257 / 0.99222
+— the HIP engine is the closer one, with the Gram-form closing stages on (HIP-vs-autocast mutual distance 0.135 with AND without them:
+they add no error of their own); ViT-B/16 1.33e-2 / 1.33e-2; unicom ViT-L/14 bf16 9.1e-2 / 8.1e-2, fp8 0.30.
+The launch counters prove that the specialised kernels the bench line is priced on really ran.
+
+unicom: ARCHITECTURE PARITY UNPINNED — the `unicom` package is absent from /root/reference; the oracle twin is the same from-memory
+restatement, so this test pins the HIP kernels to torch's kernels on that restatement, not to upstream unicom."""
+import argparse
+import math
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from nkb_classification import hip  # noqa: E402
+from oracle.torch_engine import make_optimizer  # noqa: E402
+from oracle.torch_models import OracleClassifier  # noqa: E402
+
+DEV = "cuda:0"
+OPT = dict(type="nadam", lr=1e-4, backbone_lr=1e-5, classifier_lr=1e-4, weight_decay=0.01, backbone_weight_decay=0.01,
+           classifier_weight_decay=0.2)          # bench.build
+
+
+def _flat(named):
+    return torch.cat([g.detach().float().flatten() for _, g in named])
+
+
+def _dist(g, truth):
+    return torch.nn.functional.cosine_similarity(g, truth, dim=0).item(), ((g - truth).norm() / truth.norm()).item()
+
+
+def _run(model_name, batch, dtype, classes, steps=4):
+    import bench
+    args = argparse.Namespace(model=model_name, classes=classes, batch=batch, dtype=dtype)
+    device = torch.device(DEV)
+    model, opt, crit = bench.build(args, device)
+    model.fp8_linear = dtype == "fp8"
+    cfg_model = dict(task="single", model=model_name, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                     classifier_initialization="kaiming_normal_")
+    oracles = []
+    for _ in range(2):                                   # [truth (fp32), yardstick (autocast bf16)]
+        o = OracleClassifier(cfg_model, [str(i) for i in range(classes)])
+        o.load_state_dict(model.state_dict())
+        o = o.to(device).train()
+        oracles.append((o, make_optimizer(o, OPT)))
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(batch, 3, 224, 224, generator=g).to(device)
+    tgt = torch.randint(0, classes, (batch,), generator=g).to(device)
+    model.train()
+    for k in COUNTERS:
+        hip.kernel_launches(k, reset=True)
+    names = [n for n, _ in oracles[0][0].named_parameters()]
+    out = []
+    blocks = [getattr(o.emb_model, "blocks", None) for o, _ in oracles]
+    stochastic = blocks[0] is not None and any(getattr(getattr(b, "drop_path", None), "drop_prob", 0.0) > 0 for b in blocks[0])
+    for step in range(steps):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            log = model(img)
+            loss = crit(log, tgt)
+        if stochastic:
+            # unicom's per-sample stochastic depth: both oracle runs replay the keep draws the HIP forward just made
+            eng = model._active
+            for bl in blocks:
+                for i, blk in enumerate(bl):
+                    s1, s2 = eng.saved[f"b{i}.dp1"]["scale"], eng.saved[f"b{i}.dp2"]["scale"]
+                    keeps = iter([(s1 > 0).float(), (s2 > 0).float()])
+                    blk.drop_path.forward = (lambda mod, it: (lambda t: t * next(it).to(t.dtype).reshape(-1, 1, 1) / (1.0 - mod.drop_prob)))(
+                        blk.drop_path, keeps)
+        res = []
+        for k, (o, oo) in enumerate(oracles):
+            oo.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(k == 1)):
+                ol = o(img)
+                ls = torch.nn.functional.cross_entropy(ol.float(), tgt)
+            ls.backward()
+            res.append((ol.detach().float(), ls.item(), _flat([(n, p.grad) for n, p in o.named_parameters()])))
+        loss.backward()
+        torch.cuda.synchronize()
+        hp = dict(model.named_parameters())
+        gh = _flat([(n, hp[n].grad) for n in names])
+        (tlog, tloss, tg), (ylog, yloss, yg) = res
+        cos, l2 = _dist(gh, tg)
+        ycos, yl2 = _dist(yg, tg)
+        lerr = ((log.detach().float() - tlog).abs().max() / tlog.abs().max()).item()
+        ylerr = ((ylog - tlog).abs().max() / tlog.abs().max()).item()
+        out.append(dict(step=step + 1, loss=loss.item(), ref_loss=tloss, yard_loss=yloss, cos=cos, l2=l2, ycos=ycos, yl2=yl2, logits=lerr,
+                        ylogits=ylerr, finite=bool(torch.isfinite(gh).all().item())))
+        for _, oo in oracles:
+            oo.step()
+        opt.step()
+    eng = model._active
+    counters = {k: hip.kernel_launches(k) for k in COUNTERS}
+    print(f"\n[{model_name} bs {batch} {dtype}] " + "  ".join(
+        f"step {o['step']}: loss {o['loss']:.4f} (truth {o['ref_loss']:.4f}, autocast {o['yard_loss']:.4f}) grad cos {o['cos']:.5f} "
+        f"({o['ycos']:.5f}) L2 {o['l2']:.3e} ({o['yl2']:.3e}) logits {o['logits']:.2e} ({o['ylogits']:.2e})" for o in out)
+          + f"  plans {len(eng.plans)}  launches {counters}")
+    return out, counters, len(eng.plans)
+
+
+COUNTERS = ("gemm8p", "wgrad8p", "wgrad3x3", "wgrad8f", "gram_conv", "gram_bn_apply")
+
+
+def _check(out, relative=True, cos_bar=None, l2_bar=None, loss_tol=1e-2, cos_slack=1e-3):
+    for o in (out[0], out[-1]):                       # the eager first step and the plan-replayed last one
+        assert o["finite"] and math.isfinite(o["loss"])
+        assert abs(o["loss"] - o["ref_loss"]) <= loss_tol * abs(o["ref_loss"]), o
+        if relative:                                  # not worse than 1.25x torch's own autocast run (+ slack)
+            assert o["l2"] <= 1.25 * o["yl2"] + 5e-3 and o["cos"] >= o["ycos"] - cos_slack, o
+        else:
+            assert o["cos"] >= cos_bar and o["l2"] <= l2_bar, o
+
+
+def test_resnet50_bench_configuration_matches_oracle():
+    out, n, plans = _run("resnet50", 256, "bf16", 1000)
+    _check(out, relative=True)
+    assert plans >= 2                                                      # forward + backward plans recorded and replayed
+    assert n["gemm8p"] > 0 and n["wgrad8p"] > 0 and n["wgrad3x3"] > 0      # the kernels the bench line is priced on ran
+    assert n["gram_conv"] > 0 and n["gram_bn_apply"] > 0                   # Gram-form closing stages (layer1 / layer2)
+
+
+def test_vit_b16_bench_configuration_matches_oracle():
+    out, n, plans = _run("vit_base_patch16_224", 256, "bf16", 1000)
+    _check(out, relative=True)
+    assert plans >= 2 and n["gemm8p"] > 0 and n["wgrad8p"] > 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_unicom_l14_bench_configuration_matches_oracle(dtype):
+    """unicom ViT-L/14 bs 128 (BASELINE configs[4] on one GPU).  ARCHITECTURE PARITY UNPINNED (module docstring)."""
+    out, n, plans = _run("unicom ViT-L/14", 128, dtype, 1000, steps=4 if dtype == "bf16" else 6)
+    if dtype == "bf16":
+        _check(out, relative=True, cos_slack=2e-3)
+        assert n["gemm8p"] > 0 and n["wgrad8p"] > 0
+    else:
+        _check(out, relative=False, cos_bar=0.93, l2_bar=0.36, loss_tol=2e-2)
+        assert n["wgrad8f"] > 0
+    assert plans >= 1
