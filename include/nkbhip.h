@@ -394,20 +394,6 @@ int nkb_fp8_multi(int pass, const long long* jobs, int njobs, long long total_bl
 long long nkb_wgrad_fp8_workspace_floats(int M, int Cin, int Cout);
 int nkb_wgrad_fp8(const void* gq, const void* xq, float* dw, const float* deq_g, const float* deq_x, int M, int Cin, int ldx,
                   int Cout, int ldg, float* workspace, long long workspace_floats, nkb_stream_t stream);
-/* Up to four Linear weight gradients over the SAME M tokens in one launch (the qkv / proj / fc1 / fc2 layers of a transformer
- * block): dw_j[Cout_j][Cin_j] += dY_j^T X_j (+ dbias_j += column sums of dY_j in the bf16 form).  fp8 = 0: bf16 operands
- * (M % 64 == 0); fp8 = 1: gq (e5m2) / xq (e4m3) bytes with their dequantisation factors, no bias (M % 128 == 0).
- * Cin, Cout % 256 == 0, M >= 4096.  One kernel covers every tile of every problem (fixed costs once, fewer and longer
- * token splits), per-split partial tiles are added in split order (deterministic).  Workspace:
- * nkb_wgrad_group_workspace_floats() floats (-1: not supported). */
-typedef struct NkbWgradJob {
-    const void* dy; const void* x; float* dw; float* dbias;
-    const float* deq_g; const float* deq_x;
-    int Cin, ldx, Cout, lddy;
-} NkbWgradJob;
-long long nkb_wgrad_group_workspace_floats(int fp8, int njobs, const NkbWgradJob* jobs, int M);
-int nkb_wgrad_group(int fp8, int njobs, const NkbWgradJob* jobs, int M, float* workspace, long long workspace_floats,
-                    nkb_stream_t stream);
 int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float* bias, const void* add, const void* aux,
                  int aux_mode, void* yq, float* q_state, int q_kind, const float* row_scale, int rows_per_sample,
                  void* mask_out, const void* mask_in, float* colsum, float* colsum_work, const float* deq_x, const float* deq_w,

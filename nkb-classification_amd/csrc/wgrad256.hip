@@ -36,159 +36,7 @@ struct W256Params {
     const float* deq_g = nullptr;   // fp8 kernel: dequantisation factors of dY / X (device floats)
     const float* deq_x = nullptr;
 };
-// several problems over the same M tokens in ONE launch (the Linear layers of a transformer block): a workgroup's logical id is
-// (split, tile) over the concatenated tile lists; start[j] = first tile of problem j
-struct W256Group {
-    int njobs, total_tiles;
-    int start[5];
-    W256Params job[4];
-};
 
-__global__ __launch_bounds__(512, 1) void wgrad256_kernel(const W256Params p) {
-    constexpr int SUB = 64 * 256;                 // one [64][128] sub-tile
-    constexpr int OPB = 2 * SUB;                  // one operand of one stage (256 channels)
-    constexpr int STG = 2 * OPB;                  // dY + X
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wn = wave & 3;      // wave tile: cout [128 wr, +128) x n [64 wn, +64)
-
-    const unsigned ntile = (unsigned)(p.tilesC * p.tilesN);
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);       // consecutive ids (one token range) share an XCD's L2
-    const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
-    const int tile_c = tile % p.tilesC, tile_n = tile / p.tilesC;
-    const int c0 = tile_c * 256, n0 = tile_n * 256;
-    const int m_begin = split * p.rows_per_split;
-    const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nstage = (m_end - m_begin) / 64;    // host guarantees whole stages
-    if (nstage <= 0) return;
-
-    // loader: one operand stage = 32 pieces of 1 KiB (4 token rows of one sub-tile); wave w moves pieces w, w+8, w+16, w+24
-    const int lrow = lane >> 4, lslot = lane & 15;
-    const bf16_t* asrc[4];
-    const bf16_t* bsrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int piece = wave + 8 * q, sub = piece >> 4, rg = piece & 15;
-        const int row = rg * 4 + lrow;                                        // token row inside the stage
-        const int ch = lslot ^ (((row & 3) << 2) | ((row >> 2) & 3));         // source chunk that belongs in this LDS slot
-        asrc[q] = p.dy + (size_t)(m_begin + row) * p.lddy + c0 + sub * 128 + ch * 8;
-        bsrc[q] = p.x + (size_t)(m_begin + row) * p.ldx + n0 + sub * 128 + ch * 8;
-    }
-    const size_t astep = (size_t)64 * p.lddy, bstep = (size_t)64 * p.ldx;
-    auto issue = [&](int st, int buf) {
-        unsigned char* base = smem + buf * STG;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + st * astep),
-                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * q) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + st * bstep),
-                                             (__attribute__((address_space(3))) void*)(base + OPB + (wave + 8 * q) * 1024), 16, 0, 0);
-    };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // fragment addressing (as conv_wgrad_kernel): lane (g, q4, p4) reads 8 B of token row 32 kk + 8 g + q4 (+4), chunk
-    // 2 blk + (p4 >> 1), half p4 & 1.  Every offset below is loop-invariant (the compiler keeps them in registers).
-    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
-    auto frag = [&](const unsigned char* tile, int row, int blk) -> bf16x8 {
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) bf16x4*)(tile + swz256(row, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) bf16x4*)(tile + swz256(row + 4, blk * 2 + (p4 >> 1)) + 8 * (p4 & 1)));
-        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    };
-    const int bblk0 = (wn & 1) * 4;
-    // bias gradient: the wn == 0 waves of the tile_n == 0 workgroups sum the dY fragments they load anyway (a lane holds
-    // 8 tokens of one channel per fragment); VALU work in the shadow of the MFMAs, no extra pass over dY
-    const bool do_bias = p.dbias != nullptr && tile_n == 0 && wn == 0;
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int st = 0; st < nstage; ++st) {
-        if (st + 1 < nstage) issue(st + 1, (st + 1) & 1);
-        const unsigned char* base = smem + (st & 1) * STG;
-        const unsigned char* A = base + wr * SUB;
-        const unsigned char* B = base + OPB + (wn >> 1) * SUB;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int row = 32 * kk + 8 * g + q4;
-            bf16x8 a[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = frag(A, row, i);
-            if (do_bias) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const u32x4 v = __builtin_bit_cast(u32x4, a[i]);
-                    float t = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t += __uint_as_float(v[e] << 16) + __uint_as_float(v[e] & 0xffff0000u);
-                    bsum[i] += t;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8 b = frag(B, row, bblk0 + j);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next stage has landed
-        __syncthreads();                                        // ... and everyone is done with this one
-    }
-
-    if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float t = bsum[i];
-            t += __shfl_xor(t, 16);
-            t += __shfl_xor(t, 32);
-            if (lane < 16) {
-                if (p.bpart) p.bpart[(size_t)split * p.Cout + c0 + wr * 128 + 16 * i + lane] = t;
-                else atomicAdd(p.dbias + c0 + wr * 128 + 16 * i + lane, t);
-            }
-        }
-    }
-
-    // epilogue: four passes of 64 cout rows through LDS [64][256 f32 + pad], then row-contiguous float atomics
-    // (256 B per wave instruction)
-    constexpr int EROW = 256 * 4 + 16;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        if (wr == (pass >> 1)) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int i = 4 * (pass & 1) + ii;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int rbase = 16 * ii + 4 * g, col = wn * 64 + 16 * j + li;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) *(float*)(smem + (rbase + e) * EROW + col * 4) = acc[i][j][e];
-                }
-            }
-        }
-        __syncthreads();
-        if (p.part) {
-            for (int row = wave; row < 64; row += 8) {
-                float* dst = p.part + (size_t)split * p.slab + (size_t)(c0 + pass * 64 + row) * p.Ntot + n0;
-                *(f32x4*)(dst + 4 * lane) = *(const f32x4*)(smem + row * EROW + 16 * lane);
-            }
-        } else
-        for (int row = wave; row < 64; row += 8) {
-            float* dst = p.dw + (size_t)(c0 + pass * 64 + row) * p.Ntot + n0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) atomicAdd(dst + lane + 64 * c, *(const float*)(smem + row * EROW + (lane + 64 * c) * 4));
-        }
-        __syncthreads();
-    }
-}
 
 
 // ---- the same contraction on the eight-phase schedule of gemm8p.hip ------------------------------------------------------
@@ -419,14 +267,6 @@ __global__ __launch_bounds__(512, 1) void wgrad8p_kernel(const W256Params p) {
     const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
     wgrad8p_body(p, (int)(lid % ntile), (int)(lid / ntile));
 }
-// grouped form: consecutive logical ids = every tile of every problem for ONE token range (split), so the workgroups that share
-// dY / X rows still land on one XCD
-__global__ __launch_bounds__(512, 1) void wgrad8p_group_kernel(const W256Group g) {
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tt = (int)(lid % (unsigned)g.total_tiles), split = (int)(lid / (unsigned)g.total_tiles);
-    const int j = (tt >= g.start[1]) + (tt >= g.start[2]) + (tt >= g.start[3]);
-    wgrad8p_body(g.job[j], tt - g.start[j], split);
-}
 
 // ---- fp8 weight gradient (BASELINE configs[4]): dW[cout][n] = deq * sum_m gq[m][cout] * xq[m][n] ------------------------------
 // The eight-phase schedule of wgrad8p_kernel on one-byte operands: gq = the e5m2 copy of dY that the fp8 data gradient consumed,
@@ -609,12 +449,6 @@ __global__ __launch_bounds__(512, 1) void wgrad8f_kernel(const W256Params p) {
     const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
     wgrad8f_body(p, (int)(lid % ntile), (int)(lid / ntile));
 }
-__global__ __launch_bounds__(512, 1) void wgrad8f_group_kernel(const W256Group g) {
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tt = (int)(lid % (unsigned)g.total_tiles), split = (int)(lid / (unsigned)g.total_tiles);
-    const int j = (tt >= g.start[1]) + (tt >= g.start[2]) + (tt >= g.start[3]);
-    wgrad8f_body(g.job[j], tt - g.start[j], split);
-}
 
 }  // namespace
 
@@ -679,14 +513,11 @@ int nkb_launch_wgrad256(const void* dy, const void* x, float* dw, float* dbias, 
     constexpr int lds = 2 * 4 * 64 * 256;                        // two stages of 64 KB
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipFuncSetAttribute((const void*)wgrad8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    static const int eight_phase = [] { const char* e = getenv("NKB_WGRAD8P"); return e ? atoi(e) : 1; }();
     nkb_count_launch(1);
-    if (eight_phase) hipLaunchKernelGGL(wgrad8p_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(wgrad8p_kernel, dim3((unsigned)tiles * (unsigned)p.splits), dim3(512), lds, stream, p);
     int rc = nkb_check_launch("wgrad256");
     if (rc || !workspace) return rc;
     rc = nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
@@ -747,117 +578,4 @@ extern "C" int nkb_wgrad_fp8(const void* gq, const void* xq, float* dw, const fl
     int rc = nkb_check_launch("wgrad_fp8");
     if (rc) return rc;
     return nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
-}
-
-
-// ---- grouped launch: up to four Linear weight gradients over the same M tokens in one kernel -----------------------------------
-// One launch per Linear pays its fixed costs four times per transformer block (prologue, ~450 barriers of an empty pipeline, the
-// per-split fp32 slabs: 53 us of a 210 us launch on ViT-B/16) and splits the token range 5-7 ways to fill 256 CUs with 9-36 tiles;
-// together the block's four problems have 99 (ViT-B/16) / 192 (ViT-L/14) tiles, so fewer, longer splits fill the chip.
-struct NkbWgradJob {
-    const void* dy; const void* x; float* dw; float* dbias;
-    const float* deq_g; const float* deq_x;       // fp8 form only
-    int Cin, ldx, Cout, lddy;
-};
-static int wgroup_check(int fp8, int njobs, const NkbWgradJob* jobs, int M, int* total_tiles) {
-    const int stage = fp8 ? 128 : 64, align = fp8 ? 16 : 8;
-    if (njobs < 1 || njobs > 4 || jobs == nullptr || M < 4096 || M % stage) return 1;
-    int tiles = 0;
-    for (int j = 0; j < njobs; ++j) {
-        const NkbWgradJob& q = jobs[j];
-        if (q.Cin < 256 || q.Cout < 256 || q.Cin % 256 || q.Cout % 256 || q.ldx % align || q.lddy % align || q.ldx < q.Cin || q.lddy < q.Cout ||
-            !q.dy || !q.x || !q.dw || (fp8 && (!q.deq_g || !q.deq_x || q.dbias)))
-            return 1;
-        if ((long long)M * q.ldx >= (fp8 ? 0xFFFFFFFFll : (1ll << 31)) || (long long)M * q.lddy >= (fp8 ? 0xFFFFFFFFll : (1ll << 31))) return 1;
-        tiles += (q.Cout / 256) * (q.Cin / 256);
-    }
-    *total_tiles = tiles;
-    return 0;
-}
-// split count by a cost model: rounds of workgroups x (stages per split x time per stage + per-workgroup fixed time)
-static int wgroup_splits(int fp8, int M, int tiles) {
-    static const int forced = [] { const char* e = getenv("NKB_WGROUP_SPLITS"); return e ? atoi(e) : 0; }();
-    const int stages = M / (fp8 ? 128 : 64);
-    int cus = 256;
-    { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
-    if (forced > 0) return forced < stages ? forced : stages;
-    const double per_stage = fp8 ? 1.0 : 2.1, fixed = 25.0;
-    int best = 1; double best_t = 1e30;
-    for (int s = 1; s <= 32 && s <= stages / 4; ++s) {
-        const int sps = (stages + s - 1) / s;
-        const int real = (stages + sps - 1) / sps;
-        const double rounds = (double)(((long long)tiles * real + cus - 1) / cus);
-        const double t = rounds * (sps * per_stage + fixed);
-        if (t < best_t) { best_t = t; best = real; }
-    }
-    return best;
-}
-static void wgroup_plan(int fp8, int M, int tiles, int* splits, int* rows_per_split) {
-    const int stage = fp8 ? 128 : 64, stages = M / stage;
-    const int s = wgroup_splits(fp8, M, tiles);
-    const int sps = (stages + s - 1) / s;
-    *splits = (stages + sps - 1) / sps;
-    *rows_per_split = sps * stage;
-}
-extern "C" long long nkb_wgrad_group_workspace_floats(int fp8, int njobs, const NkbWgradJob* jobs, int M) {
-    int tiles = 0;
-    if (wgroup_check(fp8, njobs, jobs, M, &tiles)) return -1;
-    int splits, rps;
-    wgroup_plan(fp8, M, tiles, &splits, &rps);
-    long long need = 0;
-    for (int j = 0; j < njobs; ++j) need += (long long)splits * ((long long)jobs[j].Cout * jobs[j].Cin + (jobs[j].dbias ? jobs[j].Cout : 0));
-    return need;
-}
-extern "C" int nkb_wgrad_group(int fp8, int njobs, const NkbWgradJob* jobs, int M, float* workspace, long long workspace_floats,
-                               hipStream_t stream) {
-    int tiles = 0;
-    if (wgroup_check(fp8, njobs, jobs, M, &tiles)) {
-        nkb_set_error("wgrad_group: 1-4 problems with Cin / Cout %% 256 == 0 over M %% %d == 0 tokens (M >= 4096), aligned rows%s", fp8 ? 128 : 64,
-                      fp8 ? ", dequantisation factors, no bias" : "");
-        return 1;
-    }
-    const long long need = nkb_wgrad_group_workspace_floats(fp8, njobs, jobs, M);
-    if (!workspace || workspace_floats < need) { nkb_set_error("wgrad_group: workspace of %lld floats needed, %lld given", need, workspace_floats); return 1; }
-    W256Group g;
-    g.njobs = njobs; g.total_tiles = tiles;
-    int splits, rps;
-    wgroup_plan(fp8, M, tiles, &splits, &rps);
-    float* wp = workspace;
-    int start = 0;
-    double flops = 0.0;
-    for (int j = 0; j < 4; ++j) {
-        g.start[j] = j < njobs ? start : 0x7fffffff;           // unused slots never match a tile id
-        if (j >= njobs) { g.job[j] = g.job[0]; continue; }
-        const NkbWgradJob& q = jobs[j];
-        W256Params& p = g.job[j];
-        p.dy = (const bf16_t*)q.dy; p.x = (const bf16_t*)q.x; p.dw = q.dw; p.dbias = q.dbias;
-        p.M = M; p.lddy = q.lddy; p.ldx = q.ldx; p.Ntot = q.Cin;
-        p.tilesC = q.Cout / 256; p.tilesN = q.Cin / 256;
-        p.splits = splits; p.rows_per_split = rps;
-        p.Cout = q.Cout; p.slab = (long long)q.Cout * q.Cin;
-        p.part = wp; wp += (size_t)splits * p.slab;
-        p.bpart = q.dbias ? wp : nullptr; if (q.dbias) wp += (size_t)splits * q.Cout;
-        p.deq_g = q.deq_g; p.deq_x = q.deq_x;
-        start += p.tilesC * p.tilesN;
-        flops += 2.0 * M * (double)q.Cout * q.Cin;
-    }
-    g.start[4] = 0x7fffffff;
-    constexpr int lds = 2 * 4 * 64 * 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)wgrad8p_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipFuncSetAttribute((const void*)wgrad8f_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    NkbProfScope prof(NKB_K_CONV_WGRAD, stream, flops);
-    const dim3 grid((unsigned)tiles * (unsigned)splits);
-    if (fp8) hipLaunchKernelGGL(wgrad8f_group_kernel, grid, dim3(512), lds, stream, g);
-    else hipLaunchKernelGGL(wgrad8p_group_kernel, grid, dim3(512), lds, stream, g);
-    int rc = nkb_check_launch("wgrad_group");
-    for (int j = 0; j < njobs && !rc; ++j) {
-        const W256Params& p = g.job[j];
-        rc = nkb_launch_wgrad_reduce(p.part, p.slab, splits, p.dw, p.slab, stream);
-        if (!rc && p.dbias) rc = nkb_launch_wgrad_reduce(p.bpart, p.Cout, splits, p.dbias, p.Cout, stream);
-    }
-    return rc;
 }

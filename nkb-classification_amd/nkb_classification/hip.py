@@ -103,8 +103,6 @@ _SIGS = {
     "nkb_fp8_multi": (i32, [i32, vp, i32, i64, vp]),
     "nkb_fp8_quantize_colsum_workspace_floats": (i64, [i64, i32]),
     "nkb_fp8_quantize_colsum": (i32, [i32, vp, i64, i32, i64, vp, vp, vp, vp, vp, i32, vp]),
-    "nkb_wgrad_group_workspace_floats": (i64, [i32, i32, vp, i32]),
-    "nkb_wgrad_group": (i32, [i32, i32, vp, i32, vp, i64, vp]),
     "nkb_wgrad_fp8_workspace_floats": (i64, [i32, i32, i32]),
     "nkb_wgrad_fp8": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
     "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]),
@@ -160,7 +158,7 @@ _PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_versi
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
                    "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config",
                    "nkb_fp8_job_blocks", "nkb_wgrad_fp8_workspace_floats",
-                   "nkb_fp8_quantize_colsum_workspace_floats", "nkb_wgrad_group_workspace_floats",
+                   "nkb_fp8_quantize_colsum_workspace_floats",
                    "nkb_gram_bn_backward_workspace_floats", "nkb_bn_apply_gram_workspace_floats"})
 
 
@@ -586,33 +584,6 @@ def fp8_quantize_colsum(kind, src, rows, C, ld, state, dst, colsum, workspace, r
     row_scale the matrix is row_scale[row // rows_per_sample] * src."""
     check(load().nkb_fp8_quantize_colsum(kind, ptr(src), rows, C, ld, ptr(state), ptr(dst), ptr(colsum), ptr(workspace),
                                          ptr(row_scale), int(rows_per_sample), stream()), "fp8_quantize_colsum")
-
-
-class WgradJob(C.Structure):
-    """struct NkbWgradJob of include/nkbhip.h."""
-    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
-                ("deq_g", C.c_void_p), ("deq_x", C.c_void_p),
-                ("Cin", C.c_int), ("ldx", C.c_int), ("Cout", C.c_int), ("lddy", C.c_int)]
-
-
-def wgrad_jobs(jobs):
-    """ctypes array of NkbWgradJob from dicts {dy, x, dw, dbias, deq_g, deq_x, Cin, ldx, Cout, lddy} (tensors or None)."""
-    arr = (WgradJob * len(jobs))()
-    for a, j in zip(arr, jobs):
-        a.dy, a.x, a.dw = ptr(j["dy"]), ptr(j["x"]), ptr(j["dw"])
-        a.dbias, a.deq_g, a.deq_x = ptr(j.get("dbias")), ptr(j.get("deq_g")), ptr(j.get("deq_x"))
-        a.Cin, a.ldx, a.Cout, a.lddy = j["Cin"], j["ldx"], j["Cout"], j["lddy"]
-    return arr
-
-
-def wgrad_group_workspace(fp8, arr, M) -> int:
-    return int(load().nkb_wgrad_group_workspace_floats(int(fp8), len(arr), C.addressof(arr), M))
-
-
-def wgrad_group(fp8, arr, M, workspace):
-    """Up to four Linear weight gradients over the same M tokens in one launch (see include/nkbhip.h)."""
-    check(load().nkb_wgrad_group(int(fp8), len(arr), C.addressof(arr), M, ptr(workspace), workspace.numel(), stream()),
-          "wgrad_group")
 
 
 def wgrad_fp8_workspace(M, Cin, Cout) -> int:

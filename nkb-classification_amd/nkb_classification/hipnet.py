@@ -39,11 +39,6 @@ _FP8_WGRAD = os.environ.get("NKB_FP8_WGRAD", "1") != "0"   # fp8 mode: weight gr
 # bias gradients summed inside the e5m2 quantisation pass of dY (main stream) instead of a column-sum pass on the side stream:
 # measured slower on unicom ViT-L/14 (65.0 vs 63.9 ms/step: the side stream has the slack, the main stream does not) — off
 _FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
-# one weight-gradient launch per transformer block (nkb_wgrad_group) instead of four.  Standalone the grouped launch is 2-5 % faster
-# (ViT-B/16 block: 861 -> 838-849 us, ViT-L/14: 948 -> 897); in the step it is not (ViT-B/16 38.0 -> 38.6 ms, unicom +-0.4 ms): the
-# four launches start as soon as their operands exist and overlap the rest of the block's backward pass, the grouped one waits for
-# the block to end.  Off.
-_WGRAD_GROUP = os.environ.get("NKB_WGRAD_GROUP", "0") != "0"
 _WPREP_FROM_SHADOW = os.environ.get("NKB_WPREP_FROM_SHADOW", "1") != "0"
 # LayerNorm dgamma / dbeta reduction (two small launches) on the side stream instead of in the backward chain: measured neutral
 # (unicom fp8 50.8-51.4 vs 50.9-51.3 ms, ViT-B/16 35.65-35.74 vs 35.74-35.78) — the other stream fills those gaps anyway.  Off.
@@ -109,8 +104,6 @@ class HipEngine:
         self._ones_cache: Dict[int, torch.Tensor] = {}
         self._gs_ready: Dict[int, torch.Tensor] = {}      # data_ptr of a gradient -> its stochastic-depth-scaled copy
         self._f8bias: Dict[str, bool] = {}          # ready sites whose producer also summed the columns (bias gradient done)
-        self._wg_pending = []                      # Linear weight gradients of the current block, launched together by end_block
-        self._wg_keep = {}                         # host job arrays of the grouped launches (kept alive for plan replay)  # site -> fp8 copy already written by the kernel that produced the tensor
         # recorded launch plans of the train step (hip.Plan): key -> (plan, workspace generation, saved-activation table)
         self.plans: Dict[tuple, tuple] = {}
         self.plan_seen: Dict[tuple, int] = {}      # key -> workspace generation after its last eager run
@@ -635,8 +628,6 @@ class HipEngine:
             hip.host_op(lambda: torch.cuda.current_stream().wait_event(ev))
 
     def end_block(self, index: int):
-        if self._wg_pending:
-            self.flush_wgrad_group()
         if self._side is not None:
             ev, side = torch.cuda.Event(), self._side
             hip.host_op(lambda: ev.record(side))
@@ -652,8 +643,6 @@ class HipEngine:
 
     def wait_side(self):
         """Main stream waits for every outstanding weight gradient (before the optimizer / the gradient exchange)."""
-        if self._wg_pending:
-            self.flush_wgrad_group()
         if self._side is not None:
             side = self._side
             hip.host_op(lambda: torch.cuda.current_stream().wait_stream(side))
@@ -916,33 +905,6 @@ class HipEngine:
     def _fp8_wgrad_ok(sv, M: int, K: int, N: int) -> bool:
         return _FP8_WGRAD and sv.get("xq") is not None and hip.wgrad_fp8_workspace(M, K, N) > 0
 
-    def flush_wgrad_group(self):
-        """Launch the weight gradients collected since the last flush (the Linear layers of one transformer block, same token
-        count) as ONE grouped kernel per operand type on the side stream."""
-        pend, self._wg_pending = self._wg_pending, []
-        for fp8 in (False, True):
-            jobs = [j for j in pend if j["fp8"] == fp8]
-            while jobs:
-                M = jobs[0]["M"]
-                batch = [j for j in jobs if j["M"] == M][:4]
-                jobs = [j for j in jobs if not any(j is b for b in batch)]
-                # the host job array is passed by address: cached by content so that recorded launch plans (and every later step:
-                # the operands live in persistent workspace buffers) keep pointing at a live one
-                sig = (fp8, M) + tuple((j["dy"].data_ptr(), j["x"].data_ptr(), j["dw"].data_ptr(), j["Cin"], j["Cout"],
-                                        0 if j.get("dbias") is None else j["dbias"].data_ptr()) for j in batch)
-                arr = self._wg_keep.get(sig)
-                if arr is None:
-                    arr = self._wg_keep[sig] = hip.wgrad_jobs(batch)
-                need = hip.wgrad_group_workspace(fp8, arr, M)
-
-                def run(arr=arr, need=need, fp8=fp8, M=M, batch=batch):
-                    work = self.ws.at_least("wgrad.slabs." + self._stream_tag(), need, torch.float32)
-                    hip.wgrad_group(fp8, arr, M, work)
-                    for j in batch:
-                        if j.get("colsum") is not None:        # fp8: bias gradient = column sums of the unquantised dY
-                            self.colsum2d(j["g"], j["colsum"], M, j["Cout"], j["Cout"])
-                self.on_side(run)
-
     def _linear_wgrad(self, sv, g: torch.Tensor, gq=None, sg=None, bias_done: bool = False):
         """Weight / bias gradient of a Linear on the side stream.  With both fp8 copies at hand (the forward operand xq and the
         data gradient's operand gq) the contraction runs on the fp8 kernel (NKB_FP8_WGRAD=0: bf16); the bias gradient is then
@@ -952,17 +914,6 @@ class HipEngine:
         N = lin.weight.shape[0]
         a = self.arena
         dbias = a.grad_flat(lin.bias) if lin.bias is not None else None
-        if _WGRAD_GROUP and K % 256 == 0 and N % 256 == 0 and M >= 4096 and self.T == torch.bfloat16 and x.is_contiguous() and g.is_contiguous():
-            # grouped with the other Linear layers of this block (launched by end_block)
-            if gq is not None and self._fp8_wgrad_ok(sv, M, K, N) and M % 128 == 0:
-                self._wg_pending.append(dict(fp8=True, M=M, dy=gq, x=sv["xq"], dw=a.grad_flat(lin.weight), dbias=None, deq_g=sg[1:2],
-                                             deq_x=sv["sx"][1:2], Cin=K, ldx=K, Cout=N, lddy=N, g=g,
-                                             colsum=dbias if (dbias is not None and not bias_done) else None))
-                return
-            if M % 64 == 0 and _DET_WGRAD:
-                self._wg_pending.append(dict(fp8=False, M=M, dy=g, x=x, dw=a.grad_flat(lin.weight), dbias=dbias, Cin=K, ldx=K, Cout=N,
-                                             lddy=N))
-                return
         if gq is not None and self._fp8_wgrad_ok(sv, M, K, N):
             xq, sx = sv["xq"], sv["sx"]
 

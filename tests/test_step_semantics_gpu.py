@@ -308,6 +308,25 @@ def test_train_py_under_torchrun_two_ranks(tmp_path):
     torch.testing.assert_close(sd["classifier.1.weight"], d1["head_weight"])          # rank 1 agrees with rank 0's checkpoint
 
 
+def test_bench_py_two_ranks_under_torchrun_prints_one_valid_line():
+    """bench.py exactly as the driver launches it for N = 2 (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2),
+    with the one-GPU rehearsal knobs (gloo transport, both ranks on this box's GPU): rank 0 prints ONE JSON line with n_gpus == 2,
+    global_batch == 512, weak scaling, and a `dist` object whose ranks_seen was counted by an all-reduce over the process group."""
+    import json
+    env = dict(os.environ, NKB_DIST_BACKEND="gloo", NKB_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(30400 + os.getpid() % 500), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-host-work", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["dist"] == {"backend": "gloo", "world": 2, "ranks_seen": 2}
+    assert d["value"] > 0 and abs(d["value"] - 512 * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]
+
+
 def test_train_py_two_ranks_odd_dataset_counts_every_image_once(tmp_path):
     """with len(dataset) % world != 0 the padded training shard repeats an index and a padded validation shard would
     too — epoch metrics and the choice of best.pth must still be computed over each image exactly once (255 train / 127 val
