@@ -401,8 +401,19 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                 apre2[i] = (u32x4){0u, 0u, 0u, 0u};
                 abit2[i] = 0xffu; obit2[i] = 0xffu;
                 if (m < p.M && co < p.Cout) {
-                    apre2[i] = *(const u32x4*)((const bf16_t*)p.add + (size_t)m * p.ldadd + co);
-                    if (p.add_bits) abit2[i] = p.add_bits[(size_t)m * (size_t)(p.ldadd >> 3) + (co >> 3)];
+                    if (p.add_h > 0) {
+                        // the residual lives on the stride-2 sub-grid (gradient of a 1x1 / stride-2 shortcut): only even (h, w)
+                        // positions receive it, from row (n, h/2, w/2) of the [N][add_h][add_w] tensor
+                        const unsigned n = fdiv((unsigned)m, p.divPQ);
+                        const unsigned rem = (unsigned)m - n * p.divPQ.d;
+                        const unsigned hh = fdiv(rem, p.divQ);
+                        const unsigned ww = rem - hh * p.divQ.d;
+                        if (((hh | ww) & 1u) == 0u)
+                            apre2[i] = *(const u32x4*)((const bf16_t*)p.add + (((size_t)n * p.add_h + (hh >> 1)) * p.add_w + (ww >> 1)) * p.ldadd + co);
+                    } else {
+                        apre2[i] = *(const u32x4*)((const bf16_t*)p.add + (size_t)m * p.ldadd + co);
+                        if (p.add_bits) abit2[i] = p.add_bits[(size_t)m * (size_t)(p.ldadd >> 3) + (co >> 3)];
+                    }
                     obit2[i] = p.bn_bits[(size_t)m * (size_t)(p.ldy >> 3) + (co >> 3)];
                 }
             }
@@ -1338,7 +1349,8 @@ extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void*
     if (relu_bits) {
         // lean epilogue instantiation for the common geometry (full-grid residual, 8-channel-aligned rows)
         static const int lean2 = [] { const char* e = getenv("NKB_LEAN_RES_EPILOGUE"); return e ? atoi(e) : 1; }();
-        if (lean2 && dtype == NKB_DT_BF16 && add != nullptr && add_h == 0 && (ldy & 7) == 0 && (ldadd & 7) == 0 && (Cout & 7) == 0 && stats != nullptr)
+        if (lean2 && dtype == NKB_DT_BF16 && add != nullptr && (add_h == 0 || add_bits == nullptr) && (ldy & 7) == 0 && (ldadd & 7) == 0 &&
+            (Cout & 7) == 0 && stats != nullptr)
             return narrow ? launch_conv<bf16_t, 64, 256, 6>(p, stream) : launch_conv<bf16_t, 128, 128, 6>(p, stream);
         if (dtype == NKB_DT_BF16) return narrow ? launch_conv<bf16_t, 64, 256, 2>(p, stream) : launch_conv<bf16_t, 128, 128, 2>(p, stream);
         return narrow ? launch_conv<float, 64, 256, 2>(p, stream) : launch_conv<float, 128, 128, 2>(p, stream);
