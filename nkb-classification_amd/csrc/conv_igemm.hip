@@ -1635,10 +1635,12 @@ static WgradPlan wgrad_plan(int esz, int M, int Cout, int Ntot, int target) {
     g.rows_per_split = rps;
     return g;
 }
+static thread_local int g_wgrad_target_override = 0;
 static int wgrad_target_wgs() {
     // swept (128..768) on ResNet-50 and ViT-B/16: fewer splits = less competition with the main stream
     static const int target_wgs = [] { const char* e = getenv("NKB_WGRAD_WGS"); return e ? atoi(e) : 256; }();
-    return target_wgs;
+    // (nkb_conv_wgrad_assign: a product the MAIN stream waits for — the Gram-form R = g^T a — fills the chip instead)
+    return g_wgrad_target_override > 0 ? g_wgrad_target_override : target_wgs;
 }
 
 // floats of workspace that make nkb_conv_wgrad deterministic for this problem (slabs of per-split partial tiles + bias
@@ -1651,8 +1653,15 @@ extern "C" long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, in
     if (!has_bias && nkb_wgrad3x3_eligible(dtype, N, P, Q, Cin, Cout, P, Q, R, S, stride, pad, 8, 8))
         return nkb_wgrad3x3_workspace_floats(N, P, Q, Cin, Cout);
     if (nkb_wgrad256_eligible(dtype, M, Cin, Cout, R, S, stride, pad)) return nkb_wgrad256_workspace_floats(M, Cin, Cout, has_bias);
-    const WgradPlan g = wgrad_plan(esz, M, Cout, R * S * Cin, wgrad_target_wgs());
-    return (long long)g.splits * Cout * R * S * Cin + (has_bias ? (long long)g.splits * g.tilesN * Cout : 0);
+    // (the larger of the two split counts a launch may take: the shared-GPU target, or nkb_conv_wgrad_assign's full-chip one)
+    static const int main_wgs = [] { const char* e = getenv("NKB_WGRAD_MAIN_WGS"); return e ? atoi(e) : 0; }();
+    long long need = 0;
+    for (int target : {wgrad_target_wgs(), main_wgs > 0 ? main_wgs : wgrad_target_wgs()}) {
+        const WgradPlan g = wgrad_plan(esz, M, Cout, R * S * Cin, target);
+        const long long n = (long long)g.splits * Cout * R * S * Cin + (has_bias ? (long long)g.splits * g.tilesN * Cout : 0);
+        if (n > need) need = n;
+    }
+    return need;
 }
 
 extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
@@ -1735,9 +1744,13 @@ extern "C" int nkb_conv_wgrad_assign(int dtype, const void* dy, const void* x, f
                                      int Cin, int ldx, int P, int Q, int Cout, int lddy, int R, int S, int stride, int pad,
                                      float* workspace, long long workspace_floats, hipStream_t stream) {
     if (workspace == nullptr) { nkb_set_error("conv_wgrad_assign: needs the slab workspace (the atomic form can only accumulate)"); return 1; }
+    // (measured neutral on ResNet-50: 18.01 / 18.02 / 18.00 ms at 256 / 768 / 512 — default: the shared-GPU target)
+    static const int main_wgs = [] { const char* e = getenv("NKB_WGRAD_MAIN_WGS"); return e ? atoi(e) : 0; }();
     g_wgrad_assign = true;
+    g_wgrad_target_override = main_wgs;
     const int rc = nkb_conv_wgrad(dtype, dy, x, dw, dbias, N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad, workspace, workspace_floats, stream);
     g_wgrad_assign = false;
+    g_wgrad_target_override = 0;
     return rc;
 }
 
