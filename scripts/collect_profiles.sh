@@ -4,7 +4,7 @@
 # summaries are copied to profiles/ by hand afterwards (profiles/ is tracked, gpurun_out/ is scratch).
 # Usage: bash scripts/collect_profiles.sh <tag> [model] [extra bench.py arguments, e.g. --batch 128 --dtype fp8]
 set -o pipefail
-TAG=${1:-r02}; MODEL=${2:-resnet50}; shift; shift; EXTRA="$*"; SUFFIX=$(echo "$EXTRA" | tr -c 'a-zA-Z0-9' '_' | sed 's/__*/_/g; s/_$//')
+TAG=${1:-r03}; MODEL=${2:-resnet50}; shift; shift; EXTRA="$*"; SUFFIX=$(echo "$EXTRA" | tr -c 'a-zA-Z0-9' '_' | sed 's/__*/_/g; s/_$//')
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_${TAG}_${MODEL//[^a-zA-Z0-9]/_}${SUFFIX:+_$SUFFIX}
 mkdir -p $OUT
@@ -20,6 +20,7 @@ T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); S=$(find $OUT/trace -n
 python3 scripts/profile_summary.py $T 5 $OUT/last5steps_serialized.csv > /dev/null && cp $S $OUT/kernel_stats.csv
 F=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python3 scripts/pmc_traffic.py $F $W $OUT/pmc_traffic.json 1 > $OUT/pmc_traffic.txt
+python3 scripts/overlap_report.py $T 5 4 > $OUT/overlap.txt
 M=$(find $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv" | head -1); MT=$(find $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1)
 python3 scripts/pmc_mfma.py $M $MT $OUT/pmc_mfma.json > $OUT/pmc_mfma.txt
 rm -rf $OUT/trace/*/*.db $OUT/pmc_*/*/*.db 2>/dev/null
