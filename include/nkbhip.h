@@ -160,6 +160,17 @@ int nkb_gram_k1w(int dtype, const void* w, const float* k1, int Cin, int Cout, v
 int nkb_conv_dgrad_bn_add(int dtype, const void* a, int lda, int K, const void* q, const float* cbias, const void* t, int ldt,
                           void* g_masked, const void* c_prev, const float* scale, const float* shift, const float* mean, float* stats,
                           long long M, int Cout, int ldy, nkb_stream_t stream);
+/* Gram form of a closing stage WITH a stride-1 projection shortcut (timm Bottleneck.downsample = conv1x1 + bn, layer1.0): both
+ * BatchNorms' statistics come from Gram matrices (of the main branch's input a and of the block input x), their scales are folded
+ * into one filter [scale3 .* W3 | scale_d .* Wd] (nkb_gram_fold2) and y = relu([a | x] . wf^T + shift3 + shift_d) is ONE launch with the
+ * ReLU bits — neither raw conv output exists; backward: two R products (g^T a, g^T x), two nkb_gram_bn_backward calls, the main
+ * branch's nkb_conv_dgrad_bn_cat and dx = [g | x] . [k1 Wd ; Qd]^T + cbias_d (nkb_conv_cat_bias). */
+int nkb_gram_fold2(int dtype, const void* w1, const float* s1, int K1, const void* w2, const float* s2, int K2, int Cout, void* out,
+                   const float* shift1, const float* shift2, float* shift_out, nkb_stream_t stream);
+int nkb_conv_cat_relu_bits(int dtype, const void* a, int lda, int K1, const void* x, int ldx, int K2, const void* wf, const float* shift,
+                           void* y, unsigned char* relu_bits, long long M, int Cout, int ldy, nkb_stream_t stream);
+int nkb_conv_cat_bias(int dtype, const void* a, int lda, int K1, const void* x, int ldx, int K2, const void* w, const float* bias, void* y,
+                      long long M, int Cout, int ldy, nkb_stream_t stream);
 int nkb_conv_dgrad_bn_cat(int dtype, const void* g, int ldg, int K1, const void* a, int lda, int K2, const void* wcat,
                           const float* cbias, void* g_masked, const void* c_prev, const float* scale, const float* shift,
                           const float* mean, float* stats, long long M, int Cout, int ldy, nkb_stream_t stream);

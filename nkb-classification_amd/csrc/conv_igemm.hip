@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, OOB, 0x00020000);
     // K-concatenated launches: the activation rows of k-tiles >= kt2 come from a second tensor (plain 1x1 geometry only)
-    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)((BNB == 1 || BNB == 7) ? p.x2 : nullptr), 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)((BNB == 1 || BNB == 7 || BNB == 4 || BNB == 8) ? p.x2 : nullptr), 0, OOB, 0x00020000);
 
     u32x4 sw[NWR], sx[NPX];
     int r = 0, s = 0, ck = 0;  // filter tap and channel-tile of the NEXT k-tile to load
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             if (++s == 3) { s = 0; if (++ck == cpk) { ck = 0; ++r; } }
             return;
         }
-        if ((BNB == 1 || BNB == 7) && p.x2 != nullptr && kt >= p.kt2) {
+        if ((BNB == 1 || BNB == 7 || BNB == 4 || BNB == 8) && p.x2 != nullptr && kt >= p.kt2) {
             const int koff = (kt - p.kt2) * 128 + cc * 16;
 #pragma unroll
             for (int i = 0; i < NWR; ++i)
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
     float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = ((BNB == 0 || BNB == 1 || BNB == 3 || BNB == 7) && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bv[e] = ((BNB == 0 || BNB == 1 || BNB == 3 || BNB == 7 || BNB == 8) && p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
     // BNB: the stage's scale / shift / mean for this tile's channels live in LDS behind the epilogue tile (keeping them
     // in registers next to the not-yet-stored accumulators cost a wave of occupancy)
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             }
     }
     __syncthreads();
-    if constexpr (BNB == 3) {
+    if constexpr (BNB == 3 || BNB == 8) {
         // plain bf16 store path (no residual operand, activation epilogue, row remap or fp32 output): ~10 VALU
         // instructions per row instead of ~70 — on the single-k-tile 1x1 shapes the general loop's address arithmetic
         // and flag tests were ~45 % of the kernel's issue time (rocprofv3 SQ_INSTS_VALU: 881 per wave for 32 MFMAs)
@@ -512,15 +512,16 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             const size_t astep = (size_t)RPP * p.ldadd;
             unsigned char* ob = p.out_bits + (size_t)mrow * (size_t)(p.ldy >> 3) + (co >> 3);
             const size_t bstep = (size_t)RPP * (size_t)(p.ldy >> 3);
-            u32x4 ar[RPH];                     // residual rows of this half, requested together
+            u32x4 ar[RPH];                     // residual rows of this half, requested together (none: K-concatenated shortcut)
 #pragma unroll
             for (int ri = 0; ri < RPH; ++ri) {
                 ar[ri] = (u32x4){0u, 0u, 0u, 0u};
-                if (mrow + RPP * ri < p.M) ar[ri] = *(const u32x4*)(ad + ri * astep);
+                if (p.add != nullptr && mrow + RPP * ri < p.M) ar[ri] = *(const u32x4*)(ad + ri * astep);
             }
             float sc[8], sh[8];
             {
-                const f32x4 a0 = *(const f32x4*)(p.oscale + co), a1 = *(const f32x4*)(p.oscale + co + 4);
+                const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
+                const f32x4 a0 = p.oscale ? *(const f32x4*)(p.oscale + co) : one, a1 = p.oscale ? *(const f32x4*)(p.oscale + co + 4) : one;
                 const f32x4 b0 = *(const f32x4*)(p.bias + co), b1 = *(const f32x4*)(p.bias + co + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { sc[e] = a0[e]; sc[4 + e] = a1[e]; sh[e] = b0[e]; sh[4 + e] = b1[e]; }
@@ -1391,6 +1392,54 @@ extern "C" int nkb_conv_affine_residual(int dtype, const void* x, const void* w,
     NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * p.M * (double)Cout * R * S * Cin,
                       ((double)N * H * W * Cin + (double)Cout * R * S * Cin + 2.0 * p.M * Cout) * 2 + (double)p.M * Cout / 8);
     return launch_conv<bf16_t, 128, 128, 4>(p, stream);
+}
+
+// Gram-form closing stage of a block WITH a projection shortcut (stride 1): both BatchNorms' scales are folded into ONE filter,
+//   y = relu([a | x] . [scale3 .* W3 | scale_d .* Wd]^T + shift3 + shift_d)   (+ ReLU bits),
+// so neither the main branch's nor the shortcut's raw conv output exists.  wf: [Cout][K1 + K2] (nkb_gram_fold2), shift [Cout].
+extern "C" int nkb_conv_cat_relu_bits(int dtype, const void* a, int lda, int K1, const void* x, int ldx, int K2, const void* wf,
+                                      const float* shift, void* y, unsigned char* relu_bits, long long M, int Cout, int ldy,
+                                      hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 || Cout <= 64 || Cout % 8 || ldy % 8 || K1 % 64 || K2 % 64 || K2 <= 0 || lda % 8 || ldx % 8 || !shift || !relu_bits) {
+        nkb_set_error("conv_cat_relu_bits: bf16, Cout=%d > 64 and %% 8, K1=%d / K2=%d %% 64", Cout, K1, K2);
+        return 1;
+    }
+    if (M * lda * 2 >= 0xFFFFFF00ll || M * ldx * 2 >= 0xFFFFFF00ll || M * ldy >= (1ll << 31)) { nkb_set_error("conv_cat_relu_bits: operand too large"); return 1; }
+    ConvParams p;
+    p.x = a; p.w = wf; p.y = y; p.add = nullptr; p.bias = shift; p.stats = nullptr;
+    p.M = (int)M; p.H = (int)M; p.W = 1; p.Cin = K1 + K2; p.ldx = lda; p.P = (int)M; p.Q = 1; p.Cout = Cout; p.ldy = ldy;
+    p.ldadd = 0; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 0; p.relu = 1;
+    p.stride_w = 1; p.pad_w = 0; p.stem_cprw = 0; p.out_f32 = 0;
+    p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
+    p.ldw = K1 + K2; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
+    p.oscale = nullptr; p.add_scale = nullptr; p.add_shift = nullptr; p.out_bits = relu_bits;
+    p.x2 = x; p.ldx2 = ldx; p.kt2 = K1 / 64;
+    nkb_count_launch(4);
+    NkbProfScope prof(NKB_K_CONV_FWD, stream, 2.0 * M * (double)Cout * (K1 + K2),
+                      ((double)M * (K1 + K2) + (double)Cout * (K1 + K2) + (double)M * Cout) * 2 + (double)M * Cout / 8);
+    return launch_conv<bf16_t, 128, 128, 4>(p, stream);
+}
+// y = [a | x] . w^T + bias, plain bf16 store: the shortcut's input gradient in the Gram form, dx = [g | x] . [k1 Wd ; Qd] + k3 Wd.
+extern "C" int nkb_conv_cat_bias(int dtype, const void* a, int lda, int K1, const void* x, int ldx, int K2, const void* w, const float* bias,
+                                 void* y, long long M, int Cout, int ldy, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 || Cout % 8 || ldy % 8 || K1 % 64 || K2 % 64 || K2 <= 0 || lda % 8 || ldx % 8) {
+        nkb_set_error("conv_cat_bias: bf16, Cout=%d %% 8, K1=%d / K2=%d %% 64", Cout, K1, K2);
+        return 1;
+    }
+    if (M * lda * 2 >= 0xFFFFFF00ll || M * ldx * 2 >= 0xFFFFFF00ll || M * ldy >= (1ll << 31)) { nkb_set_error("conv_cat_bias: operand too large"); return 1; }
+    ConvParams p;
+    p.x = a; p.w = w; p.y = y; p.add = nullptr; p.bias = bias; p.stats = nullptr;
+    p.M = (int)M; p.H = (int)M; p.W = 1; p.Cin = K1 + K2; p.ldx = lda; p.P = (int)M; p.Q = 1; p.Cout = Cout; p.ldy = ldy;
+    p.ldadd = 0; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.mode = 1; p.relu = 0;
+    p.stride_w = 1; p.pad_w = 0; p.stem_cprw = 0; p.out_f32 = 0;
+    p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
+    p.ldw = K1 + K2; p.inner = 1; p.sxo = p.sxi = p.swo = p.swi = p.syo = p.syi = 0;
+    p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
+    p.x2 = x; p.ldx2 = ldx; p.kt2 = K1 / 64;
+    NkbProfScope prof(NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)Cout * (K1 + K2), ((double)M * (K1 + K2) + (double)Cout * (K1 + K2) + (double)M * Cout) * 2);
+    static const int narrow_on = [] { const char* e = getenv("NKB_NARROW"); return e ? atoi(e) : 1; }();
+    return (Cout <= 64 && narrow_on) ? launch_conv<bf16_t, 64, 256, 8>(p, stream) : launch_conv<bf16_t, 128, 128, 8>(p, stream);
 }
 
 // Data gradient of the Gram-form closing stage (grambn.hip): with dc = k1*g + k2*c + k3 and c = a W^T never materialised,

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 3) void bn_apply_gram_kernel(const bf16_t* __r
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);     // bn_apply_kernel's expression
             u32x4 pk = pack8(v);
-            if (r < rows) *(u32x4*)(y + (size_t)r * C + cc * 8) = pk;
+            if (r < rows) { if (y) *(u32x4*)(y + (size_t)r * C + cc * 8) = pk; }
             else pk = (u32x4){0u, 0u, 0u, 0u};
             *(u32x4*)(smem + gswz(srow + RPS * i, cc)) = pk;
             float f[8];
@@ -171,6 +171,8 @@ extern "C" size_t nkb_bn_apply_gram_workspace_floats(long long rows, int C) {
     return (C == 64 || C == 128) ? (size_t)gram_grid(rows, C) * ((size_t)C * C + C) : 0;
 }
 // y = relu(c * scale + shift) (bf16, [rows][C], C = 64 or 128) and gram[0 .. C*C) = y^T y, gram[C*C .. C*C + C) = column sums of y.
+// y == NULL: only the Gram matrix / column sums (of relu(c * scale + shift)) are produced — with scale = 1, shift = 0 on a non-negative
+// tensor that is a plain streaming Gram pass.
 extern "C" int nkb_bn_apply_gram(int dtype, const void* c, void* y, const float* scale, const float* shift, long long rows, int C,
                                  float* gram, float* work, size_t work_floats, hipStream_t stream) {
     if (dtype != NKB_DT_BF16 || (C != 64 && C != 128) || rows < 1 || rows >= (1ll << 31)) {
@@ -437,6 +439,37 @@ extern "C" int nkb_gram_k1w(int dtype, const void* w, const float* k1, int Cin, 
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(gram_k1w_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)w, k1, Cin, Cout, (bf16_t*)out);
     else hipLaunchKernelGGL(gram_k1w_kernel<float>, grid, dim3(256), 0, stream, (const float*)w, k1, Cin, Cout, (float*)out);
     return nkb_check_launch("gram_k1w");
+}
+
+// out[k][0 .. K1) = s1[k] * w1[k][:], out[k][K1 .. K1 + K2) = s2[k] * w2[k][:], shift_out = shift1 + shift2: the single filter of a
+// closing stage whose projection shortcut is K-concatenated into it (nkb_conv_cat_relu_bits)
+template <typename WT>
+__global__ void gram_fold2_kernel(const WT* __restrict__ w1, const float* __restrict__ s1, int K1, const WT* __restrict__ w2,
+                                  const float* __restrict__ s2, int K2, int Cout, WT* __restrict__ out, const float* __restrict__ sh1,
+                                  const float* __restrict__ sh2, float* __restrict__ shift_out) {
+    const int K = K1 + K2;
+    const long long n = (long long)Cout * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / K), j = (int)(i - (long long)k * K);
+        const float v = j < K1 ? s1[k] * ldw<WT>(w1 + (size_t)k * K1 + j) : s2[k] * ldw<WT>(w2 + (size_t)k * K2 + (j - K1));
+        if constexpr (sizeof(WT) == 2) out[i] = f2bf(v); else out[i] = v;
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < Cout) shift_out[t] = sh1[t] + sh2[t];
+}
+extern "C" int nkb_gram_fold2(int dtype, const void* w1, const float* s1, int K1, const void* w2, const float* s2, int K2, int Cout,
+                              void* out, const float* shift1, const float* shift2, float* shift_out, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16 && dtype != NKB_DT_F32) { nkb_set_error("gram_fold2: bad dtype %d", dtype); return 1; }
+    NkbProfScope prof(NKB_K_WPREP, stream, 0);
+    const long long n = (long long)Cout * (K1 + K2);
+    const unsigned grid = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    if (dtype == NKB_DT_BF16)
+        hipLaunchKernelGGL(gram_fold2_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)w1, s1, K1, (const bf16_t*)w2, s2, K2, Cout,
+                           (bf16_t*)out, shift1, shift2, shift_out);
+    else
+        hipLaunchKernelGGL(gram_fold2_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)w1, s1, K1, (const float*)w2, s2, K2, Cout,
+                           (float*)out, shift1, shift2, shift_out);
+    return nkb_check_launch("gram_fold2");
 }
 
 // cbias[j] = sum over the coefficient kernel's blocks, in a fixed order: 16 row partitions per 64 columns, combined through LDS

@@ -138,7 +138,11 @@ class HipResNet(_ParamOnly):
             inp = x
             stages = blk.stages()
             short, short_affine = inp, None
-            if blk.downsample is not None:
+            want_gram = isinstance(blk, _Bottle) and bi + 1 < nblocks and train
+            proj = None
+            if blk.downsample is not None and want_gram and eng.gram_proj_ok(blk.downsample[0], stages[-1][0]):
+                proj = (blk.downsample[0], blk.downsample[1], inp, f"{name}.ds")     # rides inside the closing convolution
+            elif blk.downsample is not None:
                 # projection shortcut: its BatchNorm is applied inside the closing stage's pass (never materialised);
                 # the convolution itself only depends on the block input, so it runs on the side stream next to the
                 # main branch (the forward pass has nothing else to overlap)
@@ -152,17 +156,18 @@ class HipResNet(_ParamOnly):
                     shortcut()
             # Gram form of the closing stage (hipnet._conv_bn_gram): every bottleneck but the last — its backward needs the masked
             # output gradient + sums that the NEXT block's conv1 data gradient leaves (can_fuse_residual_bn_backward)
-            want_gram = isinstance(blk, _Bottle) and bi + 1 < nblocks and train
             for k, (cv, bn) in enumerate(stages[:-1]):
                 x = eng.conv_bn(f"{name}.{k}", x, cv, bn, True, None, train, gram_out=want_gram and k == len(stages) - 2)
-            if blk.downsample is not None:
+            if blk.downsample is not None and proj is None:
                 if _SIDE_SHORTCUT:
                     eng.join_side()
                 short, s_scale, s_shift = box["r"]
                 short_affine = (s_scale, s_shift) if s_scale is not None else None     # None: eval mode, already normalised
             cv, bn = stages[-1]
             gram = want_gram and eng.can_fuse_bn_backward(f"{name}.{len(stages) - 2}")
-            x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train, res_affine=short_affine, gram=gram)
+            if proj is not None and not gram:
+                raise RuntimeError(f"{name}: projection shortcut planned into a Gram-form closing stage that did not qualify")
+            x = eng.conv_bn(f"{name}.{len(stages) - 1}", x, cv, bn, True, short, train, res_affine=short_affine, gram=gram, proj=proj)
         return eng.avgpool("gap", x)
 
     def run_backward(self, eng: HipEngine, g_emb: torch.Tensor, on_done=None):
@@ -204,7 +209,9 @@ class HipResNet(_ParamOnly):
                     ga = eng.conv_backward(f"{name}.{k}", gc, f"a{k}")
                     gc = eng.bn_backward(prev, ga, f"c{k}")
             add, add_hw, add_bits = g, (0, 0), bits
-            if blk.downsample is not None:
+            if blk.downsample is not None and eng.saved[last].get("gram_ds") is not None:
+                add, add_bits, eng._gram_ds_grad = eng._gram_ds_grad, None, None      # formed by gram_closing_backward
+            elif blk.downsample is not None:
                 add_bits = None
                 gcd = eng.bn_backward(f"{name}.ds", g, "t5", g_bits=bits)
                 dconv = blk.downsample[0]

@@ -45,6 +45,9 @@ _SIGS = {
     "nkb_gram_k1w": (i32, [i32, vp, vp, i32, i32, vp, vp]),
     "nkb_conv_dgrad_bn_add": (i32, [i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "nkb_gram_bn_backward_workspace_floats": (sz, [i32, i32]),
+    "nkb_gram_fold2": (i32, [i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "nkb_conv_cat_relu_bits": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "nkb_conv_cat_bias": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, i64, i32, i32, vp]),
     "nkb_conv_dgrad_bn_cat": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "nkb_wprep_multi": (i32, [i32, vp, vp, i32, i32, vp, vp]),
     "nkb_wprep_block_elems": (i32, []),
@@ -414,6 +417,20 @@ def conv_dgrad_bn_add(dtype, a, lda, K, q, cbias, t, ldt, g_masked, c_prev, scal
 def conv_dgrad_bn_cat(dtype, g, ldg, K1, a, lda, K2, wcat, cbias, g_masked, c_prev, scale, shift, mean, stats, M, Cout, ldy):
     check(load().nkb_conv_dgrad_bn_cat(dtype, ptr(g), ldg, K1, ptr(a), lda, K2, ptr(wcat), ptr(cbias), ptr(g_masked), ptr(c_prev),
                                        ptr(scale), ptr(shift), ptr(mean), ptr(stats), M, Cout, ldy, stream()), "conv_dgrad_bn_cat")
+
+
+def gram_fold2(dtype, w1, s1, K1, w2, s2, K2, Cout, out, shift1, shift2, shift_out):
+    check(load().nkb_gram_fold2(dtype, ptr(w1), ptr(s1), K1, ptr(w2), ptr(s2), K2, Cout, ptr(out), ptr(shift1), ptr(shift2), ptr(shift_out),
+                                stream()), "gram_fold2")
+
+
+def conv_cat_relu_bits(dtype, a, lda, K1, x, ldx, K2, wf, shift, y, relu_bits, M, Cout, ldy):
+    check(load().nkb_conv_cat_relu_bits(dtype, ptr(a), lda, K1, ptr(x), ldx, K2, ptr(wf), ptr(shift), ptr(y), ptr(relu_bits), M, Cout, ldy,
+                                        stream()), "conv_cat_relu_bits")
+
+
+def conv_cat_bias(dtype, a, lda, K1, x, ldx, K2, w, bias, y, M, Cout, ldy):
+    check(load().nkb_conv_cat_bias(dtype, ptr(a), lda, K1, ptr(x), ldx, K2, ptr(w), ptr(bias), ptr(y), M, Cout, ldy, stream()), "conv_cat_bias")
 
 
 def bn_backward_ws(rows, C_):

@@ -61,6 +61,8 @@ _GRAM_BN = os.environ.get("NKB_GRAM_BN", "1") != "0"
 # idles 0.4-3.4 ms per step at the joins (the side stream still holds the previous block's weight gradients in front of the chain).  Off.
 _GRAM_SPLIT = os.environ.get("NKB_GRAM_SPLIT", "0") != "0"
 _GRAM_MAX_C = int(os.environ.get("NKB_GRAM_MAX_C", "128"))
+# a stride-1 projection shortcut (ResNet-50 layer1.0) K-concatenated into the Gram-form closing convolution (0 = separate conv + BN passes)
+_GRAM_PROJ = os.environ.get("NKB_GRAM_PROJ", "1") != "0"
 
 
 class HipEngine:
@@ -109,6 +111,7 @@ class HipEngine:
         self.plan_seen: Dict[tuple, int] = {}      # key -> workspace generation after its last eager run
         self.gram_bn = _GRAM_BN                    # Gram form of bottleneck closing stages (tests flip it per engine)
         self._gram_of = None                       # (data_ptr of an activation, its Gram matrix + column sums) from nkb_bn_apply_gram
+        self._gram_ds_grad = None                  # input gradient of a K-concatenated projection shortcut (gram_closing_backward)
 
     # ------------------------------------------------------------------ weights ----
     def register(self, convs, stems, head_weights, head_biases):
@@ -309,7 +312,8 @@ class HipEngine:
     # ------------------------------------------------------------------ forward ops ----
     def conv_bn(self, key: str, x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool,
                 res: Optional[torch.Tensor], train: bool, col_input: bool = False, pool: bool = False,
-                stem_packed=None, defer_apply: bool = False, res_affine=None, gram: bool = False, gram_out: bool = False):
+                stem_packed=None, defer_apply: bool = False, res_affine=None, gram: bool = False, gram_out: bool = False,
+                proj=None):
         """y = act(bn(conv(x)) (+ res)).  x: [N,H,W,Cin] in the compute dtype (or the im2row matrix of the stem).
         stem_packed=(N, H, W): x is the packed image of nkb_stem_pack and conv the 7x7/2 stem.
         defer_apply=True: stop after the statistics and return (c, scale, shift) — for a projection shortcut, whose
@@ -361,6 +365,9 @@ class HipEngine:
             else:
                 hip.conv_gemm(self.d, 0, x, ent[1], y, bias=ent[2], relu=relu, add=res, ldadd=co if res is not None else 0, **geom)
             return (y, None, None) if defer_apply else y
+        if proj is not None:
+            assert gram and train and self.gram_proj_ok(proj[0], conv)
+            return self._conv_bn_gram(key, x, conv, bn, None, None, geom, rows, proj=proj)
         if gram and train and self.gram_ok(conv, res, x):
             return self._conv_bn_gram(key, x, conv, bn, res, res_affine, geom, rows)
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
@@ -429,7 +436,31 @@ class HipEngine:
                 and w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1 and conv.stride == (1, 1) and conv.padding == (0, 0)
                 and w.shape[1] % 64 == 0 and w.shape[1] <= _GRAM_MAX_C and w.shape[0] > 64 and w.shape[0] % 8 == 0 and x.dim() == 4)
 
-    def _conv_bn_gram(self, key, x, conv, bn, res, res_affine, geom, rows):
+    def gram_proj_ok(self, dconv, conv) -> bool:
+        """The projection shortcut can ride inside the Gram-form closing convolution (K-concatenated): 1x1 / stride 1 / no bias on a
+        block input of 64 | Cin <= _GRAM_MAX_C channels (timm ResNet-50: layer1.0) and an eligible closing convolution."""
+        wd, w = dconv.weight, conv.weight
+        return (_GRAM_PROJ and self.gram_bn and self.T == torch.bfloat16 and wd.dim() == 4 and wd.shape[2] == 1 and wd.shape[3] == 1
+                and dconv.stride == (1, 1) and dconv.padding == (0, 0) and dconv.bias is None and wd.shape[1] % 64 == 0
+                and wd.shape[1] <= _GRAM_MAX_C and wd.shape[0] == w.shape[0]
+                and self.gram_ok(conv, wd, torch.empty(0, 0, 0, 0)))
+
+    def _gram_of_input(self, key, xin, rows, cx):
+        """G = x^T x and the column sums of a NON-NEGATIVE activation (a block input): nkb_bn_apply_gram as an identity pass (scale 1,
+        shift 0, no store) for 64 / 128 channels, the weight-gradient GEMM otherwise."""
+        gs = self.ws.get(key + ".gramx", (cx * cx + cx,), torch.float32)
+        if cx in (64, 128):
+            one = self._ones_cache.get(("f", cx))
+            if one is None:
+                one = self._ones_cache[("f", cx)] = (torch.ones(cx, device=self.device), torch.zeros(cx, device=self.device))
+            work = self.ws.at_least("gram.slabs", hip.bn_apply_gram_ws(rows, cx), torch.float32)
+            hip.bn_apply_gram(self.d, xin, None, one[0], one[1], rows, cx, gs, work)
+        else:
+            N, H, W, _ = xin.shape
+            self.wgrad(xin, xin, gs[:cx * cx], dbias=gs[cx * cx:], assign=True, N=N, H=H, W=W, Cin=cx, ldx=cx, P=H, Q=W, Cout=cx, lddy=cx)
+        return gs
+
+    def _conv_bn_gram(self, key, x, conv, bn, res, res_affine, geom, rows, proj=None):
         """Closing stage in the Gram form (train mode): G = x^T x and the column sums of x (one pass over the NARROW input), the
         batch statistics of conv(x) from them (nkb_gram_bn_stats), then y = relu(conv(x) * scale + shift + res) in ONE launch."""
         w = conv.weight
@@ -446,18 +477,37 @@ class HipEngine:
             self.wgrad(x, x, G, dbias=s, assign=True, N=N, H=P, W=Q, Cin=ci, ldx=ci, P=P, Q=Q, Cout=ci, lddy=ci)
         sc = self.ws.get(key + ".bnvec", (4, co), torch.float32)
         scale, shift, mean, invstd = sc[0], sc[1], sc[2], sc[3]
-        cov = self.ws.at_least("gram.cov", ci * ci, torch.float32)
+        cov = self.ws.at_least("gram.cov", max(ci, proj[0].weight.shape[1] if proj is not None else 0) ** 2, torch.float32)
         mu = self.ws.get(key + ".gmu", (ci,), torch.float32)
         T = self.ws.get(key + ".gT", (co, ci), torch.float32)
         hip.gram_bn_stats(self.d, self.w_fwd(w), G, s, rows, ci, co, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                           bn.momentum if bn.momentum is not None else 0.1, bn.eps, cov, mu, T, scale, shift, mean, invstd)
         y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
         bits = self.ws.get(key + ".bits", (rows, co // 8), torch.uint8)
-        hip.conv_affine_residual(self.d, x, self.w_fwd(w), y, scale, shift, res, co, res_affine[0] if res_affine else None,
-                                 res_affine[1] if res_affine else None, bits, **geom)
+        gram_ds = None
+        if proj is not None:
+            # projection shortcut inside the same launch: its BatchNorm statistics from the Gram matrix of the block input, both
+            # scales folded into one K-concatenated filter — the shortcut's raw conv output never exists either
+            dconv, dbn, xin, dkey = proj
+            cx = dconv.weight.shape[1]
+            gx = self._gram_of_input(dkey, xin, rows, cx)
+            scd = self.ws.get(dkey + ".bnvec", (4, co), torch.float32)
+            mud = self.ws.get(dkey + ".gmu", (cx,), torch.float32)
+            Td = self.ws.get(dkey + ".gT", (co, cx), torch.float32)
+            hip.gram_bn_stats(self.d, self.w_fwd(dconv.weight), gx[:cx * cx], gx[cx * cx:], rows, cx, co, dbn.weight, dbn.bias,
+                              dbn.running_mean, dbn.running_var, dbn.momentum if dbn.momentum is not None else 0.1, dbn.eps, cov, mud, Td,
+                              scd[0], scd[1], scd[2], scd[3])
+            wf = self.ws.get(key + ".gwf", (co, ci + cx), self.T)
+            shf = self.ws.get(key + ".gshift", (co,), torch.float32)
+            hip.gram_fold2(self.d, self.w_fwd(w), scale, ci, self.w_fwd(dconv.weight), scd[0], cx, co, wf, shift, scd[1], shf)
+            hip.conv_cat_relu_bits(self.d, x, ci, ci, xin, cx, cx, wf, shf, y, bits, rows, co, co)
+            gram_ds = dict(conv=dconv, bn=dbn, x=xin, T=Td, mu=mud, mean=scd[2], invstd=scd[3], key=dkey)
+        else:
+            hip.conv_affine_residual(self.d, x, self.w_fwd(w), y, scale, shift, res, co, res_affine[0] if res_affine else None,
+                                     res_affine[1] if res_affine else None, bits, **geom)
         self.saved[key] = dict(x=x, c=None, cshape=(N, P, Q, co), y=y, mean=mean, invstd=invstd, relu=True, geom=geom, conv=conv,
                                bn=bn, rows=rows, col_input=False, scale=scale, shift=shift, has_res=True, pool_idx=None,
-                               stem_packed=False, bits=bits, gram=dict(T=T, mu=mu))
+                               stem_packed=False, bits=bits, gram=dict(T=T, mu=mu), gram_ds=gram_ds)
         return y
 
     def gram_closing_backward(self, key: str, g: torch.Tensor, g_stats, prev_key: str, slot: str):
@@ -476,7 +526,7 @@ class HipEngine:
         cbias = self.ws.get(key + ".gcbias", (ci,), torch.float32)
         tiles2 = hip.stat_tiles(self.d, rows, ci)
         stats2 = self.ws.get(prev_key + ".bstats", (hip.bn_stats_floats(tiles2, ci),), torch.float32)
-        if _GRAM_SPLIT and self.overlap_wgrad:
+        if _GRAM_SPLIT and self.overlap_wgrad and sv.get("gram_ds") is None:
             q = self.ws.get(key + ".gq", (ci, ci), self.T)
 
             def algebra():
@@ -498,9 +548,26 @@ class HipEngine:
             return dx, (stats2, tiles2)
         self.wgrad(g, x, R, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
         wcat = self.ws.get(key + ".gwcat", (ci, co + ci), self.T)
-        coef = self.ws.at_least("gram.bwd", hip.gram_bn_backward_ws(ci, co), torch.float32)
+        need = hip.gram_bn_backward_ws(ci, co)
+        if sv.get("gram_ds") is not None:
+            need = max(need, hip.gram_bn_backward_ws(sv["gram_ds"]["conv"].weight.shape[1], co))
+        coef = self.ws.at_least("gram.bwd", need, torch.float32)
         hip.gram_bn_backward(self.d, self.w_fwd(w), R, sv["gram"]["T"], sv["gram"]["mu"], stats, tiles, rows, ci, co, bn.weight,
                              sv["mean"], sv["invstd"], a.grad_flat(bn.weight), a.grad_flat(bn.bias), a.grad_flat(w), wcat, cbias, coef)
+        ds = sv.get("gram_ds")
+        if ds is not None:
+            # the K-concatenated projection shortcut: same g, the block input in place of a
+            dconv, dbn, xin = ds["conv"], ds["bn"], ds["x"]
+            cx = dconv.weight.shape[1]
+            Rd = self.ws.get(ds["key"] + ".gR", (co, cx), torch.float32)
+            self.wgrad(g, xin, Rd, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=cx, ldx=cx, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
+            wcd = self.ws.get(ds["key"] + ".gwcat", (cx, co + cx), self.T)
+            cbd = self.ws.get(ds["key"] + ".gcbias", (cx,), torch.float32)
+            hip.gram_bn_backward(self.d, self.w_fwd(dconv.weight), Rd, ds["T"], ds["mu"], stats, tiles, rows, cx, co, dbn.weight,
+                                 ds["mean"], ds["invstd"], a.grad_flat(dbn.weight), a.grad_flat(dbn.bias), a.grad_flat(dconv.weight), wcd, cbd, coef)
+            dxs = self.scratch("t6", xin.shape)
+            hip.conv_cat_bias(self.d, g, co, co, xin, cx, cx, wcd, cbd, dxs, rows, cx, cx)
+            self._gram_ds_grad = dxs
         dx = self.scratch(slot, x.shape)
         hip.conv_dgrad_bn_cat(self.d, g, co, co, x, ci, ci, wcat, cbias, dx, svp["c"], svp["scale"], svp["shift"], svp["mean"],
                               stats2, rows, ci, ci)
