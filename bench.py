@@ -111,7 +111,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-work", action="store_true", help="skip the batch-4 host-work measurement (profiler runs)")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)       # >= 5 timed steps
     return ap.parse_args()
 
 
