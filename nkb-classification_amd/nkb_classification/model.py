@@ -205,7 +205,7 @@ class _HipClassifier(nn.Module):
         record = eng.plan_seen.get(key) == eng.ws.generation
         if record:
             hip.record_begin()
-        allocs = _alloc_count(img.device)
+        allocs = _alloc_count(img.device) if record else 0
         try:
             run()
         except BaseException:
@@ -263,7 +263,7 @@ class _HipClassifier(nn.Module):
                 record = eng.plan_seen.get(key) == eng.ws.generation
                 if record:
                     hip.record_begin()
-                allocs = _alloc_count(glogits.device)
+                allocs = _alloc_count(glogits.device) if record else 0
                 try:
                     run()
                 except BaseException:
