@@ -300,17 +300,17 @@ def main():
         if world > 1:
             dist.barrier()
 
-    sync()
     if os.environ.get("NKB_BENCH_GC", "1") != "0":
         # the interpreter's first full collection after model construction walks every module / tensor object (tens of
-        # ms of host time, once); take it now instead of inside the first timed step
+        # ms of host time, once); take it now instead of inside the first timed step — and BEFORE the barrier below, so
+        # that no rank enters the timed region a collection ahead of another
         import gc
         gc.collect()
         gc.freeze()
     if args.input != "hbm":
         feed = host_batches(args.steps + 2)
         step(); step()                       # pipeline primed: the first copy is not hidden behind a step
-        sync()
+    sync()                                   # barrier + synchronize: the last thing before the clock starts
     log("warm-up done; timing")
     t0 = time.perf_counter()
     step_marks = []

@@ -414,6 +414,12 @@ int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float*
  * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 768).  Tests and A/B timing. */
 void nkb_gemm8p_config(int on, int min_tiles, int min_k);
 
+/* BatchNorm statistics over many row tiles (tiles > 128; nkb_bn_finalize, nkb_bn_backward_from_stats, the Gram-form tile sums):
+ * on = 1 (default, NKB_BN_FUSED_FINALIZE) reduces and finalizes in ONE launch — the partition block that draws the last ticket
+ * finalizes; on = 0 restores the two-launch form.  Bit-identical results either way.  Returns the previous setting.  Replaces
+ * nothing in the reference (torch's batch_norm kernels behind timm's BatchNormAct2d, reference model.py:82). */
+int nkb_bn_fused_finalize(int on);
+
 /* Per-launch HIP-event profiler (bench.py's roofline leg). */
 void nkb_prof_enable(int on);
 int nkb_prof_collect(double* ms, long long* launches, double* work, double* bytes, int slots);

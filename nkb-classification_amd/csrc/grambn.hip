@@ -192,10 +192,13 @@ extern "C" int nkb_bn_apply_gram(int dtype, const void* c, void* y, const float*
     }
     NkbProfScope prof(NKB_K_WGRAD_REDUCE, stream, 0, 4.0 * ((double)G + 1.0) * slab);
     const long long n4 = (long long)slab / 4;
-    const int sg = G >= 48 ? 16 : (G >= 6 ? 4 : 1);
+    // 64 slab walkers per column when 16 would leave the launch under one workgroup per CU (C = 64: 1 040 columns = 65 workgroups
+    // of 16 columns reading 12.8 MB: 15 us; 260 workgroups of 4: 8 us)
+    const int sg = G >= 48 ? ((G >= 256 && n4 < 16 * 200) ? 64 : 16) : (G >= 6 ? 4 : 1);
     const int cols = 256 / sg;
     const unsigned grid = (unsigned)((n4 + cols - 1) / cols);
-    if (sg == 16) hipLaunchKernelGGL(gram_reduce_kernel<16>, dim3(grid), dim3(256), 0, stream, work, (long long)slab, G, gram, n4);
+    if (sg == 64) hipLaunchKernelGGL(gram_reduce_kernel<64>, dim3(grid), dim3(256), 0, stream, work, (long long)slab, G, gram, n4);
+    else if (sg == 16) hipLaunchKernelGGL(gram_reduce_kernel<16>, dim3(grid), dim3(256), 0, stream, work, (long long)slab, G, gram, n4);
     else if (sg == 4) hipLaunchKernelGGL(gram_reduce_kernel<4>, dim3(grid), dim3(256), 0, stream, work, (long long)slab, G, gram, n4);
     else hipLaunchKernelGGL(gram_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, work, (long long)slab, G, gram, n4);
     return nkb_check_launch("gram_reduce");
