@@ -420,6 +420,29 @@ void nkb_gemm8p_config(int on, int min_tiles, int min_k);
  * nothing in the reference (torch's batch_norm kernels behind timm's BatchNormAct2d, reference model.py:82). */
 int nkb_bn_fused_finalize(int on);
 
+/* Host replay of a recorded step (csrc/plan.hip).  The reference has no counterpart: its step is re-traced by the Python
+ * interpreter every iteration (engine.py:36-75 -> torch dispatcher).  nkb_classification/hip.py records the entry points one
+ * forward / backward / optimizer pass calls — every buffer lives in the persistent workspace, so the argument lists are constant
+ * — and nkb_plan_run re-issues them from a flat table: entry.fn >= 0 is an index into the recordable entry points
+ * (nkb_plan_fn_name / nkb_plan_fn_args: name and argument count; pointers and streams in .p, every integer type in .i, floats
+ * in .f, in declaration order), entry.fn < 0 one of the stream operations that sit between launches:
+ *   NKB_PLAN_EVENT_RECORD       a[0].p = hipEvent_t, a[1].p = stream
+ *   NKB_PLAN_STREAM_WAIT_EVENT  a[0].p = stream,     a[1].p = hipEvent_t
+ *   NKB_PLAN_MEMSET             a[0].p = device pointer, a[1].i = bytes (set to zero), a[2].p = stream
+ * Returns 0, or the code of the first failing entry (index in *failed, text in nkb_last_error()); later entries are not issued. */
+typedef union { void* p; long long i; float f; } NkbPlanArg;
+#define NKB_PLAN_MAX_ARGS 32
+typedef struct { int fn; int nargs; NkbPlanArg a[NKB_PLAN_MAX_ARGS]; } NkbPlanEntry;
+#define NKB_PLAN_EVENT_RECORD (-1)
+#define NKB_PLAN_STREAM_WAIT_EVENT (-2)
+#define NKB_PLAN_MEMSET (-3)
+int nkb_plan_fn_count(void);
+const char* nkb_plan_fn_name(int id);
+int nkb_plan_fn_args(int id);
+int nkb_plan_max_args(void);
+size_t nkb_plan_entry_bytes(void);
+int nkb_plan_run(const void* entries, int n, int* failed);
+
 /* Per-launch HIP-event profiler (bench.py's roofline leg). */
 void nkb_prof_enable(int on);
 int nkb_prof_collect(double* ms, long long* launches, double* work, double* bytes, int slots);

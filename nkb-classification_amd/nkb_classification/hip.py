@@ -114,6 +114,12 @@ _SIGS = {
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
     "nkb_prof_collect_raw": (i32, [vp, vp, vp, i32]),
     "nkb_kernel_name": (C.c_char_p, [i32]),
+    "nkb_plan_fn_count": (i32, []),
+    "nkb_plan_fn_name": (C.c_char_p, [i32]),
+    "nkb_plan_fn_args": (i32, [i32]),
+    "nkb_plan_max_args": (i32, []),
+    "nkb_plan_entry_bytes": (sz, []),
+    "nkb_plan_run": (i32, [vp, i32, vp]),
 }
 
 
@@ -163,7 +169,9 @@ _PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_versi
                    "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_bn_fused_finalize",
                    "nkb_fp8_job_blocks", "nkb_wgrad_fp8_workspace_floats",
                    "nkb_fp8_quantize_colsum_workspace_floats",
-                   "nkb_gram_bn_backward_workspace_floats", "nkb_bn_apply_gram_workspace_floats"})
+                   "nkb_gram_bn_backward_workspace_floats", "nkb_bn_apply_gram_workspace_floats",
+                   "nkb_plan_fn_count", "nkb_plan_fn_name", "nkb_plan_fn_args", "nkb_plan_max_args", "nkb_plan_entry_bytes",
+                   "nkb_plan_run"})
 
 
 class Seed(int):
@@ -186,11 +194,47 @@ class _RecLib:
         return call
 
 
-class Plan:
-    __slots__ = ("entries", "dyn_names")
+# The replay itself runs in C (csrc/plan.hip: nkb_plan_run walks a flat table of {function id, arguments}); Python only
+# patches the few per-step values and steps from segment to segment — a segment ends where a Python-side operation sits
+# between launches (the DDP bucket hooks, a counter bump).  NKB_PLAN_C=0 keeps the old per-entry ctypes loop (A/B, debugging).
+_PLAN_C = os.environ.get("NKB_PLAN_C", "1") != "0"
+_PLAN_MAX_ARGS = 32
+OP_EVENT_RECORD, OP_STREAM_WAIT_EVENT, OP_MEMSET = -1, -2, -3
 
-    def __init__(self, entries, dyn_names):
-        self.entries, self.dyn_names = entries, dyn_names
+
+class _PlanArg(C.Union):
+    _fields_ = [("p", C.c_void_p), ("i", C.c_longlong), ("f", C.c_float)]
+
+
+class _PlanEntry(C.Structure):
+    _fields_ = [("fn", C.c_int), ("nargs", C.c_int), ("a", _PlanArg * _PLAN_MAX_ARGS)]
+
+
+_PLAN_FN = None        # {entry point name: function id of csrc/plan_dispatch.inc}
+
+
+def _plan_fn_ids():
+    global _PLAN_FN
+    if _PLAN_FN is None:
+        lib = _LIB if _LIB is not None else load()
+        if lib.nkb_plan_max_args() != _PLAN_MAX_ARGS or lib.nkb_plan_entry_bytes() != C.sizeof(_PlanEntry):
+            raise RuntimeError("nkbhip: NkbPlanEntry layout of libnkbhip.so differs from the binding's (rebuild the library)")
+        ids = {}
+        for k in range(lib.nkb_plan_fn_count()):
+            name = lib.nkb_plan_fn_name(k).decode()
+            if name not in _SIGS or lib.nkb_plan_fn_args(k) != len(_SIGS[name][1]):
+                raise RuntimeError(f"nkbhip: plan dispatch table is stale for {name} (python scripts/gen_plan_dispatch.py; rebuild)")
+            ids[name] = k
+        _PLAN_FN = ids
+    return _PLAN_FN
+
+
+class Plan:
+    __slots__ = ("segments", "dyn_names", "keep", "entries")
+
+    def __init__(self, segments, dyn_names, keep, entries):
+        # entries: number of recorded operations (diagnostics); keep: the torch events / streams / tensors the table points at
+        self.segments, self.dyn_names, self.keep, self.entries = segments, dyn_names, keep, entries
 
 
 _REC_MAIN = None       # the compute stream of the step being recorded
@@ -214,10 +258,43 @@ def record_end(dynamic: dict) -> Plan:
     global _REC
     rec, _REC = _REC, None
     ranges = [(name, t.data_ptr(), t.data_ptr() + max(t.numel() * t.element_size(), 1)) for name, t in dynamic.items()]
-    entries = []
+    ids = _plan_fn_ids() if _PLAN_C else {}
+    segments, keep = [], []
+    cur = []            # entries of the C segment being built: (fn id, [(kind, value)], name, patches)
+
+    def flush():
+        if not cur:
+            return
+        arr = (_PlanEntry * len(cur))()
+        patches, names = [], []
+        for k, (fid, vals, name, pt) in enumerate(cur):
+            e = arr[k]
+            e.fn, e.nargs = fid, len(vals)
+            for ai, (kind, v) in enumerate(vals):
+                if kind == "f":
+                    e.a[ai].f = float(v)
+                elif kind == "p":
+                    e.a[ai].p = v
+                else:
+                    e.a[ai].i = int(v)
+            names.append(name)
+            patches += [(k, ai, dn, off) for ai, dn, off in pt]
+        segments.append((0, arr, len(cur), tuple(patches), tuple(names)))
+        cur.clear()
+
     for e in rec:
-        if e[0] != "call":
-            entries.append((2, e[1], None, None))
+        if e[0] == "py":
+            flush()
+            segments.append((2, e[1], None, None, None))
+            continue
+        if e[0] == "op":
+            _, code, vals, alive = e
+            keep.append(alive)
+            if _PLAN_C:
+                kinds = ("p", "i", "p") if code == OP_MEMSET else ("p", "p")
+                cur.append((code, list(zip(kinds, vals)), "stream operation %d" % code, ()))
+            else:
+                segments.append((2, _op_closure(code, alive), None, None, None))
             continue
         _, fn, name, args = e
         patches = []
@@ -229,23 +306,81 @@ def record_end(dynamic: dict) -> Plan:
                     if lo <= a < hi:
                         patches.append((i, dn, a - lo))
                         break
-        entries.append((1, fn, args, tuple(patches)) if patches else (0, fn, tuple(args), name))
-    return Plan(entries, tuple(dynamic))
+        if name in ids and len(args) <= _PLAN_MAX_ARGS:
+            types = _SIGS[name][1]
+            vals = [("f" if t is f32 else ("p" if t is vp else "i"), (0 if a is None and t is not vp else a)) for t, a in zip(types, args)]
+            cur.append((ids[name], vals, name, patches))
+        else:
+            flush()
+            segments.append((1, fn, list(args), tuple(patches), name))
+    flush()
+    return Plan(segments, tuple(dynamic), keep, len(rec))
+
+
+def _op_closure(code, alive):
+    """Python form of a recorded stream operation (NKB_PLAN_C=0)."""
+    if code == OP_EVENT_RECORD:
+        ev, st = alive
+        return lambda: ev.record(st)
+    if code == OP_STREAM_WAIT_EVENT:
+        ev, st = alive
+        return lambda: st.wait_event(ev)
+    t, st = alive
+
+    def memset():
+        with torch.cuda.stream(st):
+            t.zero_()
+    return memset
+
+
+_FAILED = C.c_int(0)
 
 
 def replay(plan: Plan, dynamic: dict):
     base = {name: t.data_ptr() for name, t in dynamic.items()}
-    for kind, fn, args, extra in plan.entries:
+    for kind, a, b, patches, names in plan.segments:
         if kind == 0:
-            if fn(*args):
-                raise RuntimeError(f"nkbhip {extra} failed during plan replay: {_LIB.nkb_last_error().decode()}")
+            for ei, ai, dn, off in patches:
+                a[ei].a[ai].i = base[dn] + off if dn is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+            if _LIB.nkb_plan_run(a, b, C.byref(_FAILED)):
+                raise RuntimeError(f"nkbhip {names[_FAILED.value]} failed during plan replay: {_LIB.nkb_last_error().decode()}")
         elif kind == 1:
-            for i, dn, off in extra:
-                args[i] = base[dn] + off if dn is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
-            if fn(*args):
-                raise RuntimeError(f"nkbhip call failed during plan replay: {_LIB.nkb_last_error().decode()}")
+            for i, dn, off in patches:
+                b[i] = base[dn] + off if dn is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+            if a(*b):
+                raise RuntimeError(f"nkbhip {names} failed during plan replay: {_LIB.nkb_last_error().decode()}")
         else:
-            fn()
+            a()
+
+
+# ---- stream operations between launches, recordable (a host_op closure would end the C segment) --------------------------------
+def event_record(ev: "torch.cuda.Event", st: "torch.cuda.Stream"):
+    ev.record(st)
+    if _REC is not None:
+        _REC.append(["op", OP_EVENT_RECORD, (ev.cuda_event, st.cuda_stream), (ev, st)])
+
+
+def stream_wait_event(st: "torch.cuda.Stream", ev: "torch.cuda.Event"):
+    st.wait_event(ev)
+    if _REC is not None and ev.cuda_event:          # (an event that was never recorded: torch's wait is a no-op, so is the plan's)
+        _REC.append(["op", OP_STREAM_WAIT_EVENT, (st.cuda_stream, ev.cuda_event), (ev, st)])
+
+
+def stream_wait_stream(st: "torch.cuda.Stream", other: "torch.cuda.Stream"):
+    """st waits for everything enqueued on `other` so far (torch's Stream.wait_stream with a recordable event)."""
+    ev = torch.cuda.Event()
+    event_record(ev, other)
+    stream_wait_event(st, ev)
+
+
+def zero_(t: torch.Tensor):
+    """t.zero_() on the current stream, as a recordable memset."""
+    t.zero_()
+    if _REC is not None:
+        if not t.is_contiguous():
+            raise RuntimeError("hip.zero_: recorded memsets need a contiguous tensor")
+        st = torch.cuda.current_stream()
+        _REC.append(["op", OP_MEMSET, (t.data_ptr(), t.numel() * t.element_size(), st.cuda_stream), (t, st)])
 
 
 def recording() -> bool:

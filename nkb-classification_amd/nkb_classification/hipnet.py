@@ -635,9 +635,9 @@ class HipEngine:
         """nkb_conv_wgrad into the gradient arena, deterministic (slabs + ordered reduce) unless NKB_DET_WGRAD=0.
         assign: dw (a scratch product, not the arena) is overwritten — no memset in front of the launch."""
         if assign and not _DET_WGRAD:
-            hip.host_op(dw.zero_)
+            hip.zero_(dw)
             if dbias is not None:
-                hip.host_op(dbias.zero_)
+                hip.zero_(dbias)
             assign = False
         work = None
         if _DET_WGRAD:
@@ -671,11 +671,8 @@ class HipEngine:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         ev, side = torch.cuda.Event(), self._side
-
-        def fork():
-            ev.record()
-            side.wait_event(ev)
-        hip.host_op(fork)
+        hip.event_record(ev, torch.cuda.current_stream())
+        hip.stream_wait_event(side, ev)
         with torch.cuda.stream(side):
             fn()
 
@@ -683,8 +680,7 @@ class HipEngine:
         """Main stream waits for everything enqueued on the side stream so far (forward-pass use; the backward pass
         tracks its weight gradients per block with begin_block / end_block instead)."""
         if self._side is not None and self.overlap_wgrad:
-            side = self._side
-            hip.host_op(lambda: torch.cuda.current_stream().wait_stream(side))
+            hip.stream_wait_stream(torch.cuda.current_stream(), self._side)
 
     def begin_block(self, index: int):
         """Scratch gradient buffers alternate between two sets by block parity; before a set is reused the main
@@ -692,12 +688,12 @@ class HipEngine:
         self._suffix = ".p%d" % (index & 1)
         ev = self._side_done.pop(index + 2, None)
         if ev is not None:
-            hip.host_op(lambda: torch.cuda.current_stream().wait_event(ev))
+            hip.stream_wait_event(torch.cuda.current_stream(), ev)
 
     def end_block(self, index: int):
         if self._side is not None:
-            ev, side = torch.cuda.Event(), self._side
-            hip.host_op(lambda: ev.record(side))
+            ev = torch.cuda.Event()
+            hip.event_record(ev, self._side)
             self._side_done[index] = ev
 
     def side_event(self):
@@ -711,8 +707,7 @@ class HipEngine:
     def wait_side(self):
         """Main stream waits for every outstanding weight gradient (before the optimizer / the gradient exchange)."""
         if self._side is not None:
-            side = self._side
-            hip.host_op(lambda: torch.cuda.current_stream().wait_stream(side))
+            hip.stream_wait_stream(torch.cuda.current_stream(), self._side)
         self._side_done.clear()
         self._suffix = ""
 
@@ -861,7 +856,7 @@ class HipEngine:
             dwp = self.ws.get(key + ".dwpad", (co, 224), torch.float32)
 
             def packed_wgrad():
-                hip.host_op(dwp.zero_)
+                hip.zero_(dwp)
                 work = None
                 if _DET_WGRAD:
                     work = self.ws.at_least("wgrad.slabs." + self._stream_tag(),
@@ -877,7 +872,7 @@ class HipEngine:
             dwp = self.ws.get(key + ".dwpad", (co, kp), torch.float32)
 
             def stem_wgrad():
-                hip.host_op(dwp.zero_)
+                hip.zero_(dwp)
                 self.wgrad(g_c, sv["x"], dwp, N=geom["N"], H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=co, lddy=co)
                 hip.add2d(dwp, a.grad_flat(w), co, K, kp, K)
             self.on_side(stem_wgrad)
@@ -1225,7 +1220,7 @@ class HipEngine:
                     # blocks before it: the wait begin_block(consumer_block) would make, made now
                     ev = self._side_done.pop(consumer_block + 2, None)
                     if ev is not None:
-                        hip.host_op(lambda: torch.cuda.current_stream().wait_event(ev))
+                        hip.stream_wait_event(torch.cuda.current_stream(), ev)
                     self._suffix = ".p%d" % (consumer_block & 1)
                 scaled = self.scratch("gs_" + consumer.rsplit(".", 1)[-1], (rows, D))
                 self._suffix = keep

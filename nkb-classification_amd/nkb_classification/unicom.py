@@ -207,7 +207,7 @@ class HipUnicomViT(_ParamOnly):
                            lddy=D, dbias=a.grad_flat(pr.bias))
         else:
             dwp = eng.ws.get("pe.dwpad", (D, kp), torch.float32)
-            hip.host_op(dwp.zero_)
+            hip.zero_(dwp)
             eng.wgrad(gx, sv["col"], dwp, N=M, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D, lddy=D)
             hip.add2d(dwp, a.grad_flat(pr.weight), D, K, kp, K)
             eng.colsum2d(gx, a.grad_flat(pr.bias), M, D, D)

@@ -145,7 +145,7 @@ class HipViT(_ParamOnly):
         M = B * T
         a = eng.arena
         gx = eng.scratch("gx0", (M, D))
-        hip.host_op(gx.zero_)
+        hip.zero_(gx)
         g_emb = eng.dropout_backward("head_drop", g_emb, "gemb")
         eng.layernorm_backward("norm", g_emb, gx, T * D)          # rows b*T (class tokens); everything else stays 0
         if on_done is not None:
@@ -188,7 +188,7 @@ class HipViT(_ParamOnly):
                            Q=1, Cout=D, lddy=D, dbias=a.grad_flat(pr.bias))
         else:
             dwp = eng.ws.get("pe.dwpad", (D, kp), torch.float32)
-            hip.host_op(dwp.zero_)
+            hip.zero_(dwp)
             eng.wgrad(d_tok, sv["col"], dwp, N=B * npatch, H=1, W=1, Cin=kp, ldx=kp, P=1, Q=1, Cout=D, lddy=D)
             hip.add2d(dwp, a.grad_flat(pr.weight), D, K, kp, K)
             eng.colsum2d(d_tok, a.grad_flat(pr.bias), B * npatch, D, D)

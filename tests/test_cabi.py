@@ -49,3 +49,31 @@ def test_binding_arity_matches_header():
         params = protos[name].strip()
         n = 0 if params in ("", "void") else len([a for a in params.split(",") if a.strip()])
         assert n == len(argtypes), f"{name}: header has {n} parameters, binding {len(argtypes)}"
+
+
+def test_plan_dispatch_table_is_current_and_validates_entries():
+    """csrc/plan_dispatch.inc (the typed call table behind nkb_plan_run) is what scripts/gen_plan_dispatch.py generates from the
+    binding's signature table; the library's table agrees with the binding name by name; a table walk on the host rejects a
+    bad function id / argument count before calling anything, validates an entry's geometry through the entry point itself and
+    reports the failing index."""
+    import subprocess
+    import sys
+    assert subprocess.run([sys.executable, str(ROOT / "scripts" / "gen_plan_dispatch.py"), "--check"]).returncode == 0, \
+        "plan_dispatch.inc is stale: run python scripts/gen_plan_dispatch.py and rebuild"
+    lib = hip.load()
+    ids = hip._plan_fn_ids()
+    recordable = {n for n, (res, _) in hip._SIGS.items() if res is ctypes.c_int and n not in hip._PURE}
+    assert set(ids) == recordable and lib.nkb_plan_fn_count() == len(ids)
+    failed = ctypes.c_int(-1)
+    assert lib.nkb_plan_run(None, 0, ctypes.byref(failed)) == 0
+    tab = (hip._PlanEntry * 3)()
+    # entry 0: a well-formed nkb_bn_apply whose C = 12 the entry point itself refuses (host-side validation, no launch)
+    tab[0].fn, tab[0].nargs = ids["nkb_bn_apply"], len(hip._SIGS["nkb_bn_apply"][1])
+    tab[0].a[0].i, tab[0].a[6].i, tab[0].a[7].i = 1, 10, 12
+    assert lib.nkb_plan_run(tab, 1, ctypes.byref(failed)) != 0 and failed.value == 0 and b"C=12" in lib.nkb_last_error()
+    tab[0].fn, tab[0].nargs = lib.nkb_plan_fn_count() + 5, 2
+    assert lib.nkb_plan_run(tab, 1, ctypes.byref(failed)) != 0 and b"bad function id" in lib.nkb_last_error()
+    tab[0].fn, tab[0].nargs = ids["nkb_bn_apply"], 3            # wrong argument count for that function
+    assert lib.nkb_plan_run(tab, 1, ctypes.byref(failed)) != 0 and failed.value == 0
+    tab[0].fn = -77
+    assert lib.nkb_plan_run(tab, 1, ctypes.byref(failed)) != 0 and b"unknown operation" in lib.nkb_last_error()
