@@ -63,7 +63,7 @@ def pmc_traffic(args, kernel):
     command (scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  A bench run cannot profile
     itself (counter collection needs its own rocprofv3 passes), so this is the measurement ON FILE for this workload — the line
     says so in roofline.traffic_source; a workload without a file reports null."""
-    name = PMC_TRAFFIC_FILES.get((args.model, args.batch, args.dtype))
+    name = None if head_sizes(args) else PMC_TRAFFIC_FILES.get((args.model, args.batch, args.dtype))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name) if name else None
     if not (path and os.path.exists(path)):
         return None, None, None
@@ -99,6 +99,8 @@ def parse():
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--classes", type=int, default=1000)
+    ap.add_argument("--heads", default="", help="comma-separated class counts: the multi-task model (one Linear head per task, "
+                    "FocalLoss gamma 1 summed over tasks — configs/multitask_config.py:146-176), e.g. 2,3,5,14 = BASELINE configs[3]")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
                     help="fp8: bf16 autocast with the transformer blocks' Linear contractions in per-tensor-scaled fp8 "
                          "(BASELINE configs[4]); ResNet models have no fp8 path and run as bf16")
@@ -120,15 +122,36 @@ def build(args, device):
     from nkb_classification.model import get_model
     from nkb_classification.utils import get_optimizer
     torch.manual_seed(0)
-    cfg_model = dict(task="single", model=args.model, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
-                     classifier_initialization="kaiming_normal_")
-    classes = [str(i) for i in range(args.classes)]
+    heads = head_sizes(args)
+    cfg_model = dict(task="multi" if heads else "single", model=args.model, pretrained=False, backbone_dropout=0.0,
+                     classifier_dropout=0.0, classifier_initialization="kaiming_normal_")
+    classes = task_classes(heads) if heads else [str(i) for i in range(args.classes)]
     model = get_model(cfg_model, classes, device)
     # optimizer settings of configs/singletask_config.py:235-243 (NAdam, per-group lr / decoupled wd)
     opt = get_optimizer(model, dict(type="nadam", lr=1e-4, backbone_lr=1e-5, classifier_lr=1e-4, weight_decay=0.01,
                                     backbone_weight_decay=0.01, classifier_weight_decay=0.2))
-    crit = get_loss(dict(task="single", type="CrossEntropyLoss"), device)
+    crit = get_loss(loss_config(heads), device)
     return model, opt, crit
+
+
+def head_sizes(args):
+    h = getattr(args, "heads", "") or ""
+    return [int(v) for v in h.split(",") if v.strip()]
+
+
+def task_classes(heads):
+    return {f"task{i}": [str(c) for c in range(n)] for i, n in enumerate(heads)}
+
+
+def loss_config(heads):
+    # configs/multitask_config.py:176 / configs/singletask_config.py criterion
+    return dict(task="multi", type="FocalLoss", gamma=1) if heads else dict(task="single", type="CrossEntropyLoss")
+
+
+def make_targets(heads, classes, batch, generator, device):
+    if heads:
+        return {t: torch.randint(0, n, (batch,), generator=generator).to(device) for t, n in zip(task_classes(heads), heads)}
+    return torch.randint(0, classes, (batch,), generator=generator).to(device)
 
 
 def cpu_config0(threads):
@@ -168,19 +191,21 @@ def cpu_baseline(args):
     torch.set_num_threads(threads)
     log(f"cpu baseline on {threads} threads (os.cpu_count()={os.cpu_count()})")
     torch.manual_seed(0)
-    m = OracleClassifier(dict(model=args.model, backbone_dropout=0.0, classifier_dropout=0.0),
-                         [str(i) for i in range(args.classes)])
+    heads = head_sizes(args)
+    m = OracleClassifier(dict(model=args.model, backbone_dropout=0.0, classifier_dropout=0.0, task="multi" if heads else "single"),
+                         task_classes(heads) if heads else [str(i) for i in range(args.classes)])
     opt = make_optimizer(m, dict(type="nadam", lr=1e-4, backbone_lr=1e-5, classifier_lr=1e-4, weight_decay=0.01,
                                  backbone_weight_decay=0.01, classifier_weight_decay=0.2))
-    crit = Criterion(dict(task="single", type="CrossEntropyLoss"))
+    crit = Criterion(loss_config(heads))
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(args.cpu_batch, 3, 224, 224, generator=g)
-    y = torch.randint(0, args.classes, (args.cpu_batch,), generator=g)
+    y = make_targets(heads, args.classes, args.cpu_batch, g, "cpu")
     m.train()
 
     def step():
         opt.zero_grad()
-        crit(m(x), y).backward()
+        loss = crit(m(x), y)
+        (loss["loss"] if heads else loss).backward()
         opt.step()
 
     step()  # warm-up
@@ -252,7 +277,10 @@ def main():
 
     g = torch.Generator().manual_seed(1234 + rank)
     img = torch.randn(args.batch, 3, 224, 224, generator=g).to(device)
-    tgt = torch.randint(0, args.classes, (args.batch,), generator=g).to(device)
+    heads = head_sizes(args)
+    tgt = make_targets(heads, args.classes, args.batch, g, device)
+    if heads and args.input != "hbm":
+        raise SystemExit("--heads runs with --input hbm only")
     amp = args.dtype in ("bf16", "fp8")
     model.fp8_linear = args.dtype == "fp8"
     model.train()
@@ -280,9 +308,12 @@ def main():
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=amp):
             preds = model(x)
             loss = crit(preds, t)
+        if heads:
+            loss = loss["loss"]     # MultitaskCriterion: per-task losses + their sum (losses.py:97-151)
         loss.backward()
         opt.step()
-        softmax_argmax(preds)       # the logger's per-step by-products (device side, no host sync)
+        for p_ in (preds.values() if heads else (preds,)):
+            softmax_argmax(p_)      # the logger's per-step by-products (device side, no host sync)
         return loss
 
     # first step packs the arena; broadcast rank-0 state afterwards so all ranks start identical
@@ -337,7 +368,8 @@ def main():
     # the GPU finishes each step long before the host has enqueued the next.
     host_work = None
     if rank == 0 and args.input == "hbm" and world == 1 and not force_dist and not args.no_host_work:
-        small_x, small_t = img[:4].clone(), tgt[:4].clone()
+        small_x = img[:4].clone()
+        small_t = {k: v[:4].clone() for k, v in tgt.items()} if heads else tgt[:4].clone()
         keep = (img, tgt)
         img, tgt = small_x, small_t
         try:
@@ -452,8 +484,9 @@ def main():
                                    "(PCIe-inclusive, not the headline), random-init weights",
                      "host-fp32": "synthetic fp32 NCHW batches in pinned host memory, blocking .to(device) per step "
                                   "(PCIe-inclusive, not the headline), random-init weights"}[args.input],
-            "config": {"workload": f"{args.model} single-task train step, {args.classes} classes, bs={args.batch}/GPU, "
-                                   f"{args.dtype} compute + fp32 master weights, NAdam, 3x224x224",
+            "config": {"workload": (f"{args.model} multi-task train step, heads {args.heads} (FocalLoss gamma 1 per task, summed), "
+                                    if heads else f"{args.model} single-task train step, {args.classes} classes, ") +
+                                   f"bs={args.batch}/GPU, {args.dtype} compute + fp32 master weights, NAdam, 3x224x224",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "step_tflops": round(ips * gflop / 1e3, 1) if gflop else None,
             "step_mfma_frac": round(ips * gflop / 1e3 / PEAK_TFLOPS[args.dtype], 4) if gflop else None,

@@ -49,23 +49,27 @@ def _dist(g, truth):
     return torch.nn.functional.cosine_similarity(g, truth, dim=0).item(), ((g - truth).norm() / truth.norm()).item()
 
 
-def _run(model_name, batch, dtype, classes, steps=4):
+def _run(model_name, batch, dtype, classes, steps=4, heads=""):
     import bench
-    args = argparse.Namespace(model=model_name, classes=classes, batch=batch, dtype=dtype)
+    from oracle.torch_engine import Criterion
+    args = argparse.Namespace(model=model_name, classes=classes, batch=batch, dtype=dtype, heads=heads)
     device = torch.device(DEV)
     model, opt, crit = bench.build(args, device)
     model.fp8_linear = dtype == "fp8"
-    cfg_model = dict(task="single", model=model_name, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+    hs = bench.head_sizes(args)
+    cfg_model = dict(task="multi" if hs else "single", model=model_name, pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
                      classifier_initialization="kaiming_normal_")
+    ocrit = Criterion(bench.loss_config(hs))
     oracles = []
     for _ in range(2):                                   # [truth (fp32), yardstick (autocast bf16)]
-        o = OracleClassifier(cfg_model, [str(i) for i in range(classes)])
+        o = OracleClassifier(cfg_model, bench.task_classes(hs) if hs else [str(i) for i in range(classes)])
         o.load_state_dict(model.state_dict())
         o = o.to(device).train()
         oracles.append((o, make_optimizer(o, OPT)))
     g = torch.Generator().manual_seed(1234)
     img = torch.randn(batch, 3, 224, 224, generator=g).to(device)
-    tgt = torch.randint(0, classes, (batch,), generator=g).to(device)
+    tgt = bench.make_targets(hs, classes, batch, g, device)
+    cat = (lambda d: torch.cat([d[t].float() for t in sorted(d)], dim=1)) if hs else (lambda t: t.float())
     model.train()
     for k in COUNTERS:
         hip.kernel_launches(k, reset=True)
@@ -78,6 +82,9 @@ def _run(model_name, batch, dtype, classes, steps=4):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             log = model(img)
             loss = crit(log, tgt)
+        if hs:
+            loss = loss["loss"]
+        log = cat(log)
         if stochastic:
             # unicom's per-sample stochastic depth: both oracle runs replay the keep draws the HIP forward just made
             eng = model._active
@@ -92,9 +99,12 @@ def _run(model_name, batch, dtype, classes, steps=4):
             oo.zero_grad(set_to_none=True)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(k == 1)):
                 ol = o(img)
-                ls = torch.nn.functional.cross_entropy(ol.float(), tgt)
+                if hs:                                     # the oracle's MultitaskCriterion (FocalLoss gamma 1 per task, summed)
+                    ls = ocrit({t: v.float() for t, v in ol.items()}, tgt)["loss"]
+                else:
+                    ls = torch.nn.functional.cross_entropy(ol.float(), tgt)
             ls.backward()
-            res.append((ol.detach().float(), ls.item(), _flat([(n, p.grad) for n, p in o.named_parameters()])))
+            res.append((cat(ol).detach(), ls.item(), _flat([(n, p.grad) for n, p in o.named_parameters()])))
         loss.backward()
         torch.cuda.synchronize()
         hp = dict(model.named_parameters())
@@ -137,6 +147,14 @@ def test_resnet50_bench_configuration_matches_oracle():
     assert plans >= 2                                                      # forward + backward plans recorded and replayed
     assert n["gemm8p"] > 0 and n["wgrad8p"] > 0 and n["wgrad3x3"] > 0      # the kernels the bench line is priced on ran
     assert n["gram_conv"] > 0 and n["gram_bn_apply"] > 0                   # Gram-form closing stages (layer1 / layer2)
+
+
+def test_resnet50_multitask_configs3_matches_oracle():
+    """BASELINE configs[3] on one GPU: ResNet-50, 4 heads (2 / 3 / 5 / 14 classes), FocalLoss gamma 1 summed over the tasks
+    (configs/multitask_config.py:146-176), bs 256, bf16 — `bench.py --heads 2,3,5,14`."""
+    out, n, plans = _run("resnet50", 256, "bf16", 0, heads="2,3,5,14")
+    _check(out, relative=True)
+    assert plans >= 2 and n["gemm8p"] > 0 and n["wgrad8p"] > 0 and n["gram_conv"] > 0
 
 
 def test_vit_b16_bench_configuration_matches_oracle():
