@@ -727,8 +727,9 @@ def test_launch_plans_replay_exactly_across_shape_and_mode_changes(backbone, mon
     ys = [torch.randint(0, 3, (x.shape[0],), generator=g).to(DEV) for x in xs]
     schedule = [0, 1, 2, 0, 1, 3, "eval", 2, 0, "freeze", 1, 2, 0, 1, "unfreeze", 2, 0, 1, 3, 3, 2]
 
-    def run(plans_on):
+    def run(plans_on, c_replay=True):
         monkeypatch.setattr(model_mod, "_PLANS", plans_on)
+        monkeypatch.setattr(hip, "_PLAN_C", c_replay)        # nkb_plan_run (csrc/plan.hip) vs the per-entry ctypes loop
         torch.manual_seed(0)
         model = get_model(dict(cfg_model), ["a", "b", "c"], DEV)
         opt = get_optimizer(model, dict(type="nadam", lr=1e-3, weight_decay=0.01))
@@ -752,9 +753,13 @@ def test_launch_plans_replay_exactly_across_shape_and_mode_changes(backbone, mon
             opt.step()
         torch.cuda.synchronize()
         eng = model._engines[torch.bfloat16]
-        return model.arena.flat_param.clone(), len(eng.plans)
+        kinds = [seg[0] for ent in eng.plans.values() for seg in ent[0].segments]
+        return model.arena.flat_param.clone(), len(eng.plans), kinds
 
-    p_on, n_on = run(True)
-    p_off, n_off = run(False)
-    assert n_off == 0 and n_on >= 2                  # at least one forward and one backward plan were recorded and replayed
-    assert torch.equal(p_on, p_off)
+    p_on, n_on, k_on = run(True)
+    p_py, n_py, k_py = run(True, c_replay=False)
+    p_off, n_off, _ = run(False)
+    assert n_off == 0 and n_on >= 2 and n_py == n_on # at least one forward and one backward plan were recorded and replayed
+    assert k_on.count(0) >= 2 and k_on.count(1) == 0 # C replay: every recorded call sits in a table segment (none left to ctypes)
+    assert k_py.count(0) == 0 and k_py.count(1) > 50 # Python replay: one ctypes call per entry
+    assert torch.equal(p_on, p_off) and torch.equal(p_py, p_off)
