@@ -414,12 +414,6 @@ int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float*
  * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 768).  Tests and A/B timing. */
 void nkb_gemm8p_config(int on, int min_tiles, int min_k);
 
-/* BatchNorm statistics over many row tiles (tiles > 128; nkb_bn_finalize, nkb_bn_backward_from_stats, the Gram-form tile sums):
- * on = 1 (default, NKB_BN_FUSED_FINALIZE) reduces and finalizes in ONE launch — the partition block that draws the last ticket
- * finalizes; on = 0 restores the two-launch form.  Bit-identical results either way.  Returns the previous setting.  Replaces
- * nothing in the reference (torch's batch_norm kernels behind timm's BatchNormAct2d, reference model.py:82). */
-int nkb_bn_fused_finalize(int on);
-
 /* Host replay of a recorded step (csrc/plan.hip).  The reference has no counterpart: its step is re-traced by the Python
  * interpreter every iteration (engine.py:36-75 -> torch dispatcher).  nkb_classification/hip.py records the entry points one
  * forward / backward / optimizer pass calls — every buffer lives in the persistent workspace, so the argument lists are constant

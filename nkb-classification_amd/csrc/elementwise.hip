@@ -2,7 +2,6 @@
 // stem im2row, weight re-layout.  All activations are NHWC, channel-contiguous, 16-byte vector I/O.
 #include "common.h"
 #include <stdlib.h>
-#include <mutex>
 
 static inline unsigned grid_for(size_t work_items, int block = 256, unsigned cap = 256 * 16) {
     size_t g = (work_items + block - 1) / block;
@@ -114,111 +113,6 @@ __global__ void bn_finalize_kernel(const PT* __restrict__ partials, int tiles, i
     if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
 }
 
-// ------------------------------------------------------------------------------------------
-// One-launch form of {bn_partial_reduce_kernel, bn_finalize_kernel<double> / bn_bwd_finalize_tiles_kernel<double>}: the P
-// partition blocks of a 64-channel column write their double partials, fence, and take a ticket; the block that draws the
-// last ticket re-reads all P partials (in the SAME order as the two-launch form: bit-identical results) and finalizes.
-// No block waits for another, so there is no spin and nothing to deadlock.  Ticket words are library-owned, one set per
-// stream (launches on one stream are serialized; the last block resets its word for the next launch on that stream).
-constexpr int NKB_TICKET_SETS = 8, NKB_TICKET_COLS = 32;          // C <= 2048
-__device__ unsigned g_bn_tickets[NKB_TICKET_SETS][NKB_TICKET_COLS];
-
-static int g_bn_fused_finalize = env_int("NKB_BN_FUSED_FINALIZE", 1);
-// run-time switch between the one-launch and the two-launch form (tests, same-process A/B timing); returns the previous value
-extern "C" int nkb_bn_fused_finalize(int on) {
-    const int prev = g_bn_fused_finalize;
-    g_bn_fused_finalize = on;
-    return prev;
-}
-static int bn_ticket_set(hipStream_t stream) {
-    static std::mutex mu;
-    static hipStream_t known[NKB_TICKET_SETS];
-    static int n = 0;
-    if (!g_bn_fused_finalize) return -1;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < n; ++i) if (known[i] == stream) return i;
-    if (n == NKB_TICKET_SETS) return -1;                           // more streams than sets: the two-launch form
-    known[n] = stream;
-    return n++;
-}
-
-struct BnFinalizeArgs {           // MODE 0: forward statistics -> scale / shift / running stats
-    float count; const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps;
-    float* scale; float* shift; float* save_mean; float* save_invstd;
-};
-struct BnBwdTilesArgs {           // MODE 1: backward tile sums -> sums[2][C], dgamma / dbeta +=
-    const float* invstd; float* dgamma; float* dbeta; float* sums;
-};
-
-template <int MODE, typename ARGS>
-__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partials, int tiles, int C,
-                                                                  double* __restrict__ dpart, unsigned* __restrict__ tickets, ARGS a) {
-    __shared__ double red[2][16][64];
-    __shared__ unsigned last;
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6, P = (int)gridDim.y;
-    const int c = blockIdx.x * 64 + cx;
-    double s = 0.0, ss = 0.0;
-    if (c < C) {
-        for (int t = blockIdx.y * 16 + py; t < tiles; t += 16 * P) {
-            s += (double)partials[((size_t)t * 2) * C + c];
-            ss += (double)partials[((size_t)t * 2 + 1) * C + c];
-        }
-    }
-    red[0][py][cx] = s;
-    red[1][py][cx] = ss;
-    __syncthreads();
-    if (py == 0 && c < C) {
-        s = 0.0; ss = 0.0;
-        for (int k = 0; k < 16; ++k) { s += red[0][k][cx]; ss += red[1][k][cx]; }
-        // device-scope (write-through) stores + a wait for their acknowledgement instead of __threadfence(): the fence writes back
-        // and invalidates the whole L2 of the XCD (measured: +4 us per launch, and the co-running kernel loses its lines)
-        __hip_atomic_store(&dpart[((size_t)blockIdx.y * 2) * C + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&dpart[((size_t)blockIdx.y * 2 + 1) * C + c], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);                             // vmcnt(0): the partials have reached the device-coherent level
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        last = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(P - 1);
-    __syncthreads();
-    if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    s = 0.0; ss = 0.0;
-    if (c < C) {
-        for (int t = py; t < P; t += 16) {                         // device-scope loads: served from the coherent level, not this XCD's L2
-            s += __hip_atomic_load(&dpart[((size_t)t * 2) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ss += __hip_atomic_load(&dpart[((size_t)t * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    red[0][py][cx] = s;
-    red[1][py][cx] = ss;
-    __syncthreads();
-    if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;                // ready for the next launch on this stream
-    if (py != 0 || c >= C) return;
-    s = 0.0; ss = 0.0;
-    for (int k = 0; k < 16; ++k) { s += red[0][k][cx]; ss += red[1][k][cx]; }
-    if constexpr (MODE == 0) {
-        const double m = s / a.count;
-        double v = ss / a.count - m * m;
-        if (v < 0.0) v = 0.0;
-        const float mean = (float)m, var = (float)v;
-        const float unbiased = a.count > 1.f ? (float)(v * a.count / (a.count - 1.0)) : var;
-        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
-        const float invstd = 1.0f / sqrtf(var + a.eps);
-        const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
-        a.scale[c] = g * invstd;
-        a.shift[c] = b - mean * g * invstd;
-        if (a.save_mean) { a.save_mean[c] = mean; a.save_invstd[c] = invstd; }
-    } else {
-        const float sg = (float)s, sgx = (float)(ss * (a.invstd ? (double)a.invstd[c] : 1.0));
-        a.sums[c] = sg;
-        a.sums[C + c] = sgx;
-        if (a.dbeta) a.dbeta[c] += sg;
-        if (a.dgamma) a.dgamma[c] += sgx;
-    }
-}
-
 // `partials` must have the size nkb_bn_stats_floats(tiles, C): room for the stage-A scratch behind the [tiles][2][C] block when tiles > 128.
 extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
@@ -228,19 +122,10 @@ extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long lon
     if (training && tiles > 128) {
         double* dpart = (double*)(partials + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
         const int P = bn_partitions(C);
-        const int set = C <= 64 * NKB_TICKET_COLS ? bn_ticket_set(stream) : -1;
-        if (set >= 0) {
-            unsigned* tk = nullptr;
-            hipGetSymbolAddress((void**)&tk, HIP_SYMBOL(g_bn_tickets));
-            const BnFinalizeArgs a = {(float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd};
-            hipLaunchKernelGGL((bn_reduce_finalize_kernel<0, BnFinalizeArgs>), dim3((C + 63) / 64, P), dim3(1024), 0, stream,
-                               partials, tiles, C, dpart, tk + set * NKB_TICKET_COLS, a);
-        } else {
-            hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, partials, tiles, C, dpart);
-            hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream, (const double*)dpart, P, C,
-                               (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
-                               save_mean, save_invstd);
-        }
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, partials, tiles, C, dpart);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream, (const double*)dpart, P, C,
+                           (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
+                           save_mean, save_invstd);
     } else {
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, tiles, C,
                            (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
@@ -1435,20 +1320,11 @@ __global__ void bn_bwd_finalize_tiles_kernel(const PT* __restrict__ partials, in
     if (dgamma) dgamma[c] += sgx;
 }
 
-// backward tile sums (tiles > 128), one or two launches
+// backward tile sums (tiles > 128): stage A over P partitions, then the finalize
 static void launch_bwd_tile_sums(float* stats, int tiles, int C, const float* invstd, float* dgamma, float* dbeta, float* sums,
                                  hipStream_t stream) {
     double* dpart = (double*)(stats + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
     const int P = bn_partitions(C);
-    const int set = C <= 64 * NKB_TICKET_COLS ? bn_ticket_set(stream) : -1;
-    if (set >= 0) {
-        unsigned* tk = nullptr;
-        hipGetSymbolAddress((void**)&tk, HIP_SYMBOL(g_bn_tickets));
-        const BnBwdTilesArgs a = {invstd, dgamma, dbeta, sums};
-        hipLaunchKernelGGL((bn_reduce_finalize_kernel<1, BnBwdTilesArgs>), dim3((C + 63) / 64, P), dim3(1024), 0, stream,
-                           (const float*)stats, tiles, C, dpart, tk + set * NKB_TICKET_COLS, a);
-        return;
-    }
     hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, stats, tiles, C, dpart);
     hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream,
                        (const double*)dpart, P, C, invstd, dgamma, dbeta, sums);

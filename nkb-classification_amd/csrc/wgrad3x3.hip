@@ -138,6 +138,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Params p) {
         return (bf16x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
     };
 
+    // With PW = 64 the taps (r = 2, s >= 1) of a k-step's last two dY slots reach two slots into X chunk k + 3 (and, from ring
+    // position 3, into the mirror), which is still in flight.  Those dY slots are row padding — the product is 0 x whatever the
+    // ring holds — but 0 x NaN is NaN, and at a workgroup's FIRST k-step that ring position holds what the previous kernel left
+    // in LDS (round 3: one non-finite layer1 conv2 weight gradient every few hundred ResNet-50 steps, found by
+    // scripts/soak_determinism.py).  Zero the ring once; from then on it only ever holds activations.
+    for (int i = tid; i < XRING / 16; i += 256) *(u32x4*)(smem + 16 * i) = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+
     // ---- prologue: dY chunk k_begin, X chunks k_begin .. k_begin + 2
     issue_dy(k_begin, 0);
     issue_x(k_begin); issue_x(k_begin + 1); issue_x(k_begin + 2);

@@ -20,7 +20,7 @@ FAMILIES = (  # first match wins; (substring of the kernel name, family)
     ("conv_wgrad_kernel", "conv_wgrad"),
     ("bn_apply_gram_kernel", "bn_apply"), ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
     ("bn_apply_kernel", "bn_apply"), ("bn_relu_maxpool", "stem_tail"), ("stem_", "stem"),
-    ("bn_reduce_finalize", "bn_finalize"), ("bn_partial_reduce", "bn_finalize"), ("bn_finalize", "bn_finalize"), ("bn_bwd_finalize", "bn_finalize"),
+    ("bn_partial_reduce", "bn_finalize"), ("bn_finalize", "bn_finalize"), ("bn_bwd_finalize", "bn_finalize"),
     ("gram_", "gram_algebra"),
     ("attn_fwd", "attn_fwd"), ("attn_bwd", "attn_bwd"), ("attn_", "attn_other"),
     ("layernorm", "layernorm"), ("gelu", "gelu"), ("relu6", "relu6"), ("scale_rows", "scale_rows"),

@@ -272,56 +272,6 @@ def test_batchnorm_train_fwd_bwd(dtype, C):
         torch.testing.assert_close(dx.float().cpu(), nhwc(x2.grad), **tol(dtype, 4))
 
 
-@pytest.mark.parametrize("tiles,C", [(129, 64), (6272, 64), (3136, 128), (1568, 256), (392, 1024), (300, 2048), (777, 200)])
-def test_batchnorm_one_launch_statistics_match_two_launch_form(tiles, C):
-    """nkb_bn_finalize / nkb_bn_backward_from_stats over > 128 row tiles: the one-launch form (the partition block that draws the
-    last ticket finalizes, csrc/elementwise.hip: bn_reduce_finalize_kernel) is bit-identical with the two-launch form, launch after
-    launch (the ticket words reset themselves) and on two streams at once (one ticket set per stream)."""
-    torch.manual_seed(tiles + C)
-    rows = tiles * 128
-    n = hip.bn_stats_floats(tiles, C)
-    part = torch.zeros(n, device=DEV)
-    part[:tiles * 2 * C] = torch.randn(tiles * 2 * C, device=DEV) * 37.0
-    part[:tiles * 2 * C].view(tiles, 2, C)[:, 1].abs_().mul_(50.0)          # sum of squares: large and positive
-    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
-    invstd = torch.rand(C, device=DEV) + 0.5
-    gx = torch.randn(128, C, device=DEV)
-
-    def forward(buf):
-        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-        out = [torch.empty(C, device=DEV) for _ in range(4)]
-        hip.bn_finalize(buf, tiles, C, rows, gamma, beta, rm, rv, 0.1, 1e-5, True, *out)
-        return out + [rm, rv]
-
-    def backward(buf):
-        # the elementwise half runs over a 128-row stand-in (its row count is independent of the tile count of the statistics)
-        dg, db, sums = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.empty(2 * C, device=DEV)
-        dx = torch.empty_like(gx)
-        hip.bn_backward_from_stats(hip.dt(torch.float32), gx, gx, buf, tiles, invstd, invstd, gamma, 128, C, dg, db, dx, sums)
-        return [dg, db, sums, dx]
-
-    prev = hip.bn_fused_finalize(False)
-    try:
-        ref = forward(part.clone()) + backward(part.clone())
-        hip.bn_fused_finalize(True)
-        for _ in range(3):                                     # repeated launches: tickets are back at zero every time
-            got = forward(part.clone()) + backward(part.clone())
-            torch.cuda.synchronize()
-            for a, b in zip(got, ref):
-                assert torch.equal(a, b)
-        side = torch.cuda.Stream()
-        bufs = [part.clone() for _ in range(4)]
-        torch.cuda.synchronize()
-        with torch.cuda.stream(side):
-            s1 = forward(bufs[0]) + backward(bufs[1])
-        s0 = forward(bufs[2]) + backward(bufs[3])
-        torch.cuda.synchronize()
-        for a, b, c in zip(s0, s1, ref):
-            assert torch.equal(a, c) and torch.equal(b, c)
-    finally:
-        hip.bn_fused_finalize(prev)
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_batchnorm_eval(dtype):
     torch.manual_seed(4)
