@@ -183,4 +183,5 @@ def test_resnet50_bench_step_is_bit_reproducible_over_many_steps():
     sys.path.insert(0, str(ROOT / "scripts"))
     import soak_determinism
     a, b = soak_determinism.run(120), soak_determinism.run(120)
-    assert math.isfinite(a[2]) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert math.isfinite(a[2]) and all(math.isfinite(v) for v in a[3])
+    assert a[3] == b[3] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
