@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -361,6 +362,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.item())
+    if not math.isfinite(final_loss):
+        # synthetic data, random-init weights, lr 1e-4: a non-finite loss after a few dozen steps is a bug (a kernel, a stream
+        # hazard), and a throughput measured on NaNs is not a measurement — fail instead of printing a line
+        raise SystemExit(f"bench.py: non-finite loss {final_loss} after the timed steps; refusing to report a throughput")
     log(f"timed region: {dt:.3f}s for {args.steps} steps")
 
     # host work per step: the enqueue loop above runs ahead until the HIP queue throttles it, so host_enqueue_ms_per_step is

@@ -193,10 +193,15 @@ class DeviceLoader:
         B, Hs, Ws, _ = raw.shape
         out = torch.empty(B, 3, self.size, self.size, device=self.device, dtype=torch.float32)
         hip.image_prep(raw, st["sizes"], st["flags"], out, B, Hs, Ws, self.size, self.size, self.mean, self.std, self.fill)
-        for t in (raw, st["sizes"], st["flags"]):
+        tgt = st["target"]
+        for t in (raw, st["sizes"], st["flags"], *(tgt.values() if isinstance(tgt, dict) else (tgt,))):
             if t is not None:
-                t.record_stream(cur)          # allocated on the copy stream, consumed on the compute stream
-        return out, st["target"]
+                # allocated on the copy stream, consumed on the compute stream: without this the caching allocator hands the
+                # block to the NEXT staged batch as soon as Python drops the tensor — while the loss kernel that reads it is still
+                # queued (labels overwritten by another batch's flip flags: out-of-range classes, a NaN loss; bench.py --input
+                # host-uint8 ran into it, a loop that synchronises every step does not)
+                t.record_stream(cur)
+        return out, tgt
 
     def __iter__(self):
         it = iter(self.loader)

@@ -332,6 +332,21 @@ def test_bench_py_two_ranks_under_torchrun_prints_one_valid_line():
     assert d["value"] > 0 and abs(d["value"] - 512 * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]
 
 
+def test_bench_py_host_uint8_input_keeps_its_labels_across_streams():
+    """bench.py --input host-uint8: batches arrive through dataset.DeviceLoader (H2D on a copy stream one batch ahead) and the steps
+    are enqueued without any host synchronisation.  The targets are allocated on the copy stream and read by the loss kernel on the
+    compute stream; until round 3 they were not record_stream()-ed, so the allocator gave their block to the next staged batch's
+    flip flags while the loss kernel was still queued: out-of-range classes, a NaN loss in every committed host-uint8 line.  The
+    run must end with a finite loss (bench.py itself now refuses to print a line otherwise)."""
+    import json
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--input", "host-uint8", "--steps", "30", "--warmup", "4", "--no-cpu-baseline",
+           "--no-host-work", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert math.isfinite(d["final_loss"]) and 3.0 < d["final_loss"] < 8.0, d["final_loss"]
+
+
 def test_train_py_two_ranks_odd_dataset_counts_every_image_once(tmp_path):
     """with len(dataset) % world != 0 the padded training shard repeats an index and a padded validation shard would
     too — epoch metrics and the choice of best.pth must still be computed over each image exactly once (255 train / 127 val
