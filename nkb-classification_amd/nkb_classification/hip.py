@@ -389,6 +389,7 @@ def recording() -> bool:
 def host_op(fn):
     """A torch-side operation between launches (memset, counter bump, stream / event call): run now, and re-run at this
     point of the sequence when the plan is replayed — on the stream that is current now."""
+    global _REC
     if _REC is not None:
         cur = torch.cuda.current_stream()
         if cur == _REC_MAIN:
@@ -398,6 +399,15 @@ def host_op(fn):
                 with torch.cuda.stream(cur):
                     fn()
             _REC.append(["py", on_stream])
+        # fn itself is what the plan re-runs: library calls it makes now (the bf16 gradient exchange of parallel.GradReducer
+        # casts and sums through libnkbhip on temporaries) must not ALSO be recorded as table entries — replayed, they would
+        # run a second time on pointers that were freed when fn returned
+        rec, _REC = _REC, None
+        try:
+            fn()
+        finally:
+            _REC = rec
+        return
     fn()
 
 

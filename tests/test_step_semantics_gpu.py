@@ -726,6 +726,32 @@ def test_unicom_vit_l14_full_size_train_steps(mode):
     assert len(eng._f8w) == (96 if mode == "fp8" else 0)
 
 
+def test_host_op_library_calls_are_not_recorded_twice():
+    """A Python operation recorded into a launch plan (hip.host_op) is re-run at every replay; library calls made INSIDE it while
+    the plan is being recorded (the bf16 gradient exchange casts and sums through libnkbhip on temporaries) must not also become
+    table entries — replayed, those would run again on pointers freed when the operation returned."""
+    a = torch.arange(12, device=DEV, dtype=torch.float32).reshape(3, 4).contiguous()
+    b = torch.zeros(3, 4, device=DEV)
+    calls = []
+
+    def op():
+        tmp = a.clone()                                  # a temporary that dies with the call
+        hip.add2d(tmp, b, 3, 4, 4, 4)                    # b += tmp through the library
+        calls.append(1)
+
+    hip.record_begin()
+    try:
+        hip.host_op(op)
+        hip.add2d(a, b, 3, 4, 4, 4)                      # a direct call: this one IS a table entry
+    finally:
+        plan = hip.record_end({})
+    kinds = [seg[0] for seg in plan.segments]
+    assert kinds.count(2) == 1 and sum(seg[2] for seg in plan.segments if seg[0] == 0) == 1, kinds
+    hip.replay(plan, {})
+    torch.cuda.synchronize()
+    assert len(calls) == 2 and torch.equal(b, 4 * a)     # recorded once + replayed once, each time: op (+a) and the entry (+a)
+
+
 # ------------------------------------------------------------------------------------------------- launch plans ----
 @pytest.mark.parametrize("backbone", ["resnet_tiny_bottleneck", "vit_tiny_test"])
 def test_launch_plans_replay_exactly_across_shape_and_mode_changes(backbone, monkeypatch):
