@@ -49,7 +49,7 @@ def _dist(g, truth):
     return torch.nn.functional.cosine_similarity(g, truth, dim=0).item(), ((g - truth).norm() / truth.norm()).item()
 
 
-def _run(model_name, batch, dtype, classes, steps=4, heads=""):
+def _run(model_name, batch, dtype, classes, steps=4, heads="", size=224):
     import bench
     from oracle.torch_engine import Criterion
     args = argparse.Namespace(model=model_name, classes=classes, batch=batch, dtype=dtype, heads=heads)
@@ -67,7 +67,7 @@ def _run(model_name, batch, dtype, classes, steps=4, heads=""):
         o = o.to(device).train()
         oracles.append((o, make_optimizer(o, OPT)))
     g = torch.Generator().manual_seed(1234)
-    img = torch.randn(batch, 3, 224, 224, generator=g).to(device)
+    img = torch.randn(batch, 3, size, size, generator=g).to(device)
     tgt = bench.make_targets(hs, classes, batch, g, device)
     cat = (lambda d: torch.cat([d[t].float() for t in sorted(d)], dim=1)) if hs else (lambda t: t.float())
     model.train()
@@ -155,6 +155,16 @@ def test_resnet50_multitask_configs3_matches_oracle():
     out, n, plans = _run("resnet50", 256, "bf16", 0, heads="2,3,5,14")
     _check(out, relative=True)
     assert plans >= 2 and n["gemm8p"] > 0 and n["wgrad8p"] > 0 and n["gram_conv"] > 0
+
+
+@pytest.mark.parametrize("size", [127, 200, 288])
+def test_resnet50_other_resolutions_match_oracle(size):
+    """Odd and non-224 inputs (127 -> 64, 32, 16, 8, 4; 200 -> 100, 50, 25, 13, 7; 288 -> 144 ... 9): odd extents under the stride-2
+    stages (parity-class data gradients, sub-grid shortcuts), 64-slot strips in wgrad3x3 at other widths, ragged last tiles
+    everywhere — the same bars as at the bench size, bs 64."""
+    out, n, plans = _run("resnet50", 64, "bf16", 1000, steps=4, size=size)
+    _check(out, relative=True)
+    assert plans >= 2 and n["wgrad3x3"] > 0
 
 
 def test_vit_b16_bench_configuration_matches_oracle():
