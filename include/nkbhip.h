@@ -440,7 +440,7 @@ int nkb_plan_run(const void* entries, int n, int* failed);
 /* Per-launch HIP-event profiler (bench.py's roofline leg). */
 void nkb_prof_enable(int on);
 int nkb_prof_collect(double* ms, long long* launches, double* work, double* bytes, int slots);
-int nkb_prof_collect_raw(int* kernel_id, double* ms, double* work, int cap);
+int nkb_prof_collect_raw(int* kernel_id, double* ms, double* work, double* bytes, int cap);
 const char* nkb_kernel_name(int kernel_id);
 
 #ifdef __cplusplus

@@ -84,15 +84,16 @@ extern "C" int nkb_prof_collect(double* ms, long long* launches, double* work, d
     return NKB_K_COUNT;
 }
 
-// Raw per-launch records (kernel id, milliseconds, work) in launch order; clears the log. Returns the count written.
-extern "C" int nkb_prof_collect_raw(int* kid, double* ms, double* work, int cap) {
+// Raw per-launch records (kernel id, milliseconds, algorithmic FLOPs, algorithmic bytes — `bytes` may be NULL) in launch order;
+// clears the log. Returns the count written.
+extern "C" int nkb_prof_collect_raw(int* kid, double* ms, double* work, double* bytes, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     int n = 0;
     for (auto& r : g_prof) {
         hipEventSynchronize(r.b);
         float t = 0.f;
         hipEventElapsedTime(&t, r.a, r.b);
-        if (n < cap) { kid[n] = r.kid; ms[n] = t; work[n] = r.work; ++n; }
+        if (n < cap) { kid[n] = r.kid; ms[n] = t; work[n] = r.work; if (bytes) bytes[n] = r.bytes; ++n; }
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }

@@ -111,7 +111,7 @@ _SIGS = {
     "nkb_gemm_fp8": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]),
     "nkb_prof_enable": (None, [i32]),
     "nkb_prof_collect": (i32, [vp, vp, vp, vp, i32]),
-    "nkb_prof_collect_raw": (i32, [vp, vp, vp, i32]),
+    "nkb_prof_collect_raw": (i32, [vp, vp, vp, vp, i32]),
     "nkb_kernel_name": (C.c_char_p, [i32]),
     "nkb_plan_fn_count": (i32, []),
     "nkb_plan_fn_name": (C.c_char_p, [i32]),
@@ -777,12 +777,15 @@ def prof_collect():
     return out
 
 
-def prof_collect_raw(cap: int = 1 << 16):
-    """[(kernel name, ms, work)] per launch, in launch order."""
+def prof_collect_raw(cap: int = 1 << 16, with_bytes: bool = False):
+    """[(kernel name, ms, work)] per launch, in launch order (with_bytes: + the launch's algorithmic bytes)."""
     kid = (C.c_int * cap)()
     ms = (C.c_double * cap)()
     work = (C.c_double * cap)()
-    n = load().nkb_prof_collect_raw(kid, ms, work, cap)
+    byt = (C.c_double * cap)()
+    n = load().nkb_prof_collect_raw(kid, ms, work, byt, cap)
+    if with_bytes:
+        return [(load().nkb_kernel_name(kid[i]).decode(), ms[i], work[i], byt[i]) for i in range(n)]
     return [(load().nkb_kernel_name(kid[i]).decode(), ms[i], work[i]) for i in range(n)]
 
 
