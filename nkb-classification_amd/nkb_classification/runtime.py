@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 from torch import nn
 
@@ -169,6 +171,21 @@ class ParamArena:
                 p.grad = self.grad_view(p)
 
 
+# NKB_POISON_WS=1 (debugging): every fresh workspace buffer is filled with NaN bit patterns instead of being left as the allocator
+# returned it, so a kernel that reads scratch it never wrote (an unwritten slab, padding behind a statistics block) turns the step
+# non-finite at once instead of once in a few hundred steps (scripts/soak_determinism.py runs with it)
+_POISON = os.environ.get("NKB_POISON_WS", "0") != "0"
+
+
+def _poison(t: torch.Tensor) -> torch.Tensor:
+    if _POISON and t.numel():
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        else:
+            t.view(torch.uint8).fill_(0xFF)
+    return t
+
+
 class Workspace:
     """Name-keyed persistent device buffers (activations saved for backward, scratch, statistics)."""
 
@@ -181,7 +198,7 @@ class Workspace:
         shape = tuple(int(s) for s in shape)
         t = self._bufs.get(name)
         if t is None or t.shape != shape or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype)
+            t = torch.zeros(shape, device=self.device, dtype=dtype) if zero else _poison(torch.empty(shape, device=self.device, dtype=dtype))
             self._bufs[name] = t
             self.generation += 1
         return t
@@ -190,7 +207,7 @@ class Workspace:
         """Flat scratch that only ever grows."""
         t = self._bufs.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype:
-            t = torch.empty(max(int(numel), 1), device=self.device, dtype=dtype)
+            t = _poison(torch.empty(max(int(numel), 1), device=self.device, dtype=dtype))
             self._bufs[name] = t
             self.generation += 1
         return t

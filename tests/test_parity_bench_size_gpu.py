@@ -186,12 +186,17 @@ def test_unicom_l14_bench_configuration_matches_oracle(dtype):
     assert plans >= 1
 
 
-def test_resnet50_bench_step_is_bit_reproducible_over_many_steps():
+def test_resnet50_bench_step_is_bit_reproducible_over_many_steps(monkeypatch):
     """120 steps of the bench configuration (plans replayed, weight gradients co-running on the second stream), twice from the same
     seed: parameters and BatchNorm running statistics end bit-identical.  Op-level tests run on fresh buffers; only a long run
-    on the step's own reused buffers shows a race or a stale read (scripts/soak_determinism.py)."""
+    on the step's own reused buffers shows a race or a stale read (scripts/soak_determinism.py).  The second
+    run gets every fresh workspace buffer filled with NaN (runtime._POISON, NKB_POISON_WS): a kernel that reads scratch it never
+    wrote would make it differ."""
     sys.path.insert(0, str(ROOT / "scripts"))
     import soak_determinism
-    a, b = soak_determinism.run(120), soak_determinism.run(120)
+    from nkb_classification import runtime
+    a = soak_determinism.run(120)
+    monkeypatch.setattr(runtime, "_POISON", True)
+    b = soak_determinism.run(120)
     assert math.isfinite(a[2]) and all(math.isfinite(v) for v in a[3])
     assert a[3] == b[3] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
