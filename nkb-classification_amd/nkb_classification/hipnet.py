@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import torch
 from torch import nn
 
-from . import hip
+from . import hip, runtime
 from .runtime import ParamArena, Workspace, _round_up
 
 _PACKED_STEM = os.environ.get("NKB_PACKED_STEM", "1") != "0"
@@ -136,14 +136,14 @@ class HipEngine:
             if self.packed_stem(conv):
                 buf = self._wpad.get(id(w))
                 if buf is None:
-                    buf = self._wpad[id(w)] = torch.empty(w.shape[0], hip.stem_weight_cols(self.d), device=self.device,
+                    buf = self._wpad[id(w)] = runtime.empty(w.shape[0], hip.stem_weight_cols(self.d), device=self.device,
                                                           dtype=self.T)
                 hip.stem_wprep(self.d, a.param_flat(w), buf, w.shape[0], w.shape[1])
                 continue
             K = w.shape[1] * w.shape[2] * w.shape[3]
             buf = self._wpad.get(id(w))
             if buf is None:
-                buf = self._wpad[id(w)] = torch.empty(w.shape[0], self.kpad(K), device=self.device, dtype=self.T)
+                buf = self._wpad[id(w)] = runtime.empty(w.shape[0], self.kpad(K), device=self.device, dtype=self.T)
             hip.wprep(self.d, a.param_flat(w), buf, w.shape[0], 1, K, buf.shape[1], 0)
         if need_dgrad:
             if self._wjobs is None:
@@ -174,10 +174,10 @@ class HipEngine:
         for conv in self._convs:
             w = conv.weight
             co, ci, r, s = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
-            buf = self._wd[id(w)] = torch.empty(ci, r, s, co, device=self.device, dtype=self.T)
+            buf = self._wd[id(w)] = runtime.empty(ci, r, s, co, device=self.device, dtype=self.T)
             add(a.offset_of(w), buf, co, r * s, ci, co, 1)
             if self.s2_classes(conv):
-                cls = self._wd_cls[id(w)] = [torch.empty(ci, (2 if k >> 1 else 1) * (2 if k & 1 else 1), co,
+                cls = self._wd_cls[id(w)] = [runtime.empty(ci, (2 if k >> 1 else 1) * (2 if k & 1 else 1), co,
                                                          device=self.device, dtype=self.T) for k in range(4)]
                 for k in range(4):
                     add(a.offset_of(w), cls[k], co, 9, ci, co, 2 + k)
@@ -185,7 +185,7 @@ class HipEngine:
         ctot = sum(w.shape[0] for w in hw)
         E = hw[0].shape[1]
         cp = self.kpad(ctot)
-        buf = self._wd["head"] = torch.empty(E, cp, device=self.device, dtype=self.T)
+        buf = self._wd["head"] = runtime.empty(E, cp, device=self.device, dtype=self.T)
         add(a.offset_of(hw[0]), buf, ctot, 1, E, cp, 1)
         jobs = torch.tensor(rows, dtype=torch.int64, device=self.device)
         return jobs, len(rows), nblocks
@@ -210,8 +210,8 @@ class HipEngine:
                 if not (self._fp8_shape_ok(K, N) and self._fp8_shape_ok(N, K) and id(w) in self._wd):
                     continue
                 st = torch.tensor([1.0, 1.0, 0.0], device=self.device)
-                wq = torch.empty(N, K, device=self.device, dtype=torch.uint8)
-                wdq = torch.empty(K, N, device=self.device, dtype=torch.uint8)
+                wq = runtime.empty(N, K, device=self.device, dtype=torch.uint8)
+                wdq = runtime.empty(K, N, device=self.device, dtype=torch.uint8)
                 self._f8w[id(w)] = (wq, wdq, st)
                 n = N * K
                 for src, dst, table in ((a.shadow_flat(w), wq, "both"), (self._wd[id(w)], wdq, "all")):
@@ -349,8 +349,8 @@ class HipEngine:
             if ent is None or ent[0] != self.fold_key:
                 hip.bn_finalize(None, 0, co, rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1, bn.eps, False,
                                 sc[0], sc[1], sc[2], sc[3])
-                wf = ent[1] if ent is not None else torch.empty(co, R * S * ci, device=self.device, dtype=self.T)
-                shift = ent[2] if ent is not None else torch.empty(co, device=self.device, dtype=torch.float32)
+                wf = ent[1] if ent is not None else runtime.empty(co, R * S * ci, device=self.device, dtype=self.T)
+                shift = ent[2] if ent is not None else runtime.empty(co, device=self.device, dtype=torch.float32)
                 hip.wfold(self.d, self.arena.param_flat(w), sc[0], wf, co, R * S * ci)
                 shift.copy_(sc[1])
                 ent = self._fold[key] = (self.fold_key, wf, shift)

@@ -186,6 +186,11 @@ def _poison(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def empty(*shape, **kw) -> torch.Tensor:
+    """torch.empty for the engine's persistent shadows (padded weight layouts, folded filters): poisoned under NKB_POISON_WS."""
+    return _poison(torch.empty(*shape, **kw))
+
+
 class Workspace:
     """Name-keyed persistent device buffers (activations saved for backward, scratch, statistics)."""
 
