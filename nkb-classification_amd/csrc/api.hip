@@ -50,7 +50,20 @@ static hipEvent_t get_event() {
     return e;
 }
 
+// NKB_POISON_LDS=1 (debugging): before every entry point's launches, a kernel fills the LDS of every CU with NaN bit patterns
+// (LDS keeps what the previous kernel left in it).  A kernel that reads LDS it has not written — wgrad3x3's first k-step did, two
+// slots of an X chunk still in flight, multiplied by zero — then goes non-finite at once instead of once in a few hundred steps.
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned* sink) {
+    extern __shared__ unsigned poison[];
+    for (int i = threadIdx.x; i < 40 * 1024 / 4; i += 256) poison[i] = 0x7fc07fc0u;      // NaN as fp32 and as two bf16
+    __syncthreads();
+    if (poison[threadIdx.x] == 1u && sink) *sink = 1u;                                   // (keeps the stores alive)
+}
+static const bool g_poison_lds = [] { const char* e = getenv("NKB_POISON_LDS"); return e && atoi(e) != 0; }();
+
 NkbProfScope::NkbProfScope(int kernel_id, hipStream_t s, double work, double bytes) : slot(-1), stream(s) {
+    if (g_poison_lds)       // 4 x 40 KB per CU = all 160 KB; a few rounds so that every CU's allocations are covered
+        hipLaunchKernelGGL(lds_poison_kernel, dim3(256 * 4 * 3), dim3(256), 40 * 1024, s, (unsigned*)nullptr);
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
