@@ -186,9 +186,43 @@ def _poison(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+_GUARD_BYTES = 64 * 1024
+_GUARDED: List[torch.Tensor] = []      # (poison mode) the flat allocations behind guarded buffers: [guard | payload | guard]
+
+
+def _guarded(shape, dtype, device, zero=False) -> torch.Tensor:
+    """Poison mode: the buffer sits between two 64 KB guard zones of NaN, so that a read a few rows past either end brings NaN into
+    the step, and a WRITE past either end is found by guards_intact() afterwards."""
+    n = 1
+    for v in shape:
+        n *= int(v)
+    g = _GUARD_BYTES // torch.empty(0, dtype=dtype).element_size()
+    flat = _poison(torch.empty(n + 2 * g, device=device, dtype=dtype))
+    _GUARDED.append(flat)
+    mid = flat[g:g + n].view(shape)
+    if zero:
+        mid.zero_()
+    return mid
+
+
+def guards_intact() -> bool:
+    """Poison mode: every guard zone allocated so far still holds its fill (no kernel wrote outside its buffer)."""
+    for flat in _GUARDED:
+        g = _GUARD_BYTES // flat.element_size()
+        for zone in (flat[:g], flat[-g:]):
+            b = zone.view(torch.uint8)
+            ok = torch.isnan(zone).all() if flat.is_floating_point() else (b == 0xFF).all()
+            if not bool(ok):
+                return False
+    return True
+
+
 def empty(*shape, **kw) -> torch.Tensor:
-    """torch.empty for the engine's persistent shadows (padded weight layouts, folded filters): poisoned under NKB_POISON_WS."""
-    return _poison(torch.empty(*shape, **kw))
+    """torch.empty for the engine's persistent shadows (padded weight layouts, folded filters): poisoned and guarded under NKB_POISON_WS."""
+    if _POISON:
+        return _guarded(tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape,
+                        kw.get("dtype", torch.float32), kw.get("device"))
+    return torch.empty(*shape, **kw)
 
 
 class Workspace:
@@ -203,7 +237,10 @@ class Workspace:
         shape = tuple(int(s) for s in shape)
         t = self._bufs.get(name)
         if t is None or t.shape != shape or t.dtype != dtype:
-            t = torch.zeros(shape, device=self.device, dtype=dtype) if zero else _poison(torch.empty(shape, device=self.device, dtype=dtype))
+            if _POISON:
+                t = _guarded(shape, dtype, self.device, zero)
+            else:
+                t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype)
             self._bufs[name] = t
             self.generation += 1
         return t
@@ -212,7 +249,7 @@ class Workspace:
         """Flat scratch that only ever grows."""
         t = self._bufs.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype:
-            t = _poison(torch.empty(max(int(numel), 1), device=self.device, dtype=dtype))
+            t = _guarded((max(int(numel), 1),), dtype, self.device) if _POISON else torch.empty(max(int(numel), 1), device=self.device, dtype=dtype)
             self._bufs[name] = t
             self.generation += 1
         return t

@@ -52,4 +52,9 @@ if __name__ == "__main__":
     import math
     print(f"{a.model} bs {a.batch} {a.dtype} {a.heads} {a.size}px: {a.runs} runs x {a.steps} steps, final loss {ref[2]:.6f}, finite {math.isfinite(ref[3][-1])}, "
           f"divergent runs: {bad}", flush=True)
+    from nkb_classification import runtime
+    if runtime._POISON:
+        ok = runtime.guards_intact()
+        print(f"  poison mode: guard zones around {len(runtime._GUARDED)} buffers intact: {ok}", flush=True)
+        bad += 0 if ok else 1
     sys.exit(1 if bad else 0)

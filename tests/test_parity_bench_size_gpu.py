@@ -198,5 +198,6 @@ def test_resnet50_bench_step_is_bit_reproducible_over_many_steps(monkeypatch):
     a = soak_determinism.run(120)
     monkeypatch.setattr(runtime, "_POISON", True)
     b = soak_determinism.run(120)
+    assert runtime.guards_intact()            # ... and no kernel wrote outside its buffer (64 KB NaN zones around every one)
     assert math.isfinite(a[2]) and all(math.isfinite(v) for v in a[3])
     assert a[3] == b[3] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
