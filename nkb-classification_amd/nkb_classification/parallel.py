@@ -83,8 +83,12 @@ class GradReducer:
         for a, b in self._ready:
             # send whole buckets from the tail of the interval (produced first); keep the remainder for later merging
             while b - a >= self.bucket_elems:
-                todo.append((b - self.bucket_elems, b))
-                b -= self.bucket_elems
+                # cuts at 64-element boundaries of the arena: with range starts at parameter starts (64-aligned, runtime._ALIGN)
+                # every bucket then begins 256-byte aligned, whatever the range's END is (a classifier bias of 10 elements) — the
+                # cast / sum kernels of the bf16 exchange need 16-byte-aligned slices
+                cut = max(a, (b - self.bucket_elems) // 64 * 64)
+                todo.append((cut, b))
+                b = cut
             if b > a:
                 (todo if final else keep).append((a, b) if final else [a, b])
         self._ready = keep
@@ -110,7 +114,7 @@ class GradReducer:
         # walk from the tail: those gradients were produced first
         b = hi
         while b > lo:
-            a = max(lo, b - self.bucket_elems)
+            a = max(lo, (b - self.bucket_elems) // 64 * 64)
             if self.bf16_buckets:
                 self._exchange_bf16(flat[a:b])
             else:

@@ -726,6 +726,44 @@ def test_unicom_vit_l14_full_size_train_steps(mode):
     assert len(eng._f8w) == (96 if mode == "fp8" else 0)
 
 
+def test_bf16_gradient_exchange_kernels_on_the_gpu_single_rank_rccl():
+    """The GPU form of parallel.GradReducer's bf16 bucket exchange (cast by nkb_wprep, all-to-all, fp32 sum of the received slices by
+    nkb_bucket_sum_bf16, all-gather, widening back into the arena) through a real one-rank RCCL group — the CPU / gloo tests cover
+    the protocol, not these kernels: (a) nkb_bucket_sum_bf16 against torch on W = 4 slices, fp32 and bf16 outputs, ragged length;
+    (b) a whole exchange on an arena slice that starts 64-aligned and ends at an odd element: with one rank the result is the
+    gradient rounded to bf16 once."""
+    import torch.distributed as dist
+    from nkb_classification.parallel import GradReducer
+    g = torch.Generator().manual_seed(3)
+    W, chunk, n = 4, 1016, 1003                                  # stride a multiple of 8, length not
+    parts = torch.randn(W * chunk, generator=g).to(DEV).to(torch.bfloat16)
+    out32, out16 = torch.full((n,), 7.0, device=DEV), torch.zeros(chunk, device=DEV, dtype=torch.bfloat16)
+    hip.bucket_sum_bf16(parts, chunk, W, out32, out16, n)
+    ref = torch.zeros(n, device=DEV)
+    for p_ in range(W):                                          # fp32 accumulation in part order
+        ref += parts[p_ * chunk:p_ * chunk + n].float()
+    torch.cuda.synchronize()
+    assert torch.equal(out32, ref) and torch.equal(out16[:n], ref.to(torch.bfloat16))
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{31000 + os.getpid() % 2000}",
+                            device_id=torch.device(DEV))
+    try:
+        total = 64 * 300 + 10                                    # ends in a 10-element classifier bias
+        flat = torch.randn(total, generator=g).to(DEV) * 3.0
+        model = types.SimpleNamespace(arena=types.SimpleNamespace(flat_grad=flat, total=total), grad_ready_hook=None)
+        red = GradReducer(model, None, bucket_bytes=4 * 4096, bucket_dtype="bf16")
+        assert red.bf16_buckets and red.world == 1
+        want = flat.clone()
+        lo = 64 * 37
+        want[lo:] = want[lo:].to(torch.bfloat16).float()
+        red._exchange_bf16(flat[lo:])                            # (world 1: the hooks return early, so call the exchange itself)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_host_op_library_calls_are_not_recorded_twice():
     """A Python operation recorded into a launch plan (hip.host_op) is re-run at every replay; library calls made INSIDE it while
     the plan is being recorded (the bf16 gradient exchange casts and sums through libnkbhip on temporaries) must not also become
