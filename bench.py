@@ -324,6 +324,7 @@ def main():
     log("first step done")
     if reducer is not None:
         reducer.broadcast_state(model.arena.flat_param, [b for b in model.buffers() if b.is_floating_point()])
+        model.arena.mark_dirty()          # bf16 shadow / re-laid-out filters follow the received masters (as parallel.attach does)
     for _ in range(max(args.warmup - 1, 0)):
         step()
 
