@@ -35,7 +35,7 @@ const char* nkb_last_error(void);
 int nkb_version(void);
 /* Launch counters of the specialised kernels since process start (or the last reset): which = 0 eight-phase GEMM (gemm8p), 1 eight-phase
  * weight gradient (wgrad8p / wgrad256), 2 shared-strip 3x3 weight gradient, 3 fp8 weight gradient, 4 Gram-form closing convolution,
- * 5 bn_apply fused with the Gram matrix.  Tests use them to prove that a benchmark configuration took the path it is priced on. */
+ * 5 bn_apply fused with the Gram matrix, 6 row-balanced 3x3 core (convp).  Tests use them to prove that a benchmark configuration took the path it is priced on. */
 long long nkb_kernel_launches(int which, int reset);
 
 /* Implicit-GEMM convolution / linear layer on MFMA.
@@ -98,6 +98,19 @@ int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, 
                       const void* add, int ldadd, const unsigned char* add_bits, int add_h, int add_w, int N, int H,
                       int W, int Cin, int ldx, int P, int Q, int Cout, int ldy, int R, int S, int stride, int pad,
                       nkb_stream_t stream);
+/* Row-balanced, DMA-pipelined core for 3x3 / stride-1 / pad-1 convolutions in bf16 (csrc/convp.hip) — timm Bottleneck / BasicBlock
+ * conv2 built at /root/reference/nkb_classification/model.py:82, forward from engine.py:48, data gradient from engine.py:55-58.
+ * One 512-thread workgroup per CU owns M / #workgroups consecutive output pixels; BatchNorm partial sums leave as ONE row per
+ * workgroup: stats[tiles][2][Cout] with tiles = nkb_convp_tiles(...) (0: shape not eligible -> use nkb_conv_gemm / nkb_conv_dgrad_bn;
+ * kind 0 forward, 1 data gradient).  nkb_convp_fwd: y = conv(x, w), stats = sums of y and y^2 (nkb_conv_gemm(mode 0) with stats).
+ * nkb_convp_dgrad_bn: nkb_conv_dgrad_bn's recomputed-mask form (no residual operand); w is the [Cin][3][3][Cout] data-gradient filter,
+ * Cin / ldx describe dY, Cout / ldy the produced gradient.  Both feed nkb_bn_finalize / nkb_bn_backward_from_stats with `tiles`. */
+int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int stride, int pad);
+int nkb_convp_fwd(int dtype, const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int ldx, int Cout,
+                  int ldy, nkb_stream_t stream);
+int nkb_convp_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,
+                       const float* shift, const float* mean, float* stats, int N, int H, int W, int Cin, int ldx, int Cout,
+                       int ldy, nkb_stream_t stream);
 /* relu_bits != NULL: the stage closes a residual block — its mask comes from nkb_bn_apply's bit array (scale/shift
  * unused; c and mean may then be NULL as well: only the sums of g' are produced, the Gram form takes sum g'c from R = g'^T a) and the residual operand `add` (optionally under add_bits, or on the sub-grid add_h x add_w) is still added
  * before masking, so the block-output gradient is produced, masked and reduced in the one epilogue. */

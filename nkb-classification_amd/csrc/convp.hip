@@ -1,0 +1,477 @@
+// Row-balanced, DMA-pipelined implicit-GEMM core for the 3x3 / stride-1 / pad-1 convolutions of a ResNet stage (bf16):
+// forward with BatchNorm partial sums, and the data gradient with the fused BatchNorm-backward epilogue of the stage before
+// (timm Bottleneck / BasicBlock conv2 reached from /root/reference/nkb_classification/engine.py:48, 55-58 via model.py:82).
+//
+//     y[pixel][cout] = sum over (r, s, cin) of x[pixel shifted by (r - 1, s - 1)][cin] * w[cout][r][s][cin]
+//
+// Why a second core next to conv_igemm_kernel (128 x 128 tiles, register staging, one k-tile of prefetch, 3 workgroups per
+// CU): at batch 256 the 3x3 shapes of layer2-4 are 59 GFLOP each and ran at 0.58-0.76 PFLOP/s there — latency-bound (one
+// k-tile ahead), LDS-write-bound (every operand byte goes through ds_write_b128) and, on 14 x 14 / 7 x 7 maps, a third of a
+// round of tiles short of filling the chip (784 tiles on 768 slots).  This core is built the other way round:
+//   * ROW-BALANCED grid: one 512-thread workgroup per CU, each owning M / #workgroups consecutive output pixels (rounded to
+//     16) x TC output channels; a workgroup walks its rows in sub-tiles of <= 256 pixels and multiplies only the 16-pixel
+//     fragments that exist (NF is a compile-time parameter of the sub-tile body, dispatched once per sub-tile) — 196 rows per
+//     CU on layer3 cost 13 / 16 of a tile, not a tile, and there is no remainder round.
+//   * activations through LDS by DMA (global_load_lds_dwordx4, no staging registers, no ds_write): one stage = the 258 flattened
+//     pixels (m0 - 1 .. m0 + 256) x 64 channels of ONE filter row, shared by the three column taps of that row (tap s reads the
+//     stage shifted by s rows; lanes whose left / right neighbour lies in another image row multiply zeros) — 3 loads of the
+//     activation tile per channel chunk instead of 9.  Rows outside the image come from a zero page.  Two stages; the next
+//     chunk's DMA is issued right after the one barrier per chunk (three k-tiles of MFMA time ahead of its use).
+//   * weights never meet a barrier: wave w multiplies 32 output channels and DMAs exactly those 32 filter rows (4 KB per
+//     k-tile) into two private 4 KB slots, two k-tiles ahead, ordered by its own counted s_waitcnt vmcnt only.  (TC = 128 has
+//     two pixel halves per channel group: each half streams its own copy.)
+//   * XOR-swizzled 128-byte rows on the DMA SOURCE side (the destination is lane-linear), ds_read_b128 fragments.
+//   * epilogue straight from the accumulators: the filter rows of a wave are permuted so that a lane holds 8 consecutive
+//     output channels of a pixel = one 16-byte store; BatchNorm partial sums stay in registers across all sub-tiles of the
+//     workgroup and leave as ONE partial row per workgroup: stats[workgroup][2][Cout] (<= 256 rows instead of M / 128).
+// The counted waits: every vector-memory operation of a wave is a DMA or an epilogue store, issued in a fixed order
+//   chunk top: X(chunk + 1) x 5 | k-tile g: W(g + 2) x 4 | ... | sub-tile end: NPW stores
+// so "W(g) has landed" is `all but the N youngest done` with N known at compile time (CP_* below).
+#include "common.h"
+#include "convp.h"
+#include <type_traits>
+
+namespace {
+
+struct CPParams {
+    const bf16_t* x;            // [M][ldx] source pixels (forward: the input activation, data gradient: dY)
+    const bf16_t* w;            // [Cout][3][3][Cin] (K contiguous)
+    bf16_t* y;                  // [M][ldy]
+    const bf16_t* aux;          // EPI 1: raw conv output c of the stage whose BatchNorm backward consumes y, [M][ldy]
+    const float* bn_scale;      // EPI 1: that stage's scale / shift / mean
+    const float* bn_shift;
+    const float* bn_mean;
+    float* stats;               // [nwgm][2][Cout] partial sums of this launch
+    int M, H, W, Cin, ldx, Cout, ldy, ldw;
+    int mode;                   // 0 forward, 1 data gradient (filter rows / columns mirrored)
+    int nwgm, tilesN, rows_per_wg;
+    FastDiv divHW, divW;
+};
+
+__device__ __attribute__((aligned(256))) unsigned char convp_zero_page[256];      // zero-initialised: source of out-of-image rows
+
+typedef int cp_i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void cp_glds16(const unsigned char* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void cp_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define CP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define CP_BARRIER()                                 \
+    do {                                             \
+        asm volatile("" ::: "memory");               \
+        __builtin_amdgcn_s_barrier();                \
+        asm volatile("" ::: "memory");               \
+    } while (0)
+
+__device__ __forceinline__ float cp_row16_sum(float v) {      // sum over the 16 lanes of a DPP row, every lane gets the total
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
+// TC: output channels per workgroup (256: 8 channel waves x all 16 pixel fragments; 128: 4 channel waves x 2 pixel halves).
+// EPI 0: y = rnd(acc), partial sums of y and y^2 (forward, conv_igemm's BNB == 3);
+// EPI 1: g' = mask(acc) with the ReLU mask of the previous stage recomputed from its raw output c exactly as bn_apply evaluated it,
+//        partial sums of g' and g' (c - mean) (conv_igemm's BNB == 7).
+template <int TC, int EPI>
+__global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
+    constexpr int CW = TC / 32, PW = 8 / CW, NPW = 16 / PW;
+    constexpr int XS = 40 * 1024;                  // one activation stage: 40 DMA pieces of 8 rows x 128 B (rows 0 .. 257 are read)
+    constexpr int WOFF = 2 * XS;                   // per-wave filter slots: 2 x 4 KB
+    constexpr int ROFF = WOFF + 8 * 8192;          // cross-wave reduction scratch (PW > 1)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wvc = wave % CW, pw = wave / CW;
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;       // DMA piece: row inside the piece, SOURCE chunk (swizzle)
+
+    const int lid = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid / p.nwgm, wgm = lid - tile_n * p.nwgm;
+    const int row0 = wgm * p.rows_per_wg;
+    const int row1 = min(p.M, row0 + p.rows_per_wg);           // (the host sizes the grid so that row0 < M)
+    const int nsub = (row1 - row0 + 255) >> 8;
+    const int cpk = p.Cin >> 6;
+    const int NCH = 3 * cpk;                                   // activation chunks (filter row, channel chunk) per sub-tile
+    const int GC = nsub * NCH;                                 // chunks of this workgroup's whole stream
+    const int hsign = p.mode == 0 ? 1 : -1;
+    const int c_wave = tile_n * TC + wvc * 32;
+
+    // ---- filter stream: this wave's 32 rows, slot row 16 i + r <-> channel c_wave + 8 (r >> 2) + 4 i + (r & 3), so that the two
+    // accumulator tiles of a lane hold 8 consecutive channels
+    unsigned wsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = 8 * q + lrow, i = rr >> 4, r16 = rr & 15;
+        wsrc[q] = (unsigned)(c_wave + 8 * (r16 >> 2) + 4 * i + (r16 & 3)) * (unsigned)p.ldw * 2u + (unsigned)lch * 16u;
+    }
+    unsigned char* const wslot = smem + WOFF + wave * 8192;
+    int wgi = 0, wr = 0, wck = 0, wsx = 0;                     // next k-tile of the filter stream: index, (filter row, chunk, column)
+    const int GT = GC * 3;
+    auto issue_w = [&]() {
+        if (wgi < GT) {
+            const unsigned char* s_ = (const unsigned char*)p.w + (size_t)((wr * 3 + wsx) * cpk + wck) * 128;
+            unsigned char* d_ = wslot + (wgi & 1) * 4096;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cp_glds16(s_ + wsrc[q], d_ + q * 1024);
+        }
+        ++wgi;
+        if (++wsx == 3) { wsx = 0; if (++wck == cpk) { wck = 0; if (++wr == 3) wr = 0; } }
+    };
+
+    // ---- activation stream: piece q = wave + 8 i holds stage rows 8 q .. 8 q + 7 = flattened pixels m0 - 1 + row
+    unsigned xoff[5];
+    unsigned xhm = 0u;                                         // 3 bits per piece: filter row r reads inside the image
+    auto rows_of = [&](int t) {
+        const int m0 = row0 + 256 * t;
+        const int nvt = min(256, row1 - m0);
+        xhm = 0u;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int lr = 8 * (wave + 8 * i) + lrow;
+            const int m = m0 - 1 + lr;
+            unsigned off = 0u, hb = 0u;
+            if (m >= 0 && m < p.M && lr <= nvt + 1) {
+                const unsigned n = fdiv((unsigned)m, p.divHW);
+                const unsigned rem = (unsigned)m - n * p.divHW.d;
+                const int h = (int)fdiv(rem, p.divW);
+                off = (unsigned)m * (unsigned)p.ldx * 2u + (unsigned)lch * 16u;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+                    if ((unsigned)(h + hsign * (rr - 1)) < (unsigned)p.H) hb |= 1u << rr;
+            }
+            xoff[i] = off;
+            xhm |= hb << (3 * i);
+        }
+    };
+    int xg = 0, xt = 0, xr = 0, xck = 0;                       // next chunk of the activation stream
+    auto issue_x = [&]() {
+        if (xg < GC) {
+            const long rowoff = (long)(hsign * (xr - 1) * p.W) * p.ldx * 2 + xck * 128;
+            unsigned char* d_ = smem + (xg & 1) * XS + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const bool ok = (xhm >> (3 * i + xr)) & 1u;
+                const unsigned char* s_ = ok ? (const unsigned char*)p.x + ((long)xoff[i] + rowoff)
+                                             : convp_zero_page + (lane & 7) * 16;
+                cp_glds16(s_, d_ + i * 8192);
+            }
+        }
+        ++xg;
+        if (++xck == cpk) {
+            xck = 0;
+            if (++xr == 3) { xr = 0; if (++xt < nsub) rows_of(xt); }
+        }
+    };
+
+    // ---- prologue: chunk 0, k-tiles 0 and 1 (issue order X(0) W(0) W(1): the chunk-top wait of the loop applies unchanged)
+    rows_of(0);
+    issue_x();
+    issue_w();
+    issue_w();
+
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+
+    int gc = 0;                                                // chunk being computed
+    int g = 0;                                                 // k-tile being computed
+    bool after_epi = false;                                    // NPW epilogue stores are younger than the filter tiles in flight
+
+    for (int t = 0; t < nsub; ++t) {
+        const int m0 = row0 + 256 * t;
+        const int nv = min(256, row1 - m0);
+        const int nf_all = (nv + 15) >> 4;
+        const int nf = __builtin_amdgcn_readfirstlane(max(0, min(NPW, nf_all - pw * NPW)));
+        const unsigned fmask = (unsigned)__builtin_amdgcn_readfirstlane((int)((1u << nf) - 1u));     // bit j: fragment j exists (scalar bit tests)
+        // which of this lane's pixels have a left / right neighbour in the same image row
+        unsigned lnb = 0u, rnb = 0u;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const unsigned m = (unsigned)(m0 + (pw * NPW + j) * 16 + frow);
+            const unsigned wq = m - fdiv(m, p.divW) * p.divW.d;
+            if (wq > 0u) lnb |= 1u << j;
+            if (wq + 1u < (unsigned)p.W) rnb |= 1u << j;
+        }
+
+        {
+            f32x4 acc[2][NPW];
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) { acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+            for (int ch = 0; ch < NCH; ++ch, ++gc) {
+                const bool last = gc == GC - 1;                // no activation chunk / filter tiles are issued behind this one
+                const unsigned char* xs = smem + (gc & 1) * XS;
+#pragma unroll
+                for (int s = 0; s < 3; ++s, ++g) {
+                    // ---- filter tile g has landed (own DMA, counted); at the chunk top that also covers this wave's pieces of chunk gc
+                    if (s == 0) {
+                        if (after_epi) cp_vmcnt<4 + NPW>(); else cp_vmcnt<4>();
+                        CP_BARRIER();                          // every wave's pieces of chunk gc have landed; chunk gc - 1 is read out
+                        issue_x();                             // chunk gc + 1 into the stage chunk gc - 1 used
+                    } else if (s == 1) {
+                        if (last) cp_vmcnt<0>();
+                        else if (after_epi) cp_vmcnt<9 + NPW>();
+                        else cp_vmcnt<9>();
+                    } else {
+                        if (last) cp_vmcnt<0>(); else cp_vmcnt<4>();
+                        after_epi = false;
+                    }
+                    const unsigned char* wsl = wslot + (g & 1) * 4096 + frow * 128;
+                    bf16x8 a[2][2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            a[i][ks] = *(const bf16x8*)(wsl + i * 2048 + (((4 * ks + fgrp) ^ (frow & 7)) << 4));
+                    CP_LGKM0();                                // the slot is read out: refill it with filter tile g + 2
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_w();
+                    // pixel fragments two at a time, the next pair's LDS reads issued (unconditionally: the read count per stage is
+                    // what the compiler's counted lgkmcnt waits rest on) before the current pair's MFMAs; fragments past nf only skip
+                    // their MFMAs
+                    const int shift = p.mode == 0 ? s : 2 - s;
+                    const int brow = pw * NPW * 16 + frow + shift;
+                    const int sw = brow & 7;
+                    const unsigned char* pb0 = xs + brow * 128 + ((fgrp ^ sw) << 4);
+                    const unsigned char* pb1 = xs + brow * 128 + (((4 + fgrp) ^ sw) << 4);
+                    unsigned keep = shift == 0 ? lnb : rnb;
+                    asm volatile("" : "+v"(keep));            // (opaque per k-tile: hoisted out of the loops, the 32 lane masks cost 32 registers)
+                    unsigned fm = fmask;
+                    asm volatile("" : "+s"(fm));               // (likewise: 16 hoisted booleans are 16 SGPR pairs)
+                    bf16x8 bq[2][2][2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) { bq[0][jj][0] = *(const bf16x8*)(pb0 + 2048 * jj); bq[0][jj][1] = *(const bf16x8*)(pb1 + 2048 * jj); }
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int jg = 0; jg < NPW; jg += 2) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int cur = (jg >> 1) & 1;
+                        if (jg + 2 < NPW) {
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                bq[cur ^ 1][jj][0] = *(const bf16x8*)(pb0 + 2048 * (jg + 2 + jj));
+                                bq[cur ^ 1][jj][1] = *(const bf16x8*)(pb1 + 2048 * (jg + 2 + jj));
+                            }
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = jg + jj;
+                            if ((fm >> j) & 1u) {
+                                bf16x8 b0 = bq[cur][jj][0], b1 = bq[cur][jj][1];
+                                if (shift != 1) {              // (an AND with 0 / ~0 built from the bit: a select would park 2 x 16 lane masks in SGPRs)
+                                    const int mk = -(int)((keep >> j) & 1u);
+                                    const cp_i32x4 m4 = {mk, mk, mk, mk};
+                                    b0 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(cp_i32x4, b0) & m4);
+                                    b1 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(cp_i32x4, b1) & m4);
+                                }
+                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], b0, acc[0][j], 0, 0, 0);
+                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], b0, acc[1][j], 0, 0, 0);
+                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], b1, acc[0][j], 0, 0, 0);
+                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], b1, acc[1][j], 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                }
+            }
+
+            // ---- epilogue of the sub-tile: accumulators -> 16-byte rows (8 consecutive channels of a pixel per lane)
+            const int cch = c_wave + 8 * fgrp;
+            if constexpr (EPI == 0) {
+#pragma unroll
+                for (int j = 0; j < NPW; ++j) {
+                    if ((fmask >> j) & 1u) {
+                        const int m = m0 + (pw * NPW + j) * 16 + frow;
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = acc[0][j][e]; v[4 + e] = acc[1][j][e]; }
+                        const u32x4 pk = pack8(v);
+                        if (m < row1) {
+                            __builtin_nontemporal_store(pk, (u32x4*)(p.y + (size_t)m * p.ldy + cch));
+                            unpack8(pk, v);                    // statistics see the stored value
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+                        }
+                    }
+                }
+            } else {
+                float sc[8], sh[8], mu[8];
+                {
+                    const f32x4 a0 = *(const f32x4*)(p.bn_scale + cch), a1 = *(const f32x4*)(p.bn_scale + cch + 4);
+                    const f32x4 b0 = *(const f32x4*)(p.bn_shift + cch), b1 = *(const f32x4*)(p.bn_shift + cch + 4);
+                    const f32x4 m0v = *(const f32x4*)(p.bn_mean + cch), m1v = *(const f32x4*)(p.bn_mean + cch + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sc[e] = a0[e]; sc[4 + e] = a1[e]; sh[e] = b0[e]; sh[4 + e] = b1[e]; mu[e] = m0v[e]; mu[4 + e] = m1v[e]; }
+                }
+                // the c rows in groups of 4, every group requested before its first row is used
+                constexpr int GRP = 4;
+#pragma unroll
+                for (int j0 = 0; j0 < NPW; j0 += GRP) {
+                    if ((fmask >> j0) & 1u) {
+                        u32x4 craw[GRP];
+#pragma unroll
+                        for (int jj = 0; jj < GRP; ++jj) {
+                            const int m = m0 + (pw * NPW + j0 + jj) * 16 + frow;
+                            craw[jj] = (u32x4){0u, 0u, 0u, 0u};
+                            if (m < row1) craw[jj] = *(const u32x4*)(p.aux + (size_t)m * p.ldy + cch);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < GRP; ++jj) {
+                            const int j = j0 + jj;
+                            if ((fmask >> j) & 1u) {
+                                const int m = m0 + (pw * NPW + j) * 16 + frow;
+                                float v[8], cv[8];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] = acc[0][j][e]; v[4 + e] = acc[1][j][e]; }
+                                unpack8(craw[jj], cv);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    if (!(bf2f(f2bf(cv[e] * sc[e] + sh[e])) > 0.f)) v[e] = 0.f;     // same expression / rounding as bn_apply
+                                    cv[e] -= mu[e];
+                                }
+                                const u32x4 pk = pack8(v);
+                                if (m < row1) {
+                                    __builtin_nontemporal_store(pk, (u32x4*)(p.y + (size_t)m * p.ldy + cch));
+                                    unpack8(pk, v);
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * cv[e]; }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // the epilogue's stores: NPW of them when the sub-tile was full (only a full sub-tile is followed by another one)
+        after_epi = true;
+    }
+
+    // ---- this workgroup's partial sums: the 16 pixel lanes of a channel by DPP, the pixel halves (TC = 128) through LDS
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = cp_row16_sum(ssum[e]); ssq[e] = cp_row16_sum(ssq[e]); }
+    float* srow = p.stats + (size_t)wgm * 2 * p.Cout;
+    if constexpr (PW == 1) {
+        if (frow == 0) {
+            const int cch = c_wave + 8 * fgrp;
+            *(f32x4*)(srow + cch) = (f32x4){ssum[0], ssum[1], ssum[2], ssum[3]};
+            *(f32x4*)(srow + cch + 4) = (f32x4){ssum[4], ssum[5], ssum[6], ssum[7]};
+            *(f32x4*)(srow + p.Cout + cch) = (f32x4){ssq[0], ssq[1], ssq[2], ssq[3]};
+            *(f32x4*)(srow + p.Cout + cch + 4) = (f32x4){ssq[4], ssq[5], ssq[6], ssq[7]};
+        }
+    } else {
+        float* red = (float*)(smem + ROFF);                    // [PW][2][TC]
+        if (frow == 0) {
+            const int cl = wvc * 32 + 8 * fgrp;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[(pw * 2) * TC + cl + e] = ssum[e]; red[(pw * 2 + 1) * TC + cl + e] = ssq[e]; }
+        }
+        __syncthreads();
+        if (tid < 2 * TC) {
+            const int which = tid / TC, chn = tid - which * TC;
+            float tsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < PW; ++k) tsum += red[(k * 2 + which) * TC + chn];
+            srow[which * p.Cout + tile_n * TC + chn] = tsum;
+        }
+    }
+}
+
+constexpr int CP_LDS = 2 * 40 * 1024 + 8 * 8192 + 2 * 2 * 128 * 4;
+
+int cp_cus() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        hipFuncSetAttribute((const void*)convp_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+        hipFuncSetAttribute((const void*)convp_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+        hipFuncSetAttribute((const void*)convp_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+        hipFuncSetAttribute((const void*)convp_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+
+struct CPGeom { int tc, tilesN, nwgm, rows_per_wg; };
+// the row split: as many workgroups as CUs (per channel tile), every one with the same number of 16-pixel fragments
+bool cp_geom(int M, int Cout, int cus, CPGeom& g) {
+    g.tc = Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : 0);
+    if (!g.tc) return false;
+    g.tilesN = Cout / g.tc;
+    int want = cus / g.tilesN;
+    if (want < 1) return false;
+    int rows = (M + want - 1) / want;
+    rows = (rows + 15) / 16 * 16;
+    if (rows < 64) rows = 64;                                   // (tiny problems: fewer workgroups rather than empty pipelines)
+    g.rows_per_wg = rows;
+    g.nwgm = (M + rows - 1) / rows;
+    return true;
+}
+
+}  // namespace
+
+static int cp_enabled() {
+    static const int on = [] { const char* e = getenv("NKB_CONVP"); return e ? atoi(e) : 1; }();
+    return on;
+}
+
+extern "C" int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int stride,
+                               int pad) {
+    if (!cp_enabled() || dtype != NKB_DT_BF16 || (kind != 0 && kind != 1)) return 0;
+    if (R != 3 || S != 3 || stride != 1 || pad != 1) return 0;
+    if (Cin % 64 != 0 || Cin < 64 || ldx % 8 != 0 || ldy % 8 != 0 || Cout % 128 != 0) return 0;
+    const long long M = (long long)N * H * W;
+    if (M < 4096 || M * (long long)ldx * 2 >= 0xFFFFFF00ll || M * (long long)ldy >= (1ll << 31) ||
+        (long long)Cout * 9 * Cin * 2 >= 0xFFFFFF00ll)
+        return 0;
+    CPGeom g;
+    if (!cp_geom((int)M, Cout, cp_cus(), g)) return 0;
+    return g.nwgm;
+}
+
+static int convp_launch(int kind, const void* x, const void* w, void* y, const void* c, const float* scale, const float* shift,
+                        const float* mean, float* stats, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t stream) {
+    const int tiles = nkb_convp_tiles(NKB_DT_BF16, kind, N, H, W, Cin, ldx, Cout, ldy, 3, 3, 1, 1);
+    if (!tiles) { nkb_set_error("convp: shape not eligible (N=%d H=%d W=%d Cin=%d Cout=%d)", N, H, W, Cin, Cout); return 1; }
+    if (!stats || (kind == 1 && (!c || !scale || !shift || !mean))) { nkb_set_error("convp: missing operand"); return 1; }
+    CPGeom g;
+    cp_geom(N * H * W, Cout, cp_cus(), g);
+    CPParams p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.aux = (const bf16_t*)c;
+    p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean; p.stats = stats;
+    p.M = N * H * W; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.ldw = 9 * Cin;
+    p.mode = kind; p.nwgm = g.nwgm; p.tilesN = g.tilesN; p.rows_per_wg = g.rows_per_wg;
+    p.divHW = make_fastdiv((unsigned)(H * W)); p.divW = make_fastdiv((unsigned)W);
+    const double flops = 2.0 * p.M * (double)Cout * 9 * Cin;
+    const double bytes = ((double)p.M * Cin + (double)Cout * 9 * Cin + (double)p.M * Cout * (kind == 1 ? 2 : 1)) * 2;
+    NkbProfScope prof(kind == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops, bytes);
+    nkb_count_launch(6);
+    const dim3 grid((unsigned)(g.nwgm * g.tilesN)), block(512);
+    if (g.tc == 256) {
+        if (kind == 0) hipLaunchKernelGGL((convp_kernel<256, 0>), grid, block, CP_LDS, stream, p);
+        else hipLaunchKernelGGL((convp_kernel<256, 1>), grid, block, CP_LDS, stream, p);
+    } else {
+        if (kind == 0) hipLaunchKernelGGL((convp_kernel<128, 0>), grid, block, CP_LDS, stream, p);
+        else hipLaunchKernelGGL((convp_kernel<128, 1>), grid, block, CP_LDS, stream, p);
+    }
+    return nkb_check_launch("convp");
+}
+
+extern "C" int nkb_convp_fwd(int dtype, const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int ldx,
+                             int Cout, int ldy, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16) { nkb_set_error("convp_fwd: bf16 only"); return 1; }
+    return convp_launch(0, x, w, y, nullptr, nullptr, nullptr, nullptr, stats, N, H, W, Cin, ldx, Cout, ldy, stream);
+}
+
+extern "C" int nkb_convp_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,
+                                  const float* shift, const float* mean, float* stats, int N, int H, int W, int Cin, int ldx,
+                                  int Cout, int ldy, hipStream_t stream) {
+    if (dtype != NKB_DT_BF16) { nkb_set_error("convp_dgrad_bn: bf16 only"); return 1; }
+    return convp_launch(1, dy, w, g_masked, c, scale, shift, mean, stats, N, H, W, Cin, ldx, Cout, ldy, stream);
+}

@@ -35,6 +35,9 @@ _SIGS = {
     "nkb_bn_stats_floats": (sz, [i32, i32]),
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
     "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32] + [i32] * 13 + [vp]),
+    "nkb_convp_tiles": (i32, [i32] * 13),
+    "nkb_convp_fwd": (i32, [i32, vp, vp, vp, vp] + [i32] * 7 + [vp]),
+    "nkb_convp_dgrad_bn": (i32, [i32] + [vp] * 8 + [i32] * 7 + [vp]),
     "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
     "nkb_gram_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -161,7 +164,7 @@ def exported_symbols():
 # (input images, logits, logits gradient) and dropout seeds.
 _REC = None            # list of plan entries while recording
 _REC_LIB = None
-_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_bn_stats_floats",
+_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_convp_tiles", "nkb_bn_stats_floats",
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
@@ -412,8 +415,8 @@ def host_op(fn):
 
 
 def kernel_launches(which: str, reset: bool = False) -> int:
-    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply."""
-    idx = {"gemm8p": 0, "wgrad8p": 1, "wgrad3x3": 2, "wgrad8f": 3, "gram_conv": 4, "gram_bn_apply": 5}[which]
+    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply, convp."""
+    idx = {"gemm8p": 0, "wgrad8p": 1, "wgrad3x3": 2, "wgrad8f": 3, "gram_conv": 4, "gram_bn_apply": 5, "convp": 6}[which]
     return int(load().nkb_kernel_launches(idx, int(reset)))
 
 
@@ -455,6 +458,20 @@ def conv_gemm(dtype, mode, x, w, y, *, N, H, W, Cin, ldx, P, Q, Cout, ldy, R=1, 
 
 def stat_tiles(dtype, M, Cout):
     return load().nkb_conv_gemm_stat_tiles(dtype, M, Cout)
+
+
+def convp_tiles(dtype, kind, *, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad) -> int:
+    """Partial-sum rows of the row-balanced 3x3 core for this launch (kind 0 forward, 1 data gradient); 0 = not eligible."""
+    return int(load().nkb_convp_tiles(dtype, kind, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad))
+
+
+def convp_fwd(dtype, x, w, y, stats, *, N, H, W, Cin, ldx, Cout, ldy):
+    check(load().nkb_convp_fwd(dtype, ptr(x), ptr(w), ptr(y), ptr(stats), N, H, W, Cin, ldx, Cout, ldy, stream()), "convp_fwd")
+
+
+def convp_dgrad_bn(dtype, dy, w, g_masked, c, scale, shift, mean, stats, *, N, H, W, Cin, ldx, Cout, ldy):
+    check(load().nkb_convp_dgrad_bn(dtype, ptr(dy), ptr(w), ptr(g_masked), ptr(c), ptr(scale), ptr(shift), ptr(mean), ptr(stats),
+                                    N, H, W, Cin, ldx, Cout, ldy, stream()), "convp_dgrad_bn")
 
 
 def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0, dbias=None,
