@@ -79,17 +79,27 @@ def pmc_traffic(args, kernel):
         return None, None, None
 
 
-def usable_cpus() -> int:
-    """Host cores this process may really use: affinity mask, cgroup quota, and the GPU box's 16-core share."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def usable_cpus(report: dict = None) -> int:
+    """Host cores the CPU baseline runs on: min(affinity mask, cgroup quota, the pool's share of a GPU box's host).  The GPU
+    boxes of this pool show all 256 host cores to every lease (no affinity mask, no cgroup quota) and hand each one-GPU lease a
+    16-core share by rule, so the share is what bounds the count there; NKB_CPU_THREADS overrides it (any value, e.g. 256 on a
+    box of one's own).  What was seen goes into `report` (printed, and into the line's cpu_baseline)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
     try:
-        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
+        q, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
     except Exception:
         pass
-    cap = int(os.environ.get("NKB_CPU_THREADS", "16"))
-    return max(1, min(n, cap))
+    n = min(aff, quota) if quota else aff
+    env = os.environ.get("NKB_CPU_THREADS")
+    share = 16                                       # rank 0 alone runs the baseline: one GPU lease = 16 host cores
+    used = max(1, int(env)) if env else max(1, min(n, share))
+    if report is not None:
+        report.update(affinity=aff, cgroup_quota=quota, os_cpu_count=os.cpu_count(), pool_share=share,
+                      override=int(env) if env else None)
+    return used
 
 
 def parse():
@@ -188,9 +198,11 @@ def cpu_baseline(args):
     """Oracle (kind 'port'): torch-CPU fp32 restatement of the same train step, bounded sample."""
     from oracle.torch_engine import Criterion, make_optimizer
     from oracle.torch_models import OracleClassifier
-    threads = usable_cpus()
+    seen = {}
+    threads = usable_cpus(seen)
     torch.set_num_threads(threads)
-    log(f"cpu baseline on {threads} threads (os.cpu_count()={os.cpu_count()})")
+    log(f"cpu baseline on {threads} threads (affinity {seen['affinity']}, cgroup quota {seen['cgroup_quota']}, os.cpu_count() "
+        f"{seen['os_cpu_count']}, pool share {seen['pool_share']}, NKB_CPU_THREADS {seen['override']})")
     torch.manual_seed(0)
     heads = head_sizes(args)
     m = OracleClassifier(dict(model=args.model, backbone_dropout=0.0, classifier_dropout=0.0, task="multi" if heads else "single"),
@@ -218,7 +230,8 @@ def cpu_baseline(args):
     dt = time.perf_counter() - t0
     out = dict(value=round(args.cpu_batch * args.cpu_steps / dt, 2), unit="images/sec", cores=torch.get_num_threads(),
                kind="port", sample=f"{args.model} fp32 train step, bs={args.cpu_batch}, {args.cpu_steps} timed steps "
-                                  f"after 1 warm-up, torch {torch.__version__} CPU")
+                                  f"after 1 warm-up, torch {torch.__version__} CPU",
+               cores_seen=seen)
     try:
         out["config0"] = cpu_config0(threads)
         log(f"cpu configs[0] (resnet18 bs 8): {out['config0']['value']} img/s")

@@ -406,12 +406,26 @@ def host_op(fn):
         # casts and sums through libnkbhip on temporaries) must not ALSO be recorded as table entries — replayed, they would
         # run a second time on pointers that were freed when fn returned
         rec, _REC = _REC, None
+        before = _device_allocs()
         try:
             fn()
         finally:
             _REC = rec
+            # what fn allocated is fn's own business (it runs again, allocating afresh, at every replay): the model's "the recorded
+            # run allocated nothing" test (model.py) must not count it, or a plan with a bucket hook in it would never be kept
+            global host_op_allocs
+            host_op_allocs += _device_allocs() - before
         return
     fn()
+
+
+host_op_allocs = 0     # device allocations made inside host_op closures while a plan was being recorded (monotone)
+
+
+def _device_allocs() -> int:
+    if not torch.cuda.is_available():
+        return 0
+    return int(torch.cuda.memory_stats(torch.cuda.current_device()).get("allocation.all.allocated", 0))
 
 
 def kernel_launches(which: str, reset: bool = False) -> int:

@@ -29,8 +29,23 @@ _PLANS = os.environ.get("NKB_PLAN", "1") != "0"
 
 
 def _alloc_count(device) -> int:
-    """Number of device allocations torch has served so far (cache hits included)."""
-    return int(torch.cuda.memory_stats(device).get("allocation.all.allocated", 0))
+    """Number of device allocations torch has served so far (cache hits included), without those made inside hip.host_op closures
+    (the DDP bucket hooks): a closure is re-executed at every replay and allocates its temporaries afresh, so they never end up as
+    frozen addresses in a plan."""
+    return int(torch.cuda.memory_stats(device).get("allocation.all.allocated", 0)) - hip.host_op_allocs
+
+
+_warned_plan_rejected = set()
+
+
+def _plan_rejected(kind: str, key):
+    """A recorded plan was thrown away because the recorded run allocated device memory: say so once per plan key — silently the step
+    would stay on the Python path and re-record forever."""
+    if key not in _warned_plan_rejected:
+        _warned_plan_rejected.add(key)
+        import warnings
+        warnings.warn(f"nkb_classification: the recorded {kind} launch plan was discarded (the recorded step allocated device memory "
+                      "outside the workspace); this configuration keeps running through the Python layer code", RuntimeWarning)
 
 
 class _NetFn(torch.autograd.Function):
@@ -217,6 +232,8 @@ class _HipClassifier(nn.Module):
             # persistent workspace / arena / engine buffer) — a torch temporary created inside run() would be replayed after its free
             if eng.plan_seen.get(key) == eng.ws.generation and _alloc_count(img.device) == allocs:
                 eng.plans[key] = (plan, eng.ws.generation, dict(eng.saved))
+            elif eng.plan_seen.get(key) == eng.ws.generation:
+                _plan_rejected("forward", key)
         eng.plan_seen[key] = eng.ws.generation
         return logits
 
@@ -273,6 +290,8 @@ class _HipClassifier(nn.Module):
                     plan = hip.record_end({"glogits": glogits})
                     if eng.plan_seen.get(key) == eng.ws.generation and _alloc_count(glogits.device) == allocs:
                         eng.plans[key] = (plan, eng.ws.generation, None)
+                    elif eng.plan_seen.get(key) == eng.ws.generation:
+                        _plan_rejected("backward", key)
                 eng.plan_seen[key] = eng.ws.generation
         if self.grad_done_hook is not None:
             # data parallel: the remaining buckets go out and the compute stream is made to wait for the exchange HERE, so

@@ -31,13 +31,21 @@ class GradReducer:
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.model = model
         self.group = process_group
-        self.world = dist.get_world_size(process_group)
+        self.world = dist.get_world_size(process_group)      # (bench.py's one-rank rehearsal raises this to take the multi-rank path)
+        self.group_world = self.world                        # what the collectives themselves see
         self.bucket_elems = max(1, bucket_bytes // 4)
         mode = os.environ.get("NKB_GRAD_BUCKET_DTYPE", bucket_dtype)
         if mode not in ("auto", "fp32", "bf16"):
             raise ValueError(f"bucket_dtype {mode!r}: expected auto, fp32 or bf16")
         total = getattr(getattr(model, "arena", None), "total", 0) or 0
         self.bf16_buckets = mode == "bf16" or (mode == "auto" and total > 100_000_000)
+        self._stage = {}                          # (bucket length, device) -> persistent bf16 staging buffers (_staging)
+        self.stage_allocs = 0                     # how many of them were ever allocated (tests: constant after the first step)
+        if self.bf16_buckets:
+            # rank-local rounding before the sum and one more after it: not the fp32 all-reduce's numerics
+            import logging
+            logging.getLogger("nkb_classification").info(
+                "GradReducer: bf16 gradient buckets (%s, %.0f M parameters): all-to-all + fp32 sum + all-gather", mode, total / 1e6)
         self._pending: List = []
         self._ready: List[List[int]] = []          # finished, not yet sent arena intervals [lo, hi), merged and sorted
         self._side_event = None
@@ -121,15 +129,27 @@ class GradReducer:
                 self._pending.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             b = a
 
+    def _staging(self, n: int, device):
+        """Persistent bf16 staging buffers of one bucket size: (send, recv, mine).  Buckets of a step run one after the other on
+        the communication stream, and the sizes repeat from step to step, so each distinct size allocates ONCE (the padding tail of
+        `send` is zeroed here and stays zero: the cast writes the first n elements, the all-gather writes sums of zeros behind
+        them).  No allocator traffic inside the exchange after the first step — and nothing for a recorded launch plan to trip on."""
+        key = (n, str(device))
+        st = self._stage.get(key)
+        if st is None:
+            W = self.group_world
+            chunk = -(-n // W)
+            chunk += (-chunk) % 8                               # 16-byte-aligned slices for the sum kernel
+            send = torch.zeros(W * chunk, device=device, dtype=torch.bfloat16)
+            st = self._stage[key] = (send, torch.empty_like(send), torch.empty(chunk, device=device, dtype=torch.bfloat16), chunk)
+            self.stage_allocs += 1
+        return st
+
     def _exchange_bf16(self, g: torch.Tensor):
         """In-place sum over ranks of the fp32 slice g, moved as bf16 and accumulated in fp32 (see the class docstring).  Runs in
         stream order on the communication stream (cuda) or synchronously (cpu tensors: the gloo rehearsal)."""
-        W, n = self.world, g.numel()
-        chunk = -(-n // W)
-        chunk += (-chunk) % 8                                   # 16-byte-aligned slices for the sum kernel
-        send = torch.zeros(W * chunk, device=g.device, dtype=torch.bfloat16)
-        recv = torch.empty_like(send)
-        mine = torch.empty(chunk, device=g.device, dtype=torch.bfloat16)
+        W, n = self.group_world, g.numel()
+        send, recv, mine, chunk = self._staging(n, g.device)
         if g.is_cuda:
             from . import hip
             hip.wprep(hip.BF16, g, send, 1, 1, n, n, 0)         # fp32 -> bf16 (round to nearest even)
