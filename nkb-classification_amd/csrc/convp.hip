@@ -46,11 +46,23 @@ struct CPParams {
     int mode;                   // 0 forward, 1 data gradient (filter rows / columns mirrored)
     int nwgm, tilesN, rows_per_wg;
     FastDiv divHW, divW;
+    int dbg;                    // timing experiments only (NKB_CONVP_DBG): 1 no activation DMA, 2 no filter DMA, 4 no MFMA
 };
 
-__device__ __attribute__((aligned(256))) unsigned char convp_zero_page[256];      // zero-initialised: source of out-of-image rows
+__device__ __attribute__((aligned(256))) unsigned char convp_zero_page[256];
+#ifdef NKB_CONVP_STAMPS
+// diagnostic build only (scripts/convp_stamps.sh): cycles of wave 0 and wave 4 of workgroup 0 per section of the k-tile loop
+__device__ unsigned long long convp_stamps[2][8];
+#define CP_STAMP(i)                                                                            \
+    do {                                                                                       \
+        if (stamp_on) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; } \
+    } while (0)
+#else
+#define CP_STAMP(i) do { } while (0)
+#endif      // zero-initialised: source of out-of-image rows
 
 typedef int cp_i32x4 __attribute__((ext_vector_type(4)));
+template <int V> using CPI = std::integral_constant<int, V>;
 
 __device__ __forceinline__ void cp_glds16(const unsigned char* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -89,6 +101,7 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
     const int wvc = wave % CW, pw = wave / CW;
     const int frow = lane & 15, fgrp = lane >> 4;
     const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;       // DMA piece: row inside the piece, SOURCE chunk (swizzle)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;     // LDS byte address of the array
 
     const int lid = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lid / p.nwgm, wgm = lid - tile_n * p.nwgm;
@@ -103,60 +116,58 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
 
     // ---- filter stream: this wave's 32 rows, slot row 16 i + r <-> channel c_wave + 8 (r >> 2) + 4 i + (r & 3), so that the two
     // accumulator tiles of a lane hold 8 consecutive channels
-    unsigned wsrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int rr = 8 * q + lrow, i = rr >> 4, r16 = rr & 15;
-        wsrc[q] = (unsigned)(c_wave + 8 * (r16 >> 2) + 4 * i + (r16 & 3)) * (unsigned)p.ldw * 2u + (unsigned)lch * 16u;
-    }
+    // (piece q holds slot rows 8 q + lrow: channels c_wave + 8 (lrow >> 2) + (lrow & 3) + {0, 16, 4, 20}[q] — one lane offset, four
+    // scalar row offsets)
+    const unsigned wsrc0 = (unsigned)(c_wave + 8 * (lrow >> 2) + (lrow & 3)) * (unsigned)p.ldw * 2u + (unsigned)lch * 16u;
+    const unsigned wrow = (unsigned)p.ldw * 2u;
     unsigned char* const wslot = smem + WOFF + wave * 8192;
     int wgi = 0, wr = 0, wck = 0, wsx = 0;                     // next k-tile of the filter stream: index, (filter row, chunk, column)
     const int GT = GC * 3;
     auto issue_w = [&]() {
-        if (wgi < GT) {
+        if (wgi < GT && !(p.dbg & 2)) {
             const unsigned char* s_ = (const unsigned char*)p.w + (size_t)((wr * 3 + wsx) * cpk + wck) * 128;
             unsigned char* d_ = wslot + (wgi & 1) * 4096;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cp_glds16(s_ + wsrc[q], d_ + q * 1024);
+            for (int q = 0; q < 4; ++q) cp_glds16(s_ + (size_t)((q & 1) * 16 + (q >> 1) * 4) * wrow + wsrc0, d_ + q * 1024);
         }
         ++wgi;
         if (++wsx == 3) { wsx = 0; if (++wck == cpk) { wck = 0; if (++wr == 3) wr = 0; } }
     };
 
     // ---- activation stream: piece q = wave + 8 i holds stage rows 8 q .. 8 q + 7 = flattened pixels m0 - 1 + row
-    unsigned xoff[5];
+    // (pieces of a wave are 64 stage rows apart: one lane offset for piece 0, i * 64 rows added per piece)
+    long xoff0 = 0;
     unsigned xhm = 0u;                                         // 3 bits per piece: filter row r reads inside the image
     auto rows_of = [&](int t) {
         const int m0 = row0 + 256 * t;
         const int nvt = min(256, row1 - m0);
         xhm = 0u;
+        xoff0 = ((long)(m0 - 1 + 8 * wave + lrow) * p.ldx) * 2 + lch * 16;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int lr = 8 * (wave + 8 * i) + lrow;
             const int m = m0 - 1 + lr;
-            unsigned off = 0u, hb = 0u;
+            unsigned hb = 0u;
             if (m >= 0 && m < p.M && lr <= nvt + 1) {
                 const unsigned n = fdiv((unsigned)m, p.divHW);
                 const unsigned rem = (unsigned)m - n * p.divHW.d;
                 const int h = (int)fdiv(rem, p.divW);
-                off = (unsigned)m * (unsigned)p.ldx * 2u + (unsigned)lch * 16u;
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr)
                     if ((unsigned)(h + hsign * (rr - 1)) < (unsigned)p.H) hb |= 1u << rr;
             }
-            xoff[i] = off;
             xhm |= hb << (3 * i);
         }
     };
     int xg = 0, xt = 0, xr = 0, xck = 0;                       // next chunk of the activation stream
     auto issue_x = [&]() {
-        if (xg < GC) {
+        if (xg < GC && !(p.dbg & 1)) {
             const long rowoff = (long)(hsign * (xr - 1) * p.W) * p.ldx * 2 + xck * 128;
             unsigned char* d_ = smem + (xg & 1) * XS + wave * 1024;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const bool ok = (xhm >> (3 * i + xr)) & 1u;
-                const unsigned char* s_ = ok ? (const unsigned char*)p.x + ((long)xoff[i] + rowoff)
+                const unsigned char* s_ = ok ? (const unsigned char*)p.x + (xoff0 + (long)i * 128 * p.ldx + rowoff)
                                              : convp_zero_page + (lane & 7) * 16;
                 cp_glds16(s_, d_ + i * 8192);
             }
@@ -174,13 +185,63 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
     issue_w();
     issue_w();
 
-    float ssum[8], ssq[8];
+    // BatchNorm partial sums: per sub-tile in registers (epilogue only), reduced over the 16 pixel lanes and added, in sub-tile
+    // order, to this wave's 4 x 16 floats in LDS by the frow == 0 lanes — 16 registers less across the k-loop
+    float* const wsum = (float*)(smem + ROFF + 2048) + wave * 64 + fgrp * 16;
+    if (frow == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+        for (int e = 0; e < 16; ++e) wsum[e] = 0.f;
+    }
 
+#ifdef NKB_CONVP_STAMPS
+    const bool stamp_on = blockIdx.x == 0 && (wave == 0 || wave == 4);
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#endif
     int gc = 0;                                                // chunk being computed
     int g = 0;                                                 // k-tile being computed
-    bool after_epi = false;                                    // NPW epilogue stores are younger than the filter tiles in flight
+    // The two waves of a SIMD (w and w + 4) run the same program; in step, their MFMA sections queue on the one matrix pipe and their
+    // overhead sections (waits, filter fragments, DMA issue: ~47 % of a wave's cycles, in-kernel stamps) leave it idle together.
+    // So waves 4-7 run the ROTATED loop — multiply(g), then the overhead of k-tile g + 1 — while waves 0-3 run overhead(g),
+    // multiply(g): after every barrier one group multiplies while the other one waits / issues, and they swap.  The rotated group
+    // issues a chunk's activation DMA in the overhead of the chunk's SECOND k-tile (still behind the barrier that frees the stage,
+    // still two k-tiles ahead of the wait that covers it).
+    const bool rot = (p.dbg & 64) ? false : wave >= 4;
+    const int xpos = rot ? 1 : 0;                              // position in the chunk of the k-tile whose overhead issues the activation DMA
+    int epi_cnt = 0;                                           // overheads whose filter tile is older than the last epilogue's NPW stores
+    bf16x8 a[2][2];
+    // overhead of k-tile gk (position s in its chunk): its filter tile has landed -> fragments to registers -> slot refilled with tile
+    // gk + 2.  Younger than that tile when the wait runs: tile gk + 1 (4 DMAs), the activation chunk if the previous overhead issued
+    // one (5), the epilogue's stores while epi_cnt > 0 (NPW).  The last three k-tiles drain instead (issues are skipped there).
+    auto overhead = [&](int gk, int s) {
+        CP_STAMP(0);
+        const bool x_before = ((s + 2) % 3) == xpos;            // the overhead of k-tile gk - 1 issued activation pieces
+        if (gk >= GT - 3) cp_vmcnt<0>();
+        else if (epi_cnt > 0) { if (x_before) cp_vmcnt<9 + NPW>(); else cp_vmcnt<4 + NPW>(); }
+        else { if (x_before) cp_vmcnt<9>(); else cp_vmcnt<4>(); }
+        if (epi_cnt > 0) --epi_cnt;
+        if (!rot && s == 0) CP_BARRIER();                      // every wave's pieces of this chunk have landed; the chunk before is read out
+        if (s == xpos) issue_x();                              // next chunk into the stage the previous chunk used
+        CP_STAMP(1);
+        // filter fragments: inline assembly — a compiler-issued LDS read here makes hipcc wait lgkmcnt(0) in front of every MFMA
+        // block that uses `a` (it cannot see the wait below), draining the pixel-fragment pipeline each time
+        const unsigned wa = lds0 + (unsigned)(WOFF + wave * 8192 + (gk & 1) * 4096 + frow * 128);
+        const unsigned wa0 = wa + (unsigned)((fgrp ^ (frow & 7)) << 4), wa1 = wa + (unsigned)(((4 + fgrp) ^ (frow & 7)) << 4);
+        u32x4 ar[2][2];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ar[0][0]) : "v"(wa0));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ar[0][1]) : "v"(wa1));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(ar[1][0]) : "v"(wa0));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(ar[1][1]) : "v"(wa1));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[0][0]), "+v"(ar[0][1]), "+v"(ar[1][0]), "+v"(ar[1][1]) :: "memory");   // the slot is read out: refill it
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[i][ks] = __builtin_bit_cast(bf16x8, ar[i][ks]);
+        __builtin_amdgcn_sched_barrier(0);
+        CP_STAMP(2);
+        issue_w();
+        CP_STAMP(3);
+    };
+    if (rot) overhead(0, 0);
 
     for (int t = 0; t < nsub; ++t) {
         const int m0 = row0 + 256 * t;
@@ -203,86 +264,91 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
 #pragma unroll
             for (int j = 0; j < NPW; ++j) { acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+            // the k-loop of the sub-tile, compiled per number of fragment PAIRS (straight-line LDS reads: see CP_STAGE)
+            auto chunks = [&](auto NP_) {
+            constexpr int NP = decltype(NP_)::value;
             for (int ch = 0; ch < NCH; ++ch, ++gc) {
-                const bool last = gc == GC - 1;                // no activation chunk / filter tiles are issued behind this one
-                const unsigned char* xs = smem + (gc & 1) * XS;
 #pragma unroll
                 for (int s = 0; s < 3; ++s, ++g) {
-                    // ---- filter tile g has landed (own DMA, counted); at the chunk top that also covers this wave's pieces of chunk gc
-                    if (s == 0) {
-                        if (after_epi) cp_vmcnt<4 + NPW>(); else cp_vmcnt<4>();
-                        CP_BARRIER();                          // every wave's pieces of chunk gc have landed; chunk gc - 1 is read out
-                        issue_x();                             // chunk gc + 1 into the stage chunk gc - 1 used
-                    } else if (s == 1) {
-                        if (last) cp_vmcnt<0>();
-                        else if (after_epi) cp_vmcnt<9 + NPW>();
-                        else cp_vmcnt<9>();
-                    } else {
-                        if (last) cp_vmcnt<0>(); else cp_vmcnt<4>();
-                        after_epi = false;
-                    }
-                    const unsigned char* wsl = wslot + (g & 1) * 4096 + frow * 128;
-                    bf16x8 a[2][2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks)
-                            a[i][ks] = *(const bf16x8*)(wsl + i * 2048 + (((4 * ks + fgrp) ^ (frow & 7)) << 4));
-                    CP_LGKM0();                                // the slot is read out: refill it with filter tile g + 2
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_w();
-                    // pixel fragments two at a time, the next pair's LDS reads issued (unconditionally: the read count per stage is
-                    // what the compiler's counted lgkmcnt waits rest on) before the current pair's MFMAs; fragments past nf only skip
-                    // their MFMAs
+                    if (!rot) overhead(g, s);
+                    else if (s == 0) CP_BARRIER();
+                    // pixel fragments two at a time through two register sets: stage k issues the four LDS reads of pair k + 1 and
+                    // then waits for pair k ALONE (lgkmcnt(4)) — as inline assembly, because hipcc's own wait in front of an MFMA
+                    // block under a branch is lgkmcnt(0), which parks the wave on the reads it has just issued (36 % of the wave
+                    // cycles of the first version).  Reads are unconditional (fixed counts); fragments past nf only skip their MFMAs.
                     const int shift = p.mode == 0 ? s : 2 - s;
                     const int brow = pw * NPW * 16 + frow + shift;
                     const int sw = brow & 7;
-                    const unsigned char* pb0 = xs + brow * 128 + ((fgrp ^ sw) << 4);
-                    const unsigned char* pb1 = xs + brow * 128 + (((4 + fgrp) ^ sw) << 4);
+                    const unsigned ab0 = lds0 + (unsigned)((gc & 1) * XS + brow * 128 + ((fgrp ^ sw) << 4));
+                    const unsigned ab1 = lds0 + (unsigned)((gc & 1) * XS + brow * 128 + (((4 + fgrp) ^ sw) << 4));
                     unsigned keep = shift == 0 ? lnb : rnb;
                     asm volatile("" : "+v"(keep));            // (opaque per k-tile: hoisted out of the loops, the 32 lane masks cost 32 registers)
                     unsigned fm = fmask;
                     asm volatile("" : "+s"(fm));               // (likewise: 16 hoisted booleans are 16 SGPR pairs)
-                    bf16x8 bq[2][2][2];
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) { bq[0][jj][0] = *(const bf16x8*)(pb0 + 2048 * jj); bq[0][jj][1] = *(const bf16x8*)(pb1 + 2048 * jj); }
+                    u32x4 bq[2][2][2];                         // [register set][fragment of the pair][k-step]
+                    auto mm = [&](int j, const u32x4 (&bb)[2]) {
+                        if (((fm >> j) & 1u) && !(p.dbg & 4)) {
+                            cp_i32x4 b0 = __builtin_bit_cast(cp_i32x4, bb[0]), b1 = __builtin_bit_cast(cp_i32x4, bb[1]);
+                            if (shift != 1) {                  // (an AND with 0 / ~0 built from the bit: a select would park 2 x 16 lane masks in SGPRs)
+                                const int mk = -(int)((keep >> j) & 1u);
+                                const cp_i32x4 m4 = {mk, mk, mk, mk};
+                                b0 &= m4; b1 &= m4;
+                            }
+                            const bf16x8 f0 = __builtin_bit_cast(bf16x8, b0), f1 = __builtin_bit_cast(bf16x8, b1);
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], f0, acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], f0, acc[1][j], 0, 0, 0);
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], f1, acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], f1, acc[1][j], 0, 0, 0);
+                        }
+                    };
+#define CP_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define CP_PAIR(set, J)                                                                                               \
+    do {                                                                                                              \
+        CP_DSR(bq[set][0][0], ab0, 2048 * (J)); CP_DSR(bq[set][0][1], ab1, 2048 * (J));                               \
+        CP_DSR(bq[set][1][0], ab0, 2048 * ((J) + 1)); CP_DSR(bq[set][1][1], ab1, 2048 * ((J) + 1));                   \
+    } while (0)
+#define CP_LANDED(n, set)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(bq[set][0][0]), "+v"(bq[set][0][1]), "+v"(bq[set][1][0]), "+v"(bq[set][1][1]))
+#define CP_STAGE(JG)                                                                                                  \
+    if constexpr ((JG) < 2 * NP) {                                                                                    \
+        constexpr int cur_ = ((JG) >> 1) & 1;                                                                         \
+        if constexpr ((JG) + 2 < 2 * NP) { CP_PAIR(cur_ ^ 1, (JG) + 2); CP_LANDED(4, cur_); }                         \
+        else CP_LANDED(0, cur_);                                                                                      \
+        mm((JG), bq[cur_][0]);                                                                                        \
+        mm((JG) + 1, bq[cur_][1]);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+                    if constexpr (NP > 0) CP_PAIR(0, 0);
                     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int jg = 0; jg < NPW; jg += 2) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int cur = (jg >> 1) & 1;
-                        if (jg + 2 < NPW) {
-#pragma unroll
-                            for (int jj = 0; jj < 2; ++jj) {
-                                bq[cur ^ 1][jj][0] = *(const bf16x8*)(pb0 + 2048 * (jg + 2 + jj));
-                                bq[cur ^ 1][jj][1] = *(const bf16x8*)(pb1 + 2048 * (jg + 2 + jj));
-                            }
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int j = jg + jj;
-                            if ((fm >> j) & 1u) {
-                                bf16x8 b0 = bq[cur][jj][0], b1 = bq[cur][jj][1];
-                                if (shift != 1) {              // (an AND with 0 / ~0 built from the bit: a select would park 2 x 16 lane masks in SGPRs)
-                                    const int mk = -(int)((keep >> j) & 1u);
-                                    const cp_i32x4 m4 = {mk, mk, mk, mk};
-                                    b0 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(cp_i32x4, b0) & m4);
-                                    b1 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(cp_i32x4, b1) & m4);
-                                }
-                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], b0, acc[0][j], 0, 0, 0);
-                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][0], b0, acc[1][j], 0, 0, 0);
-                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][1], b1, acc[0][j], 0, 0, 0);
-                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][1], b1, acc[1][j], 0, 0, 0);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    CP_STAGE(0) CP_STAGE(2) CP_STAGE(4) CP_STAGE(6) CP_STAGE(8) CP_STAGE(10) CP_STAGE(12) CP_STAGE(14)
+#undef CP_STAGE
+#undef CP_LANDED
+#undef CP_PAIR
+#undef CP_DSR
                     __builtin_amdgcn_s_setprio(0);
+                    CP_STAMP(4);                               // pixel fragments + MFMAs
+                    // rotated group: the next k-tile's overhead, except behind the sub-tile's last k-tile (the epilogue comes first)
+                    if (rot && !(s == 2 && ch == NCH - 1)) overhead(g + 1, (s + 1) % 3);
                 }
+            }
+            };
+            switch ((nf + 1) >> 1) {
+                case 0: chunks(CPI<0>{}); break;
+                case 1: chunks(CPI<1>{}); break;
+                case 2: chunks(CPI<2>{}); break;
+                case 3: chunks(CPI<3>{}); break;
+                case 4: chunks(CPI<(NPW >= 8 ? 4 : 0)>{}); break;
+                case 5: chunks(CPI<(NPW >= 16 ? 5 : 0)>{}); break;
+                case 6: chunks(CPI<(NPW >= 16 ? 6 : 0)>{}); break;
+                case 7: chunks(CPI<(NPW >= 16 ? 7 : 0)>{}); break;
+                default: chunks(CPI<(NPW >= 16 ? 8 : 0)>{}); break;
             }
 
             // ---- epilogue of the sub-tile: accumulators -> 16-byte rows (8 consecutive channels of a pixel per lane)
             const int cch = c_wave + 8 * fgrp;
+            float ssum[8], ssq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
             if constexpr (EPI == 0) {
 #pragma unroll
                 for (int j = 0; j < NPW; ++j) {
@@ -347,14 +413,28 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
                     }
                 }
             }
+            if (nf > 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[e] = cp_row16_sum(ssum[e]); ssq[e] = cp_row16_sum(ssq[e]); }
+                if (frow == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { wsum[e] += ssum[e]; wsum[8 + e] += ssq[e]; }
+                }
+            }
         }
-        // the epilogue's stores: NPW of them when the sub-tile was full (only a full sub-tile is followed by another one)
-        after_epi = true;
+        // the epilogue's NPW stores (a full sub-tile: only such a one is followed by another) are younger than the two filter tiles in flight
+        epi_cnt = 2;
+        if (rot && g < GT) overhead(g, 0);
     }
 
+#ifdef NKB_CONVP_STAMPS
+    CP_STAMP(5);
+    if (stamp_on && lane == 0) for (int i = 0; i < 8; ++i) convp_stamps[wave >> 2][i] = st_acc[i];
+#endif
     // ---- this workgroup's partial sums: the 16 pixel lanes of a channel by DPP, the pixel halves (TC = 128) through LDS
+    float ssum[8], ssq[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ssum[e] = cp_row16_sum(ssum[e]); ssq[e] = cp_row16_sum(ssq[e]); }
+    for (int e = 0; e < 8; ++e) { ssum[e] = wsum[e]; ssq[e] = wsum[8 + e]; }      // (meaningful in the frow == 0 lanes, which are the ones that use them)
     float* srow = p.stats + (size_t)wgm * 2 * p.Cout;
     if constexpr (PW == 1) {
         if (frow == 0) {
@@ -382,7 +462,7 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
     }
 }
 
-constexpr int CP_LDS = 2 * 40 * 1024 + 8 * 8192 + 2 * 2 * 128 * 4;
+constexpr int CP_LDS = 2 * 40 * 1024 + 8 * 8192 + 2 * 2 * 128 * 4 + 8 * 64 * 4;
 
 int cp_cus() {
     static int cus = [] {
@@ -448,6 +528,8 @@ static int convp_launch(int kind, const void* x, const void* w, void* y, const v
     p.M = N * H * W; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.ldw = 9 * Cin;
     p.mode = kind; p.nwgm = g.nwgm; p.tilesN = g.tilesN; p.rows_per_wg = g.rows_per_wg;
     p.divHW = make_fastdiv((unsigned)(H * W)); p.divW = make_fastdiv((unsigned)W);
+    static const int dbg = [] { const char* e = getenv("NKB_CONVP_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
     const double flops = 2.0 * p.M * (double)Cout * 9 * Cin;
     const double bytes = ((double)p.M * Cin + (double)Cout * 9 * Cin + (double)p.M * Cout * (kind == 1 ? 2 : 1)) * 2;
     NkbProfScope prof(kind == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops, bytes);
@@ -475,3 +557,9 @@ extern "C" int nkb_convp_dgrad_bn(int dtype, const void* dy, const void* w, void
     if (dtype != NKB_DT_BF16) { nkb_set_error("convp_dgrad_bn: bf16 only"); return 1; }
     return convp_launch(1, dy, w, g_masked, c, scale, shift, mean, stats, N, H, W, Cin, ldx, Cout, ldy, stream);
 }
+
+#ifdef NKB_CONVP_STAMPS
+extern "C" int nkb_convp_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(convp_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
