@@ -496,16 +496,22 @@ bool cp_geom(int M, int Cout, int cus, CPGeom& g) {
 
 }  // namespace
 
-static int cp_enabled() {
-    static const int on = [] { const char* e = getenv("NKB_CONVP"); return e ? atoi(e) : 1; }();
-    return on;
-}
+static int g_cp_on = [] { const char* e = getenv("NKB_CONVP"); return e ? atoi(e) : 1; }();
+static int g_cp_tc128 = 0;
+static int cp_enabled() { return g_cp_on; }
+// Envelope of the row-balanced 3x3 core: on = 0 / 1 (default 1, NKB_CONVP), tc128 = 1 also admits Cout % 256 != 0 (default 0)
+extern "C" void nkb_convp_config(int on, int tc128) { g_cp_on = on != 0; g_cp_tc128 = tc128 != 0; }
 
 extern "C" int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int stride,
                                int pad) {
     if (!cp_enabled() || dtype != NKB_DT_BF16 || (kind != 0 && kind != 1)) return 0;
     if (R != 3 || S != 3 || stride != 1 || pad != 1) return 0;
     if (Cin % 64 != 0 || Cin < 64 || ldx % 8 != 0 || ldy % 8 != 0 || Cout % 128 != 0) return 0;
+    // Cout % 256 != 0 runs as 128-channel tiles whose two pixel halves each stream their own copy of the filter: measured in the
+    // ResNet-50 step (28 x 28 x 128, batch 256) level with the 128 x 128 kernel forward and 10 us slower in the data gradient, so
+    // the train step only takes the 256-channel form (layer3 / layer4: -22 / -13 us forward, -10 / -5 us data gradient per launch);
+    // nkb_convp_config(on, 1) lets the narrow form through (tests, experiments)
+    if (Cout % 256 != 0 && !g_cp_tc128) return 0;
     const long long M = (long long)N * H * W;
     if (M < 4096 || M * (long long)ldx * 2 >= 0xFFFFFF00ll || M * (long long)ldy >= (1ll << 31) ||
         (long long)Cout * 9 * Cin * 2 >= 0xFFFFFF00ll)

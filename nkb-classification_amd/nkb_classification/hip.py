@@ -36,6 +36,7 @@ _SIGS = {
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
     "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32] + [i32] * 13 + [vp]),
     "nkb_convp_tiles": (i32, [i32] * 13),
+    "nkb_convp_config": (None, [i32, i32]),
     "nkb_convp_fwd": (i32, [i32, vp, vp, vp, vp] + [i32] * 7 + [vp]),
     "nkb_convp_dgrad_bn": (i32, [i32] + [vp] * 8 + [i32] * 7 + [vp]),
     "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
@@ -168,7 +169,7 @@ _PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_versi
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
-                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config",
+                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_convp_config",
                    "nkb_fp8_job_blocks", "nkb_wgrad_fp8_workspace_floats",
                    "nkb_fp8_quantize_colsum_workspace_floats",
                    "nkb_gram_bn_backward_workspace_floats", "nkb_bn_apply_gram_workspace_floats",
@@ -477,6 +478,10 @@ def stat_tiles(dtype, M, Cout):
 def convp_tiles(dtype, kind, *, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad) -> int:
     """Partial-sum rows of the row-balanced 3x3 core for this launch (kind 0 forward, 1 data gradient); 0 = not eligible."""
     return int(load().nkb_convp_tiles(dtype, kind, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad))
+
+
+def convp_config(on: bool = True, tc128: bool = False):
+    load().nkb_convp_config(int(on), int(tc128))
 
 
 def convp_fwd(dtype, x, w, y, stats, *, N, H, W, Cin, ldx, Cout, ldy):

@@ -63,6 +63,8 @@ _GRAM_SPLIT = os.environ.get("NKB_GRAM_SPLIT", "0") != "0"
 _GRAM_MAX_C = int(os.environ.get("NKB_GRAM_MAX_C", "128"))
 # a stride-1 projection shortcut (ResNet-50 layer1.0) K-concatenated into the Gram-form closing convolution (0 = separate conv + BN passes)
 _GRAM_PROJ = os.environ.get("NKB_GRAM_PROJ", "1") != "0"
+# 3x3 / stride-1 forward and data gradient on the row-balanced DMA-pipelined core (csrc/convp.hip) where nkb_convp_tiles says eligible
+_CONVP = os.environ.get("NKB_CONVP", "1") != "0"
 
 
 class HipEngine:
@@ -373,8 +375,16 @@ class HipEngine:
         c = self.ws.get(key + ".c", (N, P, Q, co), self.T)
         bits = None
         tiles = hip.stat_tiles(self.d, rows, co)
+        # 3x3 / stride 1 in bf16 (train mode): the row-balanced DMA-pipelined core (csrc/convp.hip), one partial-sum row per workgroup
+        tiles_p = 0
+        if train and _CONVP and not packed and not col_input and w.dim() == 4 and self.T == torch.bfloat16:
+            tiles_p = hip.convp_tiles(self.d, 0, N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, ldy=co, R=R, S=S, stride=st, pad=pad)
+        if tiles_p:
+            tiles = tiles_p
         stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
-        if packed:
+        if tiles_p:
+            hip.convp_fwd(self.d, x, self.w_fwd(w), c, stats, N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, ldy=co)
+        elif packed:
             hip.stem_conv(self.d, x, self.w_fwd(w), c, stats, N, H, W, co, co)
         elif w.dim() == 2 and self._splitk_ok(rows, ci, co):
             # skinny Linear with a very long reduction (unicom feature[0]: 128 x 262 144 -> 1 024 would be 8 workgroups of
@@ -916,6 +926,15 @@ class HipEngine:
             svp = self.saved[fuse_bn]
             residual = svp.get("bits") is not None       # the fused stage closes a residual block: mask = its bit array
             assert add is None or residual
+            if _CONVP and not residual and add is None and self.T == torch.bfloat16 and geom["P"] == H and geom["Q"] == W:
+                # interior 3x3 / stride-1 stage: the row-balanced core with the same fused BatchNorm-backward epilogue
+                tiles = hip.convp_tiles(self.d, 1, N=N, H=H, W=W, Cin=geom["Cout"], ldx=geom["Cout"], Cout=ci, ldy=ci, R=geom["R"],
+                                        S=geom["S"], stride=geom["stride"], pad=geom["pad"])
+                if tiles:
+                    stats = self.ws.get(fuse_bn + ".bstats", (hip.bn_stats_floats(tiles, ci),), torch.float32)
+                    hip.convp_dgrad_bn(self.d, g_c, self._wd[id(w)], dx, svp["c"], svp["scale"], svp["shift"], svp["mean"], stats,
+                                       N=N, H=H, W=W, Cin=geom["Cout"], ldx=geom["Cout"], Cout=ci, ldy=ci)
+                    return dx, (stats, tiles)
             tiles = hip.stat_tiles(self.d, N * H * W, ci)
             stats = self.ws.get(fuse_bn + ".bstats", (hip.bn_stats_floats(tiles, ci),), torch.float32)
             hip.conv_dgrad_bn(self.d, g_c, self._wd[id(w)], dx, svp["c"], svp["scale"], svp["shift"], svp["mean"], stats,
