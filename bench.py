@@ -346,7 +346,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    if os.environ.get("NKB_BENCH_GC", "1") != "0":
+    if True:
         # the interpreter's first full collection after model construction walks every module / tensor object (tens of
         # ms of host time, once); take it now instead of inside the first timed step — and BEFORE the barrier below, so
         # that no rank enters the timed region a collection ahead of another
@@ -364,8 +364,6 @@ def main():
         loss = step()
         step_marks.append(time.perf_counter())
     host_dt = time.perf_counter() - t0          # time to ENQUEUE the steps (host side only)
-    if os.environ.get("NKB_DEBUG_STEPS"):
-        log("enqueue ms per step: " + " ".join(f"{1e3 * (b - a):.1f}" for a, b in zip([t0] + step_marks[:-1], step_marks)))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -563,7 +563,7 @@ extern "C" int nkb_attn_forward(int dtype, const void* qkv, void* out, float* ls
         hipLaunchKernelGGL((attn_fwd_kernel<N, W>), dim3(B * H), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale, (unsigned char*)outq, q_state); \
     }
 #define NKB_ATTN_FWD(N) case N: if (waves == 2) NKB_ATTN_FWD1(N, 2) else NKB_ATTN_FWD1(N, 4) break;
-    static const int waves = getenv("NKB_ATTN_FWD_WAVES") ? atoi(getenv("NKB_ATTN_FWD_WAVES")) : NKB_ATTN_FWD_WAVES;
+    constexpr int waves = NKB_ATTN_FWD_WAVES;
     switch (nkb) {
         NKB_ATTN_FWD(1) NKB_ATTN_FWD(2) NKB_ATTN_FWD(3) NKB_ATTN_FWD(4) NKB_ATTN_FWD(5) NKB_ATTN_FWD(6) NKB_ATTN_FWD(7) NKB_ATTN_FWD(8)
         NKB_ATTN_FWD(9) NKB_ATTN_FWD(10) NKB_ATTN_FWD(11) NKB_ATTN_FWD(12) NKB_ATTN_FWD(13) NKB_ATTN_FWD(14) NKB_ATTN_FWD(15) NKB_ATTN_FWD(16)

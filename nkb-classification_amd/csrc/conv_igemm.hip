@@ -18,12 +18,8 @@
 #include "gemm8p.h"
 #include "wgrad3x3.h"
 
-// 64x256 tile (Cout <= 64) as ONE LDS stage with the pixel fragments streamed through a single register set: 164 VGPRs
-// -> 3 workgroups per CU like the 128x128 tile (was: two LDS stages, 188 VGPRs, 2 per CU).  ResNet-50 layer1 shapes
-// -12 %, step 22.5 -> 22.1 ms.  (0 restores the double-buffered form for A/B builds.)
-#ifndef NKB_NARROW3
-#define NKB_NARROW3 1
-#endif
+// (the 64x256 tile (Cout <= 64) is ONE LDS stage with the pixel fragments streamed through a single register set: 164 VGPRs -> 3
+// workgroups per CU like the 128x128 tile; the former two-stage form — 188 VGPRs, 2 per CU, layer1 shapes 12 % slower — is gone)
 
 template <typename T> struct MmaTraits;
 template <> struct MmaTraits<bf16_t> { static constexpr int KSTEPS = 2; };  // 2 x (16x16x32) per 128-byte k-tile
@@ -40,7 +36,7 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) { return row * 128 + 
 //      lanes whose left / right neighbour lies in another image row get zeros.  Activation loads per channel chunk drop
 //      from 9 tiles to 3, and two k-tiles out of three only wait for the (L2-resident) weight tile.
 template <typename T, int TC, int TP, int BNB = 0, bool HALO = false>
-__global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 64)) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, ((BNB && TC == 128) || TC == 64) ? 3 : 1) void conv_igemm_kernel(const ConvParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int KTE = 128 / (int)sizeof(T);  // elements per k-tile row
     constexpr int NWR = TC / 32;               // weight rows staged per thread
@@ -261,12 +257,9 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     store_tile(0);
     __syncthreads();
 
-    constexpr bool DBUF = (TC == 64) && !NKB_NARROW3;   // (the former two-stage form of the 64x256 tile)
-    static_assert(!(HALO && DBUF), "the shared activation tile lives in the single LDS stage");
     for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) load_tile(kt + 1);
-        const int buf = DBUF ? (kt & 1) : 0;
-        const unsigned char* base = smem + buf * STAGE_BYTES;
+        const unsigned char* base = smem;
 #pragma unroll
         for (int ks = 0; ks < MmaTraits<T>::KSTEPS; ++ks) {
             if constexpr (sizeof(T) == 2) {
@@ -292,7 +285,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
                         for (int i = 0; i < MC; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bj, acc[i][j], 0, 0, 0);
                     }
                 } else
-                if constexpr (NKB_NARROW3 && MP >= 8) {
+                if constexpr (MP >= 8) {
 #pragma unroll
                     for (int j = 0; j < MP; ++j) {
                         b[0] = *(const bf16x8*)(pb + 2048 * j);
@@ -322,13 +315,8 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
             }
         }
         if constexpr (HALO) { if (++cs == 3) cs = 0; }
-        if constexpr (DBUF) {
-            if (kt + 1 < KT) store_tile(buf ^ 1);
-            __syncthreads();
-        } else {
-            __syncthreads();                               // every wave is done reading the stage
-            if (kt + 1 < KT) { store_tile(0); __syncthreads(); }
-        }
+        __syncthreads();                                   // every wave is done reading the stage
+        if (kt + 1 < KT) { store_tile(0); __syncthreads(); }
     }
 
     // ---- epilogue: accumulators -> LDS [pixel][cout] fp32 -> coalesced global stores, one pixel half at a time ------
@@ -346,8 +334,7 @@ __global__ __launch_bounds__(256, ((BNB && TC == 128) || (NKB_NARROW3 && TC == 6
     const bool vec_ok = (co + 8 <= p.Cout) && ((p.ldy & 7) == 0) && (p.add == nullptr || (p.ldadd & 7) == 0);
     // BNB: the stage's scale / shift / mean for this tile's channels live in LDS behind the epilogue tile (keeping them
     // in registers next to the not-yet-stored accumulators cost a wave of occupancy)
-    constexpr int LDS_MAIN = (STAGE_BYTES * ((TC == 64 && !NKB_NARROW3) ? 2 : 1)) > ((TP / 2) * EROW) ? (STAGE_BYTES * ((TC == 64 && !NKB_NARROW3) ? 2 : 1))
-                                                                                       : ((TP / 2) * EROW);
+    constexpr int LDS_MAIN = STAGE_BYTES > ((TP / 2) * EROW) ? STAGE_BYTES : ((TP / 2) * EROW);
     float* bnl = (float*)(smem + LDS_MAIN);   // [3][TC]
     if constexpr (BNB == 1 || BNB == 2 || BNB == 6 || BNB == 7) {
         if (tid < TC) {
@@ -1199,15 +1186,15 @@ static int launch_conv_impl(ConvParams& p, hipStream_t stream, int batch) {
         // When the whole filter matrix does not fit next to the activation rows in one XCD's L2 (4 MB), walking "all channel
         // tiles of a few row tiles" streams the filter through L2 once per row tile.  Groups of 8 row tiles keep 8 activation
         // tiles resident and let each filter tile serve 8 workgroups at once.
-        static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
+        constexpr int gm_env = 8;
         const double wbytes = (double)p.Cout * p.R * p.S * p.Cin * sizeof(T);
         // (measured, ViT-B/16 shapes: N = 3072 334.9 -> 316.2 us, N = 2304 282.5 -> 274.9; with <= 6 channel tiles all of them are
         // resident at once either way and the grouped walk is 1-2 % slower, so it only engages for wide outputs)
-        static const int gm_min_n = [] { const char* e = getenv("NKB_GROUP_MIN_N"); return e ? atoi(e) : 12; }();
+        constexpr int gm_min_n = 12;
         p.group_m = (gm_env > 1 && batch == 1 && wbytes > 3.0e6 && p.tilesN >= gm_min_n && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     }
     constexpr int xrows = HALO ? 32 * ((TP + 2 + 31) / 32) : TP;
-    constexpr int stage = (TC + xrows) * 128 * ((TC == 64 && !NKB_NARROW3) ? 2 : 1);
+    constexpr int stage = (TC + xrows) * 128;
     constexpr int epi = (TP / 2) * (TC * 4 + 16);
     constexpr int lds = (stage > epi ? stage : epi) + ((BNB == 1 || BNB == 2 || BNB == 6 || BNB == 7) ? 3 * TC * 4 : 0);
     static bool attr_set = false;
@@ -1226,7 +1213,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream, int batch = 1);
 template <typename T, int TC, int TP>
 static int launch_conv_bn1(ConvParams& p, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
-        static const int lean1 = [] { const char* e = getenv("NKB_LEAN_BN_EPILOGUE"); return e ? atoi(e) : 1; }();
+        constexpr int lean1 = 1;
         if (lean1 && p.sub_h == 0 && p.add == nullptr && (p.ldy & 7) == 0 && (p.Cout & 7) == 0 && p.stats != nullptr && p.aux != nullptr)
             return launch_conv<T, TC, TP, 7>(p, stream);
     }
@@ -1234,7 +1221,7 @@ static int launch_conv_bn1(ConvParams& p, hipStream_t stream) {
 }
 template <typename T, int TC, int TP, int BNB>
 static int launch_conv(ConvParams& p, hipStream_t stream, int batch) {
-    if constexpr (sizeof(T) == 2 && (NKB_NARROW3 || TC != 64)) {
+    if constexpr (sizeof(T) == 2) {
         // 3x3 / stride 1 / pad 1 (forward and data gradient): the filter-row-sharing form, 3 activation tiles per
         // channel chunk instead of 9
         static const int halo_on = [] { const char* e = getenv("NKB_HALO"); return e ? atoi(e) : 1; }();
@@ -1249,7 +1236,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream, int batch) {
 template <typename T, int TC, int TP>
 static int launch_conv_auto(ConvParams& p, hipStream_t stream, int batch = 1) {
     if constexpr (sizeof(T) == 2) {
-        static const int lean_on = [] { const char* e = getenv("NKB_LEAN_EPILOGUE"); return e ? atoi(e) : 1; }();
+        constexpr int lean_on = 1;
         const bool add_ok = p.add == nullptr || (p.stats == nullptr && p.add_h == 0 && p.add_bits == nullptr && (p.ldadd & 7) == 0);
         const bool plain = lean_on && add_ok && p.act == 0 && p.sub_h == 0 && !p.out_f32 && (p.Cout & 7) == 0 &&
                            (p.ldy & 7) == 0;
@@ -1349,7 +1336,7 @@ extern "C" int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void*
     const bool narrow = Cout <= 64 && narrow_on;
     if (relu_bits) {
         // lean epilogue instantiation for the common geometry (full-grid residual, 8-channel-aligned rows)
-        static const int lean2 = [] { const char* e = getenv("NKB_LEAN_RES_EPILOGUE"); return e ? atoi(e) : 1; }();
+        constexpr int lean2 = 1;
         if (lean2 && dtype == NKB_DT_BF16 && add != nullptr && (add_h == 0 || add_bits == nullptr) && (ldy & 7) == 0 && (ldadd & 7) == 0 &&
             (Cout & 7) == 0 && stats != nullptr)
             return narrow ? launch_conv<bf16_t, 64, 256, 6>(p, stream) : launch_conv<bf16_t, 128, 128, 6>(p, stream);
@@ -1687,7 +1674,7 @@ static WgradPlan wgrad_plan(int esz, int M, int Cout, int Ntot, int target) {
 static thread_local int g_wgrad_target_override = 0;
 static int wgrad_target_wgs() {
     // swept (128..768) on ResNet-50 and ViT-B/16: fewer splits = less competition with the main stream
-    static const int target_wgs = [] { const char* e = getenv("NKB_WGRAD_WGS"); return e ? atoi(e) : 256; }();
+    constexpr int target_wgs = 256;
     // (nkb_conv_wgrad_assign: a product the MAIN stream waits for — the Gram-form R = g^T a — fills the chip instead)
     return g_wgrad_target_override > 0 ? g_wgrad_target_override : target_wgs;
 }
@@ -1703,7 +1690,7 @@ extern "C" long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, in
         return nkb_wgrad3x3_workspace_floats(N, P, Q, Cin, Cout);
     if (nkb_wgrad256_eligible(dtype, M, Cin, Cout, R, S, stride, pad)) return nkb_wgrad256_workspace_floats(M, Cin, Cout, has_bias);
     // (the larger of the two split counts a launch may take: the shared-GPU target, or nkb_conv_wgrad_assign's full-chip one)
-    static const int main_wgs = [] { const char* e = getenv("NKB_WGRAD_MAIN_WGS"); return e ? atoi(e) : 0; }();
+    constexpr int main_wgs = 0;
     long long need = 0;
     for (int target : {wgrad_target_wgs(), main_wgs > 0 ? main_wgs : wgrad_target_wgs()}) {
         const WgradPlan g = wgrad_plan(esz, M, Cout, R * S * Cin, target);
@@ -1794,7 +1781,7 @@ extern "C" int nkb_conv_wgrad_assign(int dtype, const void* dy, const void* x, f
                                      float* workspace, long long workspace_floats, hipStream_t stream) {
     if (workspace == nullptr) { nkb_set_error("conv_wgrad_assign: needs the slab workspace (the atomic form can only accumulate)"); return 1; }
     // (measured neutral on ResNet-50: 18.01 / 18.02 / 18.00 ms at 256 / 768 / 512 — default: the shared-GPU target)
-    static const int main_wgs = [] { const char* e = getenv("NKB_WGRAD_MAIN_WGS"); return e ? atoi(e) : 0; }();
+    constexpr int main_wgs = 0;
     g_wgrad_assign = true;
     g_wgrad_target_override = main_wgs;
     const int rc = nkb_conv_wgrad(dtype, dy, x, dw, dbias, N, H, W, Cin, ldx, P, Q, Cout, lddy, R, S, stride, pad, workspace, workspace_floats, stream);
@@ -1891,7 +1878,7 @@ extern "C" int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y,
 static int stem_wgrad_splits(int esz, int M, int Cout, int Ntot, int* rps_out) {
     // this is the last kernel of the backward pass (it needs the stem's BN-backward output) and runs alone on the GPU:
     // three workgroups per CU instead of the one the shared-GPU split target would give (408 -> ~150 us of pure tail)
-    static const int stem_wgs = [] { const char* e = getenv("NKB_STEM_WGRAD_WGS"); return e ? atoi(e) : 768; }();
+    constexpr int stem_wgs = 768;
     const WgradPlan g = wgrad_plan(esz, M, Cout, Ntot, stem_wgs);
     if (rps_out) *rps_out = g.rows_per_split;
     return g.splits;

@@ -46,11 +46,12 @@ struct CPParams {
     int mode;                   // 0 forward, 1 data gradient (filter rows / columns mirrored)
     int nwgm, tilesN, rows_per_wg;
     FastDiv divHW, divW;
-    int dbg;                    // timing experiments only (NKB_CONVP_DBG): 1 no activation DMA, 2 no filter DMA, 4 no MFMA
+    int dbg;                    // diagnostic build only (NKB_CONVP_STAMPS + NKB_CONVP_DBG): 1 no activation DMA, 2 no filter DMA, 4 no MFMA, 64 no rotated group
 };
 
 __device__ __attribute__((aligned(256))) unsigned char convp_zero_page[256];
 #ifdef NKB_CONVP_STAMPS
+#define CP_DBG(bit) (p.dbg & (bit))
 // diagnostic build only (scripts/convp_stamps.sh): cycles of wave 0 and wave 4 of workgroup 0 per section of the k-tile loop
 __device__ unsigned long long convp_stamps[2][8];
 #define CP_STAMP(i)                                                                            \
@@ -58,6 +59,7 @@ __device__ unsigned long long convp_stamps[2][8];
         if (stamp_on) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; } \
     } while (0)
 #else
+#define CP_DBG(bit) false
 #define CP_STAMP(i) do { } while (0)
 #endif      // zero-initialised: source of out-of-image rows
 
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
     int wgi = 0, wr = 0, wck = 0, wsx = 0;                     // next k-tile of the filter stream: index, (filter row, chunk, column)
     const int GT = GC * 3;
     auto issue_w = [&]() {
-        if (wgi < GT && !(p.dbg & 2)) {
+        if (wgi < GT && !CP_DBG(2)) {
             const unsigned char* s_ = (const unsigned char*)p.w + (size_t)((wr * 3 + wsx) * cpk + wck) * 128;
             unsigned char* d_ = wslot + (wgi & 1) * 4096;
 #pragma unroll
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
     };
     int xg = 0, xt = 0, xr = 0, xck = 0;                       // next chunk of the activation stream
     auto issue_x = [&]() {
-        if (xg < GC && !(p.dbg & 1)) {
+        if (xg < GC && !CP_DBG(1)) {
             const long rowoff = (long)(hsign * (xr - 1) * p.W) * p.ldx * 2 + xck * 128;
             unsigned char* d_ = smem + (xg & 1) * XS + wave * 1024;
 #pragma unroll
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
     // multiply(g): after every barrier one group multiplies while the other one waits / issues, and they swap.  The rotated group
     // issues a chunk's activation DMA in the overhead of the chunk's SECOND k-tile (still behind the barrier that frees the stage,
     // still two k-tiles ahead of the wait that covers it).
-    const bool rot = (p.dbg & 64) ? false : wave >= 4;
+    const bool rot = CP_DBG(64) ? false : wave >= 4;
     const int xpos = rot ? 1 : 0;                              // position in the chunk of the k-tile whose overhead issues the activation DMA
     int epi_cnt = 0;                                           // overheads whose filter tile is older than the last epilogue's NPW stores
     bf16x8 a[2][2];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
                     asm volatile("" : "+s"(fm));               // (likewise: 16 hoisted booleans are 16 SGPR pairs)
                     u32x4 bq[2][2][2];                         // [register set][fragment of the pair][k-step]
                     auto mm = [&](int j, const u32x4 (&bb)[2]) {
-                        if (((fm >> j) & 1u) && !(p.dbg & 4)) {
+                        if (((fm >> j) & 1u) && !CP_DBG(4)) {
                             cp_i32x4 b0 = __builtin_bit_cast(cp_i32x4, bb[0]), b1 = __builtin_bit_cast(cp_i32x4, bb[1]);
                             if (shift != 1) {                  // (an AND with 0 / ~0 built from the bit: a select would park 2 x 16 lane masks in SGPRs)
                                 const int mk = -(int)((keep >> j) & 1u);
@@ -534,8 +536,12 @@ static int convp_launch(int kind, const void* x, const void* w, void* y, const v
     p.M = N * H * W; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.ldw = 9 * Cin;
     p.mode = kind; p.nwgm = g.nwgm; p.tilesN = g.tilesN; p.rows_per_wg = g.rows_per_wg;
     p.divHW = make_fastdiv((unsigned)(H * W)); p.divW = make_fastdiv((unsigned)W);
-    static const int dbg = [] { const char* e = getenv("NKB_CONVP_DBG"); return e ? atoi(e) : 0; }();
+#ifdef NKB_CONVP_STAMPS
+    static const int dbg = [] { const char* e = getenv("NKB_CONVP_DBG"); return e ? atoi(e) : 0; }();      // (diagnostic build only)
     p.dbg = dbg;
+#else
+    p.dbg = 0;
+#endif
     const double flops = 2.0 * p.M * (double)Cout * 9 * Cin;
     const double bytes = ((double)p.M * Cin + (double)Cout * 9 * Cin + (double)p.M * Cout * (kind == 1 ? 2 : 1)) * 2;
     NkbProfScope prof(kind == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops, bytes);

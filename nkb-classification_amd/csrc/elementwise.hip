@@ -142,7 +142,7 @@ extern "C" size_t nkb_bn_stats_floats(int tiles, int C) {
 // Thread t owns channel chunk (t % cpr) for the whole launch: scale/shift live in registers and the row loop has
 // no integer division.  Host guarantees (gridDim*blockDim) % cpr == 0.
 static inline unsigned grid_cols(size_t rows, int cpr, unsigned want_blocks = 0) {
-    static const unsigned dflt_blocks = (unsigned)env_int("NKB_BN_BLOCKS", 256 * 8);
+    constexpr unsigned dflt_blocks = (unsigned)256 * 8;
     if (!want_blocks) want_blocks = dflt_blocks;
     auto gcd = [](unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; };
     const unsigned g0 = (unsigned)cpr / gcd((unsigned)cpr, 256u);   // grid must be a multiple of this
@@ -410,8 +410,8 @@ extern "C" int nkb_bn_backward(int dtype, const void* dy, const void* x, const v
     int threads = 256;
     while (threads < cpr) threads *= 2;
     const int tpc = threads / cpr;
-    static const int max_blocks = env_int("NKB_BNR_BLOCKS", 512);
-    static const int min_rows = env_int("NKB_BNR_ROWS", 16);     // rows per thread below which blocks are not added
+    constexpr int max_blocks = 512;
+    constexpr int min_rows = 16;     // rows per thread below which blocks are not added
     long long want = (rows + (long long)tpc * min_rows - 1) / ((long long)tpc * min_rows);
     int blocks = (int)(want > max_blocks ? max_blocks : want < 1 ? 1 : want);
     const int rpb = 0;

@@ -765,10 +765,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 }  // namespace
 
 static int g8_on = [] { const char* e = getenv("NKB_GEMM8P"); return e ? atoi(e) : 1; }();
-static int g8_min_tiles = [] { const char* e = getenv("NKB_GEMM8P_MIN_TILES"); return e ? atoi(e) : 192; }();
+static int g8_min_tiles = 192;
 // measured (scripts/gemm8p_bench.py, same process, interleaved): K >= 768 wins on every shape with >= 192 tiles (+5..50 %);
 // K = 256 / 512 lose (one workgroup per CU: the 7-half-tile prologue and the 128 KB tile store are not hidden by a neighbour)
-static int g8_min_k = [] { const char* e = getenv("NKB_GEMM8P_MIN_K"); return e ? atoi(e) : 768; }();
+static int g8_min_k = 768;
 static int gemm8p_on() { return g8_on; }
 // run-time override of the envelope (tests and same-process A/B timing): on = 0 / 1, minimum tile count and reduction depth
 extern "C" void nkb_gemm8p_config(int on, int min_tiles, int min_k) {
@@ -795,7 +795,7 @@ bool nkb_gemm8p_eligible(const ConvParams& p, int dtype, int batch) {
 }
 
 static int g8_align() {
-    static const int on = [] { const char* e = getenv("NKB_G8_ALIGN"); return e ? atoi(e) : 1; }();
+    constexpr int on = 1;
     return on;
 }
 
@@ -805,7 +805,7 @@ static int g8_align() {
 // x 3 tiles instead of 256 with a third round at 31 %; in-step A/B -0.3 ms; tile counts that are multiples of 256 are unchanged)
 static int g8_grid(int tiles, int cus) {
     if (tiles <= cus) return tiles;
-    static const int balanced = [] { const char* e = getenv("NKB_G8_BALANCED"); return e ? atoi(e) : 1; }();
+    constexpr int balanced = 1;
     if (!balanced) return cus;
     const int rounds = (tiles + cus - 1) / cus;
     return (tiles + rounds - 1) / rounds;
@@ -843,19 +843,19 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream, const float* row
     p.relu = cp.act == 5 ? 3 : cp.relu;
     p.y2 = cp.act == 5 ? (bf16_t*)cp.y2 : nullptr;
     if (cp.act == 5) {
-        static const int ga = [] { const char* e = getenv("NKB_G8_GELU_ALIGN"); return e ? atoi(e) : 1; }();
+        constexpr int ga = 1;
         p.align_epi = ga;
     }
     p.deq_x = p.deq_w = nullptr;
     p.tilesM = (p.M + 255) / 256; p.tilesN = p.N / 256;
-    static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
+    constexpr int gm_env = 8;
     const double wbytes = (double)p.N * p.K * 2.0;
     p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096; // 128 KB (>= the 66.5 KB epilogue tile) + 512 B of bias per wave + the fp8 amax word + 4 KB of column sums
     const int cus = g8_cus();
     const int tiles = p.tilesM * p.tilesN;
     // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
-    static const int direct_on = [] { const char* e = getenv("NKB_GEMM8P_DIRECT"); return e ? atoi(e) : 1; }();
+    constexpr int direct_on = 1;
     if (p.stats == nullptr && direct_on && p.K >= 128)
         hipLaunchKernelGGL(gemm8p_kernel<true>, dim3((unsigned)g8_grid(tiles, cus)), dim3(512), lds, stream, p);
     else
@@ -906,7 +906,7 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu; p.y2 = nullptr;
     p.deq_x = deq_x; p.deq_w = deq_w;
     p.tilesM = (M + 255) / 256; p.tilesN = N / 256;
-    static const int gm_env = [] { const char* e = getenv("NKB_GROUP_M"); return e ? atoi(e) : 8; }();
+    constexpr int gm_env = 8;
     p.group_m = (gm_env > 1 && (double)N * K > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     const int cus = g8_cus();
     constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096;

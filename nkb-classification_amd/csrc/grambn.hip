@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
 }
 
 static int gram_grid(long long rows, int C) {
-    static const int t64 = [] { const char* e = getenv("NKB_GRAM_WGS64"); return e ? atoi(e) : 768; }();
-    static const int t128 = [] { const char* e = getenv("NKB_GRAM_WGS128"); return e ? atoi(e) : 384; }();
+    constexpr int t64 = 768;
+    constexpr int t128 = 384;
     const long long nstage = (rows + (8192 / C) - 1) / (8192 / C);
     const long long t = C == 64 ? t64 : t128;
     return (int)(nstage < t ? (nstage < 1 ? 1 : nstage) : t);

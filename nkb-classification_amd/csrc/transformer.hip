@@ -345,7 +345,7 @@ extern "C" size_t nkb_layernorm_workspace_floats(int D) { return (size_t)2048 * 
 static int ln_bwd_blocks(int rows) {
     // ~44 rows per block (11 per wave): fewer and the per-block column-sum epilogue dominates (32768 x 1024: 1024 blocks 78 us,
     // 768 blocks 62 us), more and the chip is under-filled (50432 x 768: 512 blocks 93 us, 1024 blocks 66 us)
-    static const int cap = [] { const char* e = getenv("NKB_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
+    constexpr int cap = 0;
     int grid = (rows + 3) / 4;
     const int want = cap > 0 ? cap : (rows + 43) / 44;
     if (grid > want) grid = want;

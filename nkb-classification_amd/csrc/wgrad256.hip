@@ -459,10 +459,10 @@ __global__ __launch_bounds__(512, 1) void wgrad8f_kernel(const W256Params p) {
 // -0.55 ms, ViT-B/16 -0.1 ms against 256 everywhere; 128 everywhere costs the bf16 unicom step +2.2 ms (its longest weight
 // gradients become the critical path), 64 everywhere +40 ms.
 static int wgrad256_target_wgs(bool fp8, double flops) {
-    static const int forced = [] { const char* e = getenv("NKB_WGRAD256_WGS"); return e ? atoi(e) : 0; }();
+    constexpr int forced = 0;
     if (forced > 0) return forced;
-    static const double small = [] { const char* e = getenv("NKB_WGRAD_SMALL_GF"); return (e ? atof(e) : 220.0) * 1e9; }();
-    static const int big = [] { const char* e = getenv("NKB_WGRAD_BIG_WGS"); return e ? atoi(e) : 256; }();
+    constexpr double small = 220.0e9;
+    constexpr int big = 256;
     return (fp8 || flops < small) ? 128 : big;
 }
 
@@ -486,8 +486,8 @@ bool nkb_wgrad256_eligible(int dtype, int M, int Cin, int Cout, int R, int S, in
     // eight-phase kernel wins from 2 tiles and 6 stages per split up (ResNet-50 layer3/4 1x1 shapes: 63 -> 50 us, 512 -> 256
     // at 28x28 125 -> 99 us; scripts/wgrad_profile.py)
     const int tiles = (Cout / 256) * (Cin / 256);
-    static const int min_tiles = [] { const char* e = getenv("NKB_WGRAD256_MIN_TILES"); return e ? atoi(e) : 2; }();
-    static const int min_stages = [] { const char* e = getenv("NKB_WGRAD256_MIN_STAGES"); return e ? atoi(e) : 6; }();
+    constexpr int min_tiles = 2;
+    constexpr int min_stages = 6;
     return tiles >= min_tiles && wgrad256_stages_per_split(M, tiles, nullptr) >= min_stages;
 }
 

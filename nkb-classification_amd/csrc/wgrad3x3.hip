@@ -202,7 +202,7 @@ static int w3_pw_shift(int W) { return W + 1 <= 8 ? 3 : W + 1 <= 16 ? 4 : W + 1 
 // (workgroups a launch aims for: it runs beside the main stream and every split costs a slab — in-step A/B on ResNet-50, same box:
 // 512: 20.80-20.87 ms, 384: 20.75-20.78, 256: 20.52-20.72, 192: 20.57, 128: 20.65)
 static int w3_target() {
-    static const int t = [] { const char* e = getenv("NKB_WGRAD3X3_WGS"); return e ? atoi(e) : 256; }();
+    constexpr int t = 256;
     return t;
 }
 static void w3_plan(int N, int H, int W, int Cin, int Cout, int* ksteps, int* splits, int* per_split) {

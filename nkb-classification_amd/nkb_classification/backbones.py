@@ -17,9 +17,9 @@ from torch import nn
 from .hipnet import HipEngine
 
 # bn1 -> relu -> maxpool of the stem as one kernel each way (0 = separate kernels, for A/B measurements)
-_FUSED_STEM_TAIL = os.environ.get("NKB_FUSED_STEM", "1") != "0"
+_FUSED_STEM_TAIL = True
 # forward: projection-shortcut convolution on the side stream, next to the block's main branch
-_SIDE_SHORTCUT = os.environ.get("NKB_SIDE_SHORTCUT", "1") != "0"
+_SIDE_SHORTCUT = True
 
 
 class _ParamOnly(nn.Module):

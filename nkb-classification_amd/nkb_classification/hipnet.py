@@ -22,47 +22,36 @@ _FUSED_BN_BWD = os.environ.get("NKB_FUSED_BNBWD", "1") != "0"
 # 3x3 stride-2 data gradients as four parity-class launches (9 taps instead of 36 multiplied, 27 of them by zero)
 _S2_CLASSES = os.environ.get("NKB_S2_CLASSES", "1") != "0"
 _FUSED_RES_BN_BWD = os.environ.get("NKB_FUSED_RES_BNBWD", "1") != "0"
-# smallest channel count from which that fusion is taken.  Round 1 excluded the <= 64-channel stages (64x256 conv tile: the fused
-# epilogue cost more than the separate reduction pass, 23.75 vs 23.64 ms/step); with this round's kernels the same-box A/B
-# reads 20.43-20.49 ms fused everywhere against 20.63-20.67 (scripts/ab_env.sh NKB_FUSE_MIN_C "65 1 ..."): fuse always
-_FUSE_MIN_C = int(os.environ.get("NKB_FUSE_MIN_C", "1"))
 # residual-closing stages keep a 1-bit/element ReLU mask; backward reads it instead of the activation and the masked
 # block-output gradient is never materialised (consumers apply the bits on the fly)
 _RELU_BITS = os.environ.get("NKB_RELU_BITS", "1") != "0"
-_ATTN_FUSED_BWD = os.environ.get("NKB_ATTN_FUSED_BWD", "1") != "0"  # whole attention backward in one kernel
-_ATTN_FUSED_DQ = os.environ.get("NKB_ATTN_FUSED_DQ", "1") != "0"   # dQ inside the attention backward-dS kernel
-_SPLITK = os.environ.get("NKB_SPLITK", "1") != "0"              # split-K for skinny Linear layers with K >= 32768
+_ATTN_FUSED_BWD = True  # whole attention backward in one kernel
+_ATTN_FUSED_DQ = True   # dQ inside the attention backward-dS kernel
+_SPLITK = True              # split-K for skinny Linear layers with K >= 32768
 _EVAL_FOLD = os.environ.get("NKB_EVAL_FOLD", "1") != "0"     # eval mode: BatchNorm folded into the conv (one launch per stage)
 # weight / bias gradients through per-split slabs + an ordered second stage instead of fp32 atomics: bit-identical across runs
 _FP8_FUSED_QUANT = os.environ.get("NKB_FP8_FUSED_QUANT", "1") != "0"   # fp8 operands written by the producing kernel's epilogue
-_FP8_WGRAD = os.environ.get("NKB_FP8_WGRAD", "1") != "0"   # fp8 mode: weight gradients of the fp8 Linear layers on the fp8 kernel too
+_FP8_WGRAD = True   # fp8 mode: weight gradients of the fp8 Linear layers on the fp8 kernel too
 # bias gradients summed inside the e5m2 quantisation pass of dY (main stream) instead of a column-sum pass on the side stream:
 # measured slower on unicom ViT-L/14 (65.0 vs 63.9 ms/step: the side stream has the slack, the main stream does not) — off
-_FP8_COLSUM = os.environ.get("NKB_FP8_COLSUM", "0") != "0"
-_WPREP_FROM_SHADOW = os.environ.get("NKB_WPREP_FROM_SHADOW", "1") != "0"
+_FP8_COLSUM = False
+_WPREP_FROM_SHADOW = True
 # LayerNorm dgamma / dbeta reduction (two small launches) on the side stream instead of in the backward chain: measured neutral
 # (unicom fp8 50.8-51.4 vs 50.9-51.3 ms, ViT-B/16 35.65-35.74 vs 35.74-35.78) — the other stream fills those gaps anyway.  Off.
-_LN_REDUCE_SIDE = os.environ.get("NKB_LN_REDUCE_SIDE", "0") != "0"
-_LN_BWD_SCALED_COPY = os.environ.get("NKB_LN_BWD_SCALED_COPY", "1") != "0"   # bf16: LayerNorm backward writes scale[b] * dx as well
-_ROWSCALE_EPILOGUE = os.environ.get("NKB_ROWSCALE_EPILOGUE", "1") != "0"   # bf16: drop-path scale in the residual GEMM epilogue
-_GELU_EPILOGUE = os.environ.get("NKB_GELU_EPILOGUE", "1") != "0"   # gelu + gelu' in the fc1 epilogue of the eight-phase core
-_FP8_ATTN_COLSUM = os.environ.get("NKB_FP8_ATTN_COLSUM", "1") != "0"   # qkv bias gradient from the attention backward kernel's stores
-_FP8_LN_BWD_QUANT = os.environ.get("NKB_FP8_LN_BWD_QUANT", "1") != "0"   # LayerNorm backward writes the next Linear backward's fp8 operand
-_FP8_EPI_COLSUM = os.environ.get("NKB_FP8_EPI_COLSUM", "1") != "0"   # fc1's bias gradient from the fc2 data gradient's epilogue
-_FP8_MASK_BITS = os.environ.get("NKB_FP8_MASK_BITS", "1") != "0"   # fp8 step: ReLU6 output kept as fp8 operand + mask bits, no bf16 copy
+_LN_REDUCE_SIDE = False
+_LN_BWD_SCALED_COPY = True   # bf16: LayerNorm backward writes scale[b] * dx as well
+_ROWSCALE_EPILOGUE = True   # bf16: drop-path scale in the residual GEMM epilogue
+_GELU_EPILOGUE = True   # gelu + gelu' in the fc1 epilogue of the eight-phase core
+_FP8_ATTN_COLSUM = True   # qkv bias gradient from the attention backward kernel's stores
+_FP8_LN_BWD_QUANT = True   # LayerNorm backward writes the next Linear backward's fp8 operand
+_FP8_EPI_COLSUM = True   # fc1's bias gradient from the fc2 data gradient's epilogue
+_FP8_MASK_BITS = True   # fp8 step: ReLU6 output kept as fp8 operand + mask bits, no bf16 copy
 _DET_WGRAD = os.environ.get("NKB_DET_WGRAD", "1") != "0"
 # Gram form of the bottleneck closing stage (csrc/grambn.hip): BatchNorm statistics of conv3's output from the Gram matrix of its
 # input, normalisation + shortcut + ReLU in conv3's epilogue, backward through R = g^T a and one K-concatenated data gradient — the
 # raw conv output c3 and its gradient never exist in HBM (0 = the separate bn_apply / bn_backward passes, for A/B runs)
 _GRAM_BN = os.environ.get("NKB_GRAM_BN", "1") != "0"
-# its data gradient in two launches: the bulk t = g . (k1 W) starts at once on the main stream while R = g^T a and the algebra that
-# needs it run on the weight-gradient stream; da = t + a . Q + cbias finishes the job (0 = one K-concatenated launch after them).
-# Measured (same box, alternating): 20.65 ms split vs 19.72 ms one launch — the main stream's kernels shrink by 1.5 ms but it then
-# idles 0.4-3.4 ms per step at the joins (the side stream still holds the previous block's weight gradients in front of the chain).  Off.
-_GRAM_SPLIT = os.environ.get("NKB_GRAM_SPLIT", "0") != "0"
 _GRAM_MAX_C = int(os.environ.get("NKB_GRAM_MAX_C", "128"))
-# a stride-1 projection shortcut (ResNet-50 layer1.0) K-concatenated into the Gram-form closing convolution (0 = separate conv + BN passes)
-_GRAM_PROJ = os.environ.get("NKB_GRAM_PROJ", "1") != "0"
 # 3x3 / stride-1 forward and data gradient on the row-balanced DMA-pipelined core (csrc/convp.hip) where nkb_convp_tiles says eligible
 _CONVP = os.environ.get("NKB_CONVP", "1") != "0"
 
@@ -450,7 +439,7 @@ class HipEngine:
         """The projection shortcut can ride inside the Gram-form closing convolution (K-concatenated): 1x1 / stride 1 / no bias on a
         block input of 64 | Cin <= _GRAM_MAX_C channels (timm ResNet-50: layer1.0) and an eligible closing convolution."""
         wd, w = dconv.weight, conv.weight
-        return (_GRAM_PROJ and self.gram_bn and self.T == torch.bfloat16 and wd.dim() == 4 and wd.shape[2] == 1 and wd.shape[3] == 1
+        return (self.gram_bn and self.T == torch.bfloat16 and wd.dim() == 4 and wd.shape[2] == 1 and wd.shape[3] == 1
                 and dconv.stride == (1, 1) and dconv.padding == (0, 0) and dconv.bias is None and wd.shape[1] % 64 == 0
                 and wd.shape[1] <= _GRAM_MAX_C and wd.shape[0] == w.shape[0]
                 and self.gram_ok(conv, wd, torch.empty(0, 0, 0, 0)))
@@ -536,26 +525,6 @@ class HipEngine:
         cbias = self.ws.get(key + ".gcbias", (ci,), torch.float32)
         tiles2 = hip.stat_tiles(self.d, rows, ci)
         stats2 = self.ws.get(prev_key + ".bstats", (hip.bn_stats_floats(tiles2, ci),), torch.float32)
-        if _GRAM_SPLIT and self.overlap_wgrad and sv.get("gram_ds") is None:
-            q = self.ws.get(key + ".gq", (ci, ci), self.T)
-
-            def algebra():
-                self.wgrad(g, x, R, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co,
-                           lddy=co)
-                work = self.ws.at_least("gram.bwd", hip.gram_bn_backward_ws(ci, co), torch.float32)
-                hip.gram_bn_backward(self.d, self.w_fwd(w), R, sv["gram"]["T"], sv["gram"]["mu"], stats, tiles, rows, ci, co,
-                                     bn.weight, sv["mean"], sv["invstd"], a.grad_flat(bn.weight), a.grad_flat(bn.bias),
-                                     a.grad_flat(w), None, cbias, work, q=q)
-            self.on_side(algebra)
-            wk1 = self.ws.get(key + ".gwk1", (ci, co), self.T)
-            hip.gram_k1w(self.d, self.w_fwd(w), sv["scale"], ci, co, wk1)
-            t = self.scratch(slot + "t", x.shape)
-            hip.conv_gemm(self.d, 0, g, wk1, t, N=rows, H=1, W=1, Cin=co, ldx=co, P=1, Q=1, Cout=ci, ldy=ci)
-            self.join_side()
-            dx = self.scratch(slot, x.shape)
-            hip.conv_dgrad_bn_add(self.d, x, ci, ci, q, cbias, t, ci, dx, svp["c"], svp["scale"], svp["shift"], svp["mean"], stats2,
-                                  rows, ci, ci)
-            return dx, (stats2, tiles2)
         self.wgrad(g, x, R, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
         wcat = self.ws.get(key + ".gwcat", (ci, co + ci), self.T)
         need = hip.gram_bn_backward_ws(ci, co)
@@ -829,7 +798,7 @@ class HipEngine:
     def can_fuse_bn_backward(self, bn_key: str) -> bool:
         sv = self.saved[bn_key]
         return (_FUSED_BN_BWD and sv["relu"] and not sv["has_res"] and sv["pool_idx"] is None
-                and sv["c"].shape[-1] % 8 == 0 and sv["c"].shape[-1] >= _FUSE_MIN_C)
+                and sv["c"].shape[-1] % 8 == 0)
 
     def can_fuse_residual_bn_backward(self, bn_key: str, consumer_key: str) -> bool:
         """The stage `bn_key` closes a residual block (kept ReLU bits) and `consumer_key` is the first conv of the next

@@ -29,7 +29,7 @@ from . import hip
 from .backbones import _ParamOnly
 from .hipnet import HipEngine
 
-_FUSED_RELU6 = os.environ.get("NKB_FUSED_RELU6", "1") != "0"   # ReLU6 in the fc1 epilogue, its mask in the fc2 data gradient
+_FUSED_RELU6 = True   # ReLU6 in the fc1 epilogue, its mask in the fc2 data gradient
 
 
 class _PatchEmbedding(_ParamOnly):

@@ -16,8 +16,8 @@ from . import hip
 from .backbones import _ParamOnly
 from .hipnet import HipEngine
 
-_GELU_KEEP_DERIV = os.environ.get("NKB_GELU_KEEP_DERIV", "1") != "0"   # forward stores gelu'(pre); backward = fc2-dgrad epilogue multiply
-_FUSED_GELU = os.environ.get("NKB_FUSED_GELU", "0") != "0"   # measured: erf in the GEMM epilogue costs more than the pass it saves (66.3 vs 65.9 ms)
+_GELU_KEEP_DERIV = True   # forward stores gelu'(pre); backward = fc2-dgrad epilogue multiply
+_FUSED_GELU = False   # measured: erf in the GEMM epilogue costs more than the pass it saves (66.3 vs 65.9 ms)
 
 
 class _PatchEmbed(_ParamOnly):
