@@ -374,10 +374,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.item())
-    if not math.isfinite(final_loss):
+    all_finite = math.isfinite(final_loss)
+    if world > 1:
+        # every rank has its own synthetic batch: a hazard can hit one rank only, and the others would then sit in the next
+        # collective until it times out — agree on the verdict first (MIN over ranks), then all leave together
+        flag = torch.tensor([1.0 if all_finite else 0.0], device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_finite = bool(flag.item() > 0.5)
+    if not all_finite:
         # synthetic data, random-init weights, lr 1e-4: a non-finite loss after a few dozen steps is a bug (a kernel, a stream
         # hazard), and a throughput measured on NaNs is not a measurement — fail instead of printing a line
-        raise SystemExit(f"bench.py: non-finite loss {final_loss} after the timed steps; refusing to report a throughput")
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(f"bench.py: non-finite loss (this rank: {final_loss}) after the timed steps; refusing to report a throughput")
     log(f"timed region: {dt:.3f}s for {args.steps} steps")
 
     # host work per step: the enqueue loop above runs ahead until the HIP queue throttles it, so host_enqueue_ms_per_step is

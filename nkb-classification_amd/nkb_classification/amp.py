@@ -40,6 +40,7 @@ class HipGradScaler:
         self._host_event = None
         self._last_opt = None                           # optimizer whose previous step may have been skipped
         self._unscaled = set()
+        self._found = {}                                # id(optimizer) -> its own inf / nan flag (non-fused path)
         self._init_growth_tracker = 0
 
     # ---- torch.amp.GradScaler surface ----------------------------------------------------------------------
@@ -95,24 +96,37 @@ class HipGradScaler:
         if id(optimizer) in self._unscaled:
             raise RuntimeError("unscale_() has already been called on this optimizer since the last update().")
         if not self._fused(optimizer):
-            # per-parameter form: the same kernel over every gradient tensor, one shared device flag
+            # per-parameter form: the same kernel over every gradient tensor.  The inf / nan flag is THIS optimizer's own (as in
+            # torch.amp.GradScaler, which keeps found_inf per optimizer: an overflow in one optimizer's gradients must not skip
+            # another one's step); it is folded into the shared flag only for update()'s growth / backoff decision
+            own = None
             for group in optimizer.param_groups:
                 for p in group["params"]:
                     g = p.grad
                     if g is None:
                         continue
                     if g.is_sparse:
+                        if not g.is_coalesced():           # (torch coalesces before unscaling too: duplicates would overflow one by one)
+                            g = g.coalesce()
+                            p.grad = g
                         g = g._values()
                     if g.dtype != torch.float32 or not g.is_cuda:
                         raise RuntimeError("HipGradScaler: gradients must be fp32 tensors on a cuda device")
                     self._lazy_init(g.device)
+                    if own is None:
+                        own = self._found.get(id(optimizer))
+                        if own is None:
+                            own = self._found[id(optimizer)] = torch.zeros(1, device=g.device)
+                        own.zero_()
                     flat = g if g.is_contiguous() else None
                     if flat is None:
                         flat = g.contiguous()
                     with torch.cuda.device(g.device):
-                        hip.grad_unscale_check(flat, flat.numel(), self._state[0:1], self._state[1:2])
+                        hip.grad_unscale_check(flat, flat.numel(), self._state[0:1], own)
                     if flat is not g:
                         g.copy_(flat)
+            if own is not None:
+                torch.maximum(self._state[1:2], own, out=self._state[1:2])
             self._unscaled.add(id(optimizer))
             return
         a = optimizer.arena
@@ -130,7 +144,8 @@ class HipGradScaler:
         if not self._fused(optimizer):
             if self._state is None:                     # nothing had a gradient
                 return optimizer.step(*args, **kwargs)
-            if float(self._state[1].item()) != 0.0:     # the slow path's one host read: skip, as torch's GradScaler.step does
+            own = self._found.get(id(optimizer))
+            if own is not None and float(own.item()) != 0.0:     # the slow path's one host read: skip, as torch's GradScaler.step does
                 return None
             return optimizer.step(*args, **kwargs)
         out = optimizer.step(*args, skip_flag=self._state[1:2], **kwargs)

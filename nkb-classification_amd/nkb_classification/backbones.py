@@ -133,12 +133,17 @@ class HipResNet(_ParamOnly):
             x = eng.conv_bn("stem", col, conv, self.bn1, True, None, train, col_input=True, pool=fused)
         if not fused:
             x = eng.maxpool("pool", x, train)
-        nblocks = sum(1 for _ in self.blocks())
-        for bi, (name, blk) in enumerate(self.blocks()):
+        all_blocks = list(self.blocks())
+        nblocks = len(all_blocks)
+        for bi, (name, blk) in enumerate(all_blocks):
             inp = x
             stages = blk.stages()
             short, short_affine = inp, None
-            want_gram = isinstance(blk, _Bottle) and bi + 1 < nblocks and train
+            # the Gram form's backward needs the masked output gradient WITH its sums from the next block's first data gradient
+            # (HipEngine.can_fuse_residual_bn_backward): decide on that producer here, where the forward form is chosen — a next
+            # block whose first convolution takes the parity-class data gradient (3x3 / stride 2) cannot supply them
+            want_gram = (isinstance(blk, _Bottle) and bi + 1 < nblocks and train
+                         and not eng.s2_classes(all_blocks[bi + 1][1].stages()[0][0]))
             proj = None
             if blk.downsample is not None and want_gram and eng.gram_proj_ok(blk.downsample[0], stages[-1][0]):
                 proj = (blk.downsample[0], blk.downsample[1], inp, f"{name}.ds")     # rides inside the closing convolution

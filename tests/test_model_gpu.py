@@ -273,6 +273,21 @@ def test_train_py_end_to_end(tmp_path):
     assert len(lines) == 3 and "\t" in lines[0]
     sd = torch.load(exp / "weights" / "last.pth", map_location="cpu")
     assert "emb_model.layer4.1.bn2.running_var" in sd and "classifier.1.weight" in sd
+    # the TorchScript archive is the plain-torch twin of the HIP model that wrote it (scripted.py): its logits on a fixed batch
+    # equal those of the HIP model rebuilt from last.pth (fp32, eval mode) to 1e-3 — what configs/eval_config.py:87-90 /
+    # model.py:163-164 ("scripted": path) would load in the reference
+    scripted = torch.jit.load(str(exp / "weights" / "scripted_last.pt"), map_location="cpu").eval()
+    hip_model = get_model(dict(task="single", model="resnet18", pretrained=False, backbone_dropout=0.0, classifier_dropout=0.0,
+                               classifier_initialization="kaiming_normal_", checkpoint=str(exp / "weights" / "last.pth")),
+                          [str(i) for i in range(10)], DEV).eval()
+    xb = torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        ref_logits = scripted(xb)
+        hip_logits = hip_model(xb.to(DEV)).float().cpu()
+    assert ref_logits.shape == hip_logits.shape == (6, 10)
+    rel = ((hip_logits - ref_logits).abs().max() / ref_logits.abs().max()).item()
+    assert rel < 1e-3, rel
+    assert hip_logits.argmax(-1).tolist() == ref_logits.argmax(-1).tolist()
     # eval.py -cfg (the reference's eval.py:27-52): the checkpoint just written, one validation epoch, metrics.json
     import json
     ecfg = cfg.replace('"classifier_initialization": "kaiming_normal_"}',
