@@ -45,10 +45,10 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}   # dense MFMA peaks
 HBM_PEAK_GBS = 8000.0                          # HBM3E, MI355X_MICROARCH.md
 # HBM-side traffic ON FILE per benchmarked workload (scripts/collect_profiles.sh -> scripts/pmc_traffic.py; regenerate after any
 # kernel change).  key = (model, batch, dtype)
-PMC_TRAFFIC_FILES = {("resnet50", 256, "bf16"): "r03_resnet50_bf16_pmc_traffic.json",
-                     ("vit_base_patch16_224", 256, "bf16"): "r03_vit_b16_bf16_pmc_traffic.json",
-                     ("unicom ViT-L/14", 128, "bf16"): "r03_unicom_vit_l14_bf16_pmc_traffic.json",
-                     ("unicom ViT-L/14", 128, "fp8"): "r03_unicom_vit_l14_fp8_pmc_traffic.json"}
+PMC_TRAFFIC_FILES = {("resnet50", 256, "bf16"): "r04_resnet50_bf16_pmc_traffic.json",
+                     ("vit_base_patch16_224", 256, "bf16"): "r04_vit_b16_bf16_pmc_traffic.json",
+                     ("unicom ViT-L/14", 128, "bf16"): "r04_unicom_vit_l14_bf16_pmc_traffic.json",
+                     ("unicom ViT-L/14", 128, "fp8"): "r04_unicom_vit_l14_fp8_pmc_traffic.json"}
 # profiler tag (api.hip kernel ids) -> families of scripts/pmc_traffic.py that hold the same launches
 TRAFFIC_FAMILIES = {"conv_igemm": ("conv_igemm_fwd", "conv_igemm_bwd", "gemm8p_fwd", "gemm8p_bwd"),
                     "conv_wgrad": ("conv_wgrad", "wgrad8p", "wgrad8f", "wgrad3x3"), "bn_apply": ("bn_apply",),
