@@ -46,20 +46,27 @@ struct CPParams {
     int mode;                   // 0 forward, 1 data gradient (filter rows / columns mirrored)
     int nwgm, tilesN, rows_per_wg;
     FastDiv divHW, divW;
-    int dbg;                    // diagnostic build only (NKB_CONVP_STAMPS + NKB_CONVP_DBG): 1 no activation DMA, 2 no filter DMA, 4 no MFMA, 64 no rotated group
+    int dbg;                    // diagnostic builds only (NKB_CONVP_DIAG + NKB_CONVP_DBG): 1 no activation DMA, 2 no filter DMA, 4 no MFMA, 64 no rotated group, 128 no s_setprio
 };
 
 __device__ __attribute__((aligned(256))) unsigned char convp_zero_page[256];
-#ifdef NKB_CONVP_STAMPS
+#if defined(NKB_CONVP_STAMPS) && !defined(NKB_CONVP_DIAG)
+#define NKB_CONVP_DIAG 1
+#endif
+// diagnostic builds only (scripts/convp_stamps.sh): -DNKB_CONVP_DIAG compiles the NKB_CONVP_DBG ablation knobs in, -DNKB_CONVP_STAMPS
+// also the in-kernel cycle stamps of wave 0 and wave 4 of workgroup 0 per section of the k-tile loop
+#ifdef NKB_CONVP_DIAG
 #define CP_DBG(bit) (p.dbg & (bit))
-// diagnostic build only (scripts/convp_stamps.sh): cycles of wave 0 and wave 4 of workgroup 0 per section of the k-tile loop
+#else
+#define CP_DBG(bit) false
+#endif
+#ifdef NKB_CONVP_STAMPS
 __device__ unsigned long long convp_stamps[2][8];
 #define CP_STAMP(i)                                                                            \
     do {                                                                                       \
         if (stamp_on) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; } \
     } while (0)
 #else
-#define CP_DBG(bit) false
 #define CP_STAMP(i) do { } while (0)
 #endif      // zero-initialised: source of out-of-image rows
 
@@ -288,13 +295,14 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
                     unsigned fm = fmask;
                     asm volatile("" : "+s"(fm));               // (likewise: 16 hoisted booleans are 16 SGPR pairs)
                     u32x4 bq[2][2][2];                         // [register set][fragment of the pair][k-step]
-                    auto mm = [&](int j, const u32x4 (&bb)[2]) {
-                        if (((fm >> j) & 1u) && !CP_DBG(4)) {
+                    // GUARD: only the last fragment of an odd count can be missing (the k-loop is compiled per pair count)
+                    auto mm = [&](int j, const u32x4 (&bb)[2], auto GUARD_) {
+                        if (!decltype(GUARD_)::value || (((fm >> j) & 1u) && !CP_DBG(4))) {
                             cp_i32x4 b0 = __builtin_bit_cast(cp_i32x4, bb[0]), b1 = __builtin_bit_cast(cp_i32x4, bb[1]);
-                            if (shift != 1) {                  // (an AND with 0 / ~0 built from the bit: a select would park 2 x 16 lane masks in SGPRs)
-                                const int mk = -(int)((keep >> j) & 1u);
-                                const cp_i32x4 m4 = {mk, mk, mk, mk};
-                                b0 &= m4; b1 &= m4;
+                            if (shift != 1) {                  // an AND with 0 / ~0 built from the bit (a select would park 2 x 16 lane masks in SGPRs;
+                                const int mk = -(int)((keep >> j) & 1u);      // redirecting the edge lanes' READS to a zero slot — 4 VALU
+                                const cp_i32x4 m4 = {mk, mk, mk, mk};         // instead of 9 per fragment — measured slower: 64 -> 72 us on
+                                b0 &= m4; b1 &= m4;                            // layer3, the address now hangs on a VALU chain in front of every read)
                             }
                             const bf16x8 f0 = __builtin_bit_cast(bf16x8, b0), f1 = __builtin_bit_cast(bf16x8, b1);
                             acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][0], f0, acc[0][j], 0, 0, 0);
@@ -316,12 +324,12 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
         constexpr int cur_ = ((JG) >> 1) & 1;                                                                         \
         if constexpr ((JG) + 2 < 2 * NP) { CP_PAIR(cur_ ^ 1, (JG) + 2); CP_LANDED(4, cur_); }                         \
         else CP_LANDED(0, cur_);                                                                                      \
-        mm((JG), bq[cur_][0]);                                                                                        \
-        mm((JG) + 1, bq[cur_][1]);                                                                                    \
+        mm((JG), bq[cur_][0], CPI<0>{});                                                                              \
+        mm((JG) + 1, bq[cur_][1], CPI<((JG) + 2 == 2 * NP)>{});                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
                     if constexpr (NP > 0) CP_PAIR(0, 0);
-                    __builtin_amdgcn_s_setprio(1);
+                    if (!CP_DBG(128)) __builtin_amdgcn_s_setprio(1);
                     CP_STAGE(0) CP_STAGE(2) CP_STAGE(4) CP_STAGE(6) CP_STAGE(8) CP_STAGE(10) CP_STAGE(12) CP_STAGE(14)
 #undef CP_STAGE
 #undef CP_LANDED
@@ -536,8 +544,8 @@ static int convp_launch(int kind, const void* x, const void* w, void* y, const v
     p.M = N * H * W; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.ldw = 9 * Cin;
     p.mode = kind; p.nwgm = g.nwgm; p.tilesN = g.tilesN; p.rows_per_wg = g.rows_per_wg;
     p.divHW = make_fastdiv((unsigned)(H * W)); p.divW = make_fastdiv((unsigned)W);
-#ifdef NKB_CONVP_STAMPS
-    static const int dbg = [] { const char* e = getenv("NKB_CONVP_DBG"); return e ? atoi(e) : 0; }();      // (diagnostic build only)
+#ifdef NKB_CONVP_DIAG
+    static const int dbg = [] { const char* e = getenv("NKB_CONVP_DBG"); return e ? atoi(e) : 0; }();      // (diagnostic builds only)
     p.dbg = dbg;
 #else
     p.dbg = 0;

@@ -20,7 +20,7 @@ def run(N, H, W, Cin, Cout, kind, reps):
     x = (torch.randn(N, H, W, Cin, device=DEV)).to(torch.bfloat16)
     w = (torch.randn(Cout, 3, 3, Cin, device=DEV) * (1.0 / (3 * Cin ** 0.5))).to(torch.bfloat16)
     tiles0 = hip.stat_tiles(d, M, Cout)
-    tiles1 = hip.convp_tiles(d, kind, N=N, H=H, W=W, Cin=Cin, ldx=Cin, Cout=Cout, ldy=Cout, R=3, S=3, stride=1, pad=1)
+    tiles1 = hip.convp_config(True, True) or hip.convp_tiles(d, kind, N=N, H=H, W=W, Cin=Cin, ldx=Cin, Cout=Cout, ldy=Cout, R=3, S=3, stride=1, pad=1)
     assert tiles1 > 0, "not eligible"
     y0 = torch.empty(N, H, W, Cout, device=DEV, dtype=torch.bfloat16)
     y1 = torch.full_like(y0, float("nan"))
