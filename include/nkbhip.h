@@ -106,9 +106,10 @@ int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, 
  * nkb_convp_dgrad_bn: nkb_conv_dgrad_bn's recomputed-mask form (no residual operand); w is the [Cin][3][3][Cout] data-gradient filter,
  * Cin / ldx describe dY, Cout / ldy the produced gradient.  Both feed nkb_bn_finalize / nkb_bn_backward_from_stats with `tiles`. */
 int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int stride, int pad);
-/* on = 0 / 1: the core is used at all (default 1); tc128 = 1: also for Cout % 256 != 0 as 128-channel tiles (default 0: measured level
- * with / slower than the 128 x 128 kernel in the ResNet-50 step).  Tests and A/B timing. */
-void nkb_convp_config(int on, int tc128);
+/* on = 0 / 1: the core is used at all (default 1); narrow bit 0: also for Cout % 256 == 128 as 128-channel tiles (default 0: measured
+ * level with / slower than the 128 x 128 kernel in the ResNet-50 step); narrow bit 1: the 64 -> 64 channel form with the filter resident
+ * in registers / LDS (default 1: forward), bit 2: that form for the data gradient as well (default 0).  Tests and A/B timing. */
+void nkb_convp_config(int on, int narrow);
 int nkb_convp_fwd(int dtype, const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int ldx, int Cout,
                   int ldy, nkb_stream_t stream);
 int nkb_convp_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,

@@ -46,7 +46,7 @@ struct CPParams {
     int mode;                   // 0 forward, 1 data gradient (filter rows / columns mirrored)
     int nwgm, tilesN, rows_per_wg;
     FastDiv divHW, divW;
-    int dbg;                    // diagnostic builds only (NKB_CONVP_DIAG + NKB_CONVP_DBG): 1 no activation DMA, 2 no filter DMA, 4 no MFMA, 64 no rotated group, 128 no s_setprio
+    int dbg;                    // diagnostic builds only (NKB_CONVP_DIAG + NKB_CONVP_DBG): 1 no activation DMA, 2 no filter DMA, 4 no MFMA, 8 no forward stores, 64 no rotated group, 128 no s_setprio
 };
 
 __device__ __attribute__((aligned(256))) unsigned char convp_zero_page[256];
@@ -92,6 +92,92 @@ __device__ __forceinline__ float cp_row16_sum(float v) {      // sum over the 16
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
     return v;
+}
+
+// Epilogue of one sub-tile, straight from the accumulators: lane (frow, fgrp) holds channels cch .. cch + 7 of pixel m0 + (pw NPW + j) 16 +
+// frow in acc[0][j] | acc[1][j] -> one 16-byte row per fragment.  EPI 0: y = rnd(acc), sums of y and y^2; EPI 1: the fused
+// BatchNorm-backward form (mask recomputed from c, sums of g' and g' (c - mean)).  The sub-tile's sums are reduced over the 16 pixel
+// lanes and added to this wave's LDS accumulators (wsum) by the frow == 0 lanes.
+template <int EPI, int NPW>
+__device__ __forceinline__ void cp_epilogue(const CPParams& p, f32x4 (&acc)[2][NPW], unsigned fmask, int nf, int m0, int pw, int frow,
+                                            int cch, int row1, float* wsum) {
+                float ssum[8], ssq[8];
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+                if constexpr (EPI == 0) {
+    #pragma unroll
+                    for (int j = 0; j < NPW; ++j) {
+                        if ((fmask >> j) & 1u) {
+                            const int m = m0 + (pw * NPW + j) * 16 + frow;
+                            float v[8];
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] = acc[0][j][e]; v[4 + e] = acc[1][j][e]; }
+                            const u32x4 pk = pack8(v);
+                            if (m < row1 && !CP_DBG(8)) {
+                                __builtin_nontemporal_store(pk, (u32x4*)(p.y + (size_t)m * p.ldy + cch));
+                                unpack8(pk, v);                    // statistics see the stored value
+    #pragma unroll
+                                for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+                            }
+                        }
+                    }
+                } else {
+                    float sc[8], sh[8], mu[8];
+                    // (one group only: loaded under the group's own condition below — pending loads that a skipped group never uses make
+                    // hipcc wait for ALL vector memory, the activation DMAs in flight included, at their registers' next use in the k-loop)
+                    if (NPW > 4 || (fmask & 1u)) {
+                        const f32x4 a0 = *(const f32x4*)(p.bn_scale + cch), a1 = *(const f32x4*)(p.bn_scale + cch + 4);
+                        const f32x4 b0 = *(const f32x4*)(p.bn_shift + cch), b1 = *(const f32x4*)(p.bn_shift + cch + 4);
+                        const f32x4 m0v = *(const f32x4*)(p.bn_mean + cch), m1v = *(const f32x4*)(p.bn_mean + cch + 4);
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) { sc[e] = a0[e]; sc[4 + e] = a1[e]; sh[e] = b0[e]; sh[4 + e] = b1[e]; mu[e] = m0v[e]; mu[4 + e] = m1v[e]; }
+                    }
+                    // the c rows in groups of 4, every group requested before its first row is used
+                    constexpr int GRP = 4;
+    #pragma unroll
+                    for (int j0 = 0; j0 < NPW; j0 += GRP) {
+                        if ((fmask >> j0) & 1u) {
+                            u32x4 craw[GRP];
+    #pragma unroll
+                            for (int jj = 0; jj < GRP; ++jj) {
+                                const int m = m0 + (pw * NPW + j0 + jj) * 16 + frow;
+                                craw[jj] = (u32x4){0u, 0u, 0u, 0u};
+                                if (m < row1) craw[jj] = *(const u32x4*)(p.aux + (size_t)m * p.ldy + cch);
+                            }
+    #pragma unroll
+                            for (int jj = 0; jj < GRP; ++jj) {
+                                const int j = j0 + jj;
+                                if ((fmask >> j) & 1u) {
+                                    const int m = m0 + (pw * NPW + j) * 16 + frow;
+                                    float v[8], cv[8];
+    #pragma unroll
+                                    for (int e = 0; e < 4; ++e) { v[e] = acc[0][j][e]; v[4 + e] = acc[1][j][e]; }
+                                    unpack8(craw[jj], cv);
+    #pragma unroll
+                                    for (int e = 0; e < 8; ++e) {
+                                        if (!(bf2f(f2bf(cv[e] * sc[e] + sh[e])) > 0.f)) v[e] = 0.f;     // same expression / rounding as bn_apply
+                                        cv[e] -= mu[e];
+                                    }
+                                    const u32x4 pk = pack8(v);
+                                    if (m < row1) {
+                                        __builtin_nontemporal_store(pk, (u32x4*)(p.y + (size_t)m * p.ldy + cch));
+                                        unpack8(pk, v);
+    #pragma unroll
+                                        for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * cv[e]; }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (nf > 0) {
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) { ssum[e] = cp_row16_sum(ssum[e]); ssq[e] = cp_row16_sum(ssq[e]); }
+                    if (frow == 0) {
+    #pragma unroll
+                        for (int e = 0; e < 8; ++e) { wsum[e] += ssum[e]; wsum[8 + e] += ssq[e]; }
+                    }
+                }
 }
 
 // TC: output channels per workgroup (256: 8 channel waves x all 16 pixel fragments; 128: 4 channel waves x 2 pixel halves).
@@ -354,83 +440,7 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
                 default: chunks(CPI<(NPW >= 16 ? 8 : 0)>{}); break;
             }
 
-            // ---- epilogue of the sub-tile: accumulators -> 16-byte rows (8 consecutive channels of a pixel per lane)
-            const int cch = c_wave + 8 * fgrp;
-            float ssum[8], ssq[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-            if constexpr (EPI == 0) {
-#pragma unroll
-                for (int j = 0; j < NPW; ++j) {
-                    if ((fmask >> j) & 1u) {
-                        const int m = m0 + (pw * NPW + j) * 16 + frow;
-                        float v[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = acc[0][j][e]; v[4 + e] = acc[1][j][e]; }
-                        const u32x4 pk = pack8(v);
-                        if (m < row1) {
-                            __builtin_nontemporal_store(pk, (u32x4*)(p.y + (size_t)m * p.ldy + cch));
-                            unpack8(pk, v);                    // statistics see the stored value
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-                        }
-                    }
-                }
-            } else {
-                float sc[8], sh[8], mu[8];
-                {
-                    const f32x4 a0 = *(const f32x4*)(p.bn_scale + cch), a1 = *(const f32x4*)(p.bn_scale + cch + 4);
-                    const f32x4 b0 = *(const f32x4*)(p.bn_shift + cch), b1 = *(const f32x4*)(p.bn_shift + cch + 4);
-                    const f32x4 m0v = *(const f32x4*)(p.bn_mean + cch), m1v = *(const f32x4*)(p.bn_mean + cch + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { sc[e] = a0[e]; sc[4 + e] = a1[e]; sh[e] = b0[e]; sh[4 + e] = b1[e]; mu[e] = m0v[e]; mu[4 + e] = m1v[e]; }
-                }
-                // the c rows in groups of 4, every group requested before its first row is used
-                constexpr int GRP = 4;
-#pragma unroll
-                for (int j0 = 0; j0 < NPW; j0 += GRP) {
-                    if ((fmask >> j0) & 1u) {
-                        u32x4 craw[GRP];
-#pragma unroll
-                        for (int jj = 0; jj < GRP; ++jj) {
-                            const int m = m0 + (pw * NPW + j0 + jj) * 16 + frow;
-                            craw[jj] = (u32x4){0u, 0u, 0u, 0u};
-                            if (m < row1) craw[jj] = *(const u32x4*)(p.aux + (size_t)m * p.ldy + cch);
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < GRP; ++jj) {
-                            const int j = j0 + jj;
-                            if ((fmask >> j) & 1u) {
-                                const int m = m0 + (pw * NPW + j) * 16 + frow;
-                                float v[8], cv[8];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { v[e] = acc[0][j][e]; v[4 + e] = acc[1][j][e]; }
-                                unpack8(craw[jj], cv);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    if (!(bf2f(f2bf(cv[e] * sc[e] + sh[e])) > 0.f)) v[e] = 0.f;     // same expression / rounding as bn_apply
-                                    cv[e] -= mu[e];
-                                }
-                                const u32x4 pk = pack8(v);
-                                if (m < row1) {
-                                    __builtin_nontemporal_store(pk, (u32x4*)(p.y + (size_t)m * p.ldy + cch));
-                                    unpack8(pk, v);
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * cv[e]; }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            if (nf > 0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { ssum[e] = cp_row16_sum(ssum[e]); ssq[e] = cp_row16_sum(ssq[e]); }
-                if (frow == 0) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { wsum[e] += ssum[e]; wsum[8 + e] += ssq[e]; }
-                }
-            }
+            cp_epilogue<EPI, NPW>(p, acc, fmask, nf, m0, pw, frow, c_wave + 8 * fgrp, row1, wsum);
         }
         // the epilogue's NPW stores (a full sub-tile: only such a one is followed by another) are younger than the two filter tiles in flight
         epi_cnt = 2;
@@ -472,7 +482,308 @@ __global__ __launch_bounds__(512, 1) void convp_kernel(const CPParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The 64 -> 64 channel form (timm Bottleneck layer1 conv2, 56 x 56 maps): the whole filter — 64 x 9 x 64 bf16 = 72 KB — is read ONCE
+// per workgroup: wave (cw, pw) keeps the fragments of its 32 output channels for filter rows 0 and 1 in registers (6 k-tiles x 16 = 96;
+// the accumulators of its 64-pixel quarter are only 32) and reads those of filter row 2 from a 24 KB LDS copy (all nine in registers
+// is 144 + 32 + 32 for the pixel fragments: hipcc spills a dozen fragments and reloads them in the k-loop, and a scratch reload waits
+// for every DMA in flight).  So the k-loop has no filter stream at all: per chunk (one filter row = three k-tiles) one counted wait +
+// one barrier + five activation DMAs, per k-tile nothing but fragment reads and MFMAs.
+// Waves: 2 channel halves x 4 pixel quarters of a 256-pixel sub-tile; a workgroup walks M / #CUs pixels (3 136 at batch 256).
+// The shape is HBM-bound (59 GFLOP on 206 / 309 MB), so the activation stream runs THREE 40 KB stages — the LDS the filter slots do
+// not need — with two chunks in flight: chunk c + 2 is issued behind the barrier of chunk c into the stage chunk c - 1 was read from.
+// A sub-tile is exactly three chunks, so the stage of a chunk is its filter row: compile-time addresses everywhere.
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void convp64_kernel(const CPParams p) {
+    constexpr int NPW = 4, PW = 4;
+    constexpr int XS = 40 * 1024;
+    constexpr int WL = 3 * XS;                     // filter row 2: [channel half][column tap][channel fragment][16 rows] x 128 B, XOR-swizzled
+    constexpr int ROFF = WL + 24 * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wvc = wave & 1, pw = wave >> 1;
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int wgm = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = wgm * p.rows_per_wg;
+    const int row1 = min(p.M, row0 + p.rows_per_wg);
+    const int nsub = (row1 - row0 + 255) >> 8;
+    const int GC = nsub * 3;
+    constexpr int MODE = EPI;                      // (the forward epilogue goes with the forward tap order, the fused one with the mirrored)
+    constexpr int hsign = MODE == 0 ? 1 : -1;
+    const int c_wave = wvc * 32;
+
+    // ---- the filter: fragment (k-tile kt, channel fragment i, k-step ks) of lane (frow, fgrp) = 16 bytes of filter row
+    // c_wave + 8 (frow >> 2) + 4 i + (frow & 3) at k = 64 kt + 32 ks + 8 fgrp (the row permutation of convp_kernel: a lane ends up with
+    // 8 consecutive channels).  k-tile kt = 3 r + s is filter tap (r, s) (Cin = 64: one channel chunk per tap).
+    bf16x8 aw[6][2][2];
+    {
+        const bf16_t* wl = p.w + (size_t)(c_wave + 8 * (frow >> 2) + (frow & 3)) * p.ldw + 8 * fgrp;
+#pragma unroll
+        for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) aw[kt][i][ks] = *(const bf16x8*)(wl + (size_t)(4 * i) * p.ldw + 64 * kt + 32 * ks);
+        // filter row 2 -> LDS: 192 rows x 8 pieces of 16 bytes, three per thread
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int pc = tid + 512 * it;
+            const int R = pc >> 3, c = pc & 7;
+            const int fr = R & 15, i = (R >> 4) & 1, hs = R >> 5;              // hs = channel half * 3 + column tap
+            const int half = hs / 3, tap = hs - 3 * half;
+            const int chn = half * 32 + 8 * (fr >> 2) + 4 * i + (fr & 3);
+            const u32x4 v = *(const u32x4*)(p.w + (size_t)chn * p.ldw + 64 * (6 + tap) + 8 * c);
+            *(u32x4*)(smem + WL + R * 128 + ((c ^ (fr & 7)) << 4)) = v;
+        }
+    }
+    // pixel-fragment read addresses of fragment 0 in stage 0, per column shift (stage row = pixel row + shift): 128-byte rows, 16-byte
+    // chunk fgrp | 4 + fgrp XOR-swizzled with the row.  Stage, fragment and k-step go into the instruction's offset field.
+    unsigned sa0[3], sa1[3];
+#pragma unroll
+    for (int sh = 0; sh < 3; ++sh) {
+        const int brow = pw * NPW * 16 + frow + sh;
+        const unsigned aoff = (unsigned)(brow * 128 + ((fgrp ^ (brow & 7)) << 4));
+        sa0[sh] = lds0 + aoff;
+        sa1[sh] = lds0 + (aoff ^ 64u);
+    }
+    const unsigned wa0 = lds0 + (unsigned)(WL + (wvc * 96 + frow) * 128 + ((fgrp ^ (frow & 7)) << 4));
+    const unsigned wa1 = lds0 + (unsigned)(WL + (wvc * 96 + frow) * 128 + (((4 + fgrp) ^ (frow & 7)) << 4));
+
+    long xoff0 = 0;
+    unsigned xhm = 0u;
+    auto rows_of = [&](int t) {
+        const int m0 = row0 + 256 * t;
+        const int nvt = min(256, row1 - m0);
+        xhm = 0u;
+        int lro = lrow, lco = lch;
+        asm volatile("" : "+v"(lro), "+v"(lco));               // (opaque: hoisted, the piece rows / the widened column offset are spilled, and every reload drains the DMA queue)
+        xoff0 = ((long)(m0 - 1 + 8 * wave + lro) * p.ldx) * 2 + lco * 16;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int lr = 8 * (wave + 8 * i) + lro;
+            const int m = m0 - 1 + lr;
+            unsigned hb = 0u;
+            if (m >= 0 && m < p.M && lr <= nvt + 1) {
+                const unsigned n = fdiv((unsigned)m, p.divHW);
+                const unsigned rem = (unsigned)m - n * p.divHW.d;
+                const int h = (int)fdiv(rem, p.divW);
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+                    if ((unsigned)(h + hsign * (rr - 1)) < (unsigned)p.H) hb |= 1u << rr;
+            }
+            xhm |= hb << (3 * i);
+        }
+    };
+    int xg = 0, xt = 0;
+    // pieces I0 .. I1 - 1 of chunk xg = (sub-tile xt, filter row R) into stage R.  A wave's five pieces are issued ONE PER PIPELINE
+    // STAGE of the chunk before (all five behind the barrier, the eight waves in step: 40 KB queue up in front of the CU's one
+    // vector-memory path and every wave sits in the issue of its DMAs for ~600 cycles with its MFMAs not yet issued — in-kernel
+    // stamps: a quarter of the kernel)
+    auto issue_x = [&](auto R_, auto I0_, auto I1_) {
+        constexpr int xr = decltype(R_)::value, i0 = decltype(I0_)::value, i1 = decltype(I1_)::value;
+        if (xg < GC && !CP_DBG(1)) {
+            const long rowoff = (long)(hsign * (xr - 1) * p.W) * p.ldx * 2;
+            unsigned char* d_ = smem + xr * XS + wave * 1024;
+#pragma unroll
+            for (int i = i0; i < i1; ++i) {
+                const bool ok = (xhm >> (3 * i + xr)) & 1u;
+                const unsigned char* s_ = ok ? (const unsigned char*)p.x + (xoff0 + (long)i * 128 * p.ldx + rowoff)
+                                             : convp_zero_page + (lane & 7) * 16;
+                cp_glds16(s_, d_ + i * 8192);
+            }
+        }
+        if constexpr (i1 == 5) {
+            ++xg;
+            if constexpr (xr == 2) { if (++xt < nsub && !CP_DBG(512)) rows_of(xt); }
+        }
+    };
+
+    float* const wsum = (float*)(smem + ROFF + 2048) + wave * 64 + fgrp * 16;
+    if (frow == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wsum[e] = 0.f;
+    }
+    rows_of(0);
+    // the filter loads are waited for HERE — the fragments pass through an empty asm, so hipcc's own wait lands in front of it instead of
+    // at their first use inside the k-loop, where a vmcnt(0) would drain the activation DMAs of every sub-tile
+#pragma unroll
+    for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(aw[kt][i][0]), "+v"(aw[kt][i][1]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (nothing else may sit in front of the counted waits)
+    issue_x(CPI<0>{}, CPI<0>{}, CPI<5>{});
+    issue_x(CPI<1>{}, CPI<0>{}, CPI<5>{});
+
+#ifdef NKB_CONVP_STAMPS
+    const bool stamp_on = blockIdx.x == 0 && (wave == 0 || wave == 4);
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#endif
+    int gc = 0;
+    bool after_epi = false;
+    for (int t = 0; t < nsub; ++t) {
+        const int m0 = row0 + 256 * t;
+        const int nv = min(256, row1 - m0);
+        const int nf = __builtin_amdgcn_readfirstlane(max(0, min(NPW, ((nv + 15) >> 4) - pw * NPW)));
+        const unsigned fmask = (unsigned)__builtin_amdgcn_readfirstlane((int)((1u << nf) - 1u));
+        // edge lanes: bit j of lnb / rnb — this lane's pixel of fragment j has a left / right neighbour in its image row; bit j of the
+        // scalars lany / rany — SOME lane of fragment j has none.  Only such fragments pay for the masking (8 VALU each, and a VALU
+        // instruction is 4 issue cycles of the SIMD: on 56-wide rows two fragments in seven have an edge pixel per side)
+        unsigned lnb = 0u, rnb = 0u, lany = 0u, rany = 0u;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const unsigned m = (unsigned)(m0 + (pw * NPW + j) * 16 + frow);
+            const unsigned wq = m - fdiv(m, p.divW) * p.divW.d;
+            if (wq > 0u) lnb |= 1u << j;
+            if (wq + 1u < (unsigned)p.W) rnb |= 1u << j;
+            if (__builtin_amdgcn_ballot_w64(wq == 0u) != 0ull) lany |= 1u << j;
+            if (__builtin_amdgcn_ballot_w64(wq + 1u == (unsigned)p.W) != 0ull) rany |= 1u << j;
+        }
+        lany = (unsigned)__builtin_amdgcn_readfirstlane((int)lany);
+        rany = (unsigned)__builtin_amdgcn_readfirstlane((int)rany);
+        {
+            f32x4 acc[2][NPW];
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) { acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            auto chunk = [&](auto NP_, auto R_) {
+                constexpr int NP = decltype(NP_)::value;
+                constexpr int r = decltype(R_)::value;
+                // this wave's pieces of chunk gc have landed: younger than them are only chunk gc + 1's five and, behind an epilogue, its
+                // NPW stores (a full sub-tile: only such a one is followed by another)
+                CP_STAMP(0);
+                if (gc + 1 >= GC) cp_vmcnt<0>();
+                else if (after_epi) cp_vmcnt<5 + NPW>();
+                else cp_vmcnt<5>();
+                after_epi = false;
+                CP_STAMP(1);
+                CP_BARRIER();                                  // every wave's pieces landed; chunk gc - 1 is read out
+                CP_STAMP(2);
+                // chunk gc + 2 goes into the stage of chunk gc - 1: from here on, spread over the pipeline stages below
+                if constexpr (NP == 0) issue_x(CPI<(r + 2) % 3>{}, CPI<0>{}, CPI<5>{});
+                CP_STAMP(3);
+                // The chunk's three k-tiles as ONE software pipeline of 3 NP stages (k-tile s, fragment pair): stage q issues the LDS
+                // reads of stage q + 1 — across k-tile boundaries too — and then waits for its own alone, so the only exposed LDS
+                // latency of a chunk is its first pair's.  (Per k-tile, as in convp_kernel, every k-tile began with one: measured
+                // additive here — no filter stream to hide behind, all eight waves in step behind the barrier.)  Reads and waits are
+                // inline assembly with fixed counts (hipcc's own wait in front of an MFMA block under a branch is lgkmcnt(0)).
+                // (the register arrays are handed down as parameters: clang rejects asm operands that name a variable of an enclosing lambda)
+                u32x4 bq_[2][2][2];                            // [register set][fragment of the pair][k-step]
+                u32x4 ar_[2][2][2];                            // filter row 2: [k-tile parity][channel fragment][k-step], from the LDS copy
+                auto reads = [&](auto Q_, u32x4 (&bq)[2][2][2], u32x4 (&ar)[2][2][2]) {
+                    constexpr int Q = decltype(Q_)::value, s = Q / (NP > 0 ? NP : 1), pr = Q % (NP > 0 ? NP : 1), set = Q & 1;
+                    constexpr int shift = MODE == 0 ? s : 2 - s;
+                    constexpr int soff = r == 1 ? XS : 0;      // (stage 2 is beyond the 16-bit offset field: one add per address, kept from being hoisted)
+                    unsigned ab0 = sa0[shift], ab1 = sa1[shift];
+                    if constexpr (r == 2) { ab0 += 2 * XS; ab1 += 2 * XS; asm volatile("" : "+v"(ab0), "+v"(ab1)); }
+                    const unsigned fa0 = wa0, fa1 = wa1;
+                    if constexpr (r == 2 && pr == 0) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[s & 1][0][0]) : "v"(fa0), "n"((2 * s) * 2048));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[s & 1][0][1]) : "v"(fa1), "n"((2 * s) * 2048));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[s & 1][1][0]) : "v"(fa0), "n"((2 * s + 1) * 2048));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[s & 1][1][1]) : "v"(fa1), "n"((2 * s + 1) * 2048));
+                    }
+                    if (!CP_DBG(32)) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[set][0][0]) : "v"(ab0), "n"(soff + 2048 * (2 * pr)));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[set][0][1]) : "v"(ab1), "n"(soff + 2048 * (2 * pr)));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[set][1][0]) : "v"(ab0), "n"(soff + 2048 * (2 * pr + 1)));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[set][1][1]) : "v"(ab1), "n"(soff + 2048 * (2 * pr + 1)));
+                    }
+                };
+                auto stage = [&](auto Q_, u32x4 (&bq)[2][2][2], u32x4 (&ar)[2][2][2]) {
+                    constexpr int Q = decltype(Q_)::value, s = Q / (NP > 0 ? NP : 1), pr = Q % (NP > 0 ? NP : 1), set = Q & 1;
+                    constexpr bool more = Q + 1 < 3 * NP;
+                    constexpr bool next_a = more && r == 2 && (Q + 1) % (NP > 0 ? NP : 1) == 0;      // stage Q + 1 opens a k-tile of filter row 2
+                    if constexpr (more) reads(CPI<(more ? Q + 1 : 0)>{}, bq, ar);
+                    if constexpr (NP == 1) issue_x(CPI<(r + 2) % 3>{}, CPI<2 * Q>{}, CPI<(2 * Q + 2 < 5 ? 2 * Q + 2 : 5)>{});
+                    else if constexpr (Q < 5) issue_x(CPI<(r + 2) % 3>{}, CPI<(Q < 5 ? Q : 0)>{}, CPI<(Q < 5 ? Q + 1 : 5)>{});
+#define CP_LANDED(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(bq[set][0][0]), "+v"(bq[set][0][1]), "+v"(bq[set][1][0]), "+v"(bq[set][1][1]))
+                    if constexpr (!more) CP_LANDED(0);
+                    else if constexpr (next_a) CP_LANDED(8);
+                    else CP_LANDED(4);
+#undef CP_LANDED
+                    if constexpr (r == 2 && pr == 0)
+                        asm volatile("" : "+v"(ar[s & 1][0][0]), "+v"(ar[s & 1][0][1]), "+v"(ar[s & 1][1][0]), "+v"(ar[s & 1][1][1]));
+                    constexpr int shift = MODE == 0 ? s : 2 - s;
+                    unsigned keep = shift == 0 ? lnb : rnb;
+                    asm volatile("" : "+v"(keep));            // (opaque per stage: hoisted, the lane masks cost registers)
+                    unsigned fm = fmask, eany = shift == 0 ? lany : rany;
+                    asm volatile("" : "+s"(fm), "+s"(eany));
+                    auto mm = [&](int j, const u32x4 (&bb)[2], auto GUARD_) {
+                        if ((!decltype(GUARD_)::value || ((fm >> j) & 1u)) && !CP_DBG(4)) {
+                            cp_i32x4 b0 = __builtin_bit_cast(cp_i32x4, bb[0]), b1 = __builtin_bit_cast(cp_i32x4, bb[1]);
+                            if (shift != 1 && ((eany >> j) & 1u) && !CP_DBG(16)) {
+                                const int mk = -(int)((keep >> j) & 1u);
+                                const cp_i32x4 m4 = {mk, mk, mk, mk};
+                                b0 &= m4; b1 &= m4;
+                            }
+                            const bf16x8 f0 = __builtin_bit_cast(bf16x8, b0), f1 = __builtin_bit_cast(bf16x8, b1);
+                            bf16x8 a00, a10, a01, a11;
+                            if constexpr (r == 2) {
+                                a00 = __builtin_bit_cast(bf16x8, ar[s & 1][0][0]); a10 = __builtin_bit_cast(bf16x8, ar[s & 1][1][0]);
+                                a01 = __builtin_bit_cast(bf16x8, ar[s & 1][0][1]); a11 = __builtin_bit_cast(bf16x8, ar[s & 1][1][1]);
+                            } else {
+                                a00 = aw[3 * r + s][0][0]; a10 = aw[3 * r + s][1][0]; a01 = aw[3 * r + s][0][1]; a11 = aw[3 * r + s][1][1];
+                            }
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, f0, acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, f0, acc[1][j], 0, 0, 0);
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, f1, acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, f1, acc[1][j], 0, 0, 0);
+                        }
+                    };
+                    mm(2 * pr, bq[set][0], CPI<0>{});
+                    mm(2 * pr + 1, bq[set][1], CPI<(pr + 1 == NP)>{});      // (only the last fragment of an odd count can be missing)
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                if constexpr (NP > 0) {
+                    reads(CPI<0>{}, bq_, ar_);
+                    __builtin_amdgcn_s_setprio(1);
+                    stage(CPI<0>{}, bq_, ar_); stage(CPI<1>{}, bq_, ar_); stage(CPI<2>{}, bq_, ar_);
+                    if constexpr (NP > 1) {
+                        stage(CPI<(NP > 1 ? 3 : 0)>{}, bq_, ar_); stage(CPI<(NP > 1 ? 4 : 0)>{}, bq_, ar_); stage(CPI<(NP > 1 ? 5 : 0)>{}, bq_, ar_);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                CP_STAMP(4);
+                ++gc;
+            };
+            auto chunks = [&](auto NP_) { chunk(NP_, CPI<0>{}); chunk(NP_, CPI<1>{}); chunk(NP_, CPI<2>{}); };
+            switch ((nf + 1) >> 1) {
+                case 0: chunks(CPI<0>{}); break;
+                case 1: chunks(CPI<1>{}); break;
+                default: chunks(CPI<2>{}); break;
+            }
+            if (!CP_DBG(256)) cp_epilogue<EPI, NPW>(p, acc, fmask, nf, m0, pw, frow, c_wave + 8 * fgrp, row1, wsum);
+            else if (acc[0][0][0] + acc[1][3][3] == 12345.f) p.stats[0] = 1.f;
+            CP_STAMP(5);
+        }
+        after_epi = true;
+    }
+#ifdef NKB_CONVP_STAMPS
+    if (stamp_on && lane == 0) for (int i = 0; i < 8; ++i) convp_stamps[wave >> 2][i] = st_acc[i];
+#endif
+
+    // ---- partial sums: the four pixel quarters of a channel through LDS
+    float* red = (float*)(smem + ROFF);                        // [PW][2][64]
+    if (frow == 0) {
+        const int cl = wvc * 32 + 8 * fgrp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[(pw * 2) * 64 + cl + e] = wsum[e]; red[(pw * 2 + 1) * 64 + cl + e] = wsum[8 + e]; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, chn = tid & 63;
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) tsum += red[(k * 2 + which) * 64 + chn];
+        p.stats[((size_t)wgm * 2 + which) * p.Cout + chn] = tsum;
+    }
+}
+
 constexpr int CP_LDS = 2 * 40 * 1024 + 8 * 8192 + 2 * 2 * 128 * 4 + 8 * 64 * 4;
+constexpr int CP_LDS64 = 3 * 40 * 1024 + 24 * 1024 + 2048 + 8 * 64 * 4;
 
 int cp_cus() {
     static int cus = [] {
@@ -483,6 +794,8 @@ int cp_cus() {
         hipFuncSetAttribute((const void*)convp_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
         hipFuncSetAttribute((const void*)convp_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
         hipFuncSetAttribute((const void*)convp_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
+        hipFuncSetAttribute((const void*)convp64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS64);
+        hipFuncSetAttribute((const void*)convp64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS64);
         return n > 0 ? n : 256;
     }();
     return cus;
@@ -491,7 +804,7 @@ int cp_cus() {
 struct CPGeom { int tc, tilesN, nwgm, rows_per_wg; };
 // the row split: as many workgroups as CUs (per channel tile), every one with the same number of 16-pixel fragments
 bool cp_geom(int M, int Cout, int cus, CPGeom& g) {
-    g.tc = Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : 0);
+    g.tc = Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : (Cout == 64 ? 64 : 0));
     if (!g.tc) return false;
     g.tilesN = Cout / g.tc;
     int want = cus / g.tilesN;
@@ -506,22 +819,31 @@ bool cp_geom(int M, int Cout, int cus, CPGeom& g) {
 
 }  // namespace
 
-static int g_cp_on = [] { const char* e = getenv("NKB_CONVP"); return e ? atoi(e) : 1; }();
-static int g_cp_tc128 = 0;
+// NKB_CONVP: 0 off, 1 on with the default envelope; any higher bits are nkb_convp_config's `narrow` << 1, bit 4 standing for "none of
+// the narrow forms" (17: 256-channel tiles only, 13: the 64-channel form in both directions — A/B timing)
+static int g_cp_env = [] { const char* e = getenv("NKB_CONVP"); return e ? atoi(e) : 1; }();
+static int g_cp_on = g_cp_env & 1;
+static int g_cp_tc128 = (g_cp_env >> 1) ? ((g_cp_env >> 1) & 1) : 0;
+static int g_cp_c64 = (g_cp_env >> 1) ? (((g_cp_env >> 2) & 1) | (((g_cp_env >> 3) & 1) << 1)) : 1;
 static int cp_enabled() { return g_cp_on; }
-// Envelope of the row-balanced 3x3 core: on = 0 / 1 (default 1, NKB_CONVP), tc128 = 1 also admits Cout % 256 != 0 (default 0)
-extern "C" void nkb_convp_config(int on, int tc128) { g_cp_on = on != 0; g_cp_tc128 = tc128 != 0; }
+// Envelope of the row-balanced 3x3 core: on = 0 / 1 (default 1, NKB_CONVP); narrow bit 0 also admits Cout % 256 == 128 (default off),
+// bit 1 the 64 -> 64 channel resident-filter form (default on), bit 2 that form for the data gradient too (default off)
+extern "C" void nkb_convp_config(int on, int narrow) {
+    g_cp_on = on != 0; g_cp_tc128 = (narrow & 1) != 0; g_cp_c64 = ((narrow & 2) ? 1 : 0) | ((narrow & 4) ? 2 : 0);
+}
 
 extern "C" int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int stride,
                                int pad) {
     if (!cp_enabled() || dtype != NKB_DT_BF16 || (kind != 0 && kind != 1)) return 0;
     if (R != 3 || S != 3 || stride != 1 || pad != 1) return 0;
-    if (Cin % 64 != 0 || Cin < 64 || ldx % 8 != 0 || ldy % 8 != 0 || Cout % 128 != 0) return 0;
+    const bool c64 = Cin == 64 && Cout == 64;                   // convp64_kernel: the filter lives in registers
+    if (c64 && (!g_cp_c64 || (kind == 1 && !(g_cp_c64 & 2)))) return 0;      // (the data gradient only on request: see nkb_convp_config)
+    if (Cin % 64 != 0 || Cin < 64 || ldx % 8 != 0 || ldy % 8 != 0 || (Cout % 128 != 0 && !c64)) return 0;
     // Cout % 256 != 0 runs as 128-channel tiles whose two pixel halves each stream their own copy of the filter: measured in the
     // ResNet-50 step (28 x 28 x 128, batch 256) level with the 128 x 128 kernel forward and 10 us slower in the data gradient, so
     // the train step only takes the 256-channel form (layer3 / layer4: -22 / -13 us forward, -10 / -5 us data gradient per launch);
     // nkb_convp_config(on, 1) lets the narrow form through (tests, experiments)
-    if (Cout % 256 != 0 && !g_cp_tc128) return 0;
+    if (Cout % 256 != 0 && !c64 && !g_cp_tc128) return 0;
     const long long M = (long long)N * H * W;
     if (M < 4096 || M * (long long)ldx * 2 >= 0xFFFFFF00ll || M * (long long)ldy >= (1ll << 31) ||
         (long long)Cout * 9 * Cin * 2 >= 0xFFFFFF00ll)
@@ -555,7 +877,10 @@ static int convp_launch(int kind, const void* x, const void* w, void* y, const v
     NkbProfScope prof(kind == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, flops, bytes);
     nkb_count_launch(6);
     const dim3 grid((unsigned)(g.nwgm * g.tilesN)), block(512);
-    if (g.tc == 256) {
+    if (g.tc == 64) {
+        if (kind == 0) hipLaunchKernelGGL((convp64_kernel<0>), grid, block, CP_LDS64, stream, p);
+        else hipLaunchKernelGGL((convp64_kernel<1>), grid, block, CP_LDS64, stream, p);
+    } else if (g.tc == 256) {
         if (kind == 0) hipLaunchKernelGGL((convp_kernel<256, 0>), grid, block, CP_LDS, stream, p);
         else hipLaunchKernelGGL((convp_kernel<256, 1>), grid, block, CP_LDS, stream, p);
     } else {

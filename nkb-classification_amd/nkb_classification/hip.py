@@ -480,8 +480,8 @@ def convp_tiles(dtype, kind, *, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad)
     return int(load().nkb_convp_tiles(dtype, kind, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad))
 
 
-def convp_config(on: bool = True, tc128: bool = False):
-    load().nkb_convp_config(int(on), int(tc128))
+def convp_config(on: bool = True, tc128: bool = False, c64: bool = True, c64_dgrad: bool = False):
+    load().nkb_convp_config(int(on), int(tc128) | (2 if c64 else 0) | (4 if c64_dgrad else 0))
 
 
 def convp_fwd(dtype, x, w, y, stats, *, N, H, W, Cin, ldx, Cout, ldy):

@@ -20,7 +20,7 @@ def run(N, H, W, Cin, Cout, kind, reps):
     x = (torch.randn(N, H, W, Cin, device=DEV)).to(torch.bfloat16)
     w = (torch.randn(Cout, 3, 3, Cin, device=DEV) * (1.0 / (3 * Cin ** 0.5))).to(torch.bfloat16)
     tiles0 = hip.stat_tiles(d, M, Cout)
-    tiles1 = hip.convp_config(True, True) or hip.convp_tiles(d, kind, N=N, H=H, W=W, Cin=Cin, ldx=Cin, Cout=Cout, ldy=Cout, R=3, S=3, stride=1, pad=1)
+    tiles1 = hip.convp_config(True, True, True, True) or hip.convp_tiles(d, kind, N=N, H=H, W=W, Cin=Cin, ldx=Cin, Cout=Cout, ldy=Cout, R=3, S=3, stride=1, pad=1)
     assert tiles1 > 0, "not eligible"
     y0 = torch.empty(N, H, W, Cout, device=DEV, dtype=torch.bfloat16)
     y1 = torch.full_like(y0, float("nan"))
@@ -64,8 +64,11 @@ def run(N, H, W, Cin, Cout, kind, reps):
 if __name__ == "__main__":
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     shapes = [(32, 14, 14, 256, 256), (8, 28, 28, 128, 128), (96, 7, 7, 512, 512), (9, 23, 23, 64, 128), (24, 14, 14, 128, 384)]
+    shapes += [(4, 56, 56, 64, 64), (5, 37, 29, 64, 64), (2, 48, 48, 64, 64)]          # the resident-filter form (convp64_kernel)
     if not quick:
-        shapes += [(256, 28, 28, 128, 128), (256, 14, 14, 256, 256), (256, 7, 7, 512, 512)]
+        shapes += [(256, 28, 28, 128, 128), (256, 14, 14, 256, 256), (256, 7, 7, 512, 512), (256, 56, 56, 64, 64)]
+    if len(sys.argv) > 1 and sys.argv[1] == "c64":
+        shapes = [(4, 56, 56, 64, 64), (5, 37, 29, 64, 64), (2, 48, 48, 64, 64), (256, 56, 56, 64, 64)]
     allok = True
     for sh in shapes:
         for kind in (0, 1):

@@ -25,6 +25,8 @@ buf = (ctypes.c_ulonglong * 16)()
 lib = ctypes.CDLL(os.environ["NKBHIP_LIB"])
 assert lib.nkb_convp_read_stamps(buf) == 0
 names = ["between k-tiles", "vmcnt wait / barrier / X issue", "filter fragments", "filter DMA issue", "pixel fragments + MFMA", "tail"]
+if ci == 64 and co == 64:      # convp64_kernel: per chunk
+    names = ["between chunks", "vmcnt wait", "barrier", "rows + X issue", "fragments + MFMA (3 k-tiles)", "epilogue"]
 kt = 36 if ci == 256 else (72 if ci == 512 else 18 * ((N * H * H // 256 + 255) // 256))
 for wv in range(2):
     tot = sum(buf[wv * 8 + i] for i in range(6))

@@ -19,14 +19,16 @@ D = hip.BF16
 
 # N, H, W, Cin, Cout: 128- and 256-channel tiles, sub-tiles with 4 ... 16 fragments, a pixel count that is no multiple of 16,
 # several sub-tiles per workgroup (the last case: 640 rows per workgroup on a 256-CU chip)
+# the 64 -> 64 channel form (filter resident in registers / LDS): one partial sub-tile, ragged rows, 3.25 sub-tiles per workgroup
 SHAPES = [(6, 28, 28, 64, 128), (24, 14, 14, 128, 256), (9, 23, 23, 64, 128), (90, 7, 7, 128, 512), (40, 28, 28, 64, 256),
-          (209, 28, 28, 64, 128), (256, 14, 14, 64, 256)]
+          (209, 28, 28, 64, 128), (256, 14, 14, 64, 256), (4, 56, 56, 64, 64), (5, 37, 29, 64, 64), (67, 56, 56, 64, 64)]
 
 
 @pytest.fixture(autouse=True)
 def _narrow_tiles_too():
-    """The 128-channel form is not taken by the train step (nkb_convp_config): these tests cover it as well."""
-    hip.convp_config(True, True)
+    """The 128-channel form and the 64-channel data gradient are not taken by the train step (nkb_convp_config): these tests cover
+    them as well."""
+    hip.convp_config(True, True, True, True)
     yield
     hip.convp_config(True, False)
 
@@ -125,13 +127,19 @@ def test_convp_dgrad_with_fused_bn_backward_matches_torch_and_unfused(shape):
 def test_convp_refuses_what_it_cannot_run():
     ok = dict(N=8, H=28, W=28, Cin=64, ldx=64, Cout=128, ldy=128, R=3, S=3, stride=1, pad=1)
     assert hip.convp_tiles(D, 0, **ok) > 0
-    for bad in (dict(R=1, S=1, pad=0), dict(stride=2), dict(Cin=32, ldx=32), dict(Cout=64, ldy=64), dict(N=1), dict(Cout=192, ldy=192)):
+    for bad in (dict(R=1, S=1, pad=0), dict(stride=2), dict(Cin=32, ldx=32), dict(Cout=64, ldy=64, Cin=128, ldx=128), dict(N=1), dict(Cout=192, ldy=192)):
         assert hip.convp_tiles(D, 0, **{**ok, **bad}) == 0, bad
     hip.convp_config(True, False)                 # the train step's envelope: 256-channel tiles only
     assert hip.convp_tiles(D, 0, **ok) == 0 and hip.convp_tiles(D, 0, **{**ok, "Cout": 256, "ldy": 256}) > 0
     hip.convp_config(False, False)
     assert hip.convp_tiles(D, 0, **{**ok, "Cout": 256, "ldy": 256}) == 0
-    hip.convp_config(True, True)
+    c64 = dict(ok, H=56, W=56, Cout=64, ldy=64)
+    hip.convp_config(True, False)                 # ... and the 64-channel form forward only
+    assert hip.convp_tiles(D, 0, **c64) > 0 and hip.convp_tiles(D, 1, **c64) == 0
+    hip.convp_config(True, False, False)
+    assert hip.convp_tiles(D, 0, **c64) == 0
+    hip.convp_config(True, True, True, True)
+    assert hip.convp_tiles(D, 1, **c64) > 0
     assert hip.convp_tiles(hip.F32, 0, **ok) == 0
     x = torch.zeros(1, 28, 28, 64, device=DEV, dtype=T)
     with pytest.raises(RuntimeError, match="not eligible"):
