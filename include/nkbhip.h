@@ -35,7 +35,8 @@ const char* nkb_last_error(void);
 int nkb_version(void);
 /* Launch counters of the specialised kernels since process start (or the last reset): which = 0 eight-phase GEMM (gemm8p), 1 eight-phase
  * weight gradient (wgrad8p / wgrad256), 2 shared-strip 3x3 weight gradient, 3 fp8 weight gradient, 4 Gram-form closing convolution,
- * 5 bn_apply fused with the Gram matrix, 6 row-balanced 3x3 core (convp).  Tests use them to prove that a benchmark configuration took the path it is priced on. */
+ * 5 bn_apply fused with the Gram matrix, 6 row-balanced 3x3 core (convp), 7 pixel-resident 1x1 expansion (conv1p), 8 ring-buffered stem
+ * (stemp).  Tests use them to prove that a benchmark configuration took the path it is priced on. */
 long long nkb_kernel_launches(int which, int reset);
 
 /* Implicit-GEMM convolution / linear layer on MFMA.
@@ -106,9 +107,18 @@ int nkb_conv_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, 
  * nkb_convp_dgrad_bn: nkb_conv_dgrad_bn's recomputed-mask form (no residual operand); w is the [Cin][3][3][Cout] data-gradient filter,
  * Cin / ldx describe dY, Cout / ldy the produced gradient.  Both feed nkb_bn_finalize / nkb_bn_backward_from_stats with `tiles`. */
 int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int stride, int pad);
-/* on = 0 / 1: the core is used at all (default 1); narrow bit 0: also for Cout % 256 == 128 as 128-channel tiles (default 0: measured
- * level with / slower than the 128 x 128 kernel in the ResNet-50 step); narrow bit 1: the 64 -> 64 channel form with the filter resident
- * in registers / LDS (default 1: forward), bit 2: that form for the data gradient as well (default 0).  Tests and A/B timing. */
+/* Pixel-resident 1x1 / stride-1 convolution in bf16 for the EXPANSION stage of a bottleneck (csrc/conv1p.hip) — timm Bottleneck conv3,
+ * Cin = 256 -> Cout >= 2 Cin (multiple of 256), forward from /root/reference/nkb_classification/engine.py:48.  One workgroup per CU
+ * keeps its M / #CUs pixels x Cin in LDS and walks all output channels with the filter streamed from L2 into registers; y = conv(x, w),
+ * stats[tiles][2][Cout] = per-workgroup sums of y and y^2 (nkb_conv_gemm(mode 0) with stats; feeds nkb_bn_finalize with `tiles`).
+ * nkb_conv1p_tiles: 0 = shape not eligible -> use nkb_conv_gemm.  x is [M][ldx], w [Cout][Cin], y [M][ldy]. */
+int nkb_conv1p_tiles(int dtype, long long M, int Cin, int ldx, int Cout, int ldy);
+int nkb_conv1p_fwd(int dtype, const void* x, const void* w, void* y, float* stats, long long M, int Cin, int ldx, int Cout, int ldy,
+                   nkb_stream_t stream);
+/* The envelope of the row-resident kernels (convp, conv1p, stemp; NKB_CONVP=0 switches the family off).  on = 0 / 1 (default 1);
+ * narrow bit 0: 3x3 also for Cout % 256 == 128 as 128-channel tiles (default 0: measured level with / slower than the 128 x 128 kernel
+ * in the ResNet-50 step); bit 1: the 64 -> 64 channel 3x3 form with the filter resident in registers / LDS (default 1: forward), bit 2:
+ * that form for the data gradient as well (default 0); bit 4 / bit 5: conv1p / stemp OFF (default on).  Tests and A/B timing. */
 void nkb_convp_config(int on, int narrow);
 int nkb_convp_fwd(int dtype, const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int ldx, int Cout,
                   int ldy, nkb_stream_t stream);
@@ -218,6 +228,9 @@ int nkb_im2row(int dtype, const float* x, void* col, int N, int Cin, int H, int 
  *   nkb_stem_pack   NCHW fp32 image -> xp[N][H][Wp][4] in the compute dtype, Wp = W rounded up to even
  *   nkb_stem_wprep  fp32 master [Cout][7][7][C] -> wp[Cout][nkb_stem_weight_cols(dtype)] in the compute dtype
  *   nkb_stem_conv   y[N*P*Q][ldy] = conv(xp, wp), optional per-tile BN partial sums (as nkb_conv_gemm, mode 0)
+ *   nkb_stemp_conv  the same product for bf16 / 64 output channels with image rows streamed ONCE through an LDS ring (csrc/stemp.hip:
+ *                   one workgroup per image or band of output rows); stats[tiles][2][64] with tiles = nkb_stemp_tiles(...) (0: not
+ *                   eligible -> nkb_stem_conv) — one partial-sum row per workgroup, feeds nkb_bn_finalize like nkb_stem_conv's
  *   nkb_stem_wgrad  dwp[Cout][224] (fp32, zeroed by the caller) += dY^T x window(xp)
  *   nkb_stem_wfold  dw[Cout][7][7][C] += dwp (drops the padding columns) */
 int nkb_stem_pack(int dtype, const float* x, void* out, int N, int C, int H, int W, nkb_stream_t stream);
@@ -225,6 +238,9 @@ int nkb_stem_wprep(int dtype, const float* w, void* wp, int Cout, int C, nkb_str
 int nkb_stem_weight_cols(int dtype);
 int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y, float* stats, int N, int H, int W, int Cout,
                   int ldy, nkb_stream_t stream);
+int nkb_stemp_tiles(int dtype, int N, int H, int W, int Cout);
+int nkb_stemp_conv(int dtype, const void* xp, const void* wp, void* y, float* stats, int N, int H, int W, int Cout, int ldy,
+                   nkb_stream_t stream);
 int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N, int H, int W, int Cout, int lddy,
                    float* workspace, long long workspace_floats, nkb_stream_t stream);
 long long nkb_stem_wgrad_workspace_floats(int dtype, int N, int H, int W, int Cout);

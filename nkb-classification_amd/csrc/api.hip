@@ -29,10 +29,10 @@ extern "C" const char* nkb_last_error() { return g_err; }
 extern "C" int nkb_version() { return 100; }
 
 #include <atomic>
-static std::atomic<long long> g_launches[8];
-void nkb_count_launch(int which) { if ((unsigned)which < 8u) g_launches[which].fetch_add(1, std::memory_order_relaxed); }
+static std::atomic<long long> g_launches[16];
+void nkb_count_launch(int which) { if ((unsigned)which < 16u) g_launches[which].fetch_add(1, std::memory_order_relaxed); }
 extern "C" long long nkb_kernel_launches(int which, int reset) {
-    if ((unsigned)which >= 8u) return -1;
+    if ((unsigned)which >= 16u) return -1;
     return reset ? g_launches[which].exchange(0) : g_launches[which].load();
 }
 

@@ -782,8 +782,324 @@ __global__ __launch_bounds__(512, 1) void convp64_kernel(const CPParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The 64 -> 64 channel form, second structure: ONE activation stage per 256-pixel sub-tile, holding the sub-tile with a halo of
+// W + 1 pixels on either side (370 stage rows for W = 56), read by all NINE taps: tap (dr, dc) of pixel i, both counted from 0, is
+// stage row i + dc + dr W.  What this removes from convp64_kernel's instruction stream (the kernel is issue-bound: an MFMA holds the SIMD's
+// vector issue for 8 cycles, every other vector instruction for 4, two waves share it):
+//   * 6 DMA pieces per wave and sub-tile instead of 15 (each activation row enters LDS once per sub-tile, not once per filter row),
+//     with a clamped source row instead of the per-piece row-validity bits (what lies outside the image is masked, below);
+//   * one barrier and one counted wait per sub-tile instead of three;
+//   * no address arithmetic in the k-loop: W % 8 == 0 makes the XOR swizzle of a row invariant under +- W, so the nine taps are three
+//     base addresses (one per column shift) plus instruction offsets; the two stages differ by an add per sub-tile;
+//   * rows above / below the image are masked like the column edges — in the few fragments that have such a pixel (scalar flags).
+// One software pipeline of LDS reads runs through all nine k-tiles of a sub-tile.  EPI 1 (data gradient + fused BatchNorm backward)
+// brings the sub-tile's rows of the raw output c into LDS by DMA as well (32 KB, issued behind the sub-tile's barrier, landed long
+// before its epilogue) and keeps scale / shift / mean in LDS: the epilogue has no global load, so nothing in the kernel ever waits
+// for "all vector memory".  W is compiled in (56: timm ResNet-50 layer1 at 224 x 224).
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void convp64h_kernel(const CPParams p) {
+    constexpr int NPW = 4, PW = 4, WW = 56, HALO = WW + 1, MODE = EPI;
+    constexpr int XSH = 48 * 1024;                 // one stage: 48 DMA pieces of 8 rows (rows 0 .. 369 are read)
+    constexpr int WL = 2 * XSH;                    // filter row 2: [channel half][column tap][channel fragment][16 rows] x 128 B
+    constexpr int CL = WL + 24 * 1024;             // EPI 1: the sub-tile's rows of c, 256 x 128 B
+    constexpr int ROFF = CL + (EPI == 1 ? 32 * 1024 : 0);      // [PW][2][64] floats of the final reduction, then scale | shift | mean
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wvc = wave & 1, pw = wave >> 1;
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int wgm = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = wgm * p.rows_per_wg;
+    const int row1 = min(p.M, row0 + p.rows_per_wg);
+    const int nsub = (row1 - row0 + 255) >> 8;
+    const int c_wave = wvc * 32;
+
+    // ---- the filter: rows 0 and 1 in registers, row 2 in LDS (convp64_kernel)
+    bf16x8 aw[6][2][2];
+    {
+        const bf16_t* wl = p.w + (size_t)(c_wave + 8 * (frow >> 2) + (frow & 3)) * p.ldw + 8 * fgrp;
+#pragma unroll
+        for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) aw[kt][i][ks] = *(const bf16x8*)(wl + (size_t)(4 * i) * p.ldw + 64 * kt + 32 * ks);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int pc = tid + 512 * it;
+            const int R = pc >> 3, c = pc & 7;
+            const int fr = R & 15, i = (R >> 4) & 1, hs = R >> 5;
+            const int half = hs / 3, tap = hs - 3 * half;
+            const int chn = half * 32 + 8 * (fr >> 2) + 4 * i + (fr & 3);
+            const u32x4 v = *(const u32x4*)(p.w + (size_t)chn * p.ldw + 64 * (6 + tap) + 8 * c);
+            *(u32x4*)(smem + WL + R * 128 + ((c ^ (fr & 7)) << 4)) = v;
+        }
+        if constexpr (EPI == 1) {
+            if (tid < 192) {
+                const float* src = tid < 64 ? p.bn_scale : (tid < 128 ? p.bn_shift : p.bn_mean);
+                ((float*)(smem + ROFF + 2048))[tid] = src[tid & 63];
+            }
+        }
+    }
+    // read addresses: pixel fragments of fragment 0, filter-row tap 0, per column shift dc (stage row = pixel + dc); filter row 2;
+    // the c tile (EPI 1).  Fragment, k-step, filter row and filter tap go into the instructions' offset fields.
+    unsigned sa0[3], sa1[3];
+#pragma unroll
+    for (int dc = 0; dc < 3; ++dc) {
+        const int brow = pw * NPW * 16 + frow + dc;            // (HALO - W - 1 = 0: pixel i, tap (dr, dc) counted from 0, is stage row i + dc + dr W)
+        const unsigned aoff = (unsigned)(brow * 128 + ((fgrp ^ (brow & 7)) << 4));
+        sa0[dc] = lds0 + aoff;
+        sa1[dc] = lds0 + (aoff ^ 64u);
+    }
+    int sstep = XSH;                                           // sub-tile t reads stage t & 1
+    const unsigned wa0 = lds0 + (unsigned)(WL + (wvc * 96 + frow) * 128 + ((fgrp ^ (frow & 7)) << 4));
+    const unsigned wa1 = lds0 + (unsigned)(WL + (wvc * 96 + frow) * 128 + (((4 + fgrp) ^ (frow & 7)) << 4));
+    const int crow = pw * NPW * 16 + frow;
+    const unsigned char* const cl0 = smem + CL + crow * 128 + (((wvc * 4 + fgrp) ^ (crow & 7)) << 4);
+
+    // ---- DMA: piece q = wave + 8 i holds stage rows 8 q .. 8 q + 7 = pixels m0 - HALO + row, clamped into the tensor (what the clamp
+    // changes lies above the first / below the last image: masked); lane (lrow, chunk) fetches the chunk the XOR swizzle puts there
+    const int xm = row0 - HALO + 8 * wave + lrow;
+    auto issue_x = [&](int tn, auto I0_, auto I1_) {           // pieces I0 .. I1 - 1 of sub-tile tn into stage tn & 1
+        constexpr int i0 = decltype(I0_)::value, i1 = decltype(I1_)::value;
+        if (tn < nsub && !CP_DBG(1)) {
+            unsigned char* d_ = smem + (tn & 1) * XSH + wave * 1024;
+#pragma unroll
+            for (int i = i0; i < i1; ++i) {
+                const int m = min(max(xm + 256 * tn + 64 * i, 0), p.M - 1);
+                cp_glds16((const unsigned char*)p.x + ((size_t)m * (size_t)(p.ldx * 2) + (size_t)(lch * 16)), d_ + i * 8192);
+            }
+        }
+    };
+    auto issue_c = [&](int tn) {                                // EPI 1: the 256 rows of c of sub-tile tn, 4 pieces per wave
+        if (!CP_DBG(1)) {
+            unsigned char* d_ = smem + CL + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = min(row0 + 256 * tn + 8 * wave + lrow + 64 * i, p.M - 1);
+                cp_glds16((const unsigned char*)p.aux + ((size_t)m * (size_t)(p.ldy * 2) + (size_t)(lch * 16)), d_ + i * 8192);
+            }
+        }
+    };
+
+    float ssum[8], ssq[8];                                     // this lane's partial sums over all its sub-tiles (reduced once, at the end)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+
+    // the filter loads are waited for HERE (see convp64_kernel), then stage 0
+#pragma unroll
+    for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(aw[kt][i][0]), "+v"(aw[kt][i][1]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_x(0, CPI<0>{}, CPI<6>{});
+
+    for (int t = 0; t < nsub; ++t) {
+        const int m0 = row0 + 256 * t;
+        const int nv = min(256, row1 - m0);
+        const int nf = __builtin_amdgcn_readfirstlane(max(0, min(NPW, ((nv + 15) >> 4) - pw * NPW)));
+        const unsigned fmask = (unsigned)__builtin_amdgcn_readfirstlane((int)((1u << nf) - 1u));
+        // edge lanes: bit j of lnb / rnb / tnb / bnb — this lane's pixel of fragment j has a left / right / upper / lower neighbour inside
+        // its image; bit j of the scalars l/r/t/b-any — SOME lane of fragment j has none (only those fragments pay for the masking)
+        unsigned lnb = 0u, rnb = 0u, tnb = 0u, bnb = 0u, lany = 0u, rany = 0u, tany = 0u, bany = 0u;
+        {
+            const unsigned m = (unsigned)(m0 + pw * NPW * 16 + frow);
+            const unsigned n = fdiv(m, p.divHW);
+            const unsigned rem = m - n * p.divHW.d;
+            unsigned h = fdiv(rem, p.divW), wq = rem - h * p.divW.d;
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                if (wq > 0u) lnb |= 1u << j;
+                if (wq + 1u < (unsigned)WW) rnb |= 1u << j;
+                if (h > 0u) tnb |= 1u << j;
+                if (h + 1u < (unsigned)p.H) bnb |= 1u << j;
+                if (__builtin_amdgcn_ballot_w64(wq == 0u) != 0ull) lany |= 1u << j;
+                if (__builtin_amdgcn_ballot_w64(wq + 1u == (unsigned)WW) != 0ull) rany |= 1u << j;
+                if (__builtin_amdgcn_ballot_w64(h == 0u) != 0ull) tany |= 1u << j;
+                if (__builtin_amdgcn_ballot_w64(h + 1u == (unsigned)p.H) != 0ull) bany |= 1u << j;
+                wq += 16u;                                     // the next fragment's pixel: 16 further
+                if (wq >= (unsigned)WW) { wq -= (unsigned)WW; if (++h == (unsigned)p.H) h = 0u; }
+            }
+            lany = (unsigned)__builtin_amdgcn_readfirstlane((int)lany); rany = (unsigned)__builtin_amdgcn_readfirstlane((int)rany);
+            tany = (unsigned)__builtin_amdgcn_readfirstlane((int)tany); bany = (unsigned)__builtin_amdgcn_readfirstlane((int)bany);
+        }
+
+        // this wave's pieces of stage t have landed: younger are only the last epilogue's NPW stores (a full sub-tile came before)
+        if (t == 0) cp_vmcnt<0>(); else cp_vmcnt<NPW>();
+        CP_BARRIER();                                          // every wave's pieces; stage t + 1 and the c tile are read out
+        if constexpr (EPI == 1) issue_c(t);
+        f32x4 acc[2][NPW];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) { acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+        auto kloop = [&](auto NP_) {
+            constexpr int NP = decltype(NP_)::value;
+            constexpr int NPD = NP > 0 ? NP : 1;
+            if constexpr (NP == 0) { issue_x(t + 1, CPI<0>{}, CPI<6>{}); return; }
+            // 9 NP stages (k-tile kt = 3 r + s, fragment pair pr): stage q issues the LDS reads of stage q + 1 and, early in the loop, a
+            // DMA piece of sub-tile t + 1, then waits for its own reads alone (fixed counts: inline assembly throughout)
+            u32x4 bq_[2][2][2];                                // [register set][fragment of the pair][k-step]
+            u32x4 ar_[2][2][2];                                // filter row 2: [k-tile parity][channel fragment][k-step]
+            auto reads = [&](auto Q_, u32x4 (&bq)[2][2][2], u32x4 (&ar)[2][2][2]) {
+                constexpr int Q = decltype(Q_)::value, kt = Q / NPD, pr = Q % NPD, set = Q & 1;
+                constexpr int r = kt / 3, s = kt % 3;
+                constexpr int dr = MODE == 0 ? r : 2 - r, dc = MODE == 0 ? s : 2 - s;
+                constexpr int toff = dr * WW * 128;
+                const unsigned ab0 = sa0[dc], ab1 = sa1[dc], fa0 = wa0, fa1 = wa1;
+                if constexpr (r == 2 && pr == 0) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[s & 1][0][0]) : "v"(fa0), "n"((2 * s) * 2048));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[s & 1][0][1]) : "v"(fa1), "n"((2 * s) * 2048));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[s & 1][1][0]) : "v"(fa0), "n"((2 * s + 1) * 2048));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ar[s & 1][1][1]) : "v"(fa1), "n"((2 * s + 1) * 2048));
+                }
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[set][0][0]) : "v"(ab0), "n"(toff + 2048 * (2 * pr)));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[set][0][1]) : "v"(ab1), "n"(toff + 2048 * (2 * pr)));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[set][1][0]) : "v"(ab0), "n"(toff + 2048 * (2 * pr + 1)));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[set][1][1]) : "v"(ab1), "n"(toff + 2048 * (2 * pr + 1)));
+            };
+            auto stage = [&](auto Q_, u32x4 (&bq)[2][2][2], u32x4 (&ar)[2][2][2]) {
+                constexpr int Q = decltype(Q_)::value, kt = Q / NPD, pr = Q % NPD, set = Q & 1;
+                constexpr int r = kt / 3, s = kt % 3;
+                constexpr int dr = MODE == 0 ? r : 2 - r, dc = MODE == 0 ? s : 2 - s;
+                constexpr bool more = Q + 1 < 9 * NP;
+                constexpr bool next_a = more && (Q + 1) / NPD >= 6 && (Q + 1) % NPD == 0;      // stage Q + 1 opens a k-tile of filter row 2
+                if constexpr (more) reads(CPI<(more ? Q + 1 : 0)>{}, bq, ar);
+                // DMA pieces of sub-tile t + 1: one in each of the first six stages — early, so that the last one has twelve stages and an
+                // epilogue (~2 us) to land (spread evenly over the 18, the wait at the next sub-tile's top was a third of the wave cycles)
+                if constexpr (Q < 6) issue_x(t + 1, CPI<(Q < 6 ? Q : 0)>{}, CPI<(Q < 6 ? Q + 1 : 1)>{});
+#define CP_LANDED(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(bq[set][0][0]), "+v"(bq[set][0][1]), "+v"(bq[set][1][0]), "+v"(bq[set][1][1]))
+                if constexpr (!more) CP_LANDED(0);
+                else if constexpr (next_a) CP_LANDED(8);
+                else CP_LANDED(4);
+#undef CP_LANDED
+                if constexpr (r == 2 && pr == 0)
+                    asm volatile("" : "+v"(ar[s & 1][0][0]), "+v"(ar[s & 1][0][1]), "+v"(ar[s & 1][1][0]), "+v"(ar[s & 1][1][1]));
+                unsigned keepw = dc == 0 ? lnb : rnb, keeph = dr == 0 ? tnb : bnb;
+                asm volatile("" : "+v"(keepw), "+v"(keeph));   // (opaque per stage: hoisted, the lane masks cost registers)
+                unsigned fm = fmask, anyw = dc == 0 ? lany : rany, anyh = dr == 0 ? tany : bany;
+                asm volatile("" : "+s"(fm), "+s"(anyw), "+s"(anyh));
+                auto mm = [&](int j, const u32x4 (&bb)[2], auto GUARD_) {
+                    if ((!decltype(GUARD_)::value || ((fm >> j) & 1u)) && !CP_DBG(4)) {
+                        cp_i32x4 b0 = __builtin_bit_cast(cp_i32x4, bb[0]), b1 = __builtin_bit_cast(cp_i32x4, bb[1]);
+                        if (dc != 1 && ((anyw >> j) & 1u)) {
+                            const int mk = -(int)((keepw >> j) & 1u);
+                            const cp_i32x4 m4 = {mk, mk, mk, mk};
+                            b0 &= m4; b1 &= m4;
+                        }
+                        if (dr != 1 && ((anyh >> j) & 1u)) {
+                            const int mk = -(int)((keeph >> j) & 1u);
+                            const cp_i32x4 m4 = {mk, mk, mk, mk};
+                            b0 &= m4; b1 &= m4;
+                        }
+                        const bf16x8 f0 = __builtin_bit_cast(bf16x8, b0), f1 = __builtin_bit_cast(bf16x8, b1);
+                        bf16x8 a00, a10, a01, a11;
+                        if constexpr (r == 2) {
+                            a00 = __builtin_bit_cast(bf16x8, ar[s & 1][0][0]); a10 = __builtin_bit_cast(bf16x8, ar[s & 1][1][0]);
+                            a01 = __builtin_bit_cast(bf16x8, ar[s & 1][0][1]); a11 = __builtin_bit_cast(bf16x8, ar[s & 1][1][1]);
+                        } else {
+                            a00 = aw[r == 2 ? 0 : kt][0][0]; a10 = aw[r == 2 ? 0 : kt][1][0];
+                            a01 = aw[r == 2 ? 0 : kt][0][1]; a11 = aw[r == 2 ? 0 : kt][1][1];
+                        }
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, f0, acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, f0, acc[1][j], 0, 0, 0);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, f1, acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, f1, acc[1][j], 0, 0, 0);
+                    }
+                };
+                mm(2 * pr, bq[set][0], CPI<0>{});
+                mm(2 * pr + 1, bq[set][1], CPI<(pr + 1 == NP)>{});      // (only the last fragment of an odd count can be missing)
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            reads(CPI<0>{}, bq_, ar_);
+            __builtin_amdgcn_s_setprio(1);
+            stage(CPI<0>{}, bq_, ar_); stage(CPI<1>{}, bq_, ar_); stage(CPI<2>{}, bq_, ar_); stage(CPI<3>{}, bq_, ar_); stage(CPI<4>{}, bq_, ar_);
+            stage(CPI<5>{}, bq_, ar_); stage(CPI<6>{}, bq_, ar_); stage(CPI<7>{}, bq_, ar_); stage(CPI<8>{}, bq_, ar_);
+            if constexpr (NP > 1) {
+                stage(CPI<(NP > 1 ? 9 : 0)>{}, bq_, ar_); stage(CPI<(NP > 1 ? 10 : 0)>{}, bq_, ar_); stage(CPI<(NP > 1 ? 11 : 0)>{}, bq_, ar_);
+                stage(CPI<(NP > 1 ? 12 : 0)>{}, bq_, ar_); stage(CPI<(NP > 1 ? 13 : 0)>{}, bq_, ar_); stage(CPI<(NP > 1 ? 14 : 0)>{}, bq_, ar_);
+                stage(CPI<(NP > 1 ? 15 : 0)>{}, bq_, ar_); stage(CPI<(NP > 1 ? 16 : 0)>{}, bq_, ar_); stage(CPI<(NP > 1 ? 17 : 0)>{}, bq_, ar_);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        switch ((nf + 1) >> 1) {
+            case 0: kloop(CPI<0>{}); break;
+            case 1: kloop(CPI<1>{}); break;
+            default: kloop(CPI<2>{}); break;
+        }
+
+        // ---- epilogue, straight from the accumulators (cp_epilogue's arithmetic; c, scale, shift, mean from LDS in EPI 1)
+        const int cch = c_wave + 8 * fgrp;
+        if constexpr (EPI == 1) {
+            // the c tile: this wave's pieces are older than the (up to) six of stage t + 1; then everybody's
+            if (t + 1 < nsub) cp_vmcnt<6>(); else cp_vmcnt<0>();
+            CP_BARRIER();
+        }
+        if (!CP_DBG(256)) {
+            float sc[8], sh[8], mu[8];
+            if constexpr (EPI == 1) {
+                const float* bnc = (const float*)(smem + ROFF + 2048);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sc[e] = bnc[cch + e]; sh[e] = bnc[64 + cch + e]; mu[e] = bnc[128 + cch + e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                if ((fmask >> j) & 1u) {
+                    const int m = m0 + (pw * NPW + j) * 16 + frow;
+                    float v[8], cv[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[0][j][e]; v[4 + e] = acc[1][j][e]; }
+                    if constexpr (EPI == 1) {
+                        unpack8(*(const u32x4*)(cl0 + j * 2048), cv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (!(bf2f(f2bf(cv[e] * sc[e] + sh[e])) > 0.f)) v[e] = 0.f;     // same expression / rounding as bn_apply
+                            cv[e] -= mu[e];
+                        }
+                    }
+                    const u32x4 pk = pack8(v);
+                    if (m < row1 && !CP_DBG(8)) {
+                        __builtin_nontemporal_store(pk, (u32x4*)(p.y + (size_t)m * p.ldy + cch));
+                        unpack8(pk, v);                        // statistics see the stored value
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            ssum[e] += v[e];
+                            ssq[e] += EPI == 1 ? v[e] * cv[e] : v[e] * v[e];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc) { sa0[dc] += (unsigned)sstep; sa1[dc] += (unsigned)sstep; }
+        sstep = -sstep;
+    }
+
+    // ---- partial sums: the 16 pixel lanes of a channel by DPP, the four pixel quarters through LDS
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = cp_row16_sum(ssum[e]); ssq[e] = cp_row16_sum(ssq[e]); }
+    float* red = (float*)(smem + ROFF);                        // [PW][2][64]
+    if (frow == 0) {
+        const int cl = wvc * 32 + 8 * fgrp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[(pw * 2) * 64 + cl + e] = ssum[e]; red[(pw * 2 + 1) * 64 + cl + e] = ssq[e]; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, chn = tid & 63;
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) tsum += red[(k * 2 + which) * 64 + chn];
+        p.stats[((size_t)wgm * 2 + which) * p.Cout + chn] = tsum;
+    }
+}
+
 constexpr int CP_LDS = 2 * 40 * 1024 + 8 * 8192 + 2 * 2 * 128 * 4 + 8 * 64 * 4;
 constexpr int CP_LDS64 = 3 * 40 * 1024 + 24 * 1024 + 2048 + 8 * 64 * 4;
+constexpr int CP_LDS64H0 = 2 * 48 * 1024 + 24 * 1024 + 2048 + 1024, CP_LDS64H1 = CP_LDS64H0 + 32 * 1024;
 
 int cp_cus() {
     static int cus = [] {
@@ -796,6 +1112,8 @@ int cp_cus() {
         hipFuncSetAttribute((const void*)convp_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS);
         hipFuncSetAttribute((const void*)convp64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS64);
         hipFuncSetAttribute((const void*)convp64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS64);
+        hipFuncSetAttribute((const void*)convp64h_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS64H0);
+        hipFuncSetAttribute((const void*)convp64h_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS64H1);
         return n > 0 ? n : 256;
     }();
     return cus;
@@ -819,17 +1137,26 @@ bool cp_geom(int M, int Cout, int cus, CPGeom& g) {
 
 }  // namespace
 
-// NKB_CONVP: 0 off, 1 on with the default envelope; any higher bits are nkb_convp_config's `narrow` << 1, bit 4 standing for "none of
-// the narrow forms" (17: 256-channel tiles only, 13: the 64-channel form in both directions — A/B timing)
+// NKB_CONVP: the switch of the whole family of row-resident kernels (this file, conv1p.hip, stemp.hip): 0 off, 1 on with the default
+// envelope; any higher bits are nkb_convp_config's `narrow` << 1 (A/B timing: 17 = 1 | 8 << 1: 256-channel 3x3 tiles + conv1p + stemp
+// only, 13: the 64-channel form in both directions, 37: default without conv1p, 69: default without stemp)
 static int g_cp_env = [] { const char* e = getenv("NKB_CONVP"); return e ? atoi(e) : 1; }();
 static int g_cp_on = g_cp_env & 1;
 static int g_cp_tc128 = (g_cp_env >> 1) ? ((g_cp_env >> 1) & 1) : 0;
 static int g_cp_c64 = (g_cp_env >> 1) ? (((g_cp_env >> 2) & 1) | (((g_cp_env >> 3) & 1) << 1)) : 1;
+static int g_cp_no1p = (g_cp_env >> 5) & 1, g_cp_nostem = (g_cp_env >> 6) & 1;
+// forms 4 (conv1p.hip) and 5 (stemp.hip) ask here
+extern "C" int nkb_convp_form_enabled(int form) {
+    if (!g_cp_on) return 0;
+    return form == 4 ? !g_cp_no1p : (form == 5 ? !g_cp_nostem : 1);
+}
 static int cp_enabled() { return g_cp_on; }
-// Envelope of the row-balanced 3x3 core: on = 0 / 1 (default 1, NKB_CONVP); narrow bit 0 also admits Cout % 256 == 128 (default off),
-// bit 1 the 64 -> 64 channel resident-filter form (default on), bit 2 that form for the data gradient too (default off)
+// Envelope of the row-resident kernels: on = 0 / 1 (default 1, NKB_CONVP); narrow bit 0 also admits Cout % 256 == 128 (default off),
+// bit 1 the 64 -> 64 channel resident-filter form (default on), bit 2 that form for the data gradient too (default off), bit 4 / 5
+// switch the pixel-resident 1x1 expansion (conv1p.hip) / the ring-buffered stem (stemp.hip) OFF (default on)
 extern "C" void nkb_convp_config(int on, int narrow) {
     g_cp_on = on != 0; g_cp_tc128 = (narrow & 1) != 0; g_cp_c64 = ((narrow & 2) ? 1 : 0) | ((narrow & 4) ? 2 : 0);
+    g_cp_no1p = (narrow >> 4) & 1; g_cp_nostem = (narrow >> 5) & 1;
 }
 
 extern "C" int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int stride,
@@ -878,7 +1205,10 @@ static int convp_launch(int kind, const void* x, const void* w, void* y, const v
     nkb_count_launch(6);
     const dim3 grid((unsigned)(g.nwgm * g.tilesN)), block(512);
     if (g.tc == 64) {
-        if (kind == 0) hipLaunchKernelGGL((convp64_kernel<0>), grid, block, CP_LDS64, stream, p);
+        if (W == 56) {                                          // the one-stage halo form is compiled for 56-pixel rows
+            if (kind == 0) hipLaunchKernelGGL((convp64h_kernel<0>), grid, block, CP_LDS64H0, stream, p);
+            else hipLaunchKernelGGL((convp64h_kernel<1>), grid, block, CP_LDS64H1, stream, p);
+        } else if (kind == 0) hipLaunchKernelGGL((convp64_kernel<0>), grid, block, CP_LDS64, stream, p);
         else hipLaunchKernelGGL((convp64_kernel<1>), grid, block, CP_LDS64, stream, p);
     } else if (g.tc == 256) {
         if (kind == 0) hipLaunchKernelGGL((convp_kernel<256, 0>), grid, block, CP_LDS, stream, p);

@@ -36,6 +36,8 @@ _SIGS = {
     "nkb_bn_backward_workspace_floats": (sz, [i64, i32]),
     "nkb_conv_dgrad_bn": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32] + [i32] * 13 + [vp]),
     "nkb_convp_tiles": (i32, [i32] * 13),
+    "nkb_conv1p_tiles": (i32, [i32, i64, i32, i32, i32, i32]),
+    "nkb_conv1p_fwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "nkb_convp_config": (None, [i32, i32]),
     "nkb_convp_fwd": (i32, [i32, vp, vp, vp, vp] + [i32] * 7 + [vp]),
     "nkb_convp_dgrad_bn": (i32, [i32] + [vp] * 8 + [i32] * 7 + [vp]),
@@ -57,6 +59,8 @@ _SIGS = {
     "nkb_wprep_block_elems": (i32, []),
     "nkb_wprep_job_blocks": (i64, [i32, i32, i32, i32, i32]),
     "nkb_stem_pack": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
+    "nkb_stemp_tiles": (i32, [i32, i32, i32, i32, i32]),
+    "nkb_stemp_conv": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_stem_weight_cols": (i32, [i32]),
     "nkb_stem_conv": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -165,7 +169,7 @@ def exported_symbols():
 # (input images, logits, logits gradient) and dropout seeds.
 _REC = None            # list of plan entries while recording
 _REC_LIB = None
-_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_convp_tiles", "nkb_bn_stats_floats",
+_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_convp_tiles", "nkb_conv1p_tiles", "nkb_stemp_tiles", "nkb_bn_stats_floats",
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
@@ -430,8 +434,9 @@ def _device_allocs() -> int:
 
 
 def kernel_launches(which: str, reset: bool = False) -> int:
-    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply, convp."""
-    idx = {"gemm8p": 0, "wgrad8p": 1, "wgrad3x3": 2, "wgrad8f": 3, "gram_conv": 4, "gram_bn_apply": 5, "convp": 6}[which]
+    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply, convp, conv1p, stemp."""
+    idx = {"gemm8p": 0, "wgrad8p": 1, "wgrad3x3": 2, "wgrad8f": 3, "gram_conv": 4, "gram_bn_apply": 5, "convp": 6, "conv1p": 7,
+           "stemp": 8}[which]
     return int(load().nkb_kernel_launches(idx, int(reset)))
 
 
@@ -480,8 +485,18 @@ def convp_tiles(dtype, kind, *, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad)
     return int(load().nkb_convp_tiles(dtype, kind, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad))
 
 
-def convp_config(on: bool = True, tc128: bool = False, c64: bool = True, c64_dgrad: bool = False):
-    load().nkb_convp_config(int(on), int(tc128) | (2 if c64 else 0) | (4 if c64_dgrad else 0))
+def convp_config(on: bool = True, tc128: bool = False, c64: bool = True, c64_dgrad: bool = False, conv1p: bool = True, stemp: bool = True):
+    """Envelope of the row-resident kernel family (convp / conv1p / stemp); the defaults are the train step's."""
+    load().nkb_convp_config(int(on), int(tc128) | (2 if c64 else 0) | (4 if c64_dgrad else 0) | (0 if conv1p else 16) | (0 if stemp else 32))
+
+
+def conv1p_tiles(dtype, M, Cin, ldx, Cout, ldy) -> int:
+    """Partial-sum rows of conv1p_fwd for this 1x1 shape; 0: not eligible (use conv_gemm)."""
+    return int(load().nkb_conv1p_tiles(dtype, M, Cin, ldx, Cout, ldy))
+
+
+def conv1p_fwd(dtype, x, w, y, stats, *, M, Cin, ldx, Cout, ldy):
+    check(load().nkb_conv1p_fwd(dtype, ptr(x), ptr(w), ptr(y), ptr(stats), M, Cin, ldx, Cout, ldy, stream()), "conv1p_fwd")
 
 
 def convp_fwd(dtype, x, w, y, stats, *, N, H, W, Cin, ldx, Cout, ldy):
@@ -650,6 +665,15 @@ def stem_weight_cols(dtype) -> int:
 
 def stem_conv(dtype, xp, wp, y, stats, N, H, W, Cout, ldy):
     check(load().nkb_stem_conv(dtype, ptr(xp), ptr(wp), ptr(y), ptr(stats), N, H, W, Cout, ldy, stream()), "stem_conv")
+
+
+def stemp_tiles(dtype, N, H, W, Cout) -> int:
+    """Partial-sum rows of stemp_conv for this stem; 0: not eligible (use stem_conv)."""
+    return int(load().nkb_stemp_tiles(dtype, N, H, W, Cout))
+
+
+def stemp_conv(dtype, xp, wp, y, stats, N, H, W, Cout, ldy):
+    check(load().nkb_stemp_conv(dtype, ptr(xp), ptr(wp), ptr(y), ptr(stats), N, H, W, Cout, ldy, stream()), "stemp_conv")
 
 
 def stem_wgrad(dtype, dy, xp, dwp, N, H, W, Cout, lddy, workspace=None):

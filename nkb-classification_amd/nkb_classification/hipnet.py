@@ -368,11 +368,21 @@ class HipEngine:
         tiles_p = 0
         if train and _CONVP and not packed and not col_input and w.dim() == 4 and self.T == torch.bfloat16:
             tiles_p = hip.convp_tiles(self.d, 0, N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, ldy=co, R=R, S=S, stride=st, pad=pad)
-        if tiles_p:
-            tiles = tiles_p
+        # 1x1 / stride 1 expansions (bottleneck conv3, Cout >= 2 Cin): the pixel-resident kernel (csrc/conv1p.hip)
+        tiles_1 = 0
+        if (train and _CONVP and not packed and not col_input and w.dim() == 4 and self.T == torch.bfloat16
+                and R == 1 and S == 1 and st == 1 and pad == 0):
+            tiles_1 = hip.conv1p_tiles(self.d, rows, ci, ci, co, co)
+        tiles_s = hip.stemp_tiles(self.d, N, H, W, co) if (packed and train and _CONVP) else 0      # the stem through an LDS ring of image rows
+        if tiles_p or tiles_1 or tiles_s:
+            tiles = tiles_p or tiles_1 or tiles_s
         stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
         if tiles_p:
             hip.convp_fwd(self.d, x, self.w_fwd(w), c, stats, N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, ldy=co)
+        elif tiles_1:
+            hip.conv1p_fwd(self.d, x, self.w_fwd(w), c, stats, M=rows, Cin=ci, ldx=ci, Cout=co, ldy=co)
+        elif tiles_s:
+            hip.stemp_conv(self.d, x, self.w_fwd(w), c, stats, N, H, W, co, co)
         elif packed:
             hip.stem_conv(self.d, x, self.w_fwd(w), c, stats, N, H, W, co, co)
         elif w.dim() == 2 and self._splitk_ok(rows, ci, co):

@@ -25,4 +25,4 @@ tot = collections.defaultdict(float)
 for k, ms, w in raw: tot[k] += ms
 print("total ms", round(sum(tot.values()), 2), {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])})
 for i, (k, ms, w) in enumerate(raw):
-    if ms > 0.06: print(f"{i:4d} {k:18s} {ms*1e3:8.1f} us  {w/1e9:8.1f} GF  {w/ms/1e9 if ms else 0:7.0f} TF/s")
+    if ms > float(os.environ.get("MIN_MS", 0.06)): print(f"{i:4d} {k:18s} {ms*1e3:8.1f} us  {w/1e9:8.1f} GF  {w/ms/1e9 if ms else 0:7.0f} TF/s")

@@ -128,7 +128,7 @@ def _run(model_name, batch, dtype, classes, steps=4, heads="", size=224):
     return out, counters, len(eng.plans)
 
 
-COUNTERS = ("gemm8p", "wgrad8p", "wgrad3x3", "wgrad8f", "gram_conv", "gram_bn_apply", "convp")
+COUNTERS = ("gemm8p", "wgrad8p", "wgrad3x3", "wgrad8f", "gram_conv", "gram_bn_apply", "convp", "conv1p", "stemp")
 
 
 def _check(out, relative=True, cos_bar=None, l2_bar=None, loss_tol=1e-2, cos_slack=1e-3):
@@ -147,7 +147,8 @@ def test_resnet50_bench_configuration_matches_oracle():
     assert plans >= 2                                                      # forward + backward plans recorded and replayed
     assert n["gemm8p"] > 0 and n["wgrad8p"] > 0 and n["wgrad3x3"] > 0      # the kernels the bench line is priced on ran
     assert n["gram_conv"] > 0 and n["gram_bn_apply"] > 0                   # Gram-form closing stages (layer1 / layer2)
-    assert n["convp"] > 0                                                  # row-balanced 3x3 core (layer3 / layer4 conv2, both directions)
+    assert n["convp"] > 0                                                  # row-balanced 3x3 core (layer1 / 3 / 4 conv2)
+    assert n["conv1p"] > 0 and n["stemp"] > 0                              # pixel-resident 1x1 expansions (layer3), ring-buffered stem
 
 
 def test_resnet50_multitask_configs3_matches_oracle():
