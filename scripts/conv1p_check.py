@@ -54,9 +54,9 @@ def run(N, H, Cin, Cout, reps):
 
 if __name__ == "__main__":
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
-    shapes = [(128, 14, 256, 1024)]
+    shapes = [(128, 14, 256, 1024), (131, 14, 1024, 256)]
     if not quick:
-        shapes += [(256, 14, 256, 1024), (200, 14, 256, 1024), (256, 15, 256, 768)]
+        shapes += [(256, 14, 256, 1024), (200, 14, 256, 1024), (256, 14, 1024, 256), (256, 14, 512, 256)]
     allok = True
     for sh in shapes:
         allok &= run(*sh, 0 if quick else 7)

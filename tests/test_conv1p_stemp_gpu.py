@@ -25,7 +25,9 @@ def _stats_of(y, tiles, co, stats):
 
 
 # N, H (square maps), Cin, Cout: layer3-like tiles of 3 .. 13 fragments, a last workgroup with fewer rows
-C1_SHAPES = [(60, 14, 256, 512), (131, 14, 256, 1024), (256, 14, 256, 1024), (61, 15, 256, 768), (75, 13, 256, 512)]
+# ... and the streaming form of the reduction stage (Cin >= 512 -> Cout <= Cin / 2): one and two channel blocks, ragged rows
+C1_SHAPES = [(60, 14, 256, 512), (131, 14, 256, 1024), (256, 14, 256, 1024), (61, 15, 256, 768), (75, 13, 256, 512),
+             (256, 14, 1024, 256), (131, 14, 1024, 256), (203, 15, 1024, 512), (256, 14, 512, 256)]
 
 
 @pytest.mark.parametrize("shape", C1_SHAPES, ids=lambda s: "x".join(map(str, s)))
@@ -64,7 +66,7 @@ def test_conv1p_matches_torch_and_the_tile_kernel(shape):
 def test_conv1p_refuses_what_it_cannot_run():
     ok = dict(M=50176, Cin=256, ldx=256, Cout=1024, ldy=1024)
     assert hip.conv1p_tiles(D, **ok) > 0
-    for bad in (dict(Cin=128, ldx=128), dict(Cout=384, ldy=384), dict(Cout=256, ldy=256), dict(M=1000), dict(M=12544, Cin=512, ldx=512, Cout=2048, ldy=2048),
+    for bad in (dict(Cin=128, ldx=128), dict(Cout=384, ldy=384), dict(Cout=256, ldy=256), dict(M=1000), dict(Cin=768, ldx=768, Cout=512, ldy=512), dict(M=12544, Cin=512, ldx=512, Cout=2048, ldy=2048),
                 dict(M=802816)):
         assert hip.conv1p_tiles(D, **{**ok, **bad}) == 0, bad
     assert hip.conv1p_tiles(hip.F32, **ok) == 0
