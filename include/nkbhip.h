@@ -216,6 +216,12 @@ int nkb_bn_relu_maxpool(int dtype, int backward, const void* c, const float* sca
                         const float* mean, const float* invstd, const float* gamma, void* y_or_g, unsigned char* idx,
                         void* dc, float* dgamma, float* dbeta, float* workspace, size_t workspace_floats, int N, int H,
                         int W, int C, nkb_stream_t stream);
+/* The same with xsel [N][P][Q][C] (compute dtype, may be NULL = nkb_bn_relu_maxpool): forward also writes the raw conv output behind
+ * every pooled winner, backward's reduction reads that instead of gathering two bytes per channel from c. */
+int nkb_bn_relu_maxpool_sel(int dtype, int backward, const void* c, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, const float* gamma, void* y_or_g, unsigned char* idx,
+                            void* dc, float* dgamma, float* dbeta, float* workspace, size_t workspace_floats, void* xsel,
+                            int N, int H, int W, int C, nkb_stream_t stream);
 size_t nkb_bn_relu_maxpool_workspace_floats(int N, int H, int W, int C);
 
 /* NCHW fp32 image -> [N*P*Q][Kp] rows, k = (r*S+s)*Cin + c (stem conv / patch embedding as a GEMM). */

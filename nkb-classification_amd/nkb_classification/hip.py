@@ -68,6 +68,7 @@ _SIGS = {
     "nkb_stem_wfold": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_maxpool3x3s2": (i32, [i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nkb_bn_relu_maxpool": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
+    "nkb_bn_relu_maxpool_sel": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, i32, i32, i32, i32, vp]),
     "nkb_bn_relu_maxpool_workspace_floats": (sz, [i32, i32, i32, i32]),
     "nkb_avgpool": (i32, [i32, i32, vp, vp, i32, i32, i32, vp]),
     "nkb_im2row": (i32, [i32, vp, vp] + [i32] * 9 + [vp]),
@@ -633,10 +634,11 @@ def bn_backward_ws(rows, C_):
     return load().nkb_bn_backward_workspace_floats(rows, C_)
 
 
-def bn_relu_maxpool(dtype, backward, c, scale, shift, mean, invstd, gamma, y_or_g, idx, dc, dgamma, dbeta, work, N, H, W, C_):
-    check(load().nkb_bn_relu_maxpool(dtype, int(backward), ptr(c), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                     ptr(gamma), ptr(y_or_g), ptr(idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(work),
-                                     work.numel() if work is not None else 0, N, H, W, C_, stream()), "bn_relu_maxpool")
+def bn_relu_maxpool(dtype, backward, c, scale, shift, mean, invstd, gamma, y_or_g, idx, dc, dgamma, dbeta, work, N, H, W, C_, xsel=None):
+    """xsel [N][P][Q][C]: written by the forward call (raw conv output behind every pooled winner), read by the backward call."""
+    check(load().nkb_bn_relu_maxpool_sel(dtype, int(backward), ptr(c), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                         ptr(gamma), ptr(y_or_g), ptr(idx), ptr(dc), ptr(dgamma), ptr(dbeta), ptr(work),
+                                         work.numel() if work is not None else 0, ptr(xsel), N, H, W, C_, stream()), "bn_relu_maxpool")
 
 
 def bn_relu_maxpool_ws(N, H, W, C_) -> int:

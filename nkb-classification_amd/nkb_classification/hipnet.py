@@ -411,8 +411,11 @@ class HipEngine:
             P2, Q2 = (P - 1) // 2 + 1, (Q - 1) // 2 + 1
             y = self.ws.get(key + ".y", (N, P2, Q2, co), self.T)
             idx = self.ws.get(key + ".idx", (N, P2, Q2, co), torch.uint8)
+            # train: the raw value behind every pooled winner is kept for the backward reduction (one 16-byte read per pooled chunk there
+            # instead of eight 2-byte gathers from c)
+            xsel = self.ws.get(key + ".xsel", (N, P2, Q2, co), self.T) if train else None
             hip.bn_relu_maxpool(self.d, False, c, scale, shift, mean, invstd, None, y, idx, None, None, None, None,
-                                N, P, Q, co)
+                                N, P, Q, co, xsel=xsel)
         else:
             idx = None
             y = self.ws.get(key + ".y", (N, P, Q, co), self.T)
@@ -432,7 +435,7 @@ class HipEngine:
         if train:
             self.saved[key] = dict(x=x, c=c, y=y, mean=mean, invstd=invstd, relu=relu, geom=geom, conv=conv, bn=bn,
                                    rows=rows, col_input=col_input, scale=scale, shift=shift, has_res=res is not None,
-                                   pool_idx=idx, stem_packed=bool(packed), bits=bits)
+                                   pool_idx=idx, pool_xsel=xsel if pool else None, stem_packed=bool(packed), bits=bits)
         return y
 
     def gram_ok(self, conv, res, x) -> bool:
@@ -802,7 +805,7 @@ class HipEngine:
         gc = self.scratch(slot, sv["c"].shape)
         work = self.ws.at_least("bn.work", hip.bn_relu_maxpool_ws(N, H, W, co), torch.float32)
         hip.bn_relu_maxpool(self.d, True, sv["c"], sv["scale"], sv["shift"], sv["mean"], sv["invstd"], bn.weight, g_p,
-                            sv["pool_idx"], gc, a.grad_flat(bn.weight), a.grad_flat(bn.bias), work, N, H, W, co)
+                            sv["pool_idx"], gc, a.grad_flat(bn.weight), a.grad_flat(bn.bias), work, N, H, W, co, xsel=sv.get("pool_xsel"))
         return gc
 
     def can_fuse_bn_backward(self, bn_key: str) -> bool:

@@ -358,6 +358,20 @@ def test_stem_tail_fused_matches_unfused_kernels(dtype):
     torch.testing.assert_close(db1, db0, **st)
     torch.testing.assert_close(dg1, dg0, **st)
     torch.testing.assert_close(dc1.float(), dc0.float(), **tol(dtype, 2))
+    # the train step's form: forward also keeps the raw value behind every pooled winner (xsel) and the backward reduction reads it
+    # instead of gathering from c — same numbers, bit for bit
+    y2, i2, xs = torch.empty_like(y0), torch.empty_like(i0), torch.full_like(y0, float("nan"))
+    hip.bn_relu_maxpool(d, False, c, scale, shift, mean, invstd, None, y2, i2, None, None, None, None, N, H, W, C, xsel=xs)
+    assert torch.equal(y2, y1) and torch.equal(i2, i1)
+    pp, qq = torch.meshgrid(torch.arange(P, device=DEV), torch.arange(Q, device=DEV), indexing="ij")
+    hh = (2 * pp - 1)[None, :, :, None] + (i1.long() // 3)
+    ww = (2 * qq - 1)[None, :, :, None] + (i1.long() % 3)
+    nn = torch.arange(N, device=DEV)[:, None, None, None].expand_as(hh)
+    cc = torch.arange(C, device=DEV)[None, None, None, :].expand_as(hh)
+    assert torch.equal(xs, c[nn, hh, ww, cc])
+    dg2, db2, dc2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.empty_like(c)
+    hip.bn_relu_maxpool(d, True, c, scale, shift, mean, invstd, gamma, g, i1, dc2, dg2, db2, work1, N, H, W, C, xsel=xs)
+    assert torch.equal(dg2, dg1) and torch.equal(db2, db1) and torch.equal(dc2, dc1)
 
 
 def test_stem_tail_backward_reduction_is_exact_for_its_bf16_inputs_at_full_extent():
