@@ -15,6 +15,7 @@ import sys
 
 FAMILIES = (  # first match wins; (substring of the kernel name, family)
     ("gemm8p_kernel", "gemm8p"), ("conv_igemm_kernel", "conv_igemm"), ("convp_kernel", "conv_igemm"),
+    ("convp64", "conv_igemm"), ("conv1p_kernel", "conv_igemm"), ("conv1s_kernel", "conv_igemm"), ("stemp_kernel", "conv_igemm"),
     ("wgrad_reduce_kernel", "wgrad_reduce"), ("gram_reduce_kernel", "wgrad_reduce"),
     ("wgrad8p", "wgrad8p"), ("wgrad8f", "wgrad8f"), ("wgrad3x3_kernel", "wgrad3x3"), ("wgrad256_kernel", "wgrad8p"),
     ("conv_wgrad_kernel", "conv_wgrad"),
