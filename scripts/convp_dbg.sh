@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p /tmp/diagbuild && cd $R/nkb-classification_amd/csrc || exit 1
 for f in *.hip; do cp ../lib/obj/${f%.hip}.o /tmp/diagbuild/${f%.hip}.o; done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -I../../include -Wno-unused-result -Wno-unused-value -ffp-contract=off -DNKB_CONVP_DIAG -c convp.hip -o /tmp/diagbuild/convp.o || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -I../../include -Wno-unused-result -Wno-unused-value -ffp-contract=off -fno-slp-vectorize -DNKB_CONVP_DIAG -c convp.hip -o /tmp/diagbuild/convp.o || exit 1
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/diagbuild/*.o -o /tmp/diagbuild/libnkbhip_diag.so || exit 1
 cd $R
 for d in ${@:-0 1 2 3 4 7}; do

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p /tmp/stampbuild && cd $R/nkb-classification_amd/csrc || exit 1
 for f in *.hip; do o=/tmp/stampbuild/${f%.hip}.o; cp ../lib/obj/${f%.hip}.o $o; done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -I../../include -Wno-unused-result -Wno-unused-value -ffp-contract=off -DNKB_CONVP_STAMPS -c convp.hip -o /tmp/stampbuild/convp.o || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -I../../include -Wno-unused-result -Wno-unused-value -ffp-contract=off -fno-slp-vectorize -DNKB_CONVP_STAMPS -c convp.hip -o /tmp/stampbuild/convp.o || exit 1
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/stampbuild/*.o -o /tmp/stampbuild/libnkbhip_stamps.so || exit 1
 cd $R && NKBHIP_LIB=/tmp/stampbuild/libnkbhip_stamps.so python3 - "$@" <<'PY'
 import ctypes, os, sys, torch
