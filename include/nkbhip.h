@@ -245,6 +245,11 @@ int nkb_stem_weight_cols(int dtype);
 int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y, float* stats, int N, int H, int W, int Cout,
                   int ldy, nkb_stream_t stream);
 int nkb_stemp_tiles(int dtype, int N, int H, int W, int Cout);
+/* nkb_stem_wgrad's product on the same ring (dwp[64][224] fp32 += dY^T x window(xp); one fp32 slab per workgroup in `workspace`, summed in
+ * workgroup order): for the shapes nkb_stemp_tiles admits, workspace >= nkb_stemp_wgrad_workspace_floats floats. */
+long long nkb_stemp_wgrad_workspace_floats(int dtype, int N, int H, int W, int Cout);
+int nkb_stemp_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N, int H, int W, int Cout, int lddy, float* workspace,
+                    long long workspace_floats, nkb_stream_t stream);
 int nkb_stemp_conv(int dtype, const void* xp, const void* wp, void* y, float* stats, int N, int H, int W, int Cout, int ldy,
                    nkb_stream_t stream);
 int nkb_stem_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N, int H, int W, int Cout, int lddy,

@@ -253,6 +253,212 @@ __global__ __launch_bounds__(512, 1) void stemp_kernel(const SPParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The stem's weight gradient on the same ring:  dwp[co][32 r + e] += sum over pixels of dY[pixel][co] * window_r(pixel)[e]
+// (nkb_stem_wgrad's product, engine.py:55-58: the last kernel of the backward pass, alone on the GPU).  The generic split-over-pixels
+// kernel runs it as 128 x 128 tiles of a 64 x 224 result (44 % of its MFMAs and half of its dY loads are padding) and gathers every
+// window from global memory: 270 us for 514 MB.  Here one workgroup per image (or band of output rows) streams the image rows through
+// the ring exactly as stemp_kernel does, and dY rows (128 bytes per pixel) through three 16 KB row buffers; the contraction runs over
+// the PIXELS of an output row, 32 per MFMA, both operands through the transposing LDS read:
+//   * A = dY^T: lane (co, pixel group) wants 8 pixels of one channel: ds_read_b64_tr_b16 over 128-byte pixel rows, the 32-byte channel
+//     blocks XOR-swizzled by the pixel (conflict-free, brute-forced);
+//   * B = windows: "row" k = output pixel q is 64 contiguous ring bytes at 16 q — rows overlap, which the transposing read does not mind.
+// Waves: (output row of the step) x (four groups of the 14 window fragments); per-workgroup results leave as ONE fp32 slab
+// [64][224], summed in workgroup order by nkb_launch_wgrad_reduce.
+struct SWParams {
+    const bf16_t* dy;           // [N][P][Q][lddy]
+    const bf16_t* xp;           // [N][H][Wp][4]
+    float* part;                // [nwg][64][224]
+    int N, H, Wp, P, Q, lddy;
+    int bands, band_rows, rs, ks;      // ks: 32-pixel k-steps per output row
+};
+
+// KS: 32-pixel k-steps per output row (compile time: the k-loop is unrolled with two alternating register sets of fragments; the LDS
+// reads are inline assembly — a compiler-visible LDS read behind an LDS-DMA makes hipcc wait for vmcnt(0), i.e. for the rows it has just
+// requested two steps ahead)
+template <int KS>
+__global__ __launch_bounds__(512, 1) void stempw_kernel(const SWParams p) {
+    constexpr int SW_RING = 24;                                // ring rows here (steps s .. s + 2 span 17 image rows); the zero row is row 24
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // (SW_RING + 1) ring rows, then 6 dY rows of ks x 4 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave & 1, ng = wave >> 1;                   // output row of the step; group of window fragments
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+    const int RS = p.rs, DYB = p.ks * 4096;
+    unsigned char* const dybuf = smem + (SW_RING + 1) * RS;
+
+    const int wg = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int n = wg / p.bands, band = wg - n * p.bands;
+    const int p0 = band * p.band_rows, p1 = min(p.P, p0 + p.band_rows);
+    const int nsteps = (p1 - p0 + 1) >> 1;                     // two output rows per step
+
+    {   // zero the ring and the dY buffers (margins, the zero row and the pixels past Q stay zero)
+        const int total = (SW_RING + 1) * RS + 6 * DYB;
+        for (int o = tid * 16; o < total; o += 512 * 16) *(u32x4*)(smem + o) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+
+    const int lanes_row = p.Wp >> 1;
+    const unsigned char* const img = (const unsigned char*)p.xp + (size_t)n * p.H * p.Wp * 8;
+    auto row_ok = [&](int yy) { return yy >= 0 && yy < p.H; };
+    auto issue_row = [&](int yy) -> int {                       // image row yy into the ring; returns the DMA instructions issued
+        if (!row_ok(yy)) return 0;
+        const unsigned char* src = img + (size_t)yy * p.Wp * 8 + lane * 16;
+        unsigned char* dst = smem + (yy % SW_RING) * RS + 32;
+        if (lane < lanes_row) sp_glds16(src, dst);
+        if (lane + 64 < lanes_row) sp_glds16(src + 1024, dst + 1024);
+        return lanes_row > 64 ? 2 : 1;
+    };
+    // dY row pr -> buffer pr % 6 (the rows of steps s .. s + 2 are live): piece = 8 pixels x 128 B; lane (pixel l >> 3, position l & 7) fetches 16-byte chunk
+    // (l & 7) ^ (s(pixel) << 1), s(px) = bit 1 | bit 3 << 1: the 32-byte channel blocks of pixels 2 / 8 / 10 apart land on different banks
+    const int npieces_dy = (p.Q + 7) >> 3;
+    auto issue_dy = [&](int pr, int piece) -> int {
+        if (pr >= p1 || piece >= npieces_dy) return 0;
+        const int px = 8 * piece + (lane >> 3);
+        const int sw = (((px >> 1) & 1) | (((px >> 3) & 1) << 1)) << 1;
+        const unsigned char* src = (const unsigned char*)p.dy + (((size_t)n * p.P + pr) * p.Q + px) * (size_t)(p.lddy * 2) + (((lane & 7) ^ sw) << 4);
+        if (px < p.Q) sp_glds16(src, dybuf + (pr % 6) * DYB + piece * 1024);
+        return 1;
+    };
+    // step s = output rows p0 + 2 s, + 1: image rows 2 (p0 + 2 s) - 3 .. + 5 (nine; four new per step), dY rows p0 + 2 s, + 1.
+    // Requests run two steps ahead; wave w asks for image row (w < 4) and its share of the 2 x npieces_dy dY pieces.
+    auto issue_step = [&](int s) -> int {
+        if (s >= nsteps) return 0;
+        int c = 0;
+        if (wave < 4) c += issue_row(2 * (p0 + 2 * s) + 2 + wave);
+        for (int q = wave; q < 2 * npieces_dy; q += 8) c += issue_dy(p0 + 2 * s + (q >= npieces_dy), q >= npieces_dy ? q - npieces_dy : q);
+        return c;
+    };
+    // prologue: the first five image rows of step 0 (rows 2 p0 - 3 .. 2 p0 + 1), then steps 0 and 1
+    if (wave < 5) issue_row(2 * p0 - 3 + wave);
+    issue_step(0);
+    int pend = issue_step(1);                                  // instructions younger than the operands of the step about to run
+
+    // fragment tables: this wave's window fragments f = nf0 .. nf0 + nfc - 1 (f = 2 r + half)
+    const int nf0 = ng < 2 ? 4 * ng : 8 + 3 * (ng - 2), nfc = ng < 2 ? 4 : 3;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A address of this lane inside a dY buffer: pixel 8 g + q4 (+ 4: +512 B, + 32 per k-step: +4096 B), channel block c at chunk
+    // (2 c + (p4 >> 1)) ^ swizzle — the swizzle bits (pixel bits 1 and 3) do not depend on the k-step or on the + 4
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned aoff[4];
+    {
+        const int px = 8 * g + q4;
+        const int sw = (((px >> 1) & 1) | (((px >> 3) & 1) << 1)) << 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) aoff[c] = (unsigned)(px * 128 + (((2 * c + (p4 >> 1)) ^ sw) << 4) + 8 * (p4 & 1));
+    }
+    const unsigned boff = (unsigned)(16 * (8 * g + q4) + 8 * p4);
+
+    for (int s = 0; s < nsteps; ++s) {
+        sp_vmcnt_dyn(pend);
+        SP_BARRIER();                                          // every wave's rows of step s; step s - 1 is read out
+        pend = issue_step(s + 2);
+        asm volatile("" ::: "memory");
+        const int pr = p0 + 2 * s + kh;
+        if (pr < p1) {
+            unsigned ab[4], bb[4];                             // LDS addresses: dY row (per channel block), ring rows (per window fragment)
+            const unsigned dyr = lds0 + (unsigned)((SW_RING + 1) * RS + (pr % 6) * DYB);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ab[c] = dyr + aoff[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = nf0 + (j < nfc ? j : 0);
+                const int yy = 2 * pr - 3 + (f >> 1);
+                bb[j] = lds0 + (unsigned)((row_ok(yy) ? (yy % SW_RING) : SW_RING) * RS + 32 * (f & 1)) + boff;
+            }
+            // Units of the software pipeline: (k-step K, half 0) = channel blocks 0-1 against the window fragments (12 LDS reads, 8 MFMAs),
+            // (K, half 1) = channel blocks 2-3 against the same window fragments (4 reads, 8 MFMAs).  A unit issues the next unit's reads
+            // and waits for its own alone: at most 12 reads in flight (lgkmcnt counts to 15).
+            u32x2 fa[4][2], fb[2][4][2];                       // [channel block][pixels + 0 .. 3 | + 4 .. 7]; [k-step parity][fragment][...]
+#define SW_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define SW_READS0(K)                                                                                                  \
+    do {                                                                                                              \
+        SW_TR(fa[0][0], ab[0], 4096 * (K)); SW_TR(fa[0][1], ab[0], 4096 * (K) + 512);                                 \
+        SW_TR(fa[1][0], ab[1], 4096 * (K)); SW_TR(fa[1][1], ab[1], 4096 * (K) + 512);                                 \
+        SW_TR(fb[(K) & 1][0][0], bb[0], 512 * (K)); SW_TR(fb[(K) & 1][0][1], bb[0], 512 * (K) + 64);                  \
+        SW_TR(fb[(K) & 1][1][0], bb[1], 512 * (K)); SW_TR(fb[(K) & 1][1][1], bb[1], 512 * (K) + 64);                  \
+        SW_TR(fb[(K) & 1][2][0], bb[2], 512 * (K)); SW_TR(fb[(K) & 1][2][1], bb[2], 512 * (K) + 64);                  \
+        SW_TR(fb[(K) & 1][3][0], bb[3], 512 * (K)); SW_TR(fb[(K) & 1][3][1], bb[3], 512 * (K) + 64);                  \
+    } while (0)
+#define SW_READS1(K)                                                                                                  \
+    do {                                                                                                              \
+        SW_TR(fa[2][0], ab[2], 4096 * (K)); SW_TR(fa[2][1], ab[2], 4096 * (K) + 512);                                 \
+        SW_TR(fa[3][0], ab[3], 4096 * (K)); SW_TR(fa[3][1], ab[3], 4096 * (K) + 512);                                 \
+    } while (0)
+#define SW_LANDED0(n, K)                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[(K) & 1][0][0]), \
+                 "+v"(fb[(K) & 1][0][1]), "+v"(fb[(K) & 1][1][0]), "+v"(fb[(K) & 1][1][1]), "+v"(fb[(K) & 1][2][0]),                   \
+                 "+v"(fb[(K) & 1][2][1]), "+v"(fb[(K) & 1][3][0]), "+v"(fb[(K) & 1][3][1]))
+#define SW_LANDED1(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]))
+#define SW_MM(C0, K)                                                                                                  \
+    do {                                                                                                              \
+        bf16x8 b_[4];                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+            const u32x4 vb = {fb[(K) & 1][j][0][0], fb[(K) & 1][j][0][1], fb[(K) & 1][j][1][0], fb[(K) & 1][j][1][1]}; \
+            b_[j] = __builtin_bit_cast(bf16x8, vb);                                                                   \
+        }                                                                                                             \
+        _Pragma("unroll") for (int c = (C0); c < (C0) + 2; ++c) {                                                     \
+            const u32x4 va = {fa[c][0][0], fa[c][0][1], fa[c][1][0], fa[c][1][1]};                                    \
+            const bf16x8 a_ = __builtin_bit_cast(bf16x8, va);                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+                if (j < nfc) acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_[j], acc[c][j], 0, 0, 0);      \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
+#define SW_STEP(K)                                                                                                    \
+    if constexpr ((K) < KS) {                                                                                         \
+        SW_READS1(K); SW_LANDED0(4, K);                                                                               \
+        SW_MM(0, K);                                                                                                  \
+        if constexpr ((K) + 1 < KS) { SW_READS0((K) + 1); SW_LANDED1(12); }                                           \
+        else SW_LANDED1(0);                                                                                           \
+        SW_MM(2, K);                                                                                                  \
+    }
+            SW_READS0(0);
+            SW_STEP(0) SW_STEP(1) SW_STEP(2) SW_STEP(3) SW_STEP(4) SW_STEP(5) SW_STEP(6) SW_STEP(7)
+#undef SW_MM
+#undef SW_LANDED1
+#undef SW_LANDED0
+#undef SW_READS1
+#undef SW_READS0
+#undef SW_STEP
+#undef SW_TR
+        }
+    }
+    sp_vmcnt<0>();
+    SP_BARRIER();                                              // the ring and the dY rows are read out
+
+    // ---- the two output-row waves of a fragment group add up through LDS; lane (li, g) of fragment (c, j) holds dW[16 c + 4 g + e][16 f + li]
+    float* red = (float*)smem;                                 // [4 groups][4 c][4 j][4 e][64 lanes]
+    if (kh == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[(((ng * 4 + c) * 4 + j) * 4 + e) * 64 + lane] = acc[c][j][e];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        float* out = p.part + (size_t)wg * 64 * 224;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nfc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[c][j][e] + red[(((ng * 4 + c) * 4 + j) * 4 + e) * 64 + lane];
+                        out[(size_t)(16 * c + 4 * g + e) * 224 + 16 * (nf0 + j) + li] = v;
+                    }
+                }
+            }
+    }
+}
+
 int sp_cus() {
     static int cus = [] {
         int dev = 0, n = 0;
@@ -322,4 +528,55 @@ extern "C" int nkb_stemp_conv(int dtype, const void* xp, const void* wp, void* y
     if (g.Q == 112) hipLaunchKernelGGL(stemp_kernel<7>, dim3((unsigned)g.nwg), dim3(512), g.lds, stream, p);       // 224-pixel rows
     else hipLaunchKernelGGL(stemp_kernel<0>, dim3((unsigned)g.nwg), dim3(512), g.lds, stream, p);
     return nkb_check_launch("stemp_conv");
+}
+
+// Slab floats of nkb_stemp_wgrad for this stem (one [64][224] fp32 slab per workgroup), 0: not eligible -> nkb_stem_wgrad
+static int sw_lds(const SPGeom& g) {                           // 24 + 1 ring rows, six dY rows, at least the final reduction's 64 KB
+    const int ks = (g.Q + 31) / 32;
+    const int lds = (24 + 1) * g.rs + 6 * ks * 4096;
+    return lds < 4 * 4 * 4 * 4 * 64 * 4 ? 4 * 4 * 4 * 4 * 64 * 4 : lds;
+}
+extern "C" long long nkb_stemp_wgrad_workspace_floats(int dtype, int N, int H, int W, int Cout) {
+    const int tiles = nkb_stemp_tiles(dtype, N, H, W, Cout);
+    if (!tiles) return 0;
+    SPGeom g;
+    sp_geom(N, H, W, sp_cus(), g);
+    if (sw_lds(g) > 160 * 1024 || (g.Q + 31) / 32 > 8) return 0;
+    return (long long)tiles * 64 * 224;
+}
+
+// dwp[64][224] (fp32) += dY^T x window(xp): nkb_stem_wgrad's product (same operands, same result layout) for the shapes nkb_stemp_tiles admits
+extern "C" int nkb_stemp_wgrad(int dtype, const void* dy, const void* xp, float* dwp, int N, int H, int W, int Cout, int lddy,
+                               float* workspace, long long workspace_floats, hipStream_t stream) {
+    const long long need = nkb_stemp_wgrad_workspace_floats(dtype, N, H, W, Cout);
+    if (!need) { nkb_set_error("stemp_wgrad: shape not eligible (N=%d H=%d W=%d Cout=%d)", N, H, W, Cout); return 1; }
+    if (!workspace || workspace_floats < need || lddy % 8 != 0) { nkb_set_error("stemp_wgrad: bad operand"); return 1; }
+    SPGeom g;
+    sp_geom(N, H, W, sp_cus(), g);
+    SWParams p;
+    p.dy = (const bf16_t*)dy; p.xp = (const bf16_t*)xp; p.part = workspace;
+    p.N = N; p.H = H; p.Wp = g.Wp; p.P = g.P; p.Q = g.Q; p.lddy = lddy;
+    p.bands = g.bands; p.band_rows = g.band_rows; p.rs = g.rs; p.ks = (g.Q + 31) / 32;
+    const int lds = sw_lds(g);
+    static bool once = [] {
+#define SW_ATTR(K) (void)hipFuncSetAttribute((const void*)stempw_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        SW_ATTR(1) SW_ATTR(2) SW_ATTR(3) SW_ATTR(4) SW_ATTR(5) SW_ATTR(6) SW_ATTR(7) SW_ATTR(8)
+#undef SW_ATTR
+        return true;
+    }();
+    (void)once;
+    const double M = (double)N * g.P * g.Q;
+    {
+        NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * M * 64 * 224, ((double)N * H * g.Wp * 4 + M * 64) * 2);
+        nkb_count_launch(8);
+        switch (p.ks) {
+#define SW_GO(K) case K: hipLaunchKernelGGL(stempw_kernel<K>, dim3((unsigned)g.nwg), dim3(512), lds, stream, p); break;
+            SW_GO(1) SW_GO(2) SW_GO(3) SW_GO(4) SW_GO(5) SW_GO(6) SW_GO(7) SW_GO(8)
+#undef SW_GO
+            default: break;
+        }
+        if (int rc = nkb_check_launch("stemp_wgrad")) return rc;
+    }
+    NkbProfScope prof(NKB_K_WGRAD_REDUCE, stream, 0, 4.0 * ((double)g.nwg + 2.0) * 64 * 224);
+    return nkb_launch_wgrad_reduce(workspace, 64ll * 224, g.nwg, dwp, 64ll * 224, stream);
 }

@@ -60,6 +60,8 @@ _SIGS = {
     "nkb_wprep_job_blocks": (i64, [i32, i32, i32, i32, i32]),
     "nkb_stem_pack": (i32, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "nkb_stemp_tiles": (i32, [i32, i32, i32, i32, i32]),
+    "nkb_stemp_wgrad_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
+    "nkb_stemp_wgrad": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
     "nkb_stemp_conv": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_stem_weight_cols": (i32, [i32]),
@@ -170,7 +172,7 @@ def exported_symbols():
 # (input images, logits, logits gradient) and dropout seeds.
 _REC = None            # list of plan entries while recording
 _REC_LIB = None
-_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_convp_tiles", "nkb_conv1p_tiles", "nkb_stemp_tiles", "nkb_bn_stats_floats",
+_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_convp_tiles", "nkb_conv1p_tiles", "nkb_stemp_tiles", "nkb_stemp_wgrad_workspace_floats", "nkb_bn_stats_floats",
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
@@ -676,6 +678,16 @@ def stemp_tiles(dtype, N, H, W, Cout) -> int:
 
 def stemp_conv(dtype, xp, wp, y, stats, N, H, W, Cout, ldy):
     check(load().nkb_stemp_conv(dtype, ptr(xp), ptr(wp), ptr(y), ptr(stats), N, H, W, Cout, ldy, stream()), "stemp_conv")
+
+
+def stemp_wgrad_workspace(dtype, N, H, W, Cout) -> int:
+    """Slab floats of stemp_wgrad; 0: not eligible (use stem_wgrad)."""
+    return int(load().nkb_stemp_wgrad_workspace_floats(dtype, N, H, W, Cout))
+
+
+def stemp_wgrad(dtype, dy, xp, dwp, N, H, W, Cout, lddy, workspace):
+    check(load().nkb_stemp_wgrad(dtype, ptr(dy), ptr(xp), ptr(dwp), N, H, W, Cout, lddy, ptr(workspace), workspace.numel(), stream()),
+          "stemp_wgrad")
 
 
 def stem_wgrad(dtype, dy, xp, dwp, N, H, W, Cout, lddy, workspace=None):

@@ -850,6 +850,13 @@ class HipEngine:
             def packed_wgrad():
                 hip.zero_(dwp)
                 work = None
+                ring = hip.stemp_wgrad_workspace(self.d, geom["N"], geom["H"], geom["W"], co) if (_CONVP and _DET_WGRAD) else 0
+                if ring:
+                    # the stem's weight gradient on the LDS ring of image rows (csrc/stemp.hip): one slab per workgroup
+                    work = self.ws.at_least("wgrad.slabs." + self._stream_tag(), ring, torch.float32)
+                    hip.stemp_wgrad(self.d, g_c, sv["x"], dwp, geom["N"], geom["H"], geom["W"], co, co, work)
+                    hip.stem_wfold(self.d, dwp, a.grad_flat(w), co, w.shape[1])
+                    return
                 if _DET_WGRAD:
                     work = self.ws.at_least("wgrad.slabs." + self._stream_tag(),
                                             hip.stem_wgrad_workspace(self.d, geom["N"], geom["H"], geom["W"], co), torch.float32)

@@ -55,7 +55,28 @@ def run(N, H, W, reps):
     mb = (N * H * Wp * 4 + M * Co) * 2 / 1e6
     print(f"N={N:3d} {H:3d}x{W:<3d} tiles {tiles0:5d}/{tiles1:3d}  max|dy| {err:.3e} (ref {ref:.2f}) nonfinite {bad} outliers {mism}  "
           f"stats rel {serr:.2e}  old {med[0]:7.1f} us  new {med[1]:7.1f} us  ({mb / max(med[1], 1e-9):.2f} TB/s)", flush=True)
-    return bad == 0 and mism == 0 and err <= 0.02 * ref + 1e-3 and serr < 2e-2
+    ok = bad == 0 and mism == 0 and err <= 0.02 * ref + 1e-3 and serr < 2e-2
+    # weight gradient: the ring kernel next to the generic split-over-pixels kernel (different summation orders: fp32 tolerance)
+    dy = torch.randn(N, P, Q, Co, device=DEV).to(torch.bfloat16)
+    cols = hip.stem_weight_cols(d) - 32
+    dw0 = torch.zeros(Co, cols, device=DEV)
+    dw1 = torch.zeros(Co, cols, device=DEV)
+    work0 = torch.empty(hip.stem_wgrad_workspace(d, N, H, W, Co), device=DEV)
+    work1 = torch.empty(hip.stemp_wgrad_workspace(d, N, H, W, Co), device=DEV)
+    g0 = lambda: hip.stem_wgrad(d, dy, xp, dw0, N, H, W, Co, Co, workspace=work0)      # noqa: E731
+    g1 = lambda: hip.stemp_wgrad(d, dy, xp, dw1, N, H, W, Co, Co, work1)               # noqa: E731
+    g0(); g1()
+    torch.cuda.synchronize()
+    werr = (dw0 - dw1).abs().max().item()
+    wref = dw0.abs().max().item()
+    times = [[], []]
+    for r in range(reps):
+        for k, f in enumerate((g0, g1)):
+            ev[0].record(); f(); ev[1].record(); torch.cuda.synchronize()
+            times[k].append(ev[0].elapsed_time(ev[1]) * 1e3)
+    med = [sorted(t)[len(t) // 2] if t else 0.0 for t in times]
+    print(f"      weight gradient: max|d| {werr:.3e} (ref {wref:.1f})  old {med[0]:7.1f} us  new {med[1]:7.1f} us", flush=True)
+    return ok and werr <= 2e-3 * wref + 1e-3
 
 
 if __name__ == "__main__":

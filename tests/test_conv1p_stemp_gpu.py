@@ -120,9 +120,52 @@ def test_stemp_matches_torch_and_the_tile_kernel(shape):
     assert torch.equal(y, y2) and torch.equal(stats[: tiles * 2 * co], s2[: tiles * 2 * co])
 
 
+@pytest.mark.parametrize("shape", ST_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_stemp_weight_gradient_matches_torch_and_the_generic_kernel(shape):
+    """dW of the stem on the LDS ring (transposing reads of dY rows and of the overlapping windows): against torch's fp32 weight gradient
+    of the same bf16 operands (small batches), against the generic split-over-pixels kernel (fp32 summation order differs), and twice
+    (bit-identical: fixed order, no atomics)."""
+    N, H, W = shape
+    co = 64
+    need = hip.stemp_wgrad_workspace(D, N, H, W, co)
+    if shape == (7, 32, 250):
+        assert need > 0                           # (157 KB of LDS: the widest rows that still fit)
+    assert need > 0, shape
+    torch.manual_seed(sum(shape) + 1)
+    img = torch.randn(N, 3, H, W)
+    Wp = (W + 1) & ~1
+    xp = torch.empty(N, H, Wp, 4, device=DEV, dtype=T)
+    hip.stem_pack(D, img.to(DEV), xp, N, 3, H, W)
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(N, P, Q, co).to(T)
+    dyd = dy.to(DEV)
+    cols = 224
+    dw1 = torch.zeros(co, cols, device=DEV)
+    work1 = torch.empty(need, device=DEV)
+    n0 = hip.kernel_launches("stemp")
+    hip.stemp_wgrad(D, dyd, xp, dw1, N, H, W, co, co, work1)
+    assert hip.kernel_launches("stemp") == n0 + 1
+    dw0 = torch.zeros(co, cols, device=DEV)
+    work0 = torch.empty(hip.stem_wgrad_workspace(D, N, H, W, co), device=DEV)
+    hip.stem_wgrad(D, dyd, xp, dw0, N, H, W, co, co, workspace=work0)
+    scale = dw0.abs().max().item()
+    torch.testing.assert_close(dw1, dw0, rtol=1e-4, atol=2e-5 * scale)
+    if N <= 8:
+        wt = torch.zeros(co, 3, 7, 7, requires_grad=True)
+        F.conv2d(img.to(T).float(), wt, stride=2, padding=3).backward(dy.float().permute(0, 3, 1, 2).contiguous())
+        folded = torch.zeros(co, 7, 7, 3, device=DEV)
+        hip.stem_wfold(D, dw1, folded, co, 3)
+        torch.testing.assert_close(folded.cpu(), wt.grad.permute(0, 2, 3, 1), rtol=1e-3, atol=1e-3 * scale)
+    dw2 = torch.zeros(co, cols, device=DEV)
+    hip.stemp_wgrad(D, dyd, xp, dw2, N, H, W, co, co, work1)
+    assert torch.equal(dw1, dw2)
+
+
 def test_stemp_refuses_what_it_cannot_run():
     assert hip.stemp_tiles(D, 8, 224, 224, 64) > 0
     assert hip.stemp_tiles(D, 8, 224, 224, 32) == 0 and hip.stemp_tiles(D, 8, 224, 300, 64) == 0 and hip.stemp_tiles(hip.F32, 8, 224, 224, 64) == 0
+    assert hip.stemp_wgrad_workspace(D, 8, 224, 224, 64) == hip.stemp_tiles(D, 8, 224, 224, 64) * 64 * 224
+    assert hip.stemp_wgrad_workspace(D, 8, 224, 224, 32) == 0
     hip.convp_config(True, stemp=False)
     try:
         assert hip.stemp_tiles(D, 8, 224, 224, 64) == 0
