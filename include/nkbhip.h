@@ -36,7 +36,7 @@ int nkb_version(void);
 /* Launch counters of the specialised kernels since process start (or the last reset): which = 0 eight-phase GEMM (gemm8p), 1 eight-phase
  * weight gradient (wgrad8p / wgrad256), 2 shared-strip 3x3 weight gradient, 3 fp8 weight gradient, 4 Gram-form closing convolution,
  * 5 bn_apply fused with the Gram matrix, 6 row-balanced 3x3 core (convp), 7 pixel-resident 1x1 expansion (conv1p), 8 ring-buffered stem
- * (stemp).  Tests use them to prove that a benchmark configuration took the path it is priced on. */
+ * (stemp: forward and weight gradient), 9 streamed g^T a (gramr).  Tests use them to prove that a benchmark configuration took the path it is priced on. */
 long long nkb_kernel_launches(int which, int reset);
 
 /* Implicit-GEMM convolution / linear layer on MFMA.
@@ -118,7 +118,7 @@ int nkb_conv1p_fwd(int dtype, const void* x, const void* w, void* y, float* stat
 /* The envelope of the row-resident kernels (convp, conv1p, stemp; NKB_CONVP=0 switches the family off).  on = 0 / 1 (default 1);
  * narrow bit 0: 3x3 also for Cout % 256 == 128 as 128-channel tiles (default 0: measured level with / slower than the 128 x 128 kernel
  * in the ResNet-50 step); bit 1: the 64 -> 64 channel 3x3 form with the filter resident in registers / LDS (default 1: forward), bit 2:
- * that form for the data gradient as well (default 0); bit 4 / bit 5: conv1p / stemp OFF (default on).  Tests and A/B timing. */
+ * that form for the data gradient as well (default 0); bit 4 / 5 / 6: conv1p / stemp / gramr OFF (default on).  Tests and A/B timing. */
 void nkb_convp_config(int on, int narrow);
 int nkb_convp_fwd(int dtype, const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int ldx, int Cout,
                   int ldy, nkb_stream_t stream);
@@ -244,6 +244,14 @@ int nkb_stem_wprep(int dtype, const float* w, void* wp, int Cout, int C, nkb_str
 int nkb_stem_weight_cols(int dtype);
 int nkb_stem_conv(int dtype, const void* xp, const void* wp, void* y, float* stats, int N, int H, int W, int Cout,
                   int ldy, nkb_stream_t stream);
+/* R[co][ci] (fp32, OVERWRITTEN) = g^T a over M pixels (csrc/gramr.hip): the Gram-form closing stage's backward product on the main stream
+ * (nkb_conv_wgrad_assign's 1x1 form) for bf16, (co, ci) = (256, 64) or (512, 128): one workgroup per CU streams its pixels through LDS and
+ * keeps the whole result in registers; one fp32 slab per workgroup in `workspace` (>= nkb_gramr_workspace_floats floats; 0 = not
+ * eligible -> nkb_conv_wgrad_assign), summed in workgroup order.  g: [M][ldg], a: [M][lda].  mode bit 0: R overwritten (else accumulated
+ * into); bit 1: R stored [ci][co] — the weight gradient of a 1x1 convolution with Cin = co (g = its input), Cout = ci (a = dY). */
+long long nkb_gramr_workspace_floats(int dtype, long long M, int co, int ci);
+int nkb_gramr(int dtype, const void* g, int ldg, const void* a, int lda, float* R, long long M, int co, int ci, int mode,
+              float* workspace, long long workspace_floats, nkb_stream_t stream);
 int nkb_stemp_tiles(int dtype, int N, int H, int W, int Cout);
 /* nkb_stem_wgrad's product on the same ring (dwp[64][224] fp32 += dY^T x window(xp); one fp32 slab per workgroup in `workspace`, summed in
  * workgroup order): for the shapes nkb_stemp_tiles admits, workspace >= nkb_stemp_wgrad_workspace_floats floats. */

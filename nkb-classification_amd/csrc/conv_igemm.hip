@@ -1175,6 +1175,13 @@ int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float
     else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
     return nkb_check_launch("wgrad_reduce");
 }
+int nkb_launch_wgrad_reduce_mode(const float* part, long long slab, int splits, float* dst, long long n, int assign, hipStream_t stream) {
+    const bool keep = g_wgrad_assign;
+    g_wgrad_assign = assign != 0;
+    const int rc = nkb_launch_wgrad_reduce(part, slab, splits, dst, n, stream);
+    g_wgrad_assign = keep;
+    return rc;
+}
 
 // ------------------------------------------------------------------------------------------
 // host launchers

@@ -1139,24 +1139,24 @@ bool cp_geom(int M, int Cout, int cus, CPGeom& g) {
 
 // NKB_CONVP: the switch of the whole family of row-resident kernels (this file, conv1p.hip, stemp.hip): 0 off, 1 on with the default
 // envelope; any higher bits are nkb_convp_config's `narrow` << 1 (A/B timing: 17 = 1 | 8 << 1: 256-channel 3x3 tiles + conv1p + stemp
-// only, 13: the 64-channel form in both directions, 37: default without conv1p, 69: default without stemp)
+// only, 13: the 64-channel form in both directions, 37: default without conv1p, 69: default without stemp, 133: default without gramr)
 static int g_cp_env = [] { const char* e = getenv("NKB_CONVP"); return e ? atoi(e) : 1; }();
 static int g_cp_on = g_cp_env & 1;
 static int g_cp_tc128 = (g_cp_env >> 1) ? ((g_cp_env >> 1) & 1) : 0;
 static int g_cp_c64 = (g_cp_env >> 1) ? (((g_cp_env >> 2) & 1) | (((g_cp_env >> 3) & 1) << 1)) : 1;
-static int g_cp_no1p = (g_cp_env >> 5) & 1, g_cp_nostem = (g_cp_env >> 6) & 1;
-// forms 4 (conv1p.hip) and 5 (stemp.hip) ask here
+static int g_cp_no1p = (g_cp_env >> 5) & 1, g_cp_nostem = (g_cp_env >> 6) & 1, g_cp_nogr = (g_cp_env >> 7) & 1;
+// forms 4 (conv1p.hip), 5 (stemp.hip) and 6 (gramr.hip) ask here
 extern "C" int nkb_convp_form_enabled(int form) {
     if (!g_cp_on) return 0;
-    return form == 4 ? !g_cp_no1p : (form == 5 ? !g_cp_nostem : 1);
+    return form == 4 ? !g_cp_no1p : (form == 5 ? !g_cp_nostem : (form == 6 ? !g_cp_nogr : 1));
 }
 static int cp_enabled() { return g_cp_on; }
 // Envelope of the row-resident kernels: on = 0 / 1 (default 1, NKB_CONVP); narrow bit 0 also admits Cout % 256 == 128 (default off),
 // bit 1 the 64 -> 64 channel resident-filter form (default on), bit 2 that form for the data gradient too (default off), bit 4 / 5
-// switch the pixel-resident 1x1 expansion (conv1p.hip) / the ring-buffered stem (stemp.hip) OFF (default on)
+// / 6 switch the pixel-resident 1x1 expansion (conv1p.hip) / the ring-buffered stem (stemp.hip) / the streamed g^T a (gramr.hip) OFF
 extern "C" void nkb_convp_config(int on, int narrow) {
     g_cp_on = on != 0; g_cp_tc128 = (narrow & 1) != 0; g_cp_c64 = ((narrow & 2) ? 1 : 0) | ((narrow & 4) ? 2 : 0);
-    g_cp_no1p = (narrow >> 4) & 1; g_cp_nostem = (narrow >> 5) & 1;
+    g_cp_no1p = (narrow >> 4) & 1; g_cp_nostem = (narrow >> 5) & 1; g_cp_nogr = (narrow >> 6) & 1;
 }
 
 extern "C" int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int R, int S, int stride,

@@ -62,6 +62,8 @@ _SIGS = {
     "nkb_stemp_tiles": (i32, [i32, i32, i32, i32, i32]),
     "nkb_stemp_wgrad_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
     "nkb_stemp_wgrad": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
+    "nkb_gramr_workspace_floats": (i64, [i32, i64, i32, i32]),
+    "nkb_gramr": (i32, [i32, vp, i32, vp, i32, vp, i64, i32, i32, i32, vp, i64, vp]),
     "nkb_stemp_conv": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nkb_stem_wprep": (i32, [i32, vp, vp, i32, i32, vp]),
     "nkb_stem_weight_cols": (i32, [i32]),
@@ -172,7 +174,7 @@ def exported_symbols():
 # (input images, logits, logits gradient) and dropout seeds.
 _REC = None            # list of plan entries while recording
 _REC_LIB = None
-_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_convp_tiles", "nkb_conv1p_tiles", "nkb_stemp_tiles", "nkb_stemp_wgrad_workspace_floats", "nkb_bn_stats_floats",
+_PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_version", "nkb_last_error", "nkb_conv_gemm_stat_tiles", "nkb_convp_tiles", "nkb_conv1p_tiles", "nkb_stemp_tiles", "nkb_stemp_wgrad_workspace_floats", "nkb_gramr_workspace_floats", "nkb_bn_stats_floats",
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
@@ -437,9 +439,9 @@ def _device_allocs() -> int:
 
 
 def kernel_launches(which: str, reset: bool = False) -> int:
-    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply, convp, conv1p, stemp."""
+    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply, convp, conv1p, stemp, gramr."""
     idx = {"gemm8p": 0, "wgrad8p": 1, "wgrad3x3": 2, "wgrad8f": 3, "gram_conv": 4, "gram_bn_apply": 5, "convp": 6, "conv1p": 7,
-           "stemp": 8}[which]
+           "stemp": 8, "gramr": 9}[which]
     return int(load().nkb_kernel_launches(idx, int(reset)))
 
 
@@ -488,9 +490,11 @@ def convp_tiles(dtype, kind, *, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad)
     return int(load().nkb_convp_tiles(dtype, kind, N, H, W, Cin, ldx, Cout, ldy, R, S, stride, pad))
 
 
-def convp_config(on: bool = True, tc128: bool = False, c64: bool = True, c64_dgrad: bool = False, conv1p: bool = True, stemp: bool = True):
-    """Envelope of the row-resident kernel family (convp / conv1p / stemp); the defaults are the train step's."""
-    load().nkb_convp_config(int(on), int(tc128) | (2 if c64 else 0) | (4 if c64_dgrad else 0) | (0 if conv1p else 16) | (0 if stemp else 32))
+def convp_config(on: bool = True, tc128: bool = False, c64: bool = True, c64_dgrad: bool = False, conv1p: bool = True, stemp: bool = True,
+                 gramr: bool = True):
+    """Envelope of the row-resident kernel family (convp / conv1p / stemp / gramr); the defaults are the train step's."""
+    load().nkb_convp_config(int(on), int(tc128) | (2 if c64 else 0) | (4 if c64_dgrad else 0) | (0 if conv1p else 16) | (0 if stemp else 32)
+                            | (0 if gramr else 64))
 
 
 def conv1p_tiles(dtype, M, Cin, ldx, Cout, ldy) -> int:
@@ -669,6 +673,17 @@ def stem_weight_cols(dtype) -> int:
 
 def stem_conv(dtype, xp, wp, y, stats, N, H, W, Cout, ldy):
     check(load().nkb_stem_conv(dtype, ptr(xp), ptr(wp), ptr(y), ptr(stats), N, H, W, Cout, ldy, stream()), "stem_conv")
+
+
+def gramr_workspace(dtype, M, co, ci) -> int:
+    """Slab floats of gramr for R[co][ci] = g^T a over M pixels; 0: not eligible (use conv_wgrad(assign=True))."""
+    return int(load().nkb_gramr_workspace_floats(dtype, M, co, ci))
+
+
+def gramr(dtype, g, ldg, a, lda, R, M, co, ci, workspace, assign=True, transposed=False):
+    """R = g^T a (assign: overwritten, else accumulated into; transposed: stored [ci][co] = a 1x1 weight gradient with g = the input)."""
+    check(load().nkb_gramr(dtype, ptr(g), ldg, ptr(a), lda, ptr(R), M, co, ci, int(assign) | (2 if transposed else 0), ptr(workspace),
+                           workspace.numel(), stream()), "gramr")
 
 
 def stemp_tiles(dtype, N, H, W, Cout) -> int:

@@ -522,6 +522,11 @@ class HipEngine:
                                stem_packed=False, bits=bits, gram=dict(T=T, mu=mu), gram_ds=gram_ds)
         return y
 
+    def _gram_r(self, g, x, R, rows, co, ci, geom):
+        """R[co][ci] = g^T x over the stage's pixels, on the MAIN stream (the coefficients of the block's data gradient wait for it);
+        wgrad() takes the streaming kernel of csrc/gramr.hip where the shape is eligible, else the generic weight-gradient kernel."""
+        self.wgrad(g, x, R, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
+
     def gram_closing_backward(self, key: str, g: torch.Tensor, g_stats, prev_key: str, slot: str):
         """Backward of a Gram-form closing stage.  g: masked gradient of the block output with its per-tile sums (left by the next
         block's conv1 data gradient, nkb_conv_dgrad_bn).  R = g^T a on the main stream (its row dots with W are sum g c, which the
@@ -538,7 +543,7 @@ class HipEngine:
         cbias = self.ws.get(key + ".gcbias", (ci,), torch.float32)
         tiles2 = hip.stat_tiles(self.d, rows, ci)
         stats2 = self.ws.get(prev_key + ".bstats", (hip.bn_stats_floats(tiles2, ci),), torch.float32)
-        self.wgrad(g, x, R, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=ci, ldx=ci, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
+        self._gram_r(g, x, R, rows, co, ci, geom)
         wcat = self.ws.get(key + ".gwcat", (ci, co + ci), self.T)
         need = hip.gram_bn_backward_ws(ci, co)
         if sv.get("gram_ds") is not None:
@@ -552,7 +557,7 @@ class HipEngine:
             dconv, dbn, xin = ds["conv"], ds["bn"], ds["x"]
             cx = dconv.weight.shape[1]
             Rd = self.ws.get(ds["key"] + ".gR", (co, cx), torch.float32)
-            self.wgrad(g, xin, Rd, assign=True, N=geom["N"], H=geom["P"], W=geom["Q"], Cin=cx, ldx=cx, P=geom["P"], Q=geom["Q"], Cout=co, lddy=co)
+            self._gram_r(g, xin, Rd, rows, co, cx, geom)
             wcd = self.ws.get(ds["key"] + ".gwcat", (cx, co + cx), self.T)
             cbd = self.ws.get(ds["key"] + ".gcbias", (cx,), torch.float32)
             hip.gram_bn_backward(self.d, self.w_fwd(dconv.weight), Rd, ds["T"], ds["mu"], stats, tiles, rows, cx, co, dbn.weight,
@@ -631,6 +636,23 @@ class HipEngine:
             if dbias is not None:
                 hip.zero_(dbias)
             assign = False
+        # 1x1 products between a wide and a narrow stage (256 <-> 64, 512 <-> 128 channels) on long pixel ranges: the streaming kernel
+        # of csrc/gramr.hip (the wide operand plays g; a convolution whose OUTPUT is the narrow one gets its gradient transposed) — for the
+        # scratch products on the MAIN stream only (assign): as a side-stream weight gradient its one workgroup per CU at the full HBM
+        # rate starves the main queue (measured: the six layer1 / layer2 launches give back the 0.14 ms the main-stream ones gain)
+        if (assign and _CONVP and _DET_WGRAD and dbias is None and self.T == torch.bfloat16 and geom.get("R", 1) == 1 and geom.get("S", 1) == 1
+                and geom.get("stride", 1) == 1 and geom.get("pad", 0) == 0 and geom["ldx"] == geom["Cin"] and geom["lddy"] == geom["Cout"]
+                and geom["H"] == geom["P"] and geom["W"] == geom["Q"]):
+            rows, ci, co = geom["N"] * geom["P"] * geom["Q"], geom["Cin"], geom["Cout"]
+            wide_out = co > ci
+            need = hip.gramr_workspace(self.d, rows, max(co, ci), min(co, ci))
+            if need:
+                work = self.ws.at_least("wgrad.slabs." + self._stream_tag(), need, torch.float32)
+                if wide_out:
+                    hip.gramr(self.d, dy, co, x, ci, dw, rows, co, ci, work, assign=assign)
+                else:
+                    hip.gramr(self.d, x, ci, dy, co, dw, rows, ci, co, work, assign=assign, transposed=True)
+                return
         work = None
         if _DET_WGRAD:
             need = hip.conv_wgrad_workspace(self.d, N=geom["N"], P=geom["P"], Q=geom["Q"], Cin=geom["Cin"], Cout=geom["Cout"],

@@ -1,4 +1,5 @@
-"""The pixel-resident 1x1 expansion kernel (csrc/conv1p.hip) and the ring-buffered stem convolution (csrc/stemp.hip) through the C ABI:
+"""The pixel-resident 1x1 expansion kernel (csrc/conv1p.hip), the ring-buffered stem convolution and weight gradient (csrc/stemp.hip) and the
+streamed g^T a product (csrc/gramr.hip) through the C ABI:
 both against torch's fp32 convolution of the same bf16 operands (the oracle's arithmetic for these layers:
 /root/reference/nkb_classification/model.py:82 builds them, engine.py:48 runs them), against the tile kernels they replace in the train
 step — same MFMA instruction, same summation order: bit-identical outputs — and their BatchNorm partial sums against sums of the stored
@@ -169,5 +170,53 @@ def test_stemp_refuses_what_it_cannot_run():
     hip.convp_config(True, stemp=False)
     try:
         assert hip.stemp_tiles(D, 8, 224, 224, 64) == 0
+    finally:
+        hip.convp_config(True)
+
+
+# N, H (square maps), co, ci: both shapes of the Gram-form stages, ragged pixel counts (a last stage that is mostly zero page)
+GR_SHAPES = [(8, 56, 256, 64), (7, 53, 256, 64), (32, 28, 512, 128), (33, 27, 512, 128), (64, 56, 256, 64)]
+
+
+@pytest.mark.parametrize("shape", GR_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gramr_matches_torch_and_the_generic_weight_gradient(shape):
+    """R = g^T a streamed through LDS with both operands through the transposing read: against torch's fp32 product of the same bf16
+    operands, against nkb_conv_wgrad_assign (different fp32 summation order), in its transposed + accumulating form, and twice."""
+    N, H, co, ci = shape
+    M = N * H * H
+    need = hip.gramr_workspace(D, M, co, ci)
+    assert need > 0, shape
+    torch.manual_seed(sum(shape))
+    g = torch.randn(M, co).to(T)
+    a = torch.randn(M, ci).to(T)
+    gd, ad = g.to(DEV), a.to(DEV)
+    R1 = torch.full((co, ci), float("nan"), device=DEV)
+    work = torch.empty(need, device=DEV)
+    n0 = hip.kernel_launches("gramr")
+    hip.gramr(D, gd, co, ad, ci, R1, M, co, ci, work)
+    assert hip.kernel_launches("gramr") == n0 + 1
+    ref = g.float().t() @ a.float()
+    scale = ref.abs().max().item()
+    torch.testing.assert_close(R1.cpu(), ref, rtol=1e-4, atol=2e-5 * scale)
+    R0 = torch.full((co, ci), float("nan"), device=DEV)
+    w0 = torch.empty(hip.conv_wgrad_workspace(D, N=N, P=H, Q=H, Cin=ci, Cout=co), device=DEV)
+    hip.conv_wgrad(D, gd, ad, R0, N=N, H=H, W=H, Cin=ci, ldx=ci, P=H, Q=H, Cout=co, lddy=co, workspace=w0, assign=True)
+    torch.testing.assert_close(R1, R0, rtol=1e-4, atol=2e-5 * scale)
+    Dt = torch.ones(ci, co, device=DEV)
+    hip.gramr(D, gd, co, ad, ci, Dt, M, co, ci, work, assign=False, transposed=True)
+    torch.testing.assert_close(Dt.cpu(), 1.0 + ref.t(), rtol=1e-4, atol=2e-5 * scale)
+    R2 = torch.empty_like(R1)
+    hip.gramr(D, gd, co, ad, ci, R2, M, co, ci, work)
+    assert torch.equal(R1, R2)
+
+
+def test_gramr_refuses_what_it_cannot_run():
+    assert hip.gramr_workspace(D, 802816, 256, 64) > 0 and hip.gramr_workspace(D, 200704, 512, 128) > 0
+    for bad in ((802816, 256, 128), (802816, 128, 64), (8000, 256, 64), (802816, 64, 256)):
+        assert hip.gramr_workspace(D, *bad) == 0, bad
+    assert hip.gramr_workspace(hip.F32, 802816, 256, 64) == 0
+    hip.convp_config(True, gramr=False)
+    try:
+        assert hip.gramr_workspace(D, 802816, 256, 64) == 0
     finally:
         hip.convp_config(True)

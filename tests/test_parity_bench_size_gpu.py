@@ -128,7 +128,7 @@ def _run(model_name, batch, dtype, classes, steps=4, heads="", size=224):
     return out, counters, len(eng.plans)
 
 
-COUNTERS = ("gemm8p", "wgrad8p", "wgrad3x3", "wgrad8f", "gram_conv", "gram_bn_apply", "convp", "conv1p", "stemp")
+COUNTERS = ("gemm8p", "wgrad8p", "wgrad3x3", "wgrad8f", "gram_conv", "gram_bn_apply", "convp", "conv1p", "stemp", "gramr")
 
 
 def _check(out, relative=True, cos_bar=None, l2_bar=None, loss_tol=1e-2, cos_slack=1e-3):
@@ -149,6 +149,7 @@ def test_resnet50_bench_configuration_matches_oracle():
     assert n["gram_conv"] > 0 and n["gram_bn_apply"] > 0                   # Gram-form closing stages (layer1 / layer2)
     assert n["convp"] > 0                                                  # row-balanced 3x3 core (layer1 / 3 / 4 conv2)
     assert n["conv1p"] > 0 and n["stemp"] > 0                              # pixel-resident 1x1 expansions (layer3), ring-buffered stem
+    assert n["gramr"] > 0                                                  # streamed g^T a of the Gram-form closing stages' backward
 
 
 def test_resnet50_multitask_configs3_matches_oracle():
