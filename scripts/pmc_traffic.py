@@ -18,7 +18,7 @@ FAMILIES = (  # first match wins; (substring of the kernel name, family)
     ("convp64", "conv_igemm"), ("conv1p_kernel", "conv_igemm"), ("conv1s_kernel", "conv_igemm"), ("stemp_kernel", "conv_igemm"),
     ("wgrad_reduce_kernel", "wgrad_reduce"), ("gram_reduce_kernel", "wgrad_reduce"),
     ("wgrad8p", "wgrad8p"), ("wgrad8f", "wgrad8f"), ("wgrad3x3_kernel", "wgrad3x3"), ("wgrad256_kernel", "wgrad8p"),
-    ("conv_wgrad_kernel", "conv_wgrad"),
+    ("conv_wgrad_kernel", "conv_wgrad"), ("gramr_kernel", "conv_wgrad"), ("stempw_kernel", "conv_wgrad"),
     ("bn_apply_gram_kernel", "bn_apply"), ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
     ("bn_apply_kernel", "bn_apply"), ("bn_relu_maxpool", "stem_tail"), ("stem_", "stem"),
     ("bn_partial_reduce", "bn_finalize"), ("bn_finalize", "bn_finalize"), ("bn_bwd_finalize", "bn_finalize"),
