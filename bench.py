@@ -288,6 +288,7 @@ def main():
         if force_dist:
             reducer.world = 2        # take the multi-rank code path (bucketing, side stream, async work handles)
             opt.grad_scale = 1.0
+            hip.rowres_reserve_cus(32)      # ... and the grid sizing a real multi-rank reducer asks for (parallel.GradReducer)
 
     g = torch.Generator().manual_seed(1234 + rank)
     img = torch.randn(args.batch, 3, 224, 224, generator=g).to(device)

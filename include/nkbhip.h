@@ -120,6 +120,10 @@ int nkb_conv1p_fwd(int dtype, const void* x, const void* w, void* y, float* stat
  * in the ResNet-50 step); bit 1: the 64 -> 64 channel 3x3 form with the filter resident in registers / LDS (default 1: forward), bit 2:
  * that form for the data gradient as well (default 0); bit 4 / 5 / 6: conv1p / stemp / gramr OFF (default on).  Tests and A/B timing. */
 void nkb_convp_config(int on, int narrow);
+/* Data-parallel runs: the family's BACKWARD kernels (nkb_convp_dgrad_bn, nkb_gramr) size their one-workgroup-per-CU grids for
+ * #CUs - cus, leaving room for the collective's resident workgroups.  Call once, before the first step (0 = default). */
+void nkb_rowres_reserve_cus(int cus);
+int nkb_rowres_reserved_cus(void);
 int nkb_convp_fwd(int dtype, const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int ldx, int Cout,
                   int ldy, nkb_stream_t stream);
 int nkb_convp_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,

@@ -1145,6 +1145,12 @@ static int g_cp_on = g_cp_env & 1;
 static int g_cp_tc128 = (g_cp_env >> 1) ? ((g_cp_env >> 1) & 1) : 0;
 static int g_cp_c64 = (g_cp_env >> 1) ? (((g_cp_env >> 2) & 1) | (((g_cp_env >> 3) & 1) << 1)) : 1;
 static int g_cp_no1p = (g_cp_env >> 5) & 1, g_cp_nostem = (g_cp_env >> 6) & 1, g_cp_nogr = (g_cp_env >> 7) & 1;
+// CUs the backward-pass kernels of the family leave free (data-parallel runs: the collective's workgroups are resident on a few CUs
+// during backward, and a one-workgroup-per-CU grid that does not fit next to them runs a second round for a handful of workgroups).
+// Set ONCE, before the first step (the partial-sum row counts derived from the grid are recorded in the launch plans).
+static int g_cp_reserve = 0;
+extern "C" void nkb_rowres_reserve_cus(int cus) { g_cp_reserve = cus < 0 ? 0 : (cus > 128 ? 128 : cus); }
+extern "C" int nkb_rowres_reserved_cus() { return g_cp_reserve; }
 // forms 4 (conv1p.hip), 5 (stemp.hip) and 6 (gramr.hip) ask here
 extern "C" int nkb_convp_form_enabled(int form) {
     if (!g_cp_on) return 0;
@@ -1176,7 +1182,7 @@ extern "C" int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin
         (long long)Cout * 9 * Cin * 2 >= 0xFFFFFF00ll)
         return 0;
     CPGeom g;
-    if (!cp_geom((int)M, Cout, cp_cus(), g)) return 0;
+    if (!cp_geom((int)M, Cout, cp_cus() - (kind == 1 ? nkb_rowres_reserved_cus() : 0), g)) return 0;
     return g.nwgm;
 }
 
@@ -1186,7 +1192,7 @@ static int convp_launch(int kind, const void* x, const void* w, void* y, const v
     if (!tiles) { nkb_set_error("convp: shape not eligible (N=%d H=%d W=%d Cin=%d Cout=%d)", N, H, W, Cin, Cout); return 1; }
     if (!stats || (kind == 1 && (!c || !scale || !shift || !mean))) { nkb_set_error("convp: missing operand"); return 1; }
     CPGeom g;
-    cp_geom(N * H * W, Cout, cp_cus(), g);
+    cp_geom(N * H * W, Cout, cp_cus() - (kind == 1 ? nkb_rowres_reserved_cus() : 0), g);
     CPParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.aux = (const bf16_t*)c;
     p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean; p.stats = stats;

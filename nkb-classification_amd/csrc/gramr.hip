@@ -214,7 +214,7 @@ void gr_launch(const GRParams& p, hipStream_t stream) {
 extern "C" long long nkb_gramr_workspace_floats(int dtype, long long M, int co, int ci) {
     if (!nkb_convp_form_enabled(6) || dtype != NKB_DT_BF16 || M < 16384 || M >= (1ll << 31) / 1024) return 0;
     GRGeom g;
-    if (!gr_geom(M, co, ci, gr_cus(), g)) return 0;
+    if (!gr_geom(M, co, ci, gr_cus() - nkb_rowres_reserved_cus(), g)) return 0;
     return (long long)g.nwg * co * ci;
 }
 
@@ -226,7 +226,7 @@ extern "C" int nkb_gramr(int dtype, const void* g, int ldg, const void* a, int l
     if (!need) { nkb_set_error("gramr: shape not eligible (M=%lld co=%d ci=%d)", M, co, ci); return 1; }
     if (!workspace || workspace_floats < need || ldg % 8 != 0 || lda % 8 != 0 || ldg < co || lda < ci) { nkb_set_error("gramr: bad operand"); return 1; }
     GRGeom gg;
-    gr_geom(M, co, ci, gr_cus(), gg);
+    gr_geom(M, co, ci, gr_cus() - nkb_rowres_reserved_cus(), gg);
     GRParams p;
     p.g = (const bf16_t*)g; p.a = (const bf16_t*)a; p.part = workspace; p.M = (int)M; p.ldg = ldg; p.lda = lda;
     p.rows_per_wg = gg.rows; p.nwg = gg.nwg; p.transposed = (mode >> 1) & 1;

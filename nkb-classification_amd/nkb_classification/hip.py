@@ -38,6 +38,8 @@ _SIGS = {
     "nkb_convp_tiles": (i32, [i32] * 13),
     "nkb_conv1p_tiles": (i32, [i32, i64, i32, i32, i32, i32]),
     "nkb_conv1p_fwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "nkb_rowres_reserve_cus": (None, [i32]),
+    "nkb_rowres_reserved_cus": (i32, []),
     "nkb_convp_config": (None, [i32, i32]),
     "nkb_convp_fwd": (i32, [i32, vp, vp, vp, vp] + [i32] * 7 + [vp]),
     "nkb_convp_dgrad_bn": (i32, [i32] + [vp] * 8 + [i32] * 7 + [vp]),
@@ -178,7 +180,7 @@ _PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_versi
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
-                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_convp_config",
+                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_convp_config", "nkb_rowres_reserve_cus", "nkb_rowres_reserved_cus",
                    "nkb_fp8_job_blocks", "nkb_wgrad_fp8_workspace_floats",
                    "nkb_fp8_quantize_colsum_workspace_floats",
                    "nkb_gram_bn_backward_workspace_floats", "nkb_bn_apply_gram_workspace_floats",
@@ -495,6 +497,11 @@ def convp_config(on: bool = True, tc128: bool = False, c64: bool = True, c64_dgr
     """Envelope of the row-resident kernel family (convp / conv1p / stemp / gramr); the defaults are the train step's."""
     load().nkb_convp_config(int(on), int(tc128) | (2 if c64 else 0) | (4 if c64_dgrad else 0) | (0 if conv1p else 16) | (0 if stemp else 32)
                             | (0 if gramr else 64))
+
+
+def rowres_reserve_cus(cus: int):
+    """Data-parallel runs: CUs the row-resident family's backward kernels leave to the collective (set before the first step)."""
+    load().nkb_rowres_reserve_cus(int(cus))
 
 
 def conv1p_tiles(dtype, M, Cin, ldx, Cout, ldy) -> int:

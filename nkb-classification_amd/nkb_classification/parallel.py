@@ -26,7 +26,8 @@ class GradReducer:
     parameters — unicom ViT-L/14's 572 M parameters are 2.29 GB per step in fp32, which a ring over 153 GB/s links does not hide
     under a ~50 ms step.  Every rank ends up with bit-identical gradients in either mode."""
 
-    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes: int = 25 << 20, bucket_dtype: str = "auto"):
+    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes: int = 25 << 20, bucket_dtype: str = "auto",
+                 reserve_cus: int = 32):
         if not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.model = model
@@ -39,6 +40,11 @@ class GradReducer:
             raise ValueError(f"bucket_dtype {mode!r}: expected auto, fp32 or bf16")
         total = getattr(getattr(model, "arena", None), "total", 0) or 0
         self.bf16_buckets = mode == "bf16" or (mode == "auto" and total > 100_000_000)
+        if self.world > 1 and getattr(getattr(model, "arena", None), "device", None) is not None and model.arena.device.type == "cuda":
+            # the collective's workgroups stay resident on a few CUs while backward runs: the one-workgroup-per-CU kernels of the
+            # backward pass leave them room (a grid that does not fit runs a second round for a handful of workgroups)
+            from . import hip
+            hip.rowres_reserve_cus(reserve_cus)
         self._stage = {}                          # (bucket length, device) -> persistent bf16 staging buffers (_staging)
         self.stage_allocs = 0                     # how many of them were ever allocated (tests: constant after the first step)
         if self.bf16_buckets:
