@@ -144,3 +144,35 @@ def test_convp_refuses_what_it_cannot_run():
     x = torch.zeros(1, 28, 28, 64, device=DEV, dtype=T)
     with pytest.raises(RuntimeError, match="not eligible"):
         hip.convp_fwd(D, x, x, x, torch.zeros(8, device=DEV), N=1, H=28, W=28, Cin=64, ldx=64, Cout=128, ldy=128)
+
+
+def test_backward_grids_leave_reserved_cus_to_a_collective():
+    """nkb_rowres_reserve_cus (what a multi-rank GradReducer calls before the first step): the data-gradient kernel and the streamed
+    g^T a size their grids for #CUs - 32 — fewer partial rows / slabs, the same numbers."""
+    shape = (256, 14, 14, 256, 256)
+    N, H, W, C, Co = shape
+    g = dict(N=N, H=H, W=W, Cin=Co, ldx=Co, Cout=C, ldy=C)
+    t0 = hip.convp_tiles(D, 1, R=3, S=3, stride=1, pad=1, **g)
+    f0 = hip.convp_tiles(D, 0, R=3, S=3, stride=1, pad=1, **g)
+    w0 = hip.gramr_workspace(D, 802816, 256, 64)
+    torch.manual_seed(3)
+    c = torch.randn(N, H, W, C, device=DEV).to(T)
+    dy = torch.randn(N, H, W, Co, device=DEV).to(T)
+    wt = (torch.randn(C, 3, 3, Co, device=DEV) / math.sqrt(9 * Co)).to(T)
+    scale, shift, mean = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1, torch.randn(C, device=DEV) * 0.1
+    out = []
+    try:
+        for reserve in (0, 32):
+            hip.rowres_reserve_cus(reserve)
+            tiles = hip.convp_tiles(D, 1, R=3, S=3, stride=1, pad=1, **g)
+            g1 = torch.full((N, H, W, C), float("nan"), device=DEV, dtype=T)
+            stats = torch.full((hip.bn_stats_floats(tiles, C),), float("nan"), device=DEV)
+            hip.convp_dgrad_bn(D, dy, wt, g1, c, scale, shift, mean, stats, **g)
+            out.append((tiles, g1, stats[: tiles * 2 * C].view(tiles, 2, C).double().sum(0)))
+        assert out[0][0] == t0 and out[1][0] < t0                       # 242 -> 224 workgroups on a 256-CU chip
+        assert hip.convp_tiles(D, 0, R=3, S=3, stride=1, pad=1, **g) == f0  # the forward grid is not touched
+        assert 0 < hip.gramr_workspace(D, 802816, 256, 64) < w0
+        assert torch.equal(out[0][1], out[1][1])
+        torch.testing.assert_close(out[0][2], out[1][2], rtol=1e-5, atol=1e-2)
+    finally:
+        hip.rowres_reserve_cus(0)
