@@ -196,9 +196,239 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const W3Params p) {
             }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same strip product with the DMA actually running ahead.  In the kernel above every LDS read is compiler-visible, and a
+// compiler-visible LDS read behind an LDS-DMA makes hipcc settle vmcnt(0) in front of it: the loop issued the next k-step's chunks and
+// then WAITED for them before its first fragment read (s_waitcnt vmcnt(0) at the top of the multiply section) — a k-step cost one full
+// memory latency plus its 72 MFMAs, 1.83 us for 0.48 us of matrix work, one workgroup per CU.  Here
+//   * all fragment reads are inline assembly (ds_read_b64_tr_b16) behind counted s_waitcnt lgkmcnt: B fragments two taps ahead, the
+//     four dY fragments of the next half-step at tap 5, and the pipeline runs THROUGH the k-step boundary (the last taps of a k-step
+//     already read the next one's first fragments);
+//   * D k-steps of chunks are in flight (X ring of D + 3 positions + a 32-slot mirror of position 0, D + 1 dY buffers);
+//   * the one barrier of a k-step sits in its MIDDLE, behind a counted vmcnt: "k-step k + 1 has landed and everybody is done with
+//     k - 1" — then the chunks of k-step k + D are requested into the buffers of k - 1;
+//   * the strip walk of the DMA is incremental: a lane's column never changes (64 slots = whole strip rows), its row advances by
+//     64 / PW with at most one image wrap per chunk — no division in the loop.
+// Same MFMA instruction, same k order inside a split, same slabs: bit-identical to the kernel above.
+template <int PWS, int D>
+__global__ __launch_bounds__(256, 2) void wgrad3x3p_kernel(const W3Params p) {
+    constexpr int CH = 64 * 128;                  // one 64-slot chunk
+    constexpr int NP = D + 3, ND = D + 1;         // X ring positions, dY buffers
+    constexpr int MIRROR = NP * CH;               // first 32 slots of ring position 0 once more
+    constexpr int DYOFF = MIRROR + CH / 2;
+    constexpr int PW = 1 << PWS, RS = 64 >> PWS;  // slots per strip row, strip rows per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const unsigned ntile = (unsigned)(p.tilesCo * p.tilesCi);
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
+    const int co0 = (tile % p.tilesCo) * 64, ci0 = (tile / p.tilesCo) * 64;
+    const int k_begin = split * p.ksteps_per_split;
+    const int nk = min(p.ksteps, k_begin + p.ksteps_per_split) - k_begin;
+    if (nk <= 0) return;
+
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, OOB, 0x00020000);
+    const int lslot = lane >> 3, lpos = lane & 7;
+    const int H1 = p.H + 1;
+
+    // ---- strip walkers: piece q of a chunk = slots (wave + 4 q) * 8 + lslot; col is fixed, (n, ri) advance by RS rows per chunk
+    struct Walk { int ri, n; unsigned off; };
+    Walk wx[2], wd[2];
+    bool xcol[2], dcol[2];
+    const unsigned x_rowstep = (unsigned)(RS * p.W * p.ldx * 2), x_onerow = (unsigned)(p.W * p.ldx * 2);
+    const unsigned d_rowstep = (unsigned)(RS * p.W * p.lddy * 2), d_onerow = (unsigned)(p.W * p.lddy * 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sl = (wave + 4 * q) * 8 + lslot;                 // slot inside the chunk
+        const int sigma = k_begin * 64 + sl;
+        const int R = sigma >> PWS, c = sigma & (PW - 1);
+        const int n = (int)fdiv((unsigned)R, p.divH1), ri = R - n * H1;
+        const int sc = (((lpos >> 1) ^ swz3(sl)) << 1) | (lpos & 1);
+        wx[q].ri = ri; wx[q].n = n;
+        wx[q].off = (unsigned)((((n * p.H + ri - 1) * p.W + c - 1) * p.ldx + ci0 + sc * 8) * 2);
+        xcol[q] = c != 0 && c <= p.W;
+        wd[q].ri = ri; wd[q].n = n;
+        wd[q].off = (unsigned)((((n * p.H + ri) * p.W + c) * p.lddy + co0 + sc * 8) * 2);
+        dcol[q] = c < p.W;
+    }
+    int xpos = 0, dpos = 0;                       // next ring position / dY buffer to fill
+    auto issue_x = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pc = wave + 4 * q;
+            const unsigned off = (xcol[q] && wx[q].ri != 0 && wx[q].n < p.N) ? wx[q].off : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(smem + xpos * CH + pc * 1024), 16,
+                                                     (int)off, 0, 0, 0);
+            if (q == 0 && xpos == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(smem + MIRROR + pc * 1024), 16,
+                                                         (int)off, 0, 0, 0);
+            wx[q].ri += RS; wx[q].off += x_rowstep;
+            if (wx[q].ri >= H1) { wx[q].ri -= H1; wx[q].n += 1; wx[q].off -= x_onerow; }
+        }
+        xpos = xpos + 1 == NP ? 0 : xpos + 1;
+    };
+    auto issue_dy = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pc = wave + 4 * q;
+            const unsigned off = (dcol[q] && wd[q].ri != p.H && wd[q].n < p.N) ? wd[q].off : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)(smem + DYOFF + dpos * CH + pc * 1024),
+                                                     16, (int)off, 0, 0, 0);
+            wd[q].ri += RS; wd[q].off += d_rowstep;
+            if (wd[q].ri >= H1) { wd[q].ri -= H1; wd[q].n += 1; wd[q].off -= d_onerow; }
+        }
+        dpos = dpos + 1 == ND ? 0 : dpos + 1;
+    };
+
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addresses (the layout of the kernel above): lane (g, q4, p4) supplies slot 8 g + q4 (+ 4), bytes 8 p4 of a block
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+    const int L0 = 8 * g + q4;
+    unsigned va[4][2];                            // dY fragment (cout block i, half hi) inside a dY buffer
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi)
+            va[i][hi] = lds0 + DYOFF + (unsigned)((L0 + 4 * hi) * 128 + 8 * p4 + ((i << 5) ^ (swz3(L0 + 4 * hi) << 5)));
+    constexpr int NCLS = PWS == 3 ? 6 : 3;
+    unsigned tb[NCLS][2];                         // X fragment relative to a 16-slot-aligned ring slot, per low-bits class of the tap
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int V = (c >= 3 ? 8 + c - 3 : c) + L0 + 4 * hi;
+            tb[c][hi] = lds0 + (unsigned)(V * 128 + ((wave ^ swz3(V)) << 5) + 8 * p4);
+        }
+
+    // (the ring only ever holds activations or zeros: see the note in the kernel above)
+    for (int i = tid; i < (NP + ND) * CH / 16 + CH / 32; i += 256) *(u32x4*)(smem + 16 * i) = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // ---- prologue: k-step 0 needs X chunks 0..2 and dY chunk 0; k-steps 1 .. D-1 one more of each
+    issue_x(); issue_x(); issue_x(); issue_dy();
+#pragma unroll
+    for (int j = 1; j < D; ++j)
+        if (j < nk) { issue_x(); issue_dy(); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+#define W3_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define W3_WAIT(n, f) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(n))
+    u32x2 fa[2][4][2], fb[3][2];
+    int ub = 0, db = 0;                           // ring slot of X strip slot 64 k (relative to k_begin), byte offset of dY buffer k
+    // ring byte offset of the 16-slot-aligned base of tap t of half-step kk, `ahead` k-steps on
+    auto xbase = [&](int t, int kk, int ahead) -> unsigned {
+        const int r = t / 3, s = t - 3 * r;
+        const int o = (r << PWS) + s;
+        int slot = ub + 64 * ahead + (o & ~15) + 32 * kk;
+        if (slot >= NP * 64) slot -= NP * 64;
+        return (unsigned)slot * 128u;
+    };
+    auto xcls = [&](int t) -> int { const int r = t / 3, s = t - 3 * r; return (PWS == 3 ? 3 * (r & 1) : 0) + s; };
+
+    // pipeline fill: A fragments of (k-step 0, kk 0), B fragments of units 0 and 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { W3_TR(fa[0][i][0], va[i][0], 0); W3_TR(fa[0][i][1], va[i][1], 0); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const unsigned sb = xbase(u, 0, 0);
+        const unsigned a0 = tb[xcls(u)][0] + sb, a1 = tb[xcls(u)][1] + sb;
+        W3_TR(fb[u][0], a0, 0); W3_TR(fb[u][1], a1, 0);
+    }
+
+    for (int k = 0; k < nk; ++k) {
+        const int db_next = db + CH == ND * CH ? 0 : db + CH;
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {
+            const int kk = u / 9, t = u - 9 * kk;
+            if (u == 9) {
+                // ---- the k-step's barrier: k-step k + 1 has landed everywhere, nobody reads k - 1 any more
+                if (k + D - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 2)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (k + D < nk) { issue_x(); issue_dy(); }
+                asm volatile("" ::: "memory");
+            }
+            {   // B fragment of unit u + 2 (units 18, 19 = taps 0, 1 of the next k-step)
+                const int u2 = u + 2, ahead = u2 >= 18 ? 1 : 0, uu = u2 - 18 * ahead;
+                const int kk2 = uu / 9, t2 = uu - 9 * kk2;
+                const unsigned sb = xbase(t2, kk2, ahead);
+                const unsigned a0 = tb[xcls(t2)][0] + sb, a1 = tb[xcls(t2)][1] + sb;
+                W3_TR(fb[u2 % 3][0], a0, 0); W3_TR(fb[u2 % 3][1], a1, 0);
+            }
+            if (t == 5) {                         // A fragments of the next half-step
+                const unsigned boff = (unsigned)(kk == 0 ? db : db_next);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned a0 = va[i][0] + boff, a1 = va[i][1] + boff;
+                    if (kk == 0) { W3_TR(fa[1][i][0], a0, 4096); W3_TR(fa[1][i][1], a1, 4096); }
+                    else { W3_TR(fa[0][i][0], a0, 0); W3_TR(fa[0][i][1], a1, 0); }
+                }
+            }
+            // younger than B(u): B(u+1), B(u+2) — and the eight A reads while they are in between (taps 5, 6, 7)
+            if (t >= 5 && t <= 7) W3_WAIT(12, fb[u % 3]); else W3_WAIT(4, fb[u % 3]);
+            const u32x4 vb = {fb[u % 3][0][0], fb[u % 3][0][1], fb[u % 3][1][0], fb[u % 3][1][1]};
+            const bf16x8 b_ = __builtin_bit_cast(bf16x8, vb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (t == 0) asm volatile("" : "+v"(fa[kk][i][0]), "+v"(fa[kk][i][1]));      // (landed: older than this unit's B)
+                const u32x4 va_ = {fa[kk][i][0][0], fa[kk][i][0][1], fa[kk][i][1][0], fa[kk][i][1][1]};
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va_), b_, acc[i][t], 0, 0, 0);
+            }
+        }
+        ub = ub + 64 == NP * 64 ? 0 : ub + 64;
+        db = db_next;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments read past the last k-step (never used)
+#undef W3_TR
+#undef W3_WAIT
+
+    // ---- epilogue: acc[i][t][e] = dW[co0 + 16 i + 4 g + e][tap t][ci0 + 16 wave + (lane & 15)]
+    const int ci = ci0 + 16 * wave + li;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const size_t idx = ((size_t)(co0 + 16 * i + 4 * g + e) * 9 + t) * p.Cin + ci;
+                if (p.part) p.part[(size_t)split * p.slab + idx] = acc[i][t][e];
+                else atomicAdd(p.dw + idx, acc[i][t][e]);
+            }
+}
+
+template <int PWS, int D>
+static void w3p_launch(const W3Params& p, hipStream_t stream) {
+    constexpr int lds = (D + 3 + D + 1) * 64 * 128 + 32 * 128;
+    static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)wgrad3x3p_kernel<PWS, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((wgrad3x3p_kernel<PWS, D>), dim3((unsigned)(p.tilesCo * p.tilesCi * p.splits)), dim3(256), lds, stream, p);
+}
+
 }  // namespace
 
 static int w3_pw_shift(int W) { return W + 1 <= 8 ? 3 : W + 1 <= 16 ? 4 : W + 1 <= 32 ? 5 : 6; }
+// NKB_WGRAD3X3: 0 off (generic kernel), 1 the pipelined kernel (default), 2 the round-1 kernel, 3 the pipelined kernel two k-steps deep
+static int w3_mode() {
+    static const int m = [] { const char* e = getenv("NKB_WGRAD3X3"); return e ? atoi(e) : 1; }();
+    return m;
+}
 // (workgroups a launch aims for: it runs beside the main stream and every split costs a slab — in-step A/B on ResNet-50, same box:
 // 512: 20.80-20.87 ms, 384: 20.75-20.78, 256: 20.52-20.72, 192: 20.57, 128: 20.65)
 static int w3_target() {
@@ -219,9 +449,8 @@ static void w3_plan(int N, int H, int W, int Cin, int Cout, int* ksteps, int* sp
 
 bool nkb_wgrad3x3_eligible(int dtype, int N, int H, int W, int Cin, int Cout, int P, int Q, int R, int S, int stride, int pad,
                            int ldx, int lddy) {
-    static const int on = [] { const char* e = getenv("NKB_WGRAD3X3"); return e ? atoi(e) : 1; }();
-    return on && dtype == NKB_DT_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && P == H && Q == W && Cin % 64 == 0 &&
-           Cout % 64 == 0 && W + 1 <= 64 && ldx % 8 == 0 && lddy % 8 == 0 &&
+    return w3_mode() && dtype == NKB_DT_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && P == H && Q == W && Cin % 64 == 0 &&
+           Cout % 64 == 0 && W + 1 <= 64 && H + 1 >= (64 >> w3_pw_shift(W)) && ldx % 8 == 0 && lddy % 8 == 0 &&
            (long long)N * H * W * ldx * 2 < 0xFFFFFF00ll && (long long)N * H * W * lddy * 2 < 0xFFFFFF00ll;
 }
 
@@ -242,13 +471,29 @@ int nkb_launch_wgrad3x3(const void* dy, const void* x, float* dw, int N, int H, 
     p.tilesCo = Cout / 64; p.tilesCi = Cin / 64;
     w3_plan(N, H, W, Cin, Cout, &p.ksteps, &p.splits, &p.ksteps_per_split);
     p.divH1 = make_fastdiv((unsigned)(H + 1));
-    constexpr int lds = 5 * 64 * 128 + 2 * 64 * 128;            // X ring + mirror, two dY buffers: 56 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)wgrad3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    if (w3_mode() == 2) {
+        constexpr int lds = 5 * 64 * 128 + 2 * 64 * 128;            // X ring + mirror, two dY buffers: 56 KB
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)wgrad3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)(p.tilesCo * p.tilesCi * p.splits)), dim3(256), lds, stream, p);
+    } else if (w3_mode() == 3) {
+        switch (p.pw_shift) {
+            case 3: w3p_launch<3, 2>(p, stream); break;
+            case 4: w3p_launch<4, 2>(p, stream); break;
+            case 5: w3p_launch<5, 2>(p, stream); break;
+            default: w3p_launch<6, 2>(p, stream); break;
+        }
+    } else {
+        switch (p.pw_shift) {
+            case 3: w3p_launch<3, 3>(p, stream); break;
+            case 4: w3p_launch<4, 3>(p, stream); break;
+            case 5: w3p_launch<5, 3>(p, stream); break;
+            default: w3p_launch<6, 3>(p, stream); break;
+        }
     }
-    hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)(p.tilesCo * p.tilesCi * p.splits)), dim3(256), lds, stream, p);
     int rc = nkb_check_launch("wgrad3x3");
     if (rc || !workspace) return rc;
     return nkb_launch_wgrad_reduce(workspace, p.slab, p.splits, dw, p.slab, stream);
