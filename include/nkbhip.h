@@ -36,7 +36,7 @@ int nkb_version(void);
 /* Launch counters of the specialised kernels since process start (or the last reset): which = 0 eight-phase GEMM (gemm8p), 1 eight-phase
  * weight gradient (wgrad8p / wgrad256), 2 shared-strip 3x3 weight gradient, 3 fp8 weight gradient, 4 Gram-form closing convolution,
  * 5 bn_apply fused with the Gram matrix, 6 row-balanced 3x3 core (convp), 7 pixel-resident 1x1 expansion (conv1p), 8 ring-buffered stem
- * (stemp: forward and weight gradient), 9 streamed g^T a (gramr).  Tests use them to prove that a benchmark configuration took the path it is priced on. */
+ * (stemp: forward and weight gradient), 9 streamed g^T a (gramr), 10 row-streaming 256 x 128-tile 1x1 weight gradient (wgradr).  Tests use them to prove that a benchmark configuration took the path it is priced on. */
 long long nkb_kernel_launches(int which, int reset);
 
 /* Implicit-GEMM convolution / linear layer on MFMA.

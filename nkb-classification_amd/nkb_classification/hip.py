@@ -441,9 +441,9 @@ def _device_allocs() -> int:
 
 
 def kernel_launches(which: str, reset: bool = False) -> int:
-    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply, convp, conv1p, stemp, gramr."""
+    """Launch count of a specialised kernel family: gemm8p, wgrad8p, wgrad3x3, wgrad8f, gram_conv, gram_bn_apply, convp, conv1p, stemp, gramr, wgradr."""
     idx = {"gemm8p": 0, "wgrad8p": 1, "wgrad3x3": 2, "wgrad8f": 3, "gram_conv": 4, "gram_bn_apply": 5, "convp": 6, "conv1p": 7,
-           "stemp": 8, "gramr": 9}[which]
+           "stemp": 8, "gramr": 9, "wgradr": 10}[which]
     return int(load().nkb_kernel_launches(idx, int(reset)))
 
 
