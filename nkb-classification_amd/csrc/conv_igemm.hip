@@ -1696,7 +1696,7 @@ extern "C" long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, in
     // (3x3 / stride 1 / pad 1: the input grid equals the output grid; leading dimensions do not change the slab count)
     if (!has_bias && nkb_wgrad3x3_eligible(dtype, N, P, Q, Cin, Cout, P, Q, R, S, stride, pad, 8, 8))
         return nkb_wgrad3x3_workspace_floats(N, P, Q, Cin, Cout);
-    if (!has_bias && nkb_wgradr_eligible(dtype, M, Cin, Cout, R, S, stride, pad, 8, 8)) return nkb_wgradr_workspace_floats(M, Cin, Cout);
+    if (nkb_wgradr_eligible(dtype, M, Cin, Cout, R, S, stride, pad, 8, 8, has_bias)) return nkb_wgradr_workspace_floats(M, Cin, Cout, has_bias);
     if (nkb_wgrad256_eligible(dtype, M, Cin, Cout, R, S, stride, pad)) return nkb_wgrad256_workspace_floats(M, Cin, Cout, has_bias);
     // (the larger of the two split counts a launch may take: the shared-GPU target, or nkb_conv_wgrad_assign's full-chip one)
     constexpr int main_wgs = 0;
@@ -1736,12 +1736,12 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
                           ((double)N * H * W * Cin + (double)N * P * Q * Cout) * esz + 2.0 * 4.0 * Cout * 9 * Cin);
         return nkb_launch_wgrad3x3(dy, x, dw, N, H, W, Cin, ldx, Cout, lddy, workspace, stream);
     }
-    if (dbias == nullptr && nkb_wgradr_eligible(dtype, (long long)N * P * Q, Cin, Cout, R, S, stride, pad, ldx, lddy)) {
+    if (nkb_wgradr_eligible(dtype, (long long)N * P * Q, Cin, Cout, R, S, stride, pad, ldx, lddy, dbias != nullptr)) {
         // 1x1 / stride 1 with channel counts in multiples of 256 and 128: 256 x 128 tiles streamed over the pixels (wgradr.hip)
         const long long M = (long long)N * P * Q;
         NkbProfScope prof(NKB_K_CONV_WGRAD, stream, 2.0 * M * (double)Cout * Cin,
                           ((double)M * Cin + (double)M * Cout) * esz + 2.0 * 4.0 * Cout * Cin);
-        return nkb_launch_wgradr(dy, x, dw, M, Cin, ldx, Cout, lddy, workspace, stream);
+        return nkb_launch_wgradr(dy, x, dw, dbias, M, Cin, ldx, Cout, lddy, workspace, stream);
     }
     if (nkb_wgrad256_eligible(dtype, N * P * Q, Cin, Cout, R, S, stride, pad)) {
         // wide Linear layers: 256 x 256 tiles (wgrad256.hip)

@@ -1,22 +1,24 @@
-// Weight gradient of the 1x1 / stride-1 convolutions whose channel counts are multiples of 256 and 128 (timm Bottleneck conv1 / conv3 of
-// layer2-4 and the first blocks' conv1, built at /root/reference/nkb_classification/model.py:82; reached from loss.backward() at
-// engine.py:55-58):
+// Weight gradient of the 1x1 / stride-1 convolutions and Linear layers whose channel counts are multiples of 256 and 128 (timm Bottleneck
+// conv1 / conv3 of layer2-4, built at /root/reference/nkb_classification/model.py:82, and the qkv / proj / fc1 / fc2 layers of the ViT
+// blocks; reached from loss.backward() at engine.py:55-58):
 //
-//     dW[cout][cin] = sum over pixels m of dY[m][cout] * X[m][cin]
+//     dW[cout][cin] = sum over pixels m of dY[m][cout] * X[m][cin]          (+ dbias[cout] = sum over m of dY[m][cout])
 //
 // The eight-phase kernel (wgrad256.hip) multiplies 256 x 256 tiles: on ResNet-50's layer3 (1024 <-> 256 channels on 50 176 pixels) that
 // is 4 tiles, hence 64 pixel splits to fill the chip — 67 MB of fp32 slabs written and read back next to 128 MB of operands, and 12
-// stages per workgroup between a pipeline fill and a 256 KB tile store: 61 us against an HBM floor of 24.  Here a workgroup owns a
-// 256 (channels of `g`) x 128 (channels of `a`) tile: 8 tiles x 32 splits, half the slab bytes, twice the pixels per workgroup; the
-// other half of each operand comes out of the XCD's L2 (the tiles of one split are neighbours on one XCD).
+// stages per workgroup between a pipeline fill and a 256 KB tile store: 61 us against an HBM floor of 24.  The NARROW form here gives a
+// 4-wave workgroup a 256 (channels of `g`) x 128 (channels of `a`) tile: 8 tiles x 32 splits, half the slab bytes, twice the pixels
+// per workgroup; the other half of each operand comes out of the XCD's L2 (the tiles of one split are neighbours on one XCD).  On the
+// long Linear shapes (ViT: 50 432 tokens, 768 .. 3 072 channels) that tile is bound by the L2 -> LDS path (85 FLOP per byte: the DMA
+// alone takes 183 us of the 270 on the qkv layer, scripts/wr_dbg.sh), so those take the WIDE form: 8 waves, a 256 x 256 tile.
 //
-// The pipeline is wgrad3x3p's (wgrad3x3.hip): 4 waves, a stage = 32 pixels (one MFMA k-step: 16 KB of g + 8 KB of a) moved by LDS-DMA
-// D stages ahead into D + 1 buffers, rows XOR-swizzled by pixel on the DMA's source side (gramr.hip's conflict-free layout for
-// ds_read_b64_tr_b16), all fragment reads in inline assembly behind counted s_waitcnt lgkmcnt — `a` fragments two units ahead, the four
-// `g` fragments of the next stage in the middle of the current one —, ONE barrier per stage, in its middle ("stage s + 1 has landed,
-// nobody reads s - 1 any more"), then the DMA of stage s + D.  Wave w multiplies g channels [64 w, 64 w + 64) by all 128 a channels:
-// 32 accumulator tiles, 8 + 16 fragment reads per 32 MFMAs.  Slabs in split order -> nkb_launch_wgrad_reduce (deterministic), or fp32
-// atomics without a workspace.
+// The pipeline is wgrad3x3p's (wgrad3x3.hip): a stage = 32 pixels (one MFMA k-step) moved by LDS-DMA D stages ahead into D + 1 buffers,
+// rows XOR-swizzled by pixel on the DMA's source side (gramr.hip's conflict-free layout for ds_read_b64_tr_b16), all fragment reads in
+// inline assembly behind counted s_waitcnt lgkmcnt — `a` fragments three units ahead, the four `g` fragments of the next stage in the
+// middle of the current one —, ONE barrier per stage, in its middle ("stage s + 1 has landed, nobody reads s - 1 any more"), then the DMA
+// of stage s + D.  A wave multiplies 64 g channels by 128 a channels: 32 accumulator tiles, 8 + 16 fragment reads per 32 MFMAs.  The
+// bias gradient rides on the matrix pipe: one more MFMA per g fragment against an all-ones fragment (the workgroups of a-tile 0).
+// Slabs in split order -> nkb_launch_wgrad_reduce (deterministic), or fp32 atomics without a workspace.
 #include "common.h"
 #include "wgradr.h"
 #include "convp.h"
@@ -30,20 +32,23 @@ struct WRParams {
     const bf16_t* a;            // [M][lda]: the operand tiled by 128 channels
     float* part;                // slabs [splits][slab] (dW layout), or nullptr: atomics into dw
     float* dw;
+    float* bpart;               // bias partial sums [splits][ldb] (or dbias itself for the atomic form), nullptr: no bias
     long long slab;
-    int M, ldg, lda, ldw;
+    int M, ldg, lda, ldw, ldb;
     int tilesG, tilesA, splits, rows_per_split;
     int transposed;             // 0: dW[g channel][a channel] (g = dY, a = X); 1: dW[a channel][g channel] (g = X, a = dY)
 };
 
 __device__ __forceinline__ int wr_swz8(int px) { return (px & 3) | (((px >> 3) & 1) << 2); }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
-    constexpr int NFR = 8;                         // 16-channel fragments of `a`
-    constexpr int GROW = 512, AROW = 256;          // bytes of a pixel row inside a stage
-    constexpr int GST = 32 * GROW, AST = 32 * AROW, STAGE = GST + AST;      // 16 KB + 8 KB
+template <int D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void wgradr_kernel(const WRParams p) {
+    constexpr int NFR = 8;                         // 16-channel fragments of `a` per wave
+    constexpr int TA = WAVES == 4 ? 128 : 256;     // channels of `a` per workgroup: waves 4-7 of the wide form take the second 128
+    constexpr int GROW = 512, AROW = 2 * TA;       // bytes of a pixel row inside a stage
+    constexpr int GST = 32 * GROW, AST = 32 * AROW, STAGE = GST + AST;      // 16 KB + 8 / 16 KB
     constexpr int NS = D + 1;
+    constexpr int PG = 16 / WAVES, PA = AST / 1024 / WAVES;                  // 1 KB DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,7 +58,8 @@ __global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
     const unsigned ntile = (unsigned)(p.tilesG * p.tilesA);
     const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);      // consecutive ids = the tiles of one pixel range share an L2
     const int tile = (int)(lid % ntile), split = (int)(lid / ntile);
-    const int g0 = (tile % p.tilesG) * 256, a0 = (tile / p.tilesG) * 128;
+    const int g0 = (tile % p.tilesG) * 256, a0 = (tile / p.tilesG) * TA;
+    const int wrow = wave & 3, wcol = wave >> 2;   // this wave's 64 g channels, its 128 a channels
     const int row0 = split * p.rows_per_split;
     const int nrows = min(p.M, row0 + p.rows_per_split) - row0;
     if (nrows <= 0) return;
@@ -63,33 +69,34 @@ __global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
     constexpr unsigned OOB = 0xFFFFFF00u;
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, OOB, 0x00020000);
-    unsigned og[4], oa[2];
-    const int gpx = 2 * wave + (lane >> 5), apx = 4 * wave + (lane >> 4);           // pixel of piece 0 inside the stage (+ 8 i / + 16 i)
+    unsigned og[PG], oa[PA];
+    constexpr int APP = 1024 / AROW;               // pixels per DMA piece of `a` (4 / 2)
+    const int gpx = 2 * wave + (lane >> 5), apx = APP * wave + lane / (AROW / 16);      // pixel of piece 0 inside the stage
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int px = gpx + 8 * i, ch = lane & 31;
+    for (int i = 0; i < PG; ++i) {
+        const int px = gpx + 2 * WAVES * i, ch = lane & 31;
         og[i] = (unsigned)(((size_t)(row0 + px) * (size_t)p.ldg + g0) * 2 + (size_t)((ch ^ (wr_swz8(px) << 1)) << 4));
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int px = apx + 16 * i, ch = lane & 15;
+    for (int i = 0; i < PA; ++i) {
+        const int px = apx + APP * WAVES * i, ch = lane & (AROW / 16 - 1);
         oa[i] = (unsigned)(((size_t)(row0 + px) * (size_t)p.lda + a0) * 2 + (size_t)((ch ^ (wr_swz8(px) << 1)) << 4));
     }
     const unsigned gstep = (unsigned)(32 * p.ldg * 2), astep = (unsigned)(32 * p.lda * 2);
-    int remg = nrows - gpx, rema = nrows - apx;       // piece i of the stage is inside the range iff rem > 8 i (16 i)
+    int remg = nrows - gpx, rema = nrows - apx;       // piece i of the stage is inside the range iff rem > its pixel offset
     int dpos = 0;
     auto issue = [&]() {
         unsigned char* st = smem + dpos * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned off = remg > 8 * i ? og[i] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(st + (wave + 4 * i) * 1024), 16, (int)off, 0, 0, 0);
+        for (int i = 0; i < PG; ++i) {
+            const unsigned off = remg > 2 * WAVES * i ? og[i] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(st + (wave + WAVES * i) * 1024), 16, (int)off, 0, 0, 0);
             og[i] += gstep;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned off = rema > 16 * i ? oa[i] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(st + GST + (wave + 4 * i) * 1024), 16, (int)off, 0, 0, 0);
+        for (int i = 0; i < PA; ++i) {
+            const unsigned off = rema > APP * WAVES * i ? oa[i] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(st + GST + (wave + WAVES * i) * 1024), 16, (int)off, 0, 0, 0);
             oa[i] += astep;
         }
         remg -= 32; rema -= 32;
@@ -101,9 +108,9 @@ __global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
     {
         const int px = 8 * g4 + q4, sw = wr_swz8(px) << 1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) va[c] = lds0 + (unsigned)(px * GROW + (((2 * (4 * wave + c) + (p4 >> 1)) ^ sw) << 4) + 8 * (p4 & 1));
+        for (int c = 0; c < 4; ++c) va[c] = lds0 + (unsigned)(px * GROW + (((2 * (4 * wrow + c) + (p4 >> 1)) ^ sw) << 4) + 8 * (p4 & 1));
 #pragma unroll
-        for (int j = 0; j < NFR; ++j) vb[j] = lds0 + (unsigned)(GST + px * AROW + (((2 * j + (p4 >> 1)) ^ sw) << 4) + 8 * (p4 & 1));
+        for (int j = 0; j < NFR; ++j) vb[j] = lds0 + (unsigned)(GST + px * AROW + (((2 * (NFR * wcol + j) + (p4 >> 1)) ^ sw) << 4) + 8 * (p4 & 1));
     }
 
     f32x4 acc[4][NFR];
@@ -111,6 +118,12 @@ __global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int j = 0; j < NFR; ++j) acc[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient: column sums of g = one more MFMA per g fragment against ones (every column of the result holds the sums)
+    const bool do_bias = p.bpart != nullptr && a0 == 0 && wcol == 0;
+    f32x4 bacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones_ = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
     // ---- prologue: stages 0 .. D-1 requested, stage 0 landed
 #pragma unroll
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
                 for (int u = 0; u < NFR; ++u) {
                     if (u == 4) {
                         // ---- the stage's barrier: stage s + 1 has landed everywhere, nobody reads stage s - 1 any more
-                        if (s + D - 1 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (D - 2)) : "memory");
+                        if (s + D - 1 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PG + PA) * (D - 2)) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
@@ -172,6 +185,8 @@ __global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
                     for (int c = 0; c < 4; ++c) {
                         if (u == 0) asm volatile("" : "+v"(fa[par][c][0]), "+v"(fa[par][c][1]));
                         const u32x4 va_ = {fa[par][c][0][0], fa[par][c][0][1], fa[par][c][1][0], fa[par][c][1][1]};
+                        if (u == 1 && do_bias)
+                            bacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va_), __builtin_bit_cast(bf16x8, ones_), bacc[c], 0, 0, 0);
 #ifndef NKB_WR_NO_MFMA
                         acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va_), b_, acc[c][u], 0, 0, 0);
 #else
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int j = 0; j < NFR; ++j) {
-            const int gc = g0 + 16 * (4 * wave + c) + 4 * g4, ac = a0 + 16 * j + li;
+            const int gc = g0 + 16 * (4 * wrow + c) + 4 * g4, ac = a0 + 128 * wcol + 16 * j + li;
             if (p.transposed) {
                 float* dst = out + (size_t)ac * p.ldw + gc;
                 if (p.part) *(f32x4*)dst = acc[c][j];
@@ -209,6 +224,16 @@ __global__ __launch_bounds__(256, 2) void wgradr_kernel(const WRParams p) {
                 }
             }
         }
+    if (do_bias && li == 0) {
+        float* bo = p.part ? p.bpart + (size_t)split * p.ldb : p.bpart;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* dst = bo + g0 + 16 * (4 * wrow + c) + 4 * g4 + e;
+                if (p.part) *dst = bacc[c][e]; else atomicAdd(dst, bacc[c][e]);
+            }
+    }
 }
 
 int wr_cus() {
@@ -221,19 +246,14 @@ int wr_cus() {
     return cus;
 }
 
-// NKB_WGRAD256: 0 neither this kernel nor wgrad8p, 1 both (default), 2 wgrad8p only (the round-3 routing), 3 this kernel only on the
-// shapes wgrad8p would take
+// NKB_WGRAD256: 0 neither this kernel nor wgrad8p, 1 both (default: this one where eligible), 2 wgrad8p only (the round-3 routing)
 int wr_mode() {
     static const int m = [] { const char* e = getenv("NKB_WGRAD256"); return e ? atoi(e) : 1; }();
     return m;
 }
 
-struct WRPlan { int tilesG, tilesA, splits, rows, transposed; };
-bool wr_plan(long long M, int Cin, int Cout, WRPlan& g) {
-    if (Cout % 256 == 0 && Cin % 128 == 0) { g.transposed = 0; g.tilesG = Cout / 256; g.tilesA = Cin / 128; }
-    else if (Cin % 256 == 0 && Cout % 128 == 0) { g.transposed = 1; g.tilesG = Cin / 256; g.tilesA = Cout / 128; }
-    else return false;
-    const int ntile = g.tilesG * g.tilesA;
+struct WRPlan { int tilesG, tilesA, splits, rows, transposed, wide; };
+static void wr_split(long long M, int ntile, WRPlan& g) {
     const int target = wr_cus() - nkb_rowres_reserved_cus();
     int sp = target / ntile;
     if (sp < 1) sp = 1;
@@ -242,50 +262,65 @@ bool wr_plan(long long M, int Cin, int Cout, WRPlan& g) {
     if (rows < 256) rows = 256;                     // at least eight stages between a pipeline fill and a tile store
     g.rows = (int)rows;
     g.splits = (int)((M + rows - 1) / rows);
+}
+bool wr_plan(long long M, int Cin, int Cout, bool has_bias, WRPlan& g) {
+    g.wide = 0;
+    if (Cout % 256 == 0 && Cin % 128 == 0) { g.transposed = 0; g.tilesG = Cout / 256; g.tilesA = Cin / 128; }
+    else if (!has_bias && Cin % 256 == 0 && Cout % 128 == 0) { g.transposed = 1; g.tilesG = Cin / 256; g.tilesA = Cout / 128; }
+    else return false;
+    // the wide form where its tiles still leave long pixel ranges: at least 8 tiles of 256 x 256 and 64 stages per workgroup
+    if (Cin % 256 == 0 && Cout % 256 == 0 && (Cin / 256) * (Cout / 256) >= 8) {
+        WRPlan w = g;
+        w.tilesA = g.tilesA / 2;
+        wr_split(M, w.tilesG * w.tilesA, w);
+        if (w.rows >= 2048) { g = w; g.wide = 1; return true; }
+    }
+    wr_split(M, g.tilesG * g.tilesA, g);
     return true;
 }
 
-template <int D>
+template <int D, int WAVES>
 void wr_launch(const WRParams& p, hipStream_t stream) {
-    constexpr int lds = (D + 1) * (32 * 512 + 32 * 256);
+    constexpr int lds = (D + 1) * (32 * 512 + 32 * (WAVES == 4 ? 256 : 512));
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)wgradr_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)wgradr_kernel<D, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((wgradr_kernel<D>), dim3((unsigned)(p.tilesG * p.tilesA * p.splits)), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((wgradr_kernel<D, WAVES>), dim3((unsigned)(p.tilesG * p.tilesA * p.splits)), dim3(WAVES * 64), lds, stream, p);
 }
 
 }  // namespace
 
-bool nkb_wgradr_eligible(int dtype, long long M, int Cin, int Cout, int R, int S, int stride, int pad, int ldx, int lddy) {
-    const int mode = wr_mode();
-    if (!(mode == 1 || mode == 3 || mode == 4) || dtype != NKB_DT_BF16 || R != 1 || S != 1 || stride != 1 || pad != 0) return false;
-    if (mode == 3 && !(Cin % 256 == 0 && Cout % 256 == 0)) return false;
+bool nkb_wgradr_eligible(int dtype, long long M, int Cin, int Cout, int R, int S, int stride, int pad, int ldx, int lddy, int has_bias) {
+    if (wr_mode() != 1 || dtype != NKB_DT_BF16 || R != 1 || S != 1 || stride != 1 || pad != 0) return false;
     if (M < 4096 || ldx % 8 != 0 || lddy % 8 != 0 || M * ldx * 2 >= 0xFFFFFF00ll || M * lddy * 2 >= 0xFFFFFF00ll) return false;
     WRPlan g;
-    return wr_plan(M, Cin, Cout, g);
+    return wr_plan(M, Cin, Cout, has_bias != 0, g);
 }
 
-long long nkb_wgradr_workspace_floats(long long M, int Cin, int Cout) {
+long long nkb_wgradr_workspace_floats(long long M, int Cin, int Cout, int has_bias) {
     WRPlan g;
-    if (!wr_plan(M, Cin, Cout, g)) return 0;
-    return (long long)g.splits * Cout * Cin;
+    if (!wr_plan(M, Cin, Cout, has_bias != 0, g)) return 0;
+    return (long long)g.splits * Cout * Cin + (has_bias ? (long long)g.splits * Cout : 0);
 }
 
-int nkb_launch_wgradr(const void* dy, const void* x, float* dw, long long M, int Cin, int ldx, int Cout, int lddy, float* workspace,
-                      hipStream_t stream) {
+int nkb_launch_wgradr(const void* dy, const void* x, float* dw, float* dbias, long long M, int Cin, int ldx, int Cout, int lddy,
+                      float* workspace, hipStream_t stream) {
     WRPlan g;
-    if (!wr_plan(M, Cin, Cout, g)) { nkb_set_error("wgradr: shape not eligible (M=%lld Cin=%d Cout=%d)", M, Cin, Cout); return 1; }
+    if (!wr_plan(M, Cin, Cout, dbias != nullptr, g)) { nkb_set_error("wgradr: shape not eligible (M=%lld Cin=%d Cout=%d)", M, Cin, Cout); return 1; }
     nkb_count_launch(10);
     WRParams p;
     p.g = (const bf16_t*)(g.transposed ? x : dy); p.ldg = g.transposed ? ldx : lddy;
     p.a = (const bf16_t*)(g.transposed ? dy : x); p.lda = g.transposed ? lddy : ldx;
     p.part = workspace; p.dw = dw; p.slab = (long long)Cout * Cin;
+    p.bpart = dbias ? (workspace ? workspace + (size_t)g.splits * p.slab : dbias) : nullptr; p.ldb = Cout;
     p.M = (int)M; p.ldw = Cin; p.tilesG = g.tilesG; p.tilesA = g.tilesA; p.splits = g.splits; p.rows_per_split = g.rows;
     p.transposed = g.transposed;
-    if (wr_mode() == 4) wr_launch<2>(p, stream); else wr_launch<3>(p, stream);
-    const int rc = nkb_check_launch("wgradr");
+    if (g.wide) wr_launch<2, 8>(p, stream); else wr_launch<3, 4>(p, stream);
+    int rc = nkb_check_launch("wgradr");
     if (rc || !workspace) return rc;
-    return nkb_launch_wgrad_reduce(workspace, p.slab, g.splits, dw, p.slab, stream);
+    rc = nkb_launch_wgrad_reduce(workspace, p.slab, g.splits, dw, p.slab, stream);
+    if (!rc && dbias) rc = nkb_launch_wgrad_reduce(p.bpart, Cout, g.splits, dbias, Cout, stream);
+    return rc;
 }

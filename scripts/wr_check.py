@@ -5,18 +5,24 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 from nkb_classification import hip
 dev = "cuda"; T = torch.bfloat16; d = hip.BF16
 CASES = [(4096, 256, 128, 0), (4096, 128, 256, 0), (5000, 256, 256, 0), (8192 + 33, 512, 128, 8), (4100, 128, 512, 16), (12544, 2048, 512, 0),
-         (12544, 512, 2048, 0), (50176, 1024, 256, 0), (50176, 256, 1024, 0), (4096 + 31, 384, 256, 0), (6000, 256, 384, 0)]
-def run(M, Ci, Co, padc, ws=True):
+         (12544, 512, 2048, 0), (50176, 1024, 256, 0), (50176, 256, 1024, 0), (4096 + 31, 384, 256, 0), (6000, 256, 384, 0),
+         (70000 + 17, 512, 1024, 0), (70000, 1024, 512, 8), (4096, 256, 128, 0, True), (9000, 384, 768, 8, True), (70000 + 17, 512, 1024, 0, True),
+         (50432, 768, 2304, 0, True)]
+def run(M, Ci, Co, padc, bias=False, ws=True):
     g = torch.Generator(device="cpu").manual_seed(M + Ci)
     x = torch.randn(M, Ci + padc, generator=g).to(dev, T); dy = torch.randn(M, Co + padc, generator=g).to(dev, T)
     dw = torch.ones(Co, Ci, device=dev)
-    work = torch.full((hip.conv_wgrad_workspace(d, N=M, P=1, Q=1, Cin=Ci, Cout=Co) + 5,), float("nan"), device=dev) if ws else None
+    db = torch.ones(Co, device=dev) if bias else None
+    work = torch.full((hip.conv_wgrad_workspace(d, N=M, P=1, Q=1, Cin=Ci, Cout=Co, has_bias=bias) + 5,), float("nan"), device=dev) if ws else None
     n0 = hip.kernel_launches("wgradr")
-    hip.conv_wgrad(d, dy, x, dw, N=M, H=1, W=1, Cin=Ci, ldx=Ci + padc, P=1, Q=1, Cout=Co, lddy=Co + padc, workspace=work)
+    hip.conv_wgrad(d, dy, x, dw, N=M, H=1, W=1, Cin=Ci, ldx=Ci + padc, P=1, Q=1, Cout=Co, lddy=Co + padc, workspace=work, dbias=db)
     torch.cuda.synchronize()
     took = hip.kernel_launches("wgradr") > n0
     ref = dy[:, :Co].float().t() @ x[:, :Ci].float()
     err = (dw - 1.0 - ref).abs().max().item() / (ref.abs().max().item() + 1e-9)
+    if bias:
+        bref = dy[:, :Co].double().sum(0)
+        err = max(err, (db.double() - 1.0 - bref).abs().max().item() / (bref.abs().max().item() + 1e-9))
     tail = bool(torch.isnan(work[-5:]).all()) if ws else True
     return dw, err, took, tail
 if len(sys.argv) < 2 or sys.argv[1] != "time":
@@ -27,7 +33,7 @@ if len(sys.argv) < 2 or sys.argv[1] != "time":
         ok = err < 3e-5 and bool(torch.isfinite(dw).all()) and tail
         bad += not ok
         print(f"{c} wgradr={took} rel err {err:.2e} md5 {h} {'ok' if ok else 'BAD'}", flush=True)
-    for c in [(4096, 256, 128, 0), (5000, 128, 256, 0)]:
+    for c in [(4096, 256, 128, 0), (5000, 128, 256, 0), (4500, 256, 256, 0, True)]:
         dw, err, took, _ = run(*c, ws=False)
         print(f"atomics {c}: wgradr={took} rel err {err:.2e} {'ok' if err < 3e-5 else 'BAD'}")
         bad += err >= 3e-5

@@ -863,9 +863,9 @@ def test_gelu_fwd_bwd(dtype):
 
 @pytest.mark.parametrize("shape", [(8192, 512, 768, 0), (16384, 768, 512, 64), (4096 * 5 + 64 * 7, 1024, 1536, 0)])
 def test_linear_wgrad_256_tile_kernel(shape):
-    """Wide bf16 Linear weight gradients take the 256x256-tile kernel (wgrad256.hip): dW += dY^T X with fp32 atomics into a
-    pre-filled gradient, bias gradient alongside, operands with row padding; compared with the fp32 product of the same
-    bf16 operands and with the 128x128 kernel's result on a shape just outside the envelope."""
+    """Wide bf16 Linear weight gradients take the row-streaming kernel (wgradr.hip; the eight-phase one of wgrad256.hip under
+    NKB_WGRAD256=2): dW += dY^T X with fp32 atomics into a pre-filled gradient, bias gradient alongside, operands with row padding;
+    compared with the fp32 product of the same bf16 operands and with the 128x128 kernel's result on a shape just outside the envelope."""
     M, Cin, Cout, padc = shape
     torch.manual_seed(31)
     d = hip.BF16
@@ -893,6 +893,86 @@ def test_linear_wgrad_256_tile_kernel(shape):
     scale = ref.abs().max().item()
     assert (dw.cpu() - ref).abs().max().item() < 2e-5 * scale * math.sqrt(M / 4096)      # fp32 accumulation order only
     torch.testing.assert_close(db.cpu(), refb, rtol=1e-4, atol=1e-2)
+
+
+W3_CASES = [(2, 14, 14, 64, 64), (3, 7, 7, 128, 64), (2, 28, 28, 64, 128), (1, 56, 56, 64, 64), (3, 9, 9, 64, 192), (5, 15, 15, 64, 64),
+            (2, 31, 31, 64, 64), (1, 63, 63, 64, 64), (1, 7, 7, 64, 64), (2, 8, 20, 64, 64), (7, 12, 5, 64, 128), (33, 14, 14, 128, 128)]
+
+
+@pytest.mark.parametrize("case", W3_CASES, ids=lambda c: "N%d_%dx%d_%d-%d" % c)
+def test_wgrad3x3_strip_kernel(case):
+    """The shared-strip 3x3 weight gradient (wgrad3x3.hip, what the train step runs: no bias, slabs) against torch's fp32 weight
+    gradient of the same bf16 operands: every strip width (W + 1 <= 8 / 16 / 32 / 64, exactly full rows at W = 7 / 15 / 31 / 63),
+    non-square maps, a one-k-step launch (1 x 7 x 7: shorter than the DMA pipeline), ragged batches; bit-identical when repeated,
+    nothing written past the advertised workspace, and the atomic form."""
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV, torch.bfloat16)
+    dy = torch.randn(N, H, W, Co, generator=g).to(DEV, torch.bfloat16)
+    ref = torch.nn.grad.conv2d_weight(x.float().cpu().permute(0, 3, 1, 2), (Co, Ci, 3, 3), dy.float().cpu().permute(0, 3, 1, 2),
+                                      stride=1, padding=1).permute(0, 2, 3, 1)
+    d = hip.BF16
+    geom = dict(N=N, H=H, W=W, Cin=Ci, ldx=Ci, P=H, Q=W, Cout=Co, lddy=Co, R=3, S=3, stride=1, pad=1)
+    need = hip.conv_wgrad_workspace(d, N=N, P=H, Q=W, Cin=Ci, Cout=Co, R=3, S=3, stride=1, pad=1)
+    work = torch.full((need + 7,), float("nan"), device=DEV)
+    n0 = hip.kernel_launches("wgrad3x3")
+    runs = []
+    for _ in range(2):
+        dw = torch.ones(Co, 3, 3, Ci, device=DEV)
+        hip.conv_wgrad(d, dy, x, dw, workspace=work, **geom)
+        torch.cuda.synchronize()
+        runs.append(dw)
+    assert hip.kernel_launches("wgrad3x3") == n0 + 2
+    assert torch.equal(runs[0], runs[1]) and torch.isnan(work[need:]).all()
+    scale = ref.abs().max().item()
+    assert (runs[0].cpu() - 1.0 - ref).abs().max().item() < 2e-5 * scale
+    dwa = torch.zeros(Co, 3, 3, Ci, device=DEV)
+    hip.conv_wgrad(d, dy, x, dwa, **geom)                     # fp32 atomics
+    torch.cuda.synchronize()
+    assert (dwa.cpu() - ref).abs().max().item() < 2e-5 * scale
+
+
+WR_CASES = [(4096, 256, 128, 0, False), (4096, 128, 256, 0, False), (8192 + 33, 512, 128, 8, False), (4100, 128, 512, 16, False),
+            (12544, 2048, 512, 0, False), (12544, 512, 2048, 0, False), (4096 + 31, 384, 256, 0, False), (9000, 384, 768, 8, True),
+            (70000 + 17, 512, 1024, 0, False), (70000, 1024, 512, 8, True)]
+
+
+@pytest.mark.parametrize("case", WR_CASES, ids=lambda c: "M%d_%d-%d_p%d_b%d" % c)
+def test_wgradr_row_streaming_kernel(case):
+    """The row-streaming 1x1 weight gradient (wgradr.hip) against the fp32 product of the same bf16 operands: both orientations (the
+    256-channel tiles on dY or on X), ragged pixel counts (zero-filled last stage), padded rows, the narrow 4-wave form and the
+    wide 8-wave one (>= 8 tiles of 256 x 256 and >= 2 048 pixels per workgroup), the bias column sums on the matrix pipe;
+    bit-identical when repeated, workspace bound, atomic form."""
+    M, Ci, Co, padc, bias = case
+    g = torch.Generator().manual_seed(M + Ci)
+    x = torch.randn(M, Ci + padc, generator=g).to(DEV, torch.bfloat16)
+    dy = torch.randn(M, Co + padc, generator=g).to(DEV, torch.bfloat16)
+    ref = dy[:, :Co].float().t() @ x[:, :Ci].float()
+    refb = dy[:, :Co].double().sum(0).float()
+    d = hip.BF16
+    geom = dict(N=M, H=1, W=1, Cin=Ci, ldx=Ci + padc, P=1, Q=1, Cout=Co, lddy=Co + padc)
+    need = hip.conv_wgrad_workspace(d, N=M, P=1, Q=1, Cin=Ci, Cout=Co, has_bias=bias)
+    work = torch.full((need + 7,), float("nan"), device=DEV)
+    n0 = hip.kernel_launches("wgradr")
+    runs = []
+    for _ in range(2):
+        dw, db = torch.ones(Co, Ci, device=DEV), torch.ones(Co, device=DEV) if bias else None
+        hip.conv_wgrad(d, dy, x, dw, workspace=work, dbias=db, **geom)
+        torch.cuda.synchronize()
+        runs.append((dw, db))
+    assert hip.kernel_launches("wgradr") == n0 + 2
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.isnan(work[need:]).all()
+    scale = ref.abs().max().item()
+    assert (runs[0][0] - 1.0 - ref).abs().max().item() < 2e-5 * scale * math.sqrt(max(1.0, M / 4096))
+    if bias:
+        assert torch.equal(runs[0][1], runs[1][1])
+        torch.testing.assert_close(runs[0][1] - 1.0, refb, rtol=1e-4, atol=1e-2)
+    dwa, dba = torch.zeros(Co, Ci, device=DEV), torch.zeros(Co, device=DEV) if bias else None
+    hip.conv_wgrad(d, dy, x, dwa, dbias=dba, **geom)          # fp32 atomics
+    torch.cuda.synchronize()
+    assert (dwa - ref).abs().max().item() < 2e-5 * scale * math.sqrt(max(1.0, M / 4096))
+    if bias:
+        torch.testing.assert_close(dba, refb, rtol=1e-4, atol=1e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

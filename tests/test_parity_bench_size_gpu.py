@@ -128,7 +128,7 @@ def _run(model_name, batch, dtype, classes, steps=4, heads="", size=224):
     return out, counters, len(eng.plans)
 
 
-COUNTERS = ("gemm8p", "wgrad8p", "wgrad3x3", "wgrad8f", "gram_conv", "gram_bn_apply", "convp", "conv1p", "stemp", "gramr")
+COUNTERS = ("gemm8p", "wgrad8p", "wgrad3x3", "wgrad8f", "gram_conv", "gram_bn_apply", "convp", "conv1p", "stemp", "gramr", "wgradr")
 
 
 def _check(out, relative=True, cos_bar=None, l2_bar=None, loss_tol=1e-2, cos_slack=1e-3):
@@ -145,7 +145,7 @@ def test_resnet50_bench_configuration_matches_oracle():
     out, n, plans = _run("resnet50", 256, "bf16", 1000)
     _check(out, relative=True)
     assert plans >= 2                                                      # forward + backward plans recorded and replayed
-    assert n["gemm8p"] > 0 and n["wgrad8p"] > 0 and n["wgrad3x3"] > 0      # the kernels the bench line is priced on ran
+    assert n["gemm8p"] > 0 and n["wgradr"] > 0 and n["wgrad3x3"] > 0       # the kernels the bench line is priced on ran
     assert n["gram_conv"] > 0 and n["gram_bn_apply"] > 0                   # Gram-form closing stages (layer1 / layer2)
     assert n["convp"] > 0                                                  # row-balanced 3x3 core (layer1 / 3 / 4 conv2)
     assert n["conv1p"] > 0 and n["stemp"] > 0                              # pixel-resident 1x1 expansions (layer3), ring-buffered stem
@@ -157,7 +157,7 @@ def test_resnet50_multitask_configs3_matches_oracle():
     (configs/multitask_config.py:146-176), bs 256, bf16 — `bench.py --heads 2,3,5,14`."""
     out, n, plans = _run("resnet50", 256, "bf16", 0, heads="2,3,5,14")
     _check(out, relative=True)
-    assert plans >= 2 and n["gemm8p"] > 0 and n["wgrad8p"] > 0 and n["gram_conv"] > 0
+    assert plans >= 2 and n["gemm8p"] > 0 and n["wgradr"] > 0 and n["gram_conv"] > 0
 
 
 @pytest.mark.parametrize("size", [127, 200])
@@ -173,7 +173,7 @@ def test_resnet50_other_resolutions_match_oracle(size):
 def test_vit_b16_bench_configuration_matches_oracle():
     out, n, plans = _run("vit_base_patch16_224", 256, "bf16", 1000)
     _check(out, relative=True)
-    assert plans >= 2 and n["gemm8p"] > 0 and n["wgrad8p"] > 0
+    assert plans >= 2 and n["gemm8p"] > 0 and n["wgradr"] > 0                # (wide 256 x 256 form on qkv / fc1 / fc2, narrow on proj)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
@@ -182,7 +182,7 @@ def test_unicom_l14_bench_configuration_matches_oracle(dtype):
     out, n, plans = _run("unicom ViT-L/14", 128, dtype, 1000, steps=4 if dtype == "bf16" else 6)
     if dtype == "bf16":
         _check(out, relative=True, cos_slack=2e-3)
-        assert n["gemm8p"] > 0 and n["wgrad8p"] > 0
+        assert n["gemm8p"] > 0 and n["wgradr"] > 0
     else:
         _check(out, relative=False, cos_bar=0.93, l2_bar=0.36, loss_tol=2e-2)
         assert n["wgrad8f"] > 0

@@ -22,7 +22,7 @@ CASES = [
     ("NKB_GRAM_BN", "0", RESNET), ("NKB_GRAM_MAX_C", "256", RESNET), ("NKB_CONVP", "0", RESNET), ("NKB_WGRAD_STREAM", "0", RESNET),
     ("NKB_DET_WGRAD", "0", RESNET), ("NKB_FUSED_BNBWD", "0", RESNET), ("NKB_FUSED_RES_BNBWD", "0", RESNET), ("NKB_RELU_BITS", "0", RESNET),
     ("NKB_S2_CLASSES", "0", RESNET), ("NKB_HALO", "0", RESNET), ("NKB_PACKED_STEM", "0", RESNET), ("NKB_WGRAD3X3", "0", RESNET),
-    ("NKB_WGRAD256", "0", RESNET), ("NKB_NARROW", "0", RESNET), ("NKB_PLAN", "0", RESNET), ("NKB_PLAN_C", "0", RESNET),
+    ("NKB_WGRAD256", "0", RESNET), ("NKB_WGRAD256", "2", RESNET), ("NKB_NARROW", "0", RESNET), ("NKB_PLAN", "0", RESNET), ("NKB_PLAN_C", "0", RESNET),
     ("NKB_EVAL_FOLD", "0", RESNET), ("NKB_GEMM8P", "0", UNICOM), ("NKB_FUSED_ATTN", "0", UNICOM), ("NKB_FP8_FUSED_QUANT", "0", UNICOM8),
 ]
 # read at run time but not a choice between two implementations of the step: library path, debugging aids, rehearsal plumbing of
