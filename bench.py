@@ -51,7 +51,7 @@ PMC_TRAFFIC_FILES = {("resnet50", 256, "bf16"): "r04_resnet50_bf16_pmc_traffic.j
                      ("unicom ViT-L/14", 128, "fp8"): "r04_unicom_vit_l14_fp8_pmc_traffic.json"}
 # profiler tag (api.hip kernel ids) -> families of scripts/pmc_traffic.py that hold the same launches
 TRAFFIC_FAMILIES = {"conv_igemm": ("conv_igemm_fwd", "conv_igemm_bwd", "gemm8p_fwd", "gemm8p_bwd"),
-                    "conv_wgrad": ("conv_wgrad", "wgrad8p", "wgrad8f", "wgrad3x3"), "bn_apply": ("bn_apply",),
+                    "conv_wgrad": ("conv_wgrad", "wgrad8p", "wgrad8f", "wgrad3x3", "wgradr"), "bn_apply": ("bn_apply",),
                     "bn_bwd_apply": ("bn_bwd_apply",), "attn": ("attn_fwd", "attn_bwd", "attn_other"), "ln": ("layernorm",)}
 
 

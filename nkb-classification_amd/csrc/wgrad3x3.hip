@@ -302,10 +302,12 @@ static void w3_plan(int N, int H, int W, int Cin, int Cout, int* ksteps, int* sp
     *ksteps = ks; *per_split = per; *splits = (ks + per - 1) / per;
 }
 
+// (W <= 62: with 64-slot strip rows the taps (r = 2, s >= 1) of a k-step's last two dY slots reach into an X chunk that may still be in
+// flight — harmless while those two slots are row padding, i.e. up to W = 62)
 bool nkb_wgrad3x3_eligible(int dtype, int N, int H, int W, int Cin, int Cout, int P, int Q, int R, int S, int stride, int pad,
                            int ldx, int lddy) {
     return w3_mode() && dtype == NKB_DT_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && P == H && Q == W && Cin % 64 == 0 &&
-           Cout % 64 == 0 && W + 1 <= 64 && H + 1 >= (64 >> w3_pw_shift(W)) && ldx % 8 == 0 && lddy % 8 == 0 &&
+           Cout % 64 == 0 && W + 2 <= 64 && H + 1 >= (64 >> w3_pw_shift(W)) && ldx % 8 == 0 && lddy % 8 == 0 &&
            (long long)N * H * W * ldx * 2 < 0xFFFFFF00ll && (long long)N * H * W * lddy * 2 < 0xFFFFFF00ll;
 }
 

@@ -14,7 +14,7 @@
 //
 // The pipeline is wgrad3x3p's (wgrad3x3.hip): a stage = 32 pixels (one MFMA k-step) moved by LDS-DMA D stages ahead into D + 1 buffers,
 // rows XOR-swizzled by pixel on the DMA's source side (gramr.hip's conflict-free layout for ds_read_b64_tr_b16), all fragment reads in
-// inline assembly behind counted s_waitcnt lgkmcnt — `a` fragments three units ahead, the four `g` fragments of the next stage in the
+// inline assembly behind counted s_waitcnt lgkmcnt — `a` fragments two units ahead (never more than 14 reads in flight), the four `g` fragments of the next stage in the
 // middle of the current one —, ONE barrier per stage, in its middle ("stage s + 1 has landed, nobody reads s - 1 any more"), then the DMA
 // of stage s + D.  A wave multiplies 64 g channels by 128 a channels: 32 accumulator tiles, 8 + 16 fragment reads per 32 MFMAs.  The
 // bias gradient rides on the matrix pipe: one more MFMA per g fragment against an all-ones fragment (the workgroups of a-tile 0).
@@ -63,7 +63,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void wgradr_kernel(
     const int row0 = split * p.rows_per_split;
     const int nrows = min(p.M, row0 + p.rows_per_split) - row0;
     if (nrows <= 0) return;
-    const int ns = (nrows + 31) / 32;
+    // stages come in PAIRS (the two g fragment register sets alternate): an odd count runs one more stage of zero rows.  The pair body
+    // must be straight-line code: with the second stage under a condition hipcc resolves the fragments' phi nodes with v_mov copies at
+    // the top of a stage — copies of registers whose ds_read is still in flight (the compiler cannot know), i.e. in FRONT of the
+    // counted wait.  Alone the reads have long landed; beside the main stream's LDS traffic they sometimes had not: weight gradients
+    // that differed in the 9th digit from run to run (and a NaN once), found by the train step's bit-reproducibility soak
+    // (tests/test_parity_bench_size_gpu.py), never by an op-level test.  tests/test_cabi.py now greps the loops for such copies.
+    const int ns = ((nrows + 31) / 32 + 1) & ~1;
 
     // ---- DMA: per stage and wave four 1 KB pieces of g (2 pixels each) and two of a (4 pixels each); rows past the range: zero fill
     constexpr unsigned OOB = 0xFFFFFF00u;
@@ -137,11 +143,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void wgradr_kernel(
 #define WR_WAIT(n, f) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(n))
     u32x2 fa[2][4][2], fb[4][2];
     unsigned sb = 0;                               // byte offset of the current stage's buffer
-    // pipeline fill: the g fragments of stage 0, the a fragments of units 0, 1, 2
+    // pipeline fill: the g fragments of stage 0, the a fragments of units 0 and 1.
+    // lgkmcnt is a 4-bit counter: a wave keeps at most 15 LDS reads in flight.  The a fragments TWO units ahead: 2 + 4 + the eight g
+    // reads = 14 at most; three units ahead (16 around unit 4: the wave stalls on the counter) measured slower — ViT qkv 218 vs 195 us.
 #pragma unroll
     for (int c = 0; c < 4; ++c) { WR_TR(fa[0][c][0], va[c], 0); WR_TR(fa[0][c][1], va[c], 4 * GROW); }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { WR_TR(fb[u][0], vb[u], 0); WR_TR(fb[u][1], vb[u], 4 * AROW); }
+    for (int u = 0; u < 2; ++u) { WR_TR(fb[u][0], vb[u], 0); WR_TR(fb[u][1], vb[u], 4 * AROW); }
 
     // (two stages per iteration: the g fragment sets alternate between two register groups; eight units per stage = two turns of
     // the four a-fragment registers)
@@ -149,14 +157,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void wgradr_kernel(
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
             const int s = s0 + par;
-            if (s < ns) {
+            {
                 const unsigned sb_next = sb + STAGE == NS * STAGE ? 0u : sb + STAGE;
 #pragma unroll
                 for (int u = 0; u < NFR; ++u) {
                     if (u == 4) {
                         // ---- the stage's barrier: stage s + 1 has landed everywhere, nobody reads stage s - 1 any more
+#ifdef NKB_WR_SAFE_VM
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
                         if (s + D - 1 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PG + PA) * (D - 2)) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
 #ifndef NKB_WR_NO_DMA
@@ -164,10 +176,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void wgradr_kernel(
 #endif
                         asm volatile("" ::: "memory");
                     }
-                    {   // a fragment of unit u + 3 (units 8, 9, 10: the next stage's first three — behind the barrier of unit 4)
-                        const int u3 = u + 3;
-                        const unsigned ad = vb[u3 % NFR] + (u3 >= NFR ? sb_next : sb);
-                        WR_TR(fb[u3 % 4][0], ad, 0); WR_TR(fb[u3 % 4][1], ad, 4 * AROW);
+                    {   // a fragment of unit u + 2 (units 8, 9: the next stage's first two — behind the barrier of unit 4)
+                        const int u2 = u + 2;
+                        const unsigned ad = vb[u2 % NFR] + (u2 >= NFR ? sb_next : sb);
+                        WR_TR(fb[u2 % 4][0], ad, 0); WR_TR(fb[u2 % 4][1], ad, 4 * AROW);
                     }
                     if (u == 4) {                  // the g fragments of the next stage
 #pragma unroll
@@ -176,9 +188,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void wgradr_kernel(
                             WR_TR(fa[par ^ 1][c][0], ad, 0); WR_TR(fa[par ^ 1][c][1], ad, 4 * GROW);
                         }
                     }
-                    // younger than this unit's a fragment: the next three — and the eight g reads while they sit in between (units
-                    // 4 .. 7; at unit 0 of the next stage they are older than its fragment: landed)
-                    if (u >= 4) WR_WAIT(14, fb[u % 4]); else WR_WAIT(6, fb[u % 4]);
+                    // younger than this unit's a fragment: the next two — and the eight g reads while they sit in between (units
+                    // 4, 5, 6; at unit 7 they are older than its fragment: landed before the next stage needs them)
+#ifdef NKB_WR_SAFE_LGKM
+                    WR_WAIT(0, fb[u % 4]);
+#else
+                    if (u >= 4 && u <= 6) WR_WAIT(12, fb[u % 4]); else WR_WAIT(4, fb[u % 4]);
+#endif
                     const u32x4 vb_ = {fb[u % 4][0][0], fb[u % 4][0][1], fb[u % 4][1][0], fb[u % 4][1][1]};
                     const bf16x8 b_ = __builtin_bit_cast(bf16x8, vb_);
 #pragma unroll

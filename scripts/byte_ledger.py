@@ -110,7 +110,7 @@ if args.pmc:
     doc = json.load(open(args.pmc))
     ks = doc["kernels"]
     fam_map = {"conv_fwd": ("conv_igemm_fwd", "gemm8p_fwd"), "conv_dgrad": ("conv_igemm_bwd", "gemm8p_bwd"),
-               "conv_wgrad": ("conv_wgrad", "wgrad8p", "wgrad3x3"), "bn_apply": ("bn_apply",), "bn_bwd": ("bn_bwd_apply", "bn_bwd_reduce"),
+               "conv_wgrad": ("conv_wgrad", "wgrad8p", "wgrad3x3", "wgradr"), "bn_apply": ("bn_apply",), "bn_bwd": ("bn_bwd_apply", "bn_bwd_reduce"),
                "stem_tail": ("stem_tail",), "stem": ("stem",), "optim": ("optim",)}
     print(f"\nagainst the PMC passes ({args.pmc}): measured {doc['step_total_bytes'] / 1e9:.2f} GB per step")
     print(f"  {'family':12s} {'ledger GB':>10s} {'measured GB':>12s} {'ratio':>6s}")

@@ -13,7 +13,7 @@ for r in csv.DictReader(open(sys.argv[2])):
 fam = collections.defaultdict(lambda: [0, 0.0, 0])
 for d, busy in ctr.items():
     n = name[d]
-    key = next((k for k in ("conv_igemm", "convp", "conv1p", "conv1s", "stempw", "stemp", "gramr", "gemm8p", "conv_wgrad", "wgrad3x3", "wgrad8p", "wgrad256", "attn_fwd", "attn_bwd") if k in n), None)
+    key = next((k for k in ("conv_igemm", "convp", "conv1p", "conv1s", "stempw", "stemp", "gramr", "gemm8p", "conv_wgrad", "wgrad3x3", "wgradr", "wgrad8p", "wgrad256", "attn_fwd", "attn_bwd") if k in n), None)
     if key and d in dur:
         f = fam[key]; f[0] += 1; f[1] += busy; f[2] += dur[d]
 out = {k: dict(launches=f[0], mfma_busy_cycles=f[1], duration_ns=f[2],

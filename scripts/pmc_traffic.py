@@ -17,7 +17,7 @@ FAMILIES = (  # first match wins; (substring of the kernel name, family)
     ("gemm8p_kernel", "gemm8p"), ("conv_igemm_kernel", "conv_igemm"), ("convp_kernel", "conv_igemm"),
     ("convp64", "conv_igemm"), ("conv1p_kernel", "conv_igemm"), ("conv1s_kernel", "conv_igemm"), ("stemp_kernel", "conv_igemm"),
     ("wgrad_reduce_kernel", "wgrad_reduce"), ("gram_reduce_kernel", "wgrad_reduce"),
-    ("wgrad8p", "wgrad8p"), ("wgrad8f", "wgrad8f"), ("wgrad3x3_kernel", "wgrad3x3"), ("wgrad256_kernel", "wgrad8p"),
+    ("wgrad8p", "wgrad8p"), ("wgrad8f", "wgrad8f"), ("wgrad3x3", "wgrad3x3"), ("wgrad256_kernel", "wgrad8p"), ("wgradr_kernel", "wgradr"),
     ("conv_wgrad_kernel", "conv_wgrad"), ("gramr_kernel", "conv_wgrad"), ("stempw_kernel", "conv_wgrad"),
     ("bn_apply_gram_kernel", "bn_apply"), ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
     ("bn_apply_kernel", "bn_apply"), ("bn_relu_maxpool", "stem_tail"), ("stem_", "stem"),
