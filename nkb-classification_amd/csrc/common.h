@@ -106,6 +106,9 @@ int nkb_check_launch(const char* what);
 int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float* dst, long long n, hipStream_t stream);
 // the same with the mode given by the caller: assign != 0 overwrites dst (scratch products), 0 accumulates
 int nkb_launch_wgrad_reduce_mode(const float* part, long long slab, int splits, float* dst, long long n, int assign, hipStream_t stream);
+// the same for two ranges in ONE launch (weight slabs + the bias partials behind them)
+int nkb_launch_wgrad_reduce2(const float* part, long long slab, int splits, float* dst, long long n, const float* part2, long long slab2,
+                             float* dst2, long long n2, hipStream_t stream);
 
 // launch counters of the specialised kernels (api.hip: nkb_kernel_launches) — tests assert from them that the path a benchmark
 // configuration is supposed to take really ran (0 gemm8p, 1 wgrad8p / wgrad256, 2 wgrad3x3, 3 wgrad8f (fp8), 4 Gram-form closing

@@ -1106,18 +1106,24 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradParams p)
 // consecutive elements; SG threads share a column and each sums the splits s = sg, sg + SG, ... in order, then the SG partial
 // sums are combined in a fixed order through LDS — the association is a function of (splits, SG) only, never of timing.
 // (With one thread per column a 256-split / 4 K-element gradient took 60 us of serial dependent loads.)
+// (part2 / dst2 / n2: a second, short range — the bias partials behind the weight slabs — reduced by the same launch: its columns
+// follow the first range's; every element's association is the one a launch of its own would use)
 template <int SG, bool ASSIGN = false>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long slab, int splits,
-                                                           float* __restrict__ dst, long long n) {
+                                                           float* __restrict__ dst, long long n, const float* __restrict__ part2 = nullptr,
+                                                           long long slab2 = 0, float* __restrict__ dst2 = nullptr, long long n2 = 0) {
     constexpr int COLS = 256 / SG;
     __shared__ f32x4 red[SG > 1 ? 256 : 1];
     const int cx = threadIdx.x % COLS, sg = threadIdx.x / COLS;
-    const long long n4 = n >> 2;
-    for (long long c0 = (long long)blockIdx.x * COLS; c0 < n4; c0 += (long long)gridDim.x * COLS) {
+    const long long n4 = n >> 2, t4 = n4 + (n2 >> 2);
+    for (long long c0 = (long long)blockIdx.x * COLS; c0 < t4; c0 += (long long)gridDim.x * COLS) {
         const long long i = c0 + cx;
+        const bool second = i >= n4;
+        const float* src = second ? part2 + 4 * (i - n4) : part + 4 * i;
+        const long long sl = second ? slab2 : slab;
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (i < n4)
-            for (int s = sg; s < splits; s += SG) a += *(const f32x4*)(part + (size_t)s * slab + 4 * i);
+        if (i < t4)
+            for (int s = sg; s < splits; s += SG) a += *(const f32x4*)(src + (size_t)s * sl);
         if constexpr (SG > 1) {
             __syncthreads();
             red[threadIdx.x] = a;
@@ -1126,8 +1132,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 for (int k = 1; k < SG; ++k) a += red[k * COLS + cx];
             }
         }
-        if (sg == 0 && i < n4) {
-            f32x4* d = (f32x4*)(dst + 4 * i);
+        if (sg == 0 && i < t4) {
+            f32x4* d = (f32x4*)(second ? dst2 + 4 * (i - n4) : dst + 4 * i);
             if constexpr (ASSIGN) *d = a; else *d = *d + a;
         }
     }
@@ -1174,6 +1180,28 @@ int nkb_launch_wgrad_reduce(const float* part, long long slab, int splits, float
     if (sg == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
     else if (sg == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
     else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n);
+    return nkb_check_launch("wgrad_reduce");
+}
+// two ranges in one launch (weight slabs + bias partials of one weight gradient); falls back to two launches where the vector form
+// does not apply (unaligned, n2 not a multiple of 4)
+int nkb_launch_wgrad_reduce2(const float* part, long long slab, int splits, float* dst, long long n, const float* part2, long long slab2,
+                             float* dst2, long long n2, hipStream_t stream) {
+    if (n <= 0 || splits <= 0) return 0;
+    if (n2 <= 0 || (n & 3) || (n2 & 3) || (slab & 3) || (slab2 & 3) ||
+        (((uintptr_t)part | (uintptr_t)dst | (uintptr_t)part2 | (uintptr_t)dst2) & 15) != 0) {
+        int rc = nkb_launch_wgrad_reduce(part, slab, splits, dst, n, stream);
+        if (!rc && n2 > 0) rc = nkb_launch_wgrad_reduce(part2, slab2, splits, dst2, n2, stream);
+        return rc;
+    }
+    const long long t4 = (n + n2) >> 2;
+    const int sg = splits >= 48 ? 16 : splits >= 6 ? 4 : 1;
+    const int cols = 256 / sg;
+    long long grid = (t4 + cols - 1) / cols;
+    if (grid > 4096) grid = 4096;
+#define W_RED2(SGV, ASG) hipLaunchKernelGGL((wgrad_reduce_kernel<SGV, ASG>), dim3((unsigned)grid), dim3(256), 0, stream, part, slab, splits, dst, n, part2, slab2, dst2, n2)
+    if (g_wgrad_assign) { if (sg == 16) W_RED2(16, true); else if (sg == 4) W_RED2(4, true); else W_RED2(1, true); }
+    else { if (sg == 16) W_RED2(16, false); else if (sg == 4) W_RED2(4, false); else W_RED2(1, false); }
+#undef W_RED2
     return nkb_check_launch("wgrad_reduce");
 }
 int nkb_launch_wgrad_reduce_mode(const float* part, long long slab, int splits, float* dst, long long n, int assign, hipStream_t stream) {

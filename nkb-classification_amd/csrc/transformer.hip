@@ -120,8 +120,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // LayerNorm backward: dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ add);  dgamma += sum dy*xhat, dbeta += sum dy
-template <typename T, int VW, int NP, int QK>      // QK: -1 no second output, 0 e4m3, 1 e5m2, 2 row-scaled copy in the compute dtype
-__global__ __launch_bounds__(256, NP <= 4 ? 3 : 1) void layernorm_bwd_kernel(const T* __restrict__ dy, long long dys, const T* __restrict__ x,
+// QK: -1 no second output, 0 e4m3, 1 e5m2, 2 row-scaled copy in the compute dtype
+#ifndef NKB_LN_BWD_OCC
+#define NKB_LN_BWD_OCC 3
+#endif
+template <typename T, int VW, int NP, int QK>
+__global__ __launch_bounds__(256, NP <= 4 ? NKB_LN_BWD_OCC : 1) void layernorm_bwd_kernel(const T* __restrict__ dy, long long dys, const T* __restrict__ x,
                                                             long long xs, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const T* __restrict__ add, T* __restrict__ dx, long long dxs,
@@ -257,6 +261,101 @@ __global__ __launch_bounds__(256, NP <= 4 ? 3 : 1) void layernorm_bwd_kernel(con
     }
 }
 
+// The same backward in 64 VGPRs (bf16 rows of 256-element multiples, no second output): the transformer steps run their weight
+// gradients on a second stream, and a weight-gradient workgroup (wgradr's wide form: 8 waves x 218 VGPRs, 96 KB of LDS) holds its CU
+// for ~200 us with 64 registers per lane to spare — the kernel above (112 VGPRs at D = 768) cannot start beside it and waited for
+// whole workgroups to retire: 59 us alone, 183 us in the ViT-B/16 step, 3.1 ms per step on the critical path (scripts/quick_trace.sh;
+// with 4-wave weight gradients, which leave room, it took 114).  Here a lane keeps only the PACKED row segments (x, dy, the residual:
+// 2 registers per vector) between the two passes of a row, gamma and the per-wave dgamma / dbeta accumulators live in LDS (each wave
+// owns its own planes and adds its rows in the same order as the register form: bit-identical partial rows), and the arithmetic of a
+// vector is redone in the output pass.
+template <int NP>
+__global__ __launch_bounds__(256, 8) void layernorm_bwd_lean_kernel(const bf16_t* __restrict__ dy, long long dys, const bf16_t* __restrict__ x,
+                                                                    long long xs, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                    const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, long long dxs,
+                                                                    int rows, float* __restrict__ part) {
+    constexpr int VW = 4, D = 64 * VW * NP;
+    typedef VecIO<bf16_t, 4> IO;
+    extern __shared__ __attribute__((aligned(16))) float lsm[];      // [gamma D][wave 4][plane 2][D]
+    float* const gam = lsm;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const acc = lsm + D + (size_t)wave * 2 * D;
+    for (int i = threadIdx.x; i < D; i += 256) gam[i] = gamma[i];
+    for (int i = threadIdx.x; i < 8 * D; i += 256) lsm[D + i] = 0.f;
+    __syncthreads();
+    // rows through buffer descriptors: the row offset is a scalar, the lane's offset ONE 32-bit register for all four tensors (with
+    // 64-bit lane pointers hipcc spilled them: a scratch reload in front of every row's loads)
+    constexpr unsigned RANGE = 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(add ? add : x), 0, RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, RANGE, 0x00020000);
+    const int lo = lane * (VW * 2);                                   // byte offset of the lane's vector inside a 64-lane segment
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int ox = (int)((long long)row * xs * 2), og = (int)((long long)row * dys * 2), oo = (int)((long long)row * dxs * 2);
+        const float mu = mean[row], rs = rstd[row];
+        IO::Raw xraw[NP], graw[NP], araw[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            xraw[k] = __builtin_amdgcn_raw_buffer_load_b64(rx, lo + k * 512, ox, 0);
+            graw[k] = __builtin_amdgcn_raw_buffer_load_b64(rg, lo + k * 512, og, 0);
+        }
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int e0 = (k * 64 + lane) * VW;
+            float xh[VW], g[VW];
+            IO::cvt(xraw[k], xh); IO::cvt(graw[k], g);
+            f32x4 a0 = *(const f32x4*)(acc + e0), a1 = *(const f32x4*)(acc + D + e0);
+            const f32x4 gm = *(const f32x4*)(gam + e0);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                xh[e] = (xh[e] - mu) * rs;
+                a0[e] += g[e] * xh[e];
+                a1[e] += g[e];
+                const float gg = g[e] * gm[e];
+                c1 += gg;
+                c2 += gg * xh[e];
+            }
+            *(f32x4*)(acc + e0) = a0; *(f32x4*)(acc + D + e0) = a1;
+            asm volatile("" ::: "memory");                // (one vector at a time: hoisted, the LDS reads of all NP vectors cost 60 registers)
+        }
+        if (add) {                                             // (requested behind the first pass — its temporaries are dead — and in front of the reductions)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) araw[k] = __builtin_amdgcn_raw_buffer_load_b64(ra, lo + k * 512, oo, 0);
+        }
+        c1 = wave_sum(c1) / (float)D;
+        c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int e0 = (k * 64 + lane) * VW;
+            float xh[VW], g[VW], o[VW], a[VW];
+            IO::cvt(xraw[k], xh); IO::cvt(graw[k], g);
+            if (add) IO::cvt(araw[k], a);
+            const f32x4 gm = *(const f32x4*)(gam + e0);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                xh[e] = (xh[e] - mu) * rs;
+                g[e] *= gm[e];
+                o[e] = rs * (g[e] - c1 - xh[e] * c2);
+                if (add) o[e] += a[e];
+            }
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])}, ro, lo + k * 512, oo, 0);
+            asm volatile("" ::: "memory");
+        }
+    }
+    // per-block partial rows (the deterministic two-stage form): the four waves' planes in wave order
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256) {
+        float s0 = 0.f, t0 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s0 += lsm[D + (size_t)w * 2 * D + col]; t0 += lsm[D + (size_t)w * 2 * D + D + col]; }
+        part[((size_t)blockIdx.x * 2) * D + col] = s0;
+        part[((size_t)blockIdx.x * 2 + 1) * D + col] = t0;
+    }
+}
+
 // Second stage of the deterministic LayerNorm parameter gradients, itself in two launches: with one block per 64 columns (16 blocks
 // for D = 1024) the 1024 partial rows were read by 16 CUs and the launch took 21 us — longer than a third of the backward kernel
 // it follows.  Now LN_SLICES blocks per column group each sum a contiguous slice of the partial rows (fixed order), and a tiny
@@ -323,6 +422,15 @@ static void ln_launch(int backward, int grid, hipStream_t stream, const void* in
             if (yq && q_kind == 0) { LN_BWD(0); return; }
             if (yq && q_kind == 1) { LN_BWD(1); return; }
             if (yq) { LN_BWD(2); return; }
+        }
+        if constexpr (VW == 4 && std::is_same<T, bf16_t>::value) {
+            if (part && !yq && NP <= 3 && (long long)rows * in_stride < (1ll << 30) && (long long)rows * x_stride < (1ll << 30) &&
+                (long long)rows * out_stride < (1ll << 30)) {      // the 64-register form (shares a CU with a weight-gradient workgroup)
+                constexpr int lds = (64 * VW * NP) * 9 * 4;
+                hipLaunchKernelGGL((layernorm_bwd_lean_kernel<NP>), dim3(grid), dim3(256), lds, stream, (const bf16_t*)in, in_stride, (const bf16_t*)x,
+                                   x_stride, mean, rstd, gamma, (const bf16_t*)add, (bf16_t*)out, out_stride, rows, part);
+                return;
+            }
         }
         LN_BWD(-1);
 #undef LN_BWD

@@ -336,7 +336,6 @@ int nkb_launch_wgradr(const void* dy, const void* x, float* dw, float* dbias, lo
     if (g.wide) wr_launch<2, 8>(p, stream); else wr_launch<3, 4>(p, stream);
     int rc = nkb_check_launch("wgradr");
     if (rc || !workspace) return rc;
-    rc = nkb_launch_wgrad_reduce(workspace, p.slab, g.splits, dw, p.slab, stream);
-    if (!rc && dbias) rc = nkb_launch_wgrad_reduce(p.bpart, Cout, g.splits, dbias, Cout, stream);
-    return rc;
+    if (dbias) return nkb_launch_wgrad_reduce2(workspace, p.slab, g.splits, dw, p.slab, p.bpart, Cout, dbias, Cout, stream);
+    return nkb_launch_wgrad_reduce(workspace, p.slab, g.splits, dw, p.slab, stream);
 }
