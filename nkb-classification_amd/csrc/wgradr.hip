@@ -22,7 +22,6 @@
 #include "common.h"
 #include "wgradr.h"
 #include "convp.h"
-#include <type_traits>
 
 namespace {
 
