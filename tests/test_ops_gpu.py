@@ -845,6 +845,39 @@ def test_layernorm_fwd_bwd(dtype, D):
     torch.testing.assert_close(db.cpu(), ln.bias.grad, **tol(dtype, rows))
 
 
+@pytest.mark.parametrize("D,pad,with_add", [(256, 0, True), (512, 64, False), (768, 0, True), (768, 256, False)])
+def test_layernorm_bwd_lean_form_equals_register_form(D, pad, with_add):
+    """The 64-register LayerNorm backward (transformer.hip: bf16 rows, D <= 768, workspace form — what the ViT steps run beside their
+    weight-gradient stream) against the register form (the same entry point without a workspace): dx bit-identical on many rows
+    per wave, padded row strides, with and without the residual operand; the ordered parameter gradients agree with the atomic
+    ones to summation order, and the workspace form repeats bit for bit."""
+    torch.manual_seed(D + pad)
+    rows = 5000 + 37
+    ld = D + pad
+    x = torch.randn(rows, ld, device=DEV).to(torch.bfloat16)
+    dy = torch.randn(rows, ld, device=DEV).to(torch.bfloat16)
+    add = torch.randn(rows, ld, device=DEV).to(torch.bfloat16) if with_add else None
+    g = torch.rand(D, device=DEV) + 0.5
+    mean = x[:, :D].float().mean(1).contiguous()
+    rstd = (1.0 / torch.sqrt(x[:, :D].float().var(1, unbiased=False) + 1e-6)).contiguous()
+    d = hip.BF16
+    dx0 = torch.zeros(rows, ld, device=DEV, dtype=torch.bfloat16)
+    dg0, db0 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    hip.layernorm_bwd(d, dy, ld, x, ld, g, mean, rstd, add, dx0, ld, dg0, db0, rows, D)
+    work = torch.empty(hip.layernorm_ws(D), device=DEV)
+    runs = []
+    for _ in range(2):
+        dx1 = torch.zeros(rows, ld, device=DEV, dtype=torch.bfloat16)
+        dg1, db1 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        hip.layernorm_bwd(d, dy, ld, x, ld, g, mean, rstd, add, dx1, ld, dg1, db1, rows, D, workspace=work)
+        torch.cuda.synchronize()
+        runs.append((dx1, dg1, db1))
+    assert torch.equal(runs[0][0], dx0)
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1]))
+    torch.testing.assert_close(runs[0][1], dg0, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(runs[0][2], db0, rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gelu_fwd_bwd(dtype):
     torch.manual_seed(11)
