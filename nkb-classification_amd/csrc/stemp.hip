@@ -214,18 +214,21 @@ __global__ __launch_bounds__(512, 1) void stemp_kernel(const SPParams p) {
         _Pragma("unroll") for (int r = 0; r < 7; ++r)                                                                 \
             asm volatile("ds_read_b128 %0, %1" : "=v"(bq[set][r]) : "v"(rb[r] + 256u * (unsigned)(F)));              \
     } while (0)
-                SP_READS(0, 0);
+                // Two fragments per trip, and NOTHING in flight across a branch: both sets are requested at the top of the trip
+                // (set 1 lands under set 0's MFMAs), both waits sit in the same straight-line body.  The round-4 form carried a
+                // requested set across the loop's back edge and waited on one side of an `if`: hipcc reconciled the two paths with
+                // v_mov_b64 copies of the set IN FRONT of its wait (tests/isa_lint.py found it; with fq == 1 the copies read registers
+                // whose ds_read had been issued a few cycles earlier).  An odd fq multiplies one fragment twice (stored once).
                 for (int f = 0; f < p.fq; f += 2) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {              // (two fragments per trip: the register sets alternate at compile time)
-                        const int ff = f + u;
-                        if (ff < p.fq) {
-                            if (ff + 1 < p.fq) { SP_READS(u ^ 1, ff + 1); SP_LANDED(7, u); }
-                            else SP_LANDED(0, u);
-                            fragment(bq[u], ff, 16 * ff + frow < p.Q);
-                            ++nstores;
-                        }
-                    }
+                    const bool two = f + 1 < p.fq;
+                    const int f1 = two ? f + 1 : f;
+                    SP_READS(0, f);
+                    SP_READS(1, f1);
+                    SP_LANDED(7, 0);
+                    fragment(bq[0], f, 16 * f + frow < p.Q);
+                    SP_LANDED(0, 1);
+                    fragment(bq[1], f1, two && 16 * f1 + frow < p.Q);
+                    nstores += two ? 2 : 1;
                 }
 #undef SP_READS
             }
