@@ -120,15 +120,21 @@ int nkb_conv1p_fwd(int dtype, const void* x, const void* w, void* y, float* stat
  * in the ResNet-50 step); bit 1: the 64 -> 64 channel 3x3 form with the filter resident in registers / LDS (default 1: forward), bit 2:
  * that form for the data gradient as well (default 0); bit 4 / 5 / 6: conv1p / stemp / gramr OFF (default on).  Tests and A/B timing. */
 void nkb_convp_config(int on, int narrow);
-/* Data-parallel runs: the family's BACKWARD kernels (nkb_convp_dgrad_bn, nkb_gramr) size their one-workgroup-per-CU grids for
- * #CUs - cus, leaving room for the collective's resident workgroups.  Call once, before the first step (0 = default). */
+/* Data-parallel runs: the family's BACKWARD kernels size their one-workgroup-per-CU grids for #CUs - cus, leaving room for the
+ * collective's resident workgroups: nkb_convp_dgrad_bn (its partial-sum row count), nkb_gramr (its slab count) and the weight
+ * gradients that run on wgradr (csrc/wgradr.hip: the split count behind nkb_conv_wgrad_workspace_floats).  0 = default.  The value
+ * changes what nkb_convp_tiles(kind 1) / nkb_gramr_workspace_floats / nkb_conv_wgrad_workspace_floats answer, so buffers sized under
+ * another value are stale: every launch of the three checks the capacity it is handed (`tiles`, workspace floats) against the
+ * geometry it is about to launch and fails instead of writing past it; the Python binding also drops recorded launch plans. */
 void nkb_rowres_reserve_cus(int cus);
 int nkb_rowres_reserved_cus(void);
+/* tiles: the partial-sum rows `stats` has room for = nkb_convp_tiles(dtype, kind, ...) at the time the buffer was sized; a launch
+ * whose geometry differs (nkb_rowres_reserve_cus / nkb_convp_config changed in between) is refused. */
 int nkb_convp_fwd(int dtype, const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int ldx, int Cout,
-                  int ldy, nkb_stream_t stream);
+                  int ldy, int tiles, nkb_stream_t stream);
 int nkb_convp_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,
                        const float* shift, const float* mean, float* stats, int N, int H, int W, int Cin, int ldx, int Cout,
-                       int ldy, nkb_stream_t stream);
+                       int ldy, int tiles, nkb_stream_t stream);
 /* relu_bits != NULL: the stage closes a residual block — its mask comes from nkb_bn_apply's bit array (scale/shift
  * unused; c and mean may then be NULL as well: only the sums of g' are produced, the Gram form takes sum g'c from R = g'^T a) and the residual operand `add` (optionally under add_bits, or on the sub-grid add_h x add_w) is still added
  * before masking, so the block-output gradient is produced, masked and reduced in the one epilogue. */

@@ -1715,18 +1715,9 @@ static int wgrad_target_wgs() {
     return g_wgrad_target_override > 0 ? g_wgrad_target_override : target_wgs;
 }
 
-// floats of workspace that make nkb_conv_wgrad deterministic for this problem (slabs of per-split partial tiles + bias
-// partials); 0 is never returned for a valid problem
-extern "C" long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, int Q, int Cin, int Cout, int R, int S, int stride,
-                                                     int pad, int has_bias) {
-    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
-    const int M = N * P * Q;
-    // (3x3 / stride 1 / pad 1: the input grid equals the output grid; leading dimensions do not change the slab count)
-    if (!has_bias && nkb_wgrad3x3_eligible(dtype, N, P, Q, Cin, Cout, P, Q, R, S, stride, pad, 8, 8))
-        return nkb_wgrad3x3_workspace_floats(N, P, Q, Cin, Cout);
-    if (nkb_wgradr_eligible(dtype, M, Cin, Cout, R, S, stride, pad, 8, 8, has_bias)) return nkb_wgradr_workspace_floats(M, Cin, Cout, has_bias);
-    if (nkb_wgrad256_eligible(dtype, M, Cin, Cout, R, S, stride, pad)) return nkb_wgrad256_workspace_floats(M, Cin, Cout, has_bias);
-    // (the larger of the two split counts a launch may take: the shared-GPU target, or nkb_conv_wgrad_assign's full-chip one)
+// the generic split-over-pixels kernel's slabs (the larger of the two split counts a launch may take: the shared-GPU target, or
+// nkb_conv_wgrad_assign's full-chip one)
+static long long wgrad_generic_floats(int esz, int M, int Cin, int Cout, int R, int S, int has_bias) {
     constexpr int main_wgs = 0;
     long long need = 0;
     for (int target : {wgrad_target_wgs(), main_wgs > 0 ? main_wgs : wgrad_target_wgs()}) {
@@ -1735,6 +1726,35 @@ extern "C" long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, in
         if (n > need) need = n;
     }
     return need;
+}
+// what the kernel nkb_conv_wgrad SELECTS for these operands (their real leading dimensions decide) needs
+static long long wgrad_selected_floats(int dtype, int N, int H, int W, int P, int Q, int Cin, int ldx, int Cout, int lddy, int R, int S,
+                                       int stride, int pad, int has_bias) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int M = N * P * Q;
+    if (!has_bias && nkb_wgrad3x3_eligible(dtype, N, H, W, Cin, Cout, P, Q, R, S, stride, pad, ldx, lddy))
+        return nkb_wgrad3x3_workspace_floats(N, P, Q, Cin, Cout);
+    if (nkb_wgradr_eligible(dtype, M, Cin, Cout, R, S, stride, pad, ldx, lddy, has_bias)) return nkb_wgradr_workspace_floats(M, Cin, Cout, has_bias);
+    if (nkb_wgrad256_eligible(dtype, M, Cin, Cout, R, S, stride, pad)) return nkb_wgrad256_workspace_floats(M, Cin, Cout, has_bias);
+    return wgrad_generic_floats(esz, M, Cin, Cout, R, S, has_bias);
+}
+// floats of workspace that make nkb_conv_wgrad deterministic for this problem (slabs of per-split partial tiles + bias
+// partials); 0 is never returned for a valid problem.  The query does not know the operands' leading dimensions, and they can rule
+// a specialised kernel out at launch time (row pitch not a multiple of 8 elements, or a tensor beyond a 32-bit buffer range): the
+// answer covers every kernel the launch may fall through to, and the launch checks what it is handed against the kernel it takes
+// (a workspace sized for wgradr's split count must not reach the generic kernel).
+extern "C" long long nkb_conv_wgrad_workspace_floats(int dtype, int N, int P, int Q, int Cin, int Cout, int R, int S, int stride,
+                                                     int pad, int has_bias) {
+    const int esz = dtype == NKB_DT_BF16 ? 2 : 4;
+    const int M = N * P * Q;
+    // (3x3 / stride 1 / pad 1: the input grid equals the output grid)
+    long long need = wgrad_selected_floats(dtype, N, P, Q, P, Q, Cin, 8 * ((Cin + 7) / 8), Cout, 8 * ((Cout + 7) / 8), R, S, stride, pad, has_bias);
+    if (nkb_wgrad256_eligible(dtype, M, Cin, Cout, R, S, stride, pad)) {
+        const long long n = nkb_wgrad256_workspace_floats(M, Cin, Cout, has_bias);
+        if (n > need) need = n;
+    }
+    const long long n = wgrad_generic_floats(esz, M, Cin, Cout, R, S, has_bias);
+    return n > need ? n : need;
 }
 
 extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
@@ -1752,10 +1772,10 @@ extern "C" int nkb_conv_wgrad(int dtype, const void* dy, const void* x, float* d
         nkb_set_error("conv_wgrad: tensor exceeds 2^31 elements");
         return 1;
     }
-    const long long need = nkb_conv_wgrad_workspace_floats(dtype, N, P, Q, Cin, Cout, R, S, stride, pad, dbias != nullptr);
+    const long long need = wgrad_selected_floats(dtype, N, H, W, P, Q, Cin, ldx, Cout, lddy, R, S, stride, pad, dbias != nullptr);
     if (workspace != nullptr && workspace_floats < need) {
-        nkb_set_error("conv_wgrad: workspace of %lld floats given, %lld needed (nkb_conv_wgrad_workspace_floats)",
-                      workspace_floats, need);
+        nkb_set_error("conv_wgrad: workspace of %lld floats given, %lld needed by the kernel this launch takes "
+                      "(nkb_conv_wgrad_workspace_floats; the count follows nkb_rowres_reserve_cus)", workspace_floats, need);
         return 1;
     }
     if (dbias == nullptr && nkb_wgrad3x3_eligible(dtype, N, H, W, Cin, Cout, P, Q, R, S, stride, pad, ldx, lddy)) {

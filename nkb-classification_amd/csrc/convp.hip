@@ -1147,7 +1147,8 @@ static int g_cp_c64 = (g_cp_env >> 1) ? (((g_cp_env >> 2) & 1) | (((g_cp_env >> 
 static int g_cp_no1p = (g_cp_env >> 5) & 1, g_cp_nostem = (g_cp_env >> 6) & 1, g_cp_nogr = (g_cp_env >> 7) & 1;
 // CUs the backward-pass kernels of the family leave free (data-parallel runs: the collective's workgroups are resident on a few CUs
 // during backward, and a one-workgroup-per-CU grid that does not fit next to them runs a second round for a handful of workgroups).
-// Set ONCE, before the first step (the partial-sum row counts derived from the grid are recorded in the launch plans).
+// The partial-sum row / slab / split counts derived from the grid are sized into buffers and recorded in launch plans: every launch
+// checks the capacity it is handed against its own geometry (convp_launch, nkb_gramr, nkb_conv_wgrad), hip.rowres_reserve_cus drops the plans.
 static int g_cp_reserve = 0;
 extern "C" void nkb_rowres_reserve_cus(int cus) { g_cp_reserve = cus < 0 ? 0 : (cus > 128 ? 128 : cus); }
 extern "C" int nkb_rowres_reserved_cus() { return g_cp_reserve; }
@@ -1187,9 +1188,17 @@ extern "C" int nkb_convp_tiles(int dtype, int kind, int N, int H, int W, int Cin
 }
 
 static int convp_launch(int kind, const void* x, const void* w, void* y, const void* c, const float* scale, const float* shift,
-                        const float* mean, float* stats, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t stream) {
+                        const float* mean, float* stats, int N, int H, int W, int Cin, int ldx, int Cout, int ldy, int stats_rows,
+                        hipStream_t stream) {
     const int tiles = nkb_convp_tiles(NKB_DT_BF16, kind, N, H, W, Cin, ldx, Cout, ldy, 3, 3, 1, 1);
     if (!tiles) { nkb_set_error("convp: shape not eligible (N=%d H=%d W=%d Cin=%d Cout=%d)", N, H, W, Cin, Cout); return 1; }
+    // the grid (and with it the number of partial-sum rows the kernel writes and the consumer sums) follows run-time settings:
+    // a buffer or a recorded launch plan made under other settings must not be replayed into
+    if (stats_rows != tiles) {
+        nkb_set_error("convp: stats sized for %d partial-sum rows, this launch writes %d (nkb_rowres_reserve_cus / nkb_convp_config "
+                      "changed after the buffer or the launch plan was made)", stats_rows, tiles);
+        return 1;
+    }
     if (!stats || (kind == 1 && (!c || !scale || !shift || !mean))) { nkb_set_error("convp: missing operand"); return 1; }
     CPGeom g;
     cp_geom(N * H * W, Cout, cp_cus() - (kind == 1 ? nkb_rowres_reserved_cus() : 0), g);
@@ -1227,16 +1236,16 @@ static int convp_launch(int kind, const void* x, const void* w, void* y, const v
 }
 
 extern "C" int nkb_convp_fwd(int dtype, const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int ldx,
-                             int Cout, int ldy, hipStream_t stream) {
+                             int Cout, int ldy, int tiles, hipStream_t stream) {
     if (dtype != NKB_DT_BF16) { nkb_set_error("convp_fwd: bf16 only"); return 1; }
-    return convp_launch(0, x, w, y, nullptr, nullptr, nullptr, nullptr, stats, N, H, W, Cin, ldx, Cout, ldy, stream);
+    return convp_launch(0, x, w, y, nullptr, nullptr, nullptr, nullptr, stats, N, H, W, Cin, ldx, Cout, ldy, tiles, stream);
 }
 
 extern "C" int nkb_convp_dgrad_bn(int dtype, const void* dy, const void* w, void* g_masked, const void* c, const float* scale,
                                   const float* shift, const float* mean, float* stats, int N, int H, int W, int Cin, int ldx,
-                                  int Cout, int ldy, hipStream_t stream) {
+                                  int Cout, int ldy, int tiles, hipStream_t stream) {
     if (dtype != NKB_DT_BF16) { nkb_set_error("convp_dgrad_bn: bf16 only"); return 1; }
-    return convp_launch(1, dy, w, g_masked, c, scale, shift, mean, stats, N, H, W, Cin, ldx, Cout, ldy, stream);
+    return convp_launch(1, dy, w, g_masked, c, scale, shift, mean, stats, N, H, W, Cin, ldx, Cout, ldy, tiles, stream);
 }
 
 #ifdef NKB_CONVP_STAMPS

@@ -41,8 +41,8 @@ _SIGS = {
     "nkb_rowres_reserve_cus": (None, [i32]),
     "nkb_rowres_reserved_cus": (i32, []),
     "nkb_convp_config": (None, [i32, i32]),
-    "nkb_convp_fwd": (i32, [i32, vp, vp, vp, vp] + [i32] * 7 + [vp]),
-    "nkb_convp_dgrad_bn": (i32, [i32] + [vp] * 8 + [i32] * 7 + [vp]),
+    "nkb_convp_fwd": (i32, [i32, vp, vp, vp, vp] + [i32] * 8 + [vp]),
+    "nkb_convp_dgrad_bn": (i32, [i32] + [vp] * 8 + [i32] * 8 + [vp]),
     "nkb_conv_dgrad_s2class": (i32, [i32] + [vp] * 9 + [i32] * 14 + [vp]),
     "nkb_bn_backward_from_stats": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
     "nkb_gram_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -499,9 +499,24 @@ def convp_config(on: bool = True, tc128: bool = False, c64: bool = True, c64_dgr
                             | (0 if gramr else 64))
 
 
+_geometry_epoch = 0
+
+
+def geometry_epoch() -> int:
+    """Bumped whenever a setting that sizes grids (and through them stats / slab buffers) changes: runtime.Workspace.generation
+    carries it, so launch plans recorded under the old setting are dropped instead of replayed."""
+    return _geometry_epoch
+
+
 def rowres_reserve_cus(cus: int):
-    """Data-parallel runs: CUs the row-resident family's backward kernels leave to the collective (set before the first step)."""
-    load().nkb_rowres_reserve_cus(int(cus))
+    """Data-parallel runs: CUs the row-resident family's backward kernels (convp data gradient, gramr, wgradr) leave to the
+    collective.  Changing it after a step has run is allowed: recorded plans are invalidated and the next eager pass re-sizes the
+    partial-sum / slab buffers; a stale buffer handed to the library is refused by the launch itself."""
+    global _geometry_epoch
+    lib = load()
+    if int(lib.nkb_rowres_reserved_cus()) != max(0, min(128, int(cus))):
+        _geometry_epoch += 1
+    lib.nkb_rowres_reserve_cus(int(cus))
 
 
 def conv1p_tiles(dtype, M, Cin, ldx, Cout, ldy) -> int:
@@ -513,13 +528,14 @@ def conv1p_fwd(dtype, x, w, y, stats, *, M, Cin, ldx, Cout, ldy):
     check(load().nkb_conv1p_fwd(dtype, ptr(x), ptr(w), ptr(y), ptr(stats), M, Cin, ldx, Cout, ldy, stream()), "conv1p_fwd")
 
 
-def convp_fwd(dtype, x, w, y, stats, *, N, H, W, Cin, ldx, Cout, ldy):
-    check(load().nkb_convp_fwd(dtype, ptr(x), ptr(w), ptr(y), ptr(stats), N, H, W, Cin, ldx, Cout, ldy, stream()), "convp_fwd")
+def convp_fwd(dtype, x, w, y, stats, *, N, H, W, Cin, ldx, Cout, ldy, tiles):
+    """tiles: the partial-sum rows `stats` was sized for (convp_tiles at that time); the launch is refused if its grid differs."""
+    check(load().nkb_convp_fwd(dtype, ptr(x), ptr(w), ptr(y), ptr(stats), N, H, W, Cin, ldx, Cout, ldy, int(tiles), stream()), "convp_fwd")
 
 
-def convp_dgrad_bn(dtype, dy, w, g_masked, c, scale, shift, mean, stats, *, N, H, W, Cin, ldx, Cout, ldy):
+def convp_dgrad_bn(dtype, dy, w, g_masked, c, scale, shift, mean, stats, *, N, H, W, Cin, ldx, Cout, ldy, tiles):
     check(load().nkb_convp_dgrad_bn(dtype, ptr(dy), ptr(w), ptr(g_masked), ptr(c), ptr(scale), ptr(shift), ptr(mean), ptr(stats),
-                                    N, H, W, Cin, ldx, Cout, ldy, stream()), "convp_dgrad_bn")
+                                    N, H, W, Cin, ldx, Cout, ldy, int(tiles), stream()), "convp_dgrad_bn")
 
 
 def conv_wgrad(dtype, dy, x, dw, *, N, H, W, Cin, ldx, P, Q, Cout, lddy, R=1, S=1, stride=1, pad=0, dbias=None,

@@ -378,7 +378,7 @@ class HipEngine:
             tiles = tiles_p or tiles_1 or tiles_s
         stats = self.ws.get(key + ".stats", (hip.bn_stats_floats(tiles, co),), torch.float32) if train else None
         if tiles_p:
-            hip.convp_fwd(self.d, x, self.w_fwd(w), c, stats, N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, ldy=co)
+            hip.convp_fwd(self.d, x, self.w_fwd(w), c, stats, N=N, H=H, W=W, Cin=ci, ldx=ci, Cout=co, ldy=co, tiles=tiles_p)
         elif tiles_1:
             hip.conv1p_fwd(self.d, x, self.w_fwd(w), c, stats, M=rows, Cin=ci, ldx=ci, Cout=co, ldy=co)
         elif tiles_s:
@@ -944,7 +944,7 @@ class HipEngine:
                 if tiles:
                     stats = self.ws.get(fuse_bn + ".bstats", (hip.bn_stats_floats(tiles, ci),), torch.float32)
                     hip.convp_dgrad_bn(self.d, g_c, self._wd[id(w)], dx, svp["c"], svp["scale"], svp["shift"], svp["mean"], stats,
-                                       N=N, H=H, W=W, Cin=geom["Cout"], ldx=geom["Cout"], Cout=ci, ldy=ci)
+                                       N=N, H=H, W=W, Cin=geom["Cout"], ldx=geom["Cout"], Cout=ci, ldy=ci, tiles=tiles)
                     return dx, (stats, tiles)
             tiles = hip.stat_tiles(self.d, N * H * W, ci)
             stats = self.ws.get(fuse_bn + ".bstats", (hip.bn_stats_floats(tiles, ci),), torch.float32)

@@ -231,7 +231,13 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self._bufs: Dict[str, torch.Tensor] = {}
-        self.generation = 0       # bumped by every (re)allocation: recorded launch plans hold raw pointers into these buffers
+        self._allocs = 0          # bumped by every (re)allocation: recorded launch plans hold raw pointers into these buffers
+
+    @property
+    def generation(self):
+        """What a recorded launch plan is valid for: this workspace's allocations AND the library's grid-sizing settings (a plan
+        recorded under another nkb_rowres_reserve_cus replays launches whose partial-row / slab counts no longer match its buffers)."""
+        return (self._allocs, hip.geometry_epoch())
 
     def get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
         shape = tuple(int(s) for s in shape)
@@ -242,7 +248,7 @@ class Workspace:
             else:
                 t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype)
             self._bufs[name] = t
-            self.generation += 1
+            self._allocs += 1
         return t
 
     def at_least(self, name: str, numel: int, dtype) -> torch.Tensor:
@@ -251,7 +257,7 @@ class Workspace:
         if t is None or t.numel() < numel or t.dtype != dtype:
             t = _guarded((max(int(numel), 1),), dtype, self.device) if _POISON else torch.empty(max(int(numel), 1), device=self.device, dtype=dtype)
             self._bufs[name] = t
-            self.generation += 1
+            self._allocs += 1
         return t
 
     def nbytes(self) -> int:
@@ -259,4 +265,4 @@ class Workspace:
 
     def clear(self):
         self._bufs.clear()
-        self.generation += 1
+        self._allocs += 1

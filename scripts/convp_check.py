@@ -29,14 +29,14 @@ def run(N, H, W, Cin, Cout, kind, reps):
     geom = dict(N=N, H=H, W=W, Cin=Cin, ldx=Cin, P=H, Q=W, Cout=Cout, ldy=Cout, R=3, S=3, stride=1, pad=1)
     if kind == 0:
         f0 = lambda: hip.conv_gemm(d, 0, x, w, y0, stats=s0, **geom)                                     # noqa: E731
-        f1 = lambda: hip.convp_fwd(d, x, w, y1, s1, N=N, H=H, W=W, Cin=Cin, ldx=Cin, Cout=Cout, ldy=Cout)  # noqa: E731
+        f1 = lambda: hip.convp_fwd(d, x, w, y1, s1, N=N, H=H, W=W, Cin=Cin, ldx=Cin, Cout=Cout, ldy=Cout, tiles=tiles1)  # noqa: E731
     else:
         c = torch.randn(N, H, W, Cout, device=DEV).to(torch.bfloat16)
         scale = (torch.rand(Cout, device=DEV) + 0.5)
         shift = torch.randn(Cout, device=DEV) * 0.3
         mean = torch.randn(Cout, device=DEV) * 0.1
         f0 = lambda: hip.conv_dgrad_bn(d, x, w, y0, c, scale, shift, mean, s0, **geom)                    # noqa: E731
-        f1 = lambda: hip.convp_dgrad_bn(d, x, w, y1, c, scale, shift, mean, s1, N=N, H=H, W=W, Cin=Cin, ldx=Cin, Cout=Cout, ldy=Cout)  # noqa: E731
+        f1 = lambda: hip.convp_dgrad_bn(d, x, w, y1, c, scale, shift, mean, s1, N=N, H=H, W=W, Cin=Cin, ldx=Cin, Cout=Cout, ldy=Cout, tiles=tiles1)  # noqa: E731
     f0(); f1()
     torch.cuda.synchronize()
     a, b = y0.float(), y1.float()

@@ -10,6 +10,6 @@ tiles = hip.convp_tiles(d, kind, N=N, H=H, W=H, Cin=ci, ldx=ci, Cout=co, ldy=co,
 st = torch.zeros(hip.bn_stats_floats(tiles, co), device=dev)
 c = torch.randn(N, H, H, co, device=dev).to(T); sc = torch.ones(co, device=dev); sh = torch.zeros(co, device=dev)
 for _ in range(5):
-    if kind == 0: hip.convp_fwd(d, x, w, y, st, N=N, H=H, W=H, Cin=ci, ldx=ci, Cout=co, ldy=co)
-    else: hip.convp_dgrad_bn(d, x, w, y, c, sc, sh, sh, st, N=N, H=H, W=H, Cin=ci, ldx=ci, Cout=co, ldy=co)
+    if kind == 0: hip.convp_fwd(d, x, w, y, st, N=N, H=H, W=H, Cin=ci, ldx=ci, Cout=co, ldy=co, tiles=tiles)
+    else: hip.convp_dgrad_bn(d, x, w, y, c, sc, sh, sh, st, N=N, H=H, W=H, Cin=ci, ldx=ci, Cout=co, ldy=co, tiles=tiles)
 torch.cuda.synchronize()

@@ -54,7 +54,7 @@ def test_convp_forward_matches_torch_and_the_128x128_kernel(shape):
     y = torch.full((N, H, W, Cout), float("nan"), device=DEV, dtype=T)
     stats = torch.full((hip.bn_stats_floats(tiles, Cout),), float("nan"), device=DEV)
     n0 = hip.kernel_launches("convp")
-    hip.convp_fwd(D, xd, wd, y, stats, **g)
+    hip.convp_fwd(D, xd, wd, y, stats, tiles=tiles, **g)
     assert hip.kernel_launches("convp") == n0 + 1
     # the kernel it replaces, same operands
     y0 = torch.empty_like(y)
@@ -62,7 +62,7 @@ def test_convp_forward_matches_torch_and_the_128x128_kernel(shape):
     s0 = torch.zeros(hip.bn_stats_floats(t0, Cout), device=DEV)
     hip.conv_gemm(D, 0, xd, wd, y0, stats=s0, N=N, H=H, W=W, Cin=Cin, ldx=Cin, P=H, Q=W, Cout=Cout, ldy=Cout, R=3, S=3, stride=1, pad=1)
     y2, stats2 = torch.empty_like(y), torch.empty_like(stats)
-    hip.convp_fwd(D, xd, wd, y2, stats2, **g)
+    hip.convp_fwd(D, xd, wd, y2, stats2, tiles=tiles, **g)
     torch.cuda.synchronize()
     ref = _nhwc(F.conv2d(x, w, padding=1))
     torch.testing.assert_close(y.float().cpu(), ref, rtol=2e-2, atol=2e-2 * math.sqrt(9 * Cin) / 4)
@@ -107,7 +107,7 @@ def test_convp_dgrad_with_fused_bn_backward_matches_torch_and_unfused(shape):
     # fused, new core
     g1 = torch.full_like(g0, float("nan"))
     stats = torch.full((hip.bn_stats_floats(tiles, C),), float("nan"), device=DEV)
-    hip.convp_dgrad_bn(D, dy, wt, g1, c, scale, shift, mean, stats, **g)
+    hip.convp_dgrad_bn(D, dy, wt, g1, c, scale, shift, mean, stats, tiles=tiles, **g)
     dg1, db1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dc1 = torch.empty_like(c)
     sums = torch.empty(2 * C, device=DEV)
@@ -143,7 +143,7 @@ def test_convp_refuses_what_it_cannot_run():
     assert hip.convp_tiles(hip.F32, 0, **ok) == 0
     x = torch.zeros(1, 28, 28, 64, device=DEV, dtype=T)
     with pytest.raises(RuntimeError, match="not eligible"):
-        hip.convp_fwd(D, x, x, x, torch.zeros(8, device=DEV), N=1, H=28, W=28, Cin=64, ldx=64, Cout=128, ldy=128)
+        hip.convp_fwd(D, x, x, x, torch.zeros(8, device=DEV), N=1, H=28, W=28, Cin=64, ldx=64, Cout=128, ldy=128, tiles=1)
 
 
 def test_backward_grids_leave_reserved_cus_to_a_collective():
@@ -167,8 +167,11 @@ def test_backward_grids_leave_reserved_cus_to_a_collective():
             tiles = hip.convp_tiles(D, 1, R=3, S=3, stride=1, pad=1, **g)
             g1 = torch.full((N, H, W, C), float("nan"), device=DEV, dtype=T)
             stats = torch.full((hip.bn_stats_floats(tiles, C),), float("nan"), device=DEV)
-            hip.convp_dgrad_bn(D, dy, wt, g1, c, scale, shift, mean, stats, **g)
+            hip.convp_dgrad_bn(D, dy, wt, g1, c, scale, shift, mean, stats, tiles=tiles, **g)
             out.append((tiles, g1, stats[: tiles * 2 * C].view(tiles, 2, C).double().sum(0)))
+            if reserve:                                                 # a buffer (or a recorded plan) sized under the other setting is refused
+                with pytest.raises(RuntimeError, match="partial-sum rows"):
+                    hip.convp_dgrad_bn(D, dy, wt, g1, c, scale, shift, mean, stats, tiles=t0, **g)
         assert out[0][0] == t0 and out[1][0] < t0                       # 242 -> 224 workgroups on a 256-CU chip
         assert hip.convp_tiles(D, 0, R=3, S=3, stride=1, pad=1, **g) == f0  # the forward grid is not touched
         assert 0 < hip.gramr_workspace(D, 802816, 256, 64) < w0

@@ -279,3 +279,22 @@ def test_get_dataset_sampling_options(tmp_path):
     raw, hw, label = FolderDataset(str(tmp_path), size=16, raw=True)[0]
     assert raw.dtype == torch.uint8 and raw.shape == (16, 16, 3) and hw.tolist() == [10, 16] and label == 0
     assert raw[10:].abs().sum() == 0
+
+
+def test_changing_the_reserved_cus_invalidates_recorded_plans():
+    """nkb_rowres_reserve_cus sizes the grids (partial-sum rows, slab counts) of the backward kernels; a launch plan recorded
+    under another value must not be replayed.  Workspace.generation — what a plan is keyed on — carries the setting's epoch."""
+    from nkb_classification import hip, runtime
+    ws = runtime.Workspace("cpu")
+    try:
+        hip.rowres_reserve_cus(0)
+        g0 = ws.generation
+        hip.rowres_reserve_cus(0)                       # same value: plans stay
+        assert ws.generation == g0
+        hip.rowres_reserve_cus(32)
+        g1 = ws.generation
+        assert g1 != g0 and hip.load().nkb_rowres_reserved_cus() == 32
+        ws.get("a", (4,), __import__("torch").float32)  # allocations still count
+        assert ws.generation != g1
+    finally:
+        hip.rowres_reserve_cus(0)

@@ -965,6 +965,41 @@ def test_wgrad3x3_strip_kernel(case):
     assert (dwa.cpu() - ref).abs().max().item() < 2e-5 * scale
 
 
+def test_wgradr_split_count_follows_the_reserved_cus_and_refuses_a_stale_workspace():
+    """nkb_rowres_reserve_cus also sizes wgradr's pixel split (csrc/wgradr.hip: splits x tiles <= #CUs - reserve): the workspace
+    query answers for the CURRENT setting, the product is the same under either, and a workspace sized under the smaller split
+    count is refused by the launch instead of being written past."""
+    M, Ci, Co = 50432, 768, 768                     # (ViT-B/16 proj: 9 tiles of 256 x 256, the split count moves with the CU budget)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, Ci, generator=g).to(DEV, torch.bfloat16)
+    dy = torch.randn(M, Co, generator=g).to(DEV, torch.bfloat16)
+    ref = dy.float().t() @ x.float()
+    d = hip.BF16
+    geom = dict(N=M, H=1, W=1, Cin=Ci, ldx=Ci, P=1, Q=1, Cout=Co, lddy=Co)
+    out, need = [], []
+    try:
+        for reserve in (0, 32):
+            hip.rowres_reserve_cus(reserve)
+            need.append(hip.conv_wgrad_workspace(d, N=M, P=1, Q=1, Cin=Ci, Cout=Co))
+            work = torch.full((need[-1] + 7,), float("nan"), device=DEV)
+            dw = torch.zeros(Co, Ci, device=DEV)
+            n0 = hip.kernel_launches("wgradr")
+            hip.conv_wgrad(d, dy, x, dw, workspace=work, **geom)
+            torch.cuda.synchronize()
+            assert hip.kernel_launches("wgradr") == n0 + 1 and torch.isnan(work[need[-1]:]).all()
+            out.append(dw)
+        assert need[0] != need[1]
+        scale = ref.abs().max().item()
+        for dw in out:
+            assert (dw - ref).abs().max().item() < 1e-4 * scale
+        small, big_setting = (need[0], 32) if need[0] < need[1] else (need[1], 0)
+        hip.rowres_reserve_cus(big_setting)
+        with pytest.raises(RuntimeError):
+            hip.conv_wgrad(d, dy, x, torch.zeros(Co, Ci, device=DEV), workspace=torch.empty(small, device=DEV), **geom)
+    finally:
+        hip.rowres_reserve_cus(0)
+
+
 WR_CASES = [(4096, 256, 128, 0, False), (4096, 128, 256, 0, False), (8192 + 33, 512, 128, 8, False), (4100, 128, 512, 16, False),
             (12544, 2048, 512, 0, False), (12544, 512, 2048, 0, False), (4096 + 31, 384, 256, 0, False), (9000, 384, 768, 8, True),
             (70000 + 17, 512, 1024, 0, False), (70000, 1024, 512, 8, True)]
