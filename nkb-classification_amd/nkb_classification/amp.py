@@ -21,6 +21,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import weakref
+
 import torch
 
 from . import hip
@@ -40,7 +42,7 @@ class HipGradScaler:
         self._host_event = None
         self._last_opt = None                           # optimizer whose previous step may have been skipped
         self._unscaled = set()
-        self._found = {}                                # id(optimizer) -> its own inf / nan flag (non-fused path)
+        self._found = weakref.WeakKeyDictionary()       # optimizer -> its own inf / nan flag (non-fused path); dies with the optimizer
         self._init_growth_tracker = 0
 
     # ---- torch.amp.GradScaler surface ----------------------------------------------------------------------
@@ -114,9 +116,9 @@ class HipGradScaler:
                         raise RuntimeError("HipGradScaler: gradients must be fp32 tensors on a cuda device")
                     self._lazy_init(g.device)
                     if own is None:
-                        own = self._found.get(id(optimizer))
+                        own = self._found.get(optimizer)
                         if own is None:
-                            own = self._found[id(optimizer)] = torch.zeros(1, device=g.device)
+                            own = self._found[optimizer] = torch.zeros(1, device=g.device)
                         own.zero_()
                     flat = g if g.is_contiguous() else None
                     if flat is None:
@@ -144,7 +146,7 @@ class HipGradScaler:
         if not self._fused(optimizer):
             if self._state is None:                     # nothing had a gradient
                 return optimizer.step(*args, **kwargs)
-            own = self._found.get(id(optimizer))
+            own = self._found.get(optimizer)
             if own is not None and float(own.item()) != 0.0:     # the slow path's one host read: skip, as torch's GradScaler.step does
                 return None
             return optimizer.step(*args, **kwargs)
@@ -165,6 +167,8 @@ class HipGradScaler:
             self._host.copy_(self._state[2:3], non_blocking=True)
             self._host_event = torch.cuda.Event()
             self._host_event.record()
+        for own in self._found.values():                # a flag belongs to ONE step: an optimizer without gradients next step
+            own.zero_()                                 # must not inherit this step's overflow
         self._unscaled.clear()
 
     def state_dict(self):
