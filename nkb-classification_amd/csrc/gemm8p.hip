@@ -29,6 +29,13 @@
 #include "gemm8p.h"
 #include <type_traits>
 
+#ifdef NKB_G8_STAMPS
+// diagnostic build only (scripts/g8_stamps.py): s_memtime of wave 0 / wave 4 of every workgroup at the top of a tile's first four
+// k-tiles, in front of its epilogue and behind it — [workgroup][tile of the workgroup < 12][8 slots][2 waves]
+__device__ unsigned long long g8_stamps[256 * 12 * 8 * 2];
+extern "C" int nkb_g8_read_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g8_stamps), sizeof(g8_stamps)); }
+#endif
+
 namespace {
 
 struct G8Params {
@@ -66,6 +73,7 @@ struct G8Params {
     float* colpart;
     int aux_mode;         // 0: the result is multiplied by aux; 1: the result is kept where 0 < aux < 6 (ReLU6 backward mask)
     int align_epi;        // DIRECT: both wave groups run the epilogue side by side (NKB_G8_ALIGN, default 1)
+    unsigned stagger;     // DIRECT: shader cycles over which the workgroups that walk one tile fewer than the others spread their start
 };
 
 template <int V> using G8I = std::integral_constant<int, V>;
@@ -152,6 +160,15 @@ __device__ __forceinline__ void g8_gelu2(g8_f32x2 x, g8_f32x2& u, g8_f32x2& du) 
     } while (0)
 #define G8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define G8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#ifdef NKB_G8_STAMPS
+#define G8_STAMP(slot)                                                                                                \
+    do {                                                                                                              \
+        if (DIRECT && (wave & 3) == 0 && lane == 0 && blockIdx.x < 256 && tcount < 12)                                \
+            g8_stamps[((blockIdx.x * 12 + tcount) * 8 + (slot)) * 2 + (wave >> 2)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+#else
+#define G8_STAMP(slot) do { } while (0)
+#endif
 
 // DIRECT = false: one tile per workgroup, epilogue through LDS (coalesced 16-byte rows, BatchNorm partial sums).
 // DIRECT = true : persistent workgroups (grid = min(tiles, CUs), tile = id, id + grid, ...) with ONE continuous DMA stream
@@ -249,6 +266,23 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 
     if constexpr (QOUT) {
         if (tid == 0) *(unsigned*)(smem + 2 * BUF + 4096) = 0u;    // (ordered before every wave's first epilogue by the k-loop's barriers)
+    }
+    if constexpr (DIRECT) {
+        // Round 5 (in-kernel stamps, scripts/g8_stamps.py): identical tiles keep every CU in lockstep, so all of them store their
+        // 128 KB tile in the same few microseconds — 25-33 MB per round against the fabric's write rate: 4-5 us per tile during
+        // which a wave can issue no vector-memory instruction, 19 % of a K = 768 tile — while the rest of the tile moves almost
+        // nothing.  When the tile count is no multiple of the grid, the workgroups that walk one tile FEWER have a whole tile of
+        // slack: they start spread over `stagger` cycles, their stores then fall between the bursts of the others, and the long
+        // walkers (the critical path) burst in a smaller crowd.  Same tiles, same arithmetic, same bits.
+        if (p.stagger) {
+            const int most = (ntiles + step - 1) / step;
+            const int first_short = ntiles - (most - 1) * step;       // workgroups lid >= first_short walk most - 1 tiles
+            if (lid >= first_short) {
+                const unsigned long long wait = (unsigned long long)p.stagger * (unsigned)(lid - first_short + 1) / (unsigned)(step - first_short + 1);
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);   // (bounded: the clock only runs forward)
+            }
+        }
     }
     // ---- prologue: seven half-tiles in flight, the first k-tile landed
     G8_ISSUE_AT(0, 0, 0, xo, wo); G8_ISSUE_AT(0, 0, 1, xo, wo); G8_ISSUE_AT(0, 0, 2, xo, wo); G8_ISSUE_AT(0, 0, 3, xo, wo);
@@ -444,7 +478,40 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             }
         };
         constexpr bool has_q = QOUT;
-        if constexpr (PRE) {
+#ifndef NKB_G8_PRE_ALL
+#define NKB_G8_PRE_ALL 0      // measured (round 5, scripts/gemm8p_epi_bench.py, same box, alternating builds): 105.0 vs 105.5 / 333.5 vs 334.7 us — no gain
+#endif
+        if constexpr (PRE && NKB_G8_PRE_ALL && !QOUT) {
+            // round 5: BOTH halves of the operand are requested up front — the fragment registers of the k-loop (64 of them) are dead
+            // between the last phase of a tile and the next phase 1, exactly the sixteen 16-byte rows of this lane.  One exposed
+            // memory round trip per tile instead of two: half 0 is multiplied and stored while half 1 is still landing, and the
+            // wait for half 1 counts half 0's eight stores as the youngest operations (no load ever waits behind a store).
+            u32x4 raw0[2][4], raw1[2][4];
+            load_half(0, raw0);
+            load_half(1, raw1);
+            G8_WAIT_HALF(8, raw0);                     // (also the DMA stream's youngest half-tiles, issued a k-tile ago)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float bv[8];
+                bias_of(q, bv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 out = value(q, j, bv, raw0[q][j], raw0[q][j]);
+                    __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
+                }
+            }
+            G8_WAIT_HALF(8, raw1);                     // younger than half 1's loads: exactly the eight stores above
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float bv[8];
+                bias_of(2 + q, bv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 out = value(2 + q, j, bv, raw1[q][j], raw1[q][j]);
+                    __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
+                }
+            }
+        } else if constexpr (PRE) {
             u32x4 raw[2][4], pk[2][4];
             load_half(0, raw);
             G8_WAIT_HALF(0, raw);                      // (also the DMA stream's three youngest half-tiles, issued a k-tile ago)
@@ -553,10 +620,12 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     };
 
     int t = 0;                                    // local k-tile of stream k-tile g
+    [[maybe_unused]] int tcount = 0;              // (stamps) tiles this workgroup has finished
     for (int g = 0; g < GT; ++g) {
         const unsigned char* base = smem + (g & 1) * BUF;
         const unsigned char* pa = base + a_base;
         const unsigned char* pb = base + b_base;
+        if (t < 4) G8_STAMP(t);
         if constexpr (DIRECT) {
             // first k-tile of a tile: this wave's 128 bias values go to its 512 bytes of LDS behind the staging buffers by DMA
             // (no registers, and nothing in the epilogue waits on vmcnt for them: they are older than the three half-tiles
@@ -634,7 +703,9 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 // The two wave groups drop their one-barrier stagger for it (group 0 waits one barrier before, group 1 one
                 // after): run one after the other — each overlapping only 16 MFMAs of the other — the two epilogues cost
                 // 6-10 us per tile, 18-29 % of a K = 768 / 1024 launch; side by side their store latencies overlap.
+                G8_STAMP(4);
                 if (p.align_epi && wr == 0) G8_BARRIER();
+                G8_STAMP(5);
                 const bool fullt = tile_m * 256 + 256 <= p.M;
                 if constexpr (QOUT) {             // the two producers of the fp8 train step; everything else takes the run-time form
                     if (fullt && !p.add && !p.aux && p.relu == 2) epilogue(G8I<1>{}, G8I<0>{}, G8I<0>{}, G8I<2>{});
@@ -653,7 +724,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     if (p.aux_mode == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<1>{}, G8I<0>{});
                     else epilogue(G8I<1>{}, G8I<0>{}, G8I<2>{}, G8I<0>{});
                 } else epilogue(G8I<1>{}, G8I<-1>{}, G8I<-1>{}, G8I<-1>{});
+                G8_STAMP(6);
                 if (p.align_epi && wr == 1) G8_BARRIER();
+                G8_STAMP(7);
+                ++tcount;
                 // the next tile becomes the current one; the one after it becomes "next"
                 t = 0;
                 lid += step;
@@ -803,12 +877,20 @@ static int g8_align() {
 // the SMALLEST one that still finishes in that many rounds — every workgroup then walks the same number of tiles (no idle tail),
 // and the CUs it leaves free run the side stream's weight gradients for the whole launch (ViT-B/16: 591 tiles -> 197 workgroups
 // x 3 tiles instead of 256 with a third round at 31 %; in-step A/B -0.3 ms; tile counts that are multiples of 256 are unchanged)
+#ifndef NKB_G8_STAGGER
+#define NKB_G8_STAGGER 0      // measured (round 5): the epilogue is not bound by the CROWD (3 workgroups alone take as long per tile as 197), see DESIGN 3.5
+#endif
 static int g8_grid(int tiles, int cus) {
     if (tiles <= cus) return tiles;
-    constexpr int balanced = 1;
-    if (!balanced) return cus;
+    if (NKB_G8_STAGGER) return cus;              // round 5: every CU, the short walkers staggered (see the kernel's prologue)
     const int rounds = (tiles + cus - 1) / cus;
     return (tiles + rounds - 1) / rounds;
+}
+// shader cycles a 256 x 256 tile of `kt` k-tiles takes (stamps: 3 000-3 100 per k-tile, 8 000-9 000 around the epilogue), less a margin:
+// a short walker must not become the last one to finish
+static unsigned g8_stagger(int tiles, int cus, int kt) {
+    if (!NKB_G8_STAGGER || tiles <= cus || tiles % cus == 0) return 0u;
+    return (unsigned)((kt * 3000 + 8000) * 0.85);
 }
 
 static int g8_cus() {
@@ -856,6 +938,7 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream, const float* row
     const int tiles = p.tilesM * p.tilesN;
     // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
     constexpr int direct_on = 1;
+    p.stagger = g8_stagger(tiles, cus, p.K / 64);
     if (p.stats == nullptr && direct_on && p.K >= 128)
         hipLaunchKernelGGL(gemm8p_kernel<true>, dim3((unsigned)g8_grid(tiles, cus)), dim3(512), lds, stream, p);
     else
@@ -912,6 +995,7 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096;
     const int tiles = p.tilesM * p.tilesN;
     NkbProfScope prof(mode == 0 ? NKB_K_CONV_FWD : NKB_K_CONV_DGRAD, stream, 2.0 * M * (double)N * K);
+    p.stagger = g8_stagger(tiles, cus, K / 128);
     const dim3 grid((unsigned)g8_grid(tiles, cus));
     if (yq) {
         if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<true, 1, true>), grid, dim3(512), lds, stream, p);
