@@ -2,6 +2,7 @@
 // stem im2row, weight re-layout.  All activations are NHWC, channel-contiguous, 16-byte vector I/O.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 static inline unsigned grid_for(size_t work_items, int block = 256, unsigned cap = 256 * 16) {
     size_t g = (work_items + block - 1) / block;
@@ -31,6 +32,11 @@ static inline int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
+// -DNKB_BN_FUSED=0: the two-launch BatchNorm statistics (partition sums, then the finalize) instead of the one-launch form (A/B builds)
+#ifndef NKB_BN_FUSED
+#define NKB_BN_FUSED 1
+#endif
+static constexpr int g_bn_fused = NKB_BN_FUSED;
 
 template <int NC>
 __device__ __forceinline__ void ldvec(const float* __restrict__ p, float* o) {
@@ -48,8 +54,10 @@ __device__ __forceinline__ void ldvec(const float* __restrict__ p, float* o) {
 // stage A (only for many tiles): grid (C/64, P) blocks of 64 channels x 16 tile lanes -> dpart[P][2][C] doubles; P partitions:
 // 16 for wide layers, more for narrow ones (C = 64: one block column — 16 blocks read the 3.2 MB of partials of a 56 x 56 layer)
 static inline int bn_partitions(int C) { return C <= 128 ? 64 : (C <= 256 ? 32 : 16); }
-__global__ void bn_partial_reduce_kernel(const float* __restrict__ partials, int tiles, int C, double* __restrict__ dpart) {
-    __shared__ double red[2][16][64];
+// WT: the partition sums leave write-through (sc1: the fused kernels below hand them to another workgroup inside the launch)
+template <bool WT>
+__device__ __forceinline__ void bn_partial_reduce_body(const float* __restrict__ partials, int tiles, int C, double* __restrict__ dpart,
+                                                       double (&red)[2][16][64]) {
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double s = 0.0, ss = 0.0;
@@ -65,19 +73,61 @@ __global__ void bn_partial_reduce_kernel(const float* __restrict__ partials, int
     if (py != 0 || c >= C) return;
     s = 0.0; ss = 0.0;
     for (int k = 0; k < 16; ++k) { s += red[0][k][cx]; ss += red[1][k][cx]; }
-    dpart[((size_t)blockIdx.y * 2) * C + c] = s;
-    dpart[((size_t)blockIdx.y * 2 + 1) * C + c] = ss;
+    double* d0 = dpart + ((size_t)blockIdx.y * 2) * C + c;
+    double* d1 = dpart + ((size_t)blockIdx.y * 2 + 1) * C + c;
+    if constexpr (WT) {
+        __hip_atomic_store(d0, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d1, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *d0 = s; *d1 = ss;
+    }
+}
+__global__ void bn_partial_reduce_kernel(const float* __restrict__ partials, int tiles, int C, double* __restrict__ dpart) {
+    __shared__ double red[2][16][64];
+    bn_partial_reduce_body<false>(partials, tiles, C, dpart, red);
+}
+
+// ---- the two stages in ONE launch (round 5): every (channel column, partition) workgroup reduces its share of the
+// tile rows as above; the workgroup of a column that arrives LAST then finishes the column.  Same two-level summation order as the
+// two launches (bit-identical results), one launch and one kernel boundary fewer per BatchNorm in each direction.  Hand-off
+// (cdna_hip_programming.md Guideline 16, counter form): partition sums stored write-through (sc1), every storing wave's
+// s_waitcnt vmcnt(0), workgroup barrier, one agent-scope ticket per workgroup; the last arriver resets the ticket (all partitions have
+// arrived: the slot is clean for its next user), runs ONE agent-scope acquire (this CU's L1 may hold stale lines of the scratch from an
+// earlier launch), and only then do its waves read.  Nobody waits for anybody: no spin, every workgroup runs to completion.
+__device__ unsigned g_bn_tickets[128 * 32];        // zero at load and between launches; slot = 32 channel columns of one call
+__device__ __forceinline__ bool bn_arrive_last(unsigned* ticket, unsigned parts) {
+    __shared__ unsigned last_flag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == parts - 1;
+        if (last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        last_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return last_flag != 0u;
+}
+static unsigned* bn_ticket_slot(int cols) {
+    static std::atomic<unsigned> next{0};
+    if (cols > 32) return nullptr;
+    unsigned* base = nullptr;
+    if (hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_bn_tickets)) != hipSuccess || !base) return nullptr;
+    return base + (next.fetch_add(1u) % 128u) * 32u;
 }
 
 template <typename PT>
-__global__ void bn_finalize_kernel(const PT* __restrict__ partials, int tiles, int C, float count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float momentum, float eps, int training, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd) {
+__device__ __forceinline__ void bn_finalize_body(const PT* __restrict__ partials, int tiles, int C, float count,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                 float momentum, float eps, int training, float* __restrict__ scale,
+                                                 float* __restrict__ shift, float* __restrict__ save_mean,
+                                                 float* __restrict__ save_invstd, double (&red)[2][16][64]) {
     // block = 64 channels x 16 tile-partitions; partition sums are combined through LDS in a fixed order
-    __shared__ double red[2][16][64];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double s = 0.0, ss = 0.0;
@@ -112,6 +162,30 @@ __global__ void bn_finalize_kernel(const PT* __restrict__ partials, int tiles, i
     shift[c] = b - mean * g * invstd;
     if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
 }
+template <typename PT>
+__global__ void bn_finalize_kernel(const PT* __restrict__ partials, int tiles, int C, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, int training, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+    __shared__ double red[2][16][64];
+    bn_finalize_body<PT>(partials, tiles, C, count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
+                         save_mean, save_invstd, red);
+}
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partials, int tiles, int C, double* __restrict__ dpart,
+                                                                  unsigned* __restrict__ tickets, float count,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                  float momentum, float eps, float* __restrict__ scale,
+                                                                  float* __restrict__ shift, float* __restrict__ save_mean,
+                                                                  float* __restrict__ save_invstd) {
+    __shared__ double red[2][16][64];
+    bn_partial_reduce_body<true>(partials, tiles, C, dpart, red);
+    if (!bn_arrive_last(tickets + blockIdx.x, gridDim.y)) return;
+    bn_finalize_body<double>(dpart, (int)gridDim.y, C, count, gamma, beta, running_mean, running_var, momentum, eps, 1, scale, shift,
+                             save_mean, save_invstd, red);
+}
 
 // `partials` must have the size nkb_bn_stats_floats(tiles, C): room for the stage-A scratch behind the [tiles][2][C] block when tiles > 128.
 extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long long count, const float* gamma,
@@ -122,10 +196,16 @@ extern "C" int nkb_bn_finalize(const float* partials, int tiles, int C, long lon
     if (training && tiles > 128) {
         double* dpart = (double*)(partials + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
         const int P = bn_partitions(C);
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, partials, tiles, C, dpart);
-        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream, (const double*)dpart, P, C,
-                           (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
-                           save_mean, save_invstd);
+        unsigned* tickets = g_bn_fused ? bn_ticket_slot((C + 63) / 64) : nullptr;
+        if (tickets) {
+            hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, partials, tiles, C, dpart, tickets,
+                               (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+        } else {
+            hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, partials, tiles, C, dpart);
+            hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream, (const double*)dpart, P, C,
+                               (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
+                               save_mean, save_invstd);
+        }
     } else {
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, stream, partials, tiles, C,
                            (float)count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
@@ -1318,10 +1398,9 @@ extern "C" int nkb_stem_wfold(int dtype, const float* dwp, float* dw, int Cout, 
 // `stats` holds per-row-tile sum(g') and sum(g'*(c-mean)), g is the masked gradient g'.  Finalize (double accumulation,
 // fixed order) + the elementwise pass dx = gamma*invstd*(g' - sum_g/M - xhat*sum_gx/M).
 template <typename PT>
-__global__ void bn_bwd_finalize_tiles_kernel(const PT* __restrict__ partials, int tiles, int C,
-                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                             float* __restrict__ dbeta, float* __restrict__ sums) {
-    __shared__ double red[2][16][64];
+__device__ __forceinline__ void bn_bwd_finalize_tiles_body(const PT* __restrict__ partials, int tiles, int C,
+                                                           const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ sums, double (&red)[2][16][64]) {
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double a = 0.0, b = 0.0;
@@ -1343,12 +1422,35 @@ __global__ void bn_bwd_finalize_tiles_kernel(const PT* __restrict__ partials, in
     if (dbeta) dbeta[c] += sg;
     if (dgamma) dgamma[c] += sgx;
 }
+template <typename PT>
+__global__ void bn_bwd_finalize_tiles_kernel(const PT* __restrict__ partials, int tiles, int C,
+                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                             float* __restrict__ dbeta, float* __restrict__ sums) {
+    __shared__ double red[2][16][64];
+    bn_bwd_finalize_tiles_body<PT>(partials, tiles, C, invstd, dgamma, dbeta, sums, red);
+}
+// stage A + the finish by each column's last-arriving workgroup (see bn_reduce_finalize_kernel)
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const float* __restrict__ stats, int tiles, int C, double* __restrict__ dpart,
+                                                                      unsigned* __restrict__ tickets, const float* __restrict__ invstd,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      float* __restrict__ sums) {
+    __shared__ double red[2][16][64];
+    bn_partial_reduce_body<true>(stats, tiles, C, dpart, red);
+    if (!bn_arrive_last(tickets + blockIdx.x, gridDim.y)) return;
+    bn_bwd_finalize_tiles_body<double>(dpart, (int)gridDim.y, C, invstd, dgamma, dbeta, sums, red);
+}
 
 // backward tile sums (tiles > 128): stage A over P partitions, then the finalize
 static void launch_bwd_tile_sums(float* stats, int tiles, int C, const float* invstd, float* dgamma, float* dbeta, float* sums,
                                  hipStream_t stream) {
     double* dpart = (double*)(stats + (((size_t)tiles * 2 * C + 1) & ~(size_t)1));
     const int P = bn_partitions(C);
+    unsigned* tickets = g_bn_fused ? bn_ticket_slot((C + 63) / 64) : nullptr;
+    if (tickets) {
+        hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, stats, tiles, C, dpart, tickets,
+                           invstd, dgamma, dbeta, sums);
+        return;
+    }
     hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C + 63) / 64, P), dim3(1024), 0, stream, stats, tiles, C, dpart);
     hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, stream,
                        (const double*)dpart, P, C, invstd, dgamma, dbeta, sums);

@@ -1000,6 +1000,56 @@ def test_wgradr_split_count_follows_the_reserved_cus_and_refuses_a_stale_workspa
         hip.rowres_reserve_cus(0)
 
 
+@pytest.mark.parametrize("C,tiles", [(64, 1568), (256, 392), (1024, 392), (2048, 130)])
+def test_bn_statistics_in_one_launch_hand_off_under_load(C, tiles):
+    """nkb_bn_finalize / nkb_bn_backward_from_stats with > 128 tile rows: partition sums and the finish run in ONE launch, the
+    last-arriving workgroup of a channel column finishes it (elementwise.hip, bn_reduce_finalize_kernel).  The hand-off is
+    exercised the way the CDNA guide asks: the SAME scratch serves alternating inputs (a reader with a stale L1 line would
+    return the previous launch's sums), a streaming kernel keeps the chip unevenly busy on a second stream, every output
+    word is compared with a float64 reference, and both directions are bit-identical when repeated."""
+    g = torch.Generator().manual_seed(C + tiles)
+    rows = tiles * 128
+    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV)
+    stats = torch.zeros(hip.bn_stats_floats(tiles, C), device=DEV)
+    view = stats[: tiles * 2 * C].view(tiles, 2, C)
+    inputs = []
+    for k in range(3):
+        s1 = torch.randn(tiles, C, generator=g) * (10.0 + k) + k          # per-tile sums of x
+        s2 = (torch.rand(tiles, C, generator=g) + 1.0) * (400.0 + 50.0 * k)   # per-tile sums of x^2 (> mean^2 * count)
+        inputs.append((s1.to(DEV), s2.to(DEV)))
+    side = torch.cuda.Stream()
+    noise = torch.empty(64 << 20, device=DEV)
+    outs = {}
+    for it in range(12):
+        k = it % 3
+        view[:, 0].copy_(inputs[k][0]); view[:, 1].copy_(inputs[k][1])
+        with torch.cuda.stream(side):
+            noise.add_(1.0)                                                # uneven load beside the launch
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        scale, shift, mean, invstd = (torch.empty(C, device=DEV) for _ in range(4))
+        hip.bn_finalize(stats, tiles, C, rows, gamma, beta, rm, rv, 0.1, 1e-5, True, scale, shift, mean, invstd)
+        sums = torch.empty(2 * C, device=DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx = torch.empty(8, C, device=DEV, dtype=torch.bfloat16)
+        gsmall = torch.zeros(8, C, device=DEV, dtype=torch.bfloat16)
+        hip.bn_backward_from_stats(hip.BF16, gsmall, gsmall, stats, tiles, mean, invstd, gamma, 8, C, dg, db, dx, sums)
+        torch.cuda.synchronize()
+        got = (scale.clone(), shift.clone(), mean.clone(), invstd.clone(), rm.clone(), rv.clone(), sums.clone(), dg.clone(), db.clone())
+        s1, s2 = inputs[k][0].double().sum(0), inputs[k][1].double().sum(0)
+        m = s1 / rows
+        var = (s2 / rows - m * m).clamp_min(0)
+        torch.testing.assert_close(mean.double(), m, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(invstd.double(), (var + 1e-5).rsqrt(), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(scale.double(), gamma.double() * (var + 1e-5).rsqrt(), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(rm.double(), 0.1 * m, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(sums[:C].double(), s1, rtol=1e-6, atol=1e-4)                    # the backward call sums the same rows
+        torch.testing.assert_close(sums[C:].double(), s2 * invstd.double(), rtol=1e-5, atol=1e-2)
+        torch.testing.assert_close(db.double(), s1, rtol=1e-6, atol=1e-4)
+        if k in outs:
+            assert all(torch.equal(a, b) for a, b in zip(outs[k], got)), (it, k)
+        outs[k] = got
+
+
 WR_CASES = [(4096, 256, 128, 0, False), (4096, 128, 256, 0, False), (8192 + 33, 512, 128, 8, False), (4100, 128, 512, 16, False),
             (12544, 2048, 512, 0, False), (12544, 512, 2048, 0, False), (4096 + 31, 384, 256, 0, False), (9000, 384, 768, 8, True),
             (70000 + 17, 512, 1024, 0, False), (70000, 1024, 512, 8, True)]
