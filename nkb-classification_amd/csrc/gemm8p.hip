@@ -261,6 +261,44 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         has_next = lid + step < ntiles;
         if (has_next) tile_of(lid + step, next_m, next_n);
     }
+    // ---- Round 5: the DMA stream as DATA instead of control (NKB_G8_SDMA; persistent kernels only).
+    // SQ counters of the round-4 loop (profiles/r05_gemm8p_sq_counters.txt): 3.9 non-MFMA instructions per MFMA, 1.4 of them scalar —
+    // the `k-tile of this tile, or of the next one, or nothing` decision around every half-tile compiled into 25-30 scalar
+    // instructions and 4-6 branches per phase, in the wave whose LDS reads + DMA issue + barrier have to fit under the partner
+    // wave's 16 MFMAs (256 cycles; measured 363).  Now the stream keeps its OWN cursor: byte offsets of the tile it is in (so[]),
+    // its local k-tile (kl2); every phase issues its half-tile unconditionally (scalar base + 32-bit lane offset: no vector
+    // address arithmetic, inline assembly), and a half-tile kind switches to the next tile's offsets right after its last issue
+    // for the old one — once per tile and kind.  Past the workgroup's last tile the stream re-reads that tile (7 half-tiles from
+    // L2, never read) and the kernel drains them before it ends.
+#ifndef NKB_G8_SDMA
+#define NKB_G8_SDMA 1
+#endif
+    constexpr bool SDMA = DIRECT && NKB_G8_SDMA;
+    [[maybe_unused]] const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    [[maybe_unused]] unsigned so[4][2];           // byte offsets of this lane's two pieces of half-tile kind hh in the stream's tile
+    [[maybe_unused]] int kl2 = 0;                 // local k-tile of the stream's NEXT X lo / X hi / W lo (W hi runs one k-tile behind)
+    [[maybe_unused]] int s_lid = lid, s_m = tile_m, s_n = tile_n;     // the tile that k-tile belongs to
+    [[maybe_unused]] auto stream_offsets = [&](int tm, int tn, auto HH_) {
+        constexpr int hh = decltype(HH_)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) so[hh][q] = offset_one(tm, tn, hh, q) * (unsigned)ESZ;
+    };
+#define G8_DMA(hh, gk, kl)                                                                                            \
+    do {                                                                                                              \
+        const unsigned lds_ = lds0 + (unsigned)((((gk) & 1) * BUF) + (hh) * HT) + (unsigned)wave * 1024u;             \
+        const unsigned char* sb_ = (const unsigned char*)((hh) < 2 ? p.x : p.w) + (size_t)(kl) * 128;                 \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t" \
+                     "global_load_lds_dwordx4 %3, %1"                                                                 \
+                     :: "v"(so[hh][0]), "s"(sb_), "s"(lds_), "v"(so[hh][1]) : "memory", "m0");                        \
+    } while (0)
+    // the stream moves on by one k-tile (after its W lo has been issued); at a tile's end its cursor goes to the workgroup's next tile
+    [[maybe_unused]] auto stream_advance = [&]() {
+        if (++kl2 == KT) {
+            kl2 = 0;
+            if (s_lid + step < ntiles) { s_lid += step; tile_of(s_lid, s_m, s_n); }
+            stream_offsets(s_m, s_n, G8I<0>{}); stream_offsets(s_m, s_n, G8I<1>{}); stream_offsets(s_m, s_n, G8I<2>{});
+        }
+    };
     // k-tiles of this workgroup's whole DMA stream
     const int GT = DIRECT ? KT * ((ntiles - lid + step - 1) / step) : KT;
 
@@ -285,12 +323,22 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         }
     }
     // ---- prologue: seven half-tiles in flight, the first k-tile landed
+    if constexpr (SDMA) {                          // (KT >= 2: stream k-tiles 0 and 1 are the first tile's)
+        stream_offsets(tile_m, tile_n, G8I<0>{}); stream_offsets(tile_m, tile_n, G8I<1>{});
+        stream_offsets(tile_m, tile_n, G8I<2>{}); stream_offsets(tile_m, tile_n, G8I<3>{});
+        G8_DMA(0, 0, 0); G8_DMA(1, 0, 0); G8_DMA(2, 0, 0); G8_DMA(3, 0, 0);
+        stream_advance();
+        G8_DMA(0, 1, 1); G8_DMA(1, 1, 1); G8_DMA(2, 1, 1);
+        stream_advance();
+        G8_VMCNT(6);
+    } else {
     G8_ISSUE_AT(0, 0, 0, xo, wo); G8_ISSUE_AT(0, 0, 1, xo, wo); G8_ISSUE_AT(0, 0, 2, xo, wo); G8_ISSUE_AT(0, 0, 3, xo, wo);
     if (GT > 1) {                                  // (DIRECT: KT >= 2, so stream k-tile 1 is k-tile 1 of the first tile)
         G8_ISSUE_AT(1, 1, 0, xo, wo); G8_ISSUE_AT(1, 1, 1, xo, wo); G8_ISSUE_AT(1, 1, 2, xo, wo);
         G8_VMCNT(6);
     } else {
         G8_VMCNT(0);
+    }
     }
     G8_BARRIER();
     if (wr == 1) G8_BARRIER();                    // stagger: the second wave group runs one barrier behind
@@ -314,7 +362,16 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     // stream k-tile g + d (d = 1, 2): local k-tile t + d of the current tile, or t + d - KT of the next one
 #define G8_ISSUE_AHEAD(d, hh)                                                                                         \
     do {                                                                                                              \
-        if (t + (d) < KT) G8_ISSUE_AT(g + (d), t + (d), hh, xo, wo);                                                  \
+        if constexpr (SDMA) {                                                                                         \
+            if constexpr ((hh) == 3) {                                                                                \
+                /* W hi of stream k-tile g + 1: the k-tile whose other three kinds went out in the previous k-tile */ \
+                G8_DMA(3, g + 1, kl2 == 0 ? KT - 1 : kl2 - 1);                                                        \
+                if (kl2 == 0) stream_offsets(s_m, s_n, G8I<3>{});     /* that was the old tile's last one */          \
+            } else {                                                                                                  \
+                G8_DMA(hh, g + 2, kl2);                                                                               \
+                if constexpr ((hh) == 2) stream_advance();                                                            \
+            }                                                                                                         \
+        } else if (t + (d) < KT) G8_ISSUE_AT(g + (d), t + (d), hh, xo, wo);                                           \
         else if (DIRECT && has_next) {                                                                                \
             unsigned char* d_ = smem + ((g + (d)) & 1) * BUF + (hh) * HT + wave * 1024;                               \
             const unsigned char* s_ = (const unsigned char*)((hh) < 2 ? p.x : p.w) + (size_t)(t + (d) - KT) * 128;    \
@@ -688,7 +745,8 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         // ---------------- phase 4: no reads; DMA: W lo of stream k-tile g+2; the counted wait that retires k-tile g+1
         G8_ISSUE_AHEAD(2, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (g + 2 < GT) G8_VMCNT(6);
+        if constexpr (SDMA) G8_VMCNT(6);           // (the stream never stops: the three youngest half-tiles are always in flight)
+        else if (g + 2 < GT) G8_VMCNT(6);
         else if (g + 1 < GT) G8_VMCNT(0);
         G8_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
@@ -731,14 +789,19 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 // the next tile becomes the current one; the one after it becomes "next"
                 t = 0;
                 lid += step;
+                if constexpr (SDMA) {
+                    if (lid < ntiles) tile_of(lid, tile_m, tile_n);
+                } else {
                 tile_m = next_m; tile_n = next_n;
                 offsets_of(tile_m, tile_n, xo, wo);
                 has_next = lid + step < ntiles;
                 if (has_next) tile_of(lid + step, next_m, next_n);
+                }
             }
         }
     }
     if (wr == 0) G8_BARRIER();
+    if constexpr (SDMA) G8_VMCNT(0);              // the stream's last half-tiles (never read) have landed before the LDS is given back
 
     if constexpr (QOUT) {                         // one global atomicMax per workgroup
         __syncthreads();
@@ -930,7 +993,10 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream, const float* row
     }
     p.deq_x = p.deq_w = nullptr;
     p.tilesM = (p.M + 255) / 256; p.tilesN = p.N / 256;
-    constexpr int gm_env = 8;
+#ifndef NKB_G8_GROUPM
+#define NKB_G8_GROUPM 8
+#endif
+    constexpr int gm_env = NKB_G8_GROUPM;
     const double wbytes = (double)p.N * p.K * 2.0;
     p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096; // 128 KB (>= the 66.5 KB epilogue tile) + 512 B of bias per wave + the fp8 amax word + 4 KB of column sums
@@ -989,7 +1055,7 @@ extern "C" int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, c
     p.stats = nullptr; p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldadd = ldadd; p.relu = relu; p.y2 = nullptr;
     p.deq_x = deq_x; p.deq_w = deq_w;
     p.tilesM = (M + 255) / 256; p.tilesN = N / 256;
-    constexpr int gm_env = 8;
+    constexpr int gm_env = NKB_G8_GROUPM;
     p.group_m = (gm_env > 1 && (double)N * K > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
     const int cus = g8_cus();
     constexpr int lds = 2 * 4 * 128 * 128 + 4096 + 64 + 4096;

@@ -10,7 +10,7 @@ OBJS=""
 for f in $C/*.hip; do
   b=$(basename $f .hip); obj=$R/nkb-classification_amd/lib/obj/$b.o
   for s in "$@"; do if [ "$s" = "$b.hip" ]; then
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$C -I$R/include -Wno-unused-result -Wno-unused-value -ffp-contract=off -fno-slp-vectorize $FLAGS -c $f -o $O/$b.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$C -I$R/include -Wno-unused-result -Wno-unused-value -Wno-inline-asm -ffp-contract=off -fno-slp-vectorize $FLAGS -c $f -o $O/$b.o
     obj=$O/$b.o
   fi; done
   OBJS="$OBJS $obj"
