@@ -151,6 +151,22 @@ __device__ __forceinline__ void g8_gelu2(g8_f32x2 x, g8_f32x2& u, g8_f32x2& du) 
     du = __builtin_elementwise_fma(x * (g8_f32x2){0.3989422804014327f, 0.3989422804014327f}, e, c);
 }
 
+// gfx9 hazard (LLVM: VmemSgprWaitStates): a vector-memory instruction that reads an SGPR needs 5 wait states behind a VALU write of
+// that SGPR — and with 50-100 spilled SGPRs in these kernels a scalar operand of an asm statement may have come out of a VGPR lane
+// (v_readlane) one instruction earlier.  hipcc pads its own instructions; it cannot see into an asm string.  Round 5: the run-time
+// epilogue's loads, rewritten as assembly, read a stale base that way (memory fault on ragged fp8 tiles) — every asm memory
+// instruction with a scalar operand now brings its own wait states.
+#define G8_SGPR_SETTLE "s_nop 4\n\t"
+// a uniform device float through the scalar cache, waited for on the spot (lgkmcnt: not the counter the DMA stream lives on; and no
+// load the compiler's wait-count pass could see — see the note at the row_scale load)
+__device__ __forceinline__ float g8_sload(const float* ptr) {
+#if defined(NKB_G8_NO_SLOAD)
+    return *ptr;
+#endif
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    return __uint_as_float(v);
+}
 // raw s_barrier (no vmcnt drain, unlike __syncthreads) between two compiler-level memory barriers
 #define G8_BARRIER()                                 \
     do {                                             \
@@ -280,14 +296,26 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     [[maybe_unused]] int s_lid = lid, s_m = tile_m, s_n = tile_n;     // the tile that k-tile belongs to
     [[maybe_unused]] auto stream_offsets = [&](int tm, int tn, auto HH_) {
         constexpr int hh = decltype(HH_)::value;
+        // the lane constants are rebuilt from the lane id at every switch (once per tile and kind), not carried through the k-loop:
+        // hoisted, they were the 6-8 registers that tipped this 256-register kernel into spills — and a spill reload is a load the
+        // wait-count pass sees (tests/test_isa_guard.py: no compiler-visible load in the persistent kernels)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lrow_ = ln >> 3, chunk_ = (ln & 7) ^ lrow_;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) so[hh][q] = offset_one(tm, tn, hh, q) * (unsigned)ESZ;
+        for (int q = 0; q < 2; ++q) {
+            const int r = (wave + 8 * q) * 8 + lrow_;
+            unsigned o;
+            if constexpr (hh < 2) o = (unsigned)min(tm * 256 + (hh & 1) * 128 + r, p.M - 1) * (unsigned)p.ldx + chunk_ * CE;
+            else o = (unsigned)(tn * 256 + (hh & 1) * 128 + ((r & 0x63) | ((r & 0x0c) << 1) | ((r & 0x10) >> 2))) * (unsigned)p.ldw + chunk_ * CE;
+            so[hh][q] = o * (unsigned)ESZ;
+        }
     };
 #define G8_DMA(hh, gk, kl)                                                                                            \
     do {                                                                                                              \
         const unsigned lds_ = lds0 + (unsigned)((((gk) & 1) * BUF) + (hh) * HT) + (unsigned)wave * 1024u;             \
         const unsigned char* sb_ = (const unsigned char*)((hh) < 2 ? p.x : p.w) + (size_t)(kl) * 128;                 \
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t" \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t" \
                      "global_load_lds_dwordx4 %3, %1"                                                                 \
                      :: "v"(so[hh][0]), "s"(sb_), "s"(lds_), "v"(so[hh][1]) : "memory", "m0");                        \
     } while (0)
@@ -395,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         const int relu = RELU < 0 ? p.relu : RELU;
         const int em0 = tile_m * 256, en0 = tile_n * 256;
         float deq = 1.f;
-        if constexpr (F8 != 0) deq = *p.deq_x * *p.deq_w;
+        if constexpr (F8 != 0) deq = g8_sload(p.deq_x) * g8_sload(p.deq_w);
         int lrow = wc * 64 + frow;
         const int lcol = wr * 128 + 8 * fgrp;
         asm volatile("" : "+v"(lrow));                 // the lane offsets are built here, per tile, not carried through the k-loop
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         const unsigned ystep = 32u * (unsigned)p.ldy, astep = 32u * (unsigned)p.ldadd;   // 16 rows, in bytes
         [[maybe_unused]] unsigned char* qbase = p.yq + ((size_t)em0 * p.ldq + en0);
         [[maybe_unused]] const unsigned qo = (unsigned)lrow * (unsigned)p.ldq + lcol, qstep = 16u * (unsigned)p.ldq;
-        [[maybe_unused]] const float qscale = QOUT ? p.q_state[0] : 1.f;
+        [[maybe_unused]] const float qscale = QOUT ? g8_sload(p.q_state) : 1.f;
         [[maybe_unused]] const float qlim = p.q_kind == 0 ? 448.f : 57344.f;
         // vmcnt is in order: a load issued behind a store waits for that store's acknowledgement (microseconds), and a
         // wait for ANY load also drains the DMA stream.  So the compile-time variants with an operand (PRE) work in two
@@ -428,7 +456,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 for (int j = 0; j < 4; ++j) {
                     const unsigned char* sb = ADD > 0 ? abase : xbase;
                     const unsigned vo = ADD > 0 ? ao + j * astep + 64 * (2 * half + q) : yo + j * ystep + 64 * (2 * half + q);
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[q][j]) : "v"(vo), "s"(sb) : "memory");
+                    asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2" : "=v"(raw[q][j]) : "v"(vo), "s"(sb) : "memory");
                 }
         };
 #define G8_WAIT_HALF(n, raw)                                                                                          \
@@ -448,7 +476,14 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 float af[8];
                 unpack8(araw, af);
                 if (p.row_scale) {                     // (uniform) stochastic depth: scale the branch, then add the trunk
-                    const float rs = p.row_scale[fdiv((unsigned)(em0 + lrow + 16 * j), p.div_rows)];
+                    // (inline assembly + its own wait, like every other load of this kernel: a load the compiler can see makes its
+                    // wait-count pass put vmcnt(0) wherever it believes a result register is overwritten — once that was the top of
+                    // the k-loop, the whole DMA stream drained per k-tile; tests/test_isa_guard.py now looks for it)
+                    float rs;
+                    {
+                        const unsigned ro_ = fdiv((unsigned)(em0 + lrow + 16 * j), p.div_rows) * 4u;
+                        asm volatile(G8_SGPR_SETTLE "global_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(rs) : "v"(ro_), "s"(p.row_scale) : "memory");
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= rs;
                 }
@@ -615,7 +650,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             for (int pr = 0; pr < 4; ++pr)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    asm volatile("global_load_ubyte %0, %1, %2" : "=v"(mb[pr][j]) : "v"(mo + j * mstep + 4 * pr), "s"(mb_base) : "memory");
+                    asm volatile(G8_SGPR_SETTLE "global_load_ubyte %0, %1, %2" : "=v"(mb[pr][j]) : "v"(mo + j * mstep + 4 * pr), "s"(mb_base) : "memory");
             asm volatile("s_waitcnt vmcnt(0)"
                          : "+v"(mb[0][0]), "+v"(mb[0][1]), "+v"(mb[0][2]), "+v"(mb[0][3]), "+v"(mb[1][0]), "+v"(mb[1][1]), "+v"(mb[1][2]),
                            "+v"(mb[1][3]), "+v"(mb[2][0]), "+v"(mb[2][1]), "+v"(mb[2][2]), "+v"(mb[2][3]), "+v"(mb[3][0]), "+v"(mb[3][1]),
@@ -661,11 +696,23 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     const bool ok = FULL > 0 || em0 + lrow + 16 * j < p.M;
                     u32x4 araw = (u32x4){0u, 0u, 0u, 0u}, xraw = (u32x4){0u, 0u, 0u, 0u};
                     unsigned mbits = 0xffu;
+#if defined(NKB_G8_NO_ASMLOADS)
                     if (has_add && ok) araw = *(const u32x4*)(abase + (ao + j * astep + 64 * pr));
                     if (aux_kind == 3) { if (ok) mbits = p.mask_in[morg + (mo + j * mstep + 4 * pr)]; }
                     else if (aux_kind && ok) xraw = *(const u32x4*)(xbase + (yo + j * ystep + 64 * pr));
+#else
+                    if (has_add && ok) asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(araw) : "v"(ao + j * astep + 64 * pr), "s"(abase) : "memory");
+                    if (aux_kind == 3) { if (ok) asm volatile(G8_SGPR_SETTLE "global_load_ubyte %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(mbits) : "v"(mo + j * mstep + 4 * pr), "s"(p.mask_in + morg) : "memory"); }
+                    else if (aux_kind && ok) asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(xraw) : "v"(yo + j * ystep + 64 * pr), "s"(xbase) : "memory");
+                    // (each load is waited for inside its own statement: the run-time form serves rare tiles, one row at a time)
+#endif
                     const u32x4 out = value(pr, j, bv, araw, xraw, mbits);
+#if defined(NKB_G8_DIAG_NOSTORE)                  /* diagnostic builds only: how much of a tile is the store drain */
+                    if (ok && p.y && pr >= NKB_G8_DIAG_NOSTORE) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                    else asm volatile("" :: "v"(out));
+#else
                     if (ok && p.y) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+#endif
                     if (has_q) quant_store(out, pr, j, ok);
                 }
             }
@@ -688,12 +735,22 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             // (no registers, and nothing in the epilogue waits on vmcnt for them: they are older than the three half-tiles
             // this k-tile issues in phases 2-4, so its phase-4 vmcnt(6) covers them)
             if (t == 0 && p.bias) {
-                const float* bsrc = p.bias + tile_n * 256 + wr * 128 + lane;
+                const float* bsrc = p.bias + tile_n * 256 + wr * 128;
+                if constexpr (SDMA) {
+                    // (inline assembly like the half-tiles: a compiler-visible LDS-DMA in this loop makes hipcc put vmcnt(0) in front of
+                    // the next k-tile's LDS reads — the whole stream drained once per k-tile, +8 % on every launch when it happened)
+                    const unsigned bl = lds0 + (unsigned)(2 * BUF) + (unsigned)wave * 512u;
+                    const unsigned bo = (unsigned)lane * 4u;
+                    // (two statements, two scalar bases: an instruction offset would move the LDS address along with the global one)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dword %0, %1" :: "v"(bo), "s"(bsrc), "s"(bl) : "memory", "m0");
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dword %0, %1" :: "v"(bo), "s"(bsrc + 64), "s"(bl + 256u) : "memory", "m0");
+                } else {
                 unsigned char* bdst = smem + 2 * BUF + wave * 512;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc,
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + lane),
                                                  (__attribute__((address_space(3))) void*)bdst, 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + 64),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + lane + 64),
                                                  (__attribute__((address_space(3))) void*)(bdst + 256), 4, 0, 0);
+                }
             }
         }
         // ---------------- phase 1: all X fragments + W fragments 0-3; DMA: W hi of stream k-tile g+1
@@ -745,7 +802,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         // ---------------- phase 4: no reads; DMA: W lo of stream k-tile g+2; the counted wait that retires k-tile g+1
         G8_ISSUE_AHEAD(2, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (SDMA) G8_VMCNT(6);           // (the stream never stops: the three youngest half-tiles are always in flight)
+        // (the stream never stops: the three youngest half-tiles are always in flight.  Measured and NOT kept, round 5: W hi of the
+        // next k-tile issued in FRONT of the epilogue's stores and this wait counting the stores in (vmcnt(22)) instead of waiting
+        // for them — correct, 1 % slower: behind the stores the next half-tiles queue physically, whatever the counter says)
+        if constexpr (SDMA) G8_VMCNT(6);
         else if (g + 2 < GT) G8_VMCNT(6);
         else if (g + 1 < GT) G8_VMCNT(0);
         G8_BARRIER();

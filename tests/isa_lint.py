@@ -185,3 +185,59 @@ def lint(text: str, kernel_regex: str):
                     flow(pc, lg, vm)
                     break
     return findings, per_kernel
+
+
+_SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+
+
+def _sregs(text: str) -> set:
+    out = set()
+    for m in _SREG.finditer(text):
+        if m.group(1):
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def lint_vmem_sgpr_hazard(text: str, kernel_regex: str, wait_states: int = 5):
+    """gfx9: a vector-memory instruction that READS an SGPR needs `wait_states` wait states behind a VALU instruction that WROTE it
+    (v_readlane / v_readfirstlane / v_cmp ... — LLVM's VmemSgprWaitStates).  hipcc pads the instructions it emits itself, never the
+    inside of an asm string: with SGPRs spilled to VGPR lanes, the scalar base of an inline-assembly load can come out of a
+    v_readlane one instruction earlier (round 5: a memory fault on ragged fp8 tiles).  Walks each kernel's text in program order
+    (a label does not reset the distances: a fall-through is the short path) and reports every INLINE-ASSEMBLY vector-memory
+    instruction whose scalar operand is younger than that.  -> (findings, number of asm vector-memory instructions seen)"""
+    findings, seen = [], 0
+    for name, lines in _functions(text, kernel_regex):
+        age = {}                                   # SGPR -> wait states since its last VALU write
+        in_asm = False
+        for i, raw in enumerate(lines):
+            if ";;#ASMSTART" in raw:
+                in_asm = True
+                continue
+            if ";;#ASMEND" in raw:
+                in_asm = False
+                continue
+            code = raw.split(";")[0].strip()
+            if not code or code.endswith(":") or code.startswith("."):
+                continue
+            op = code.split()[0]
+            operands = code[len(op):]
+            if in_asm and op.startswith(_VMEM):
+                seen += 1
+                young = sorted(r for r in _sregs(operands) if age.get(r, 99) < wait_states)
+                if young:
+                    findings.append(Finding(name, i, raw, tuple(("s", r) for r in young)))
+            step = 1
+            if op == "s_nop":
+                try:
+                    step = int(operands.strip(), 0) + 1
+                except ValueError:
+                    step = 1
+            for r in list(age):
+                age[r] += step
+            if op.startswith("v_") and not op.startswith("v_mfma"):
+                first = operands.split(",")[0]
+                for r in _sregs(first):            # VALU with a scalar destination (v_readlane, v_readfirstlane, v_cmp_* e64)
+                    age[r] = 0
+    return findings, seen

@@ -152,3 +152,60 @@ def test_weight_gradient_pipelines_keep_their_main_loops_free_of_register_traffi
             assert not [l for l in loop if "v_mov_b64" in l or "v_accvgpr" in l or "scratch_" in l], name
             movs = {l.split(",")[-1].strip() for l in loop if "v_mov_b32" in l}
             assert len(movs) <= 1, (name, sorted(movs))
+
+
+def test_assembly_memory_instructions_wait_for_valu_written_scalar_operands():
+    """gemm8p.hip is the one source whose inline-assembly loads take SCALAR operands (saddr bases, M0 for the LDS-DMA): each must
+    stand 5 wait states behind a VALU write of that SGPR (v_readlane out of an SGPR spill) — see isa_lint.lint_vmem_sgpr_hazard."""
+    bad = """
+_Z9bad_kernelv:
+	v_readlane_b32 s12, v255, 13
+	v_readlane_b32 s13, v255, 14
+	v_add_u32_e32 v0, s18, v215
+	;;#ASMSTART
+	global_load_dwordx4 v[0:3], v0, s[12:13]
+	;;#ASMEND
+	s_endpgm
+.Lfunc_end0:
+"""
+    findings, seen = isa_lint.lint_vmem_sgpr_hazard(bad, "bad_kernel")
+    assert seen == 1 and len(findings) == 1
+    findings, _ = isa_lint.lint_vmem_sgpr_hazard(bad.replace("\tglobal_load", "\ts_nop 4\n\tglobal_load"), "bad_kernel")
+    assert findings == []
+    findings, seen = isa_lint.lint_vmem_sgpr_hazard(_assembly("gemm8p.hip"), "gemm8p_kernel")
+    assert seen >= 100, seen
+    assert not findings, "; ".join(str(f) for f in findings[:5])
+    for src in sorted(set(STRICT) | set(COPIES)):                     # nobody else feeds scalar operands to assembly loads today
+        if src != "gemm8p.hip":
+            f2, _ = isa_lint.lint_vmem_sgpr_hazard(_assembly(src), STRICT.get(src, COPIES.get(src))[0])
+            assert not f2, (src, str(f2[0]))
+
+
+def test_persistent_gemm_loops_never_drain_the_dma_stream():
+    """Round 5: a compiler-VISIBLE load anywhere in gemm8p's persistent kernels lets hipcc's wait-count pass put `s_waitcnt vmcnt(0)`
+    where it believes a result register is overwritten — twice that was the top of the k-loop (the whole LDS-DMA stream drained once
+    per k-tile: +8 % on every launch; the fp8 kernels had carried one since they were written).  The bf16 / fp8 kernels without the
+    quantised second output must hold no compiler-visible global load at all, no spill traffic inside the k-loop, and exactly ONE wait on
+    the vector-memory counter there: the counted vmcnt(6) of phase 4."""
+    text = _assembly("gemm8p.hip")
+    found = 0
+    for m in re.finditer(r"\n(_Z\w*gemm8p_kernelILb1ELi[012]ELb0E\w*):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", text, flags=re.S):
+        found += 1
+        lines = m.group(2).split("\n")
+        in_asm, visible = False, []
+        for l in lines:
+            if ";;#ASMSTART" in l:
+                in_asm = True
+            elif ";;#ASMEND" in l:
+                in_asm = False
+            elif not in_asm and re.match(r"\s*(global_load|buffer_load|flat_load)", l):
+                visible.append(l.strip())
+        assert not visible, (m.group(1), visible[:3])
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        head = max(i for i in range(mf[0]) if "Loop Header" in lines[i])
+        loop = lines[head:mf[-1]]
+        # (a spilled register may be reloaded in an epilogue; inside the k-loop a reload — or any wait the pass derives from one — is the drain)
+        assert not [l for l in loop if "scratch_" in l], m.group(1)
+        waits = [l.strip() for l in loop if "vmcnt" in l]
+        assert waits == ["s_waitcnt vmcnt(6)"], (m.group(1), waits)
+    assert found == 3
