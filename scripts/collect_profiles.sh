@@ -24,7 +24,7 @@ python3 scripts/pmc_traffic.py $F $W $OUT/pmc_traffic.json 1 > $OUT/pmc_traffic.
 declare -A PUB=( ["resnet50"]="resnet50_bf16" ["vit_base_patch16_224"]="vit_b16_bf16" ["unicom ViT-L/14--batch 128"]="unicom_vit_l14_bf16" ["unicom ViT-L/14--batch 128 --dtype fp8"]="unicom_vit_l14_fp8" )
 N=${PUB["$MODEL${EXTRA:+--$EXTRA}"]}
 [ -n "$N" ] && cp $OUT/pmc_traffic.json profiles/${TAG}_${N}_pmc_traffic.json
-python3 $ROOT/bench.py --no-host-work $EXTRA --model "$MODEL" --steps 30 --warmup 8 > $OUT/line.json 2> $OUT/line.err && echo "line ok"
+python3 $ROOT/bench.py $EXTRA --model "$MODEL" --steps 30 --warmup 8 > $OUT/line.json 2> $OUT/line.err && echo "line ok"
 python3 scripts/overlap_report.py $T 5 4 > $OUT/overlap.txt
 M=$(find $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv" | head -1); MT=$(find $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1)
 python3 scripts/pmc_mfma.py $M $MT $OUT/pmc_mfma.json > $OUT/pmc_mfma.txt
