@@ -76,6 +76,14 @@ struct G8Params {
     unsigned stagger;     // DIRECT: shader cycles over which the workgroups that walk one tile fewer than the others spread their start
 };
 
+#ifndef NKB_G8_DIAG_EPI
+#define NKB_G8_DIAG_EPI 0     // diagnostic builds only: bit 0 = plain instead of non-temporal stores, bit 1 = drain the DMA stream in front of the epilogue
+#endif
+#if NKB_G8_DIAG_EPI & 1
+#define G8_NT_STORE(v, ptr) (*(ptr) = (v))
+#else
+#define G8_NT_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#endif
 template <int V> using G8I = std::integral_constant<int, V>;
 
 __device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* dst) {
@@ -422,18 +430,41 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         const int aux_kind = AUX < 0 ? (p.aux ? 1 + p.aux_mode : (QOUT && p.mask_in ? 3 : 0)) : AUX;   // 0 none, 1 multiply, 2 ReLU6 mask (0 < aux < 6), 3 mask bits
         const int relu = RELU < 0 ? p.relu : RELU;
         const int em0 = tile_m * 256, en0 = tile_n * 256;
+        if constexpr ((NKB_G8_DIAG_EPI & 2) != 0) G8_VMCNT(0);
         float deq = 1.f;
         if constexpr (F8 != 0) deq = g8_sload(p.deq_x) * g8_sload(p.deq_w);
         int lrow = wc * 64 + frow;
         const int lcol = wr * 128 + 8 * fgrp;
         asm volatile("" : "+v"(lrow));                 // the lane offsets are built here, per tile, not carried through the k-loop
+        // ROW ORDER (round 5, scripts/ubench/epi_probe.hip): the accumulator layout puts the 16 pixel rows of a fragment on CONSECUTIVE
+        // lanes (lane = 16 * chunk + row), so a 1 KB store instruction is 64 separate 16-byte requests: 128 KB leave an idle CU in
+        // 3.5 us, a crowded one in 6.8.  With lane = 4 * row + chunk (four consecutive lanes = 64 contiguous bytes) the same bytes
+        // take 1.0 / 3.5 us.  Every packed register crosses the lanes once through ds_bpermute (the LDS crossbar, no LDS memory);
+        // operand rows are loaded in row order and brought to the accumulator layout the same way; arithmetic stays where it was.
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        const int rrow = wc * 64 + (lane_ >> 2), rcol = wr * 128 + 8 * (lane_ & 3);   // this lane's pixel row / first column in row order
+        const int to_rows_ = (((lane_ & 3) << 4) | (lane_ >> 2)) << 2;                // row-order lane l takes the value of lane 16 * (l % 4) + l / 4
+        const int from_rows_ = ((4 * (lane_ & 15)) + (lane_ >> 4)) << 2;              // and back
+        auto to_rows = [&](u32x4 v) -> u32x4 {
+            u32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_ds_bpermute(to_rows_, (int)v[e]);
+            return r;
+        };
+        auto from_rows = [&](u32x4 v) -> u32x4 {
+            u32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_ds_bpermute(from_rows_, (int)v[e]);
+            return r;
+        };
         unsigned char* ybase = (unsigned char*)(p.y + ((size_t)em0 * p.ldy + en0));
         const unsigned char* xbase = (const unsigned char*)(p.aux + ((size_t)em0 * p.ldy + en0));
         const unsigned char* abase = (const unsigned char*)(p.add + ((size_t)em0 * p.ldadd + en0));
-        const unsigned yo = ((unsigned)lrow * (unsigned)p.ldy + lcol) * 2u, ao = ((unsigned)lrow * (unsigned)p.ldadd + lcol) * 2u;
+        const unsigned yo = ((unsigned)rrow * (unsigned)p.ldy + rcol) * 2u, ao = ((unsigned)rrow * (unsigned)p.ldadd + rcol) * 2u;   // row order
         const unsigned ystep = 32u * (unsigned)p.ldy, astep = 32u * (unsigned)p.ldadd;   // 16 rows, in bytes
         [[maybe_unused]] unsigned char* qbase = p.yq + ((size_t)em0 * p.ldq + en0);
-        [[maybe_unused]] const unsigned qo = (unsigned)lrow * (unsigned)p.ldq + lcol, qstep = 16u * (unsigned)p.ldq;
+        [[maybe_unused]] const unsigned qo = (unsigned)rrow * (unsigned)p.ldq + rcol, qstep = 16u * (unsigned)p.ldq;                       // row order
         [[maybe_unused]] const float qscale = QOUT ? g8_sload(p.q_state) : 1.f;
         [[maybe_unused]] const float qlim = p.q_kind == 0 ? 448.f : 57344.f;
         // vmcnt is in order: a load issued behind a store waits for that store's acknowledgement (microseconds), and a
@@ -445,7 +476,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         constexpr bool PRE = (ADD > 0) != (AUX > 0 && AUX < 3);
         constexpr bool BITS = AUX == 3;                // ReLU6 mask as bits: 16 one-byte loads up front, nothing else to wait for
         [[maybe_unused]] const unsigned mld = (unsigned)p.N >> 3;
-        [[maybe_unused]] const unsigned mo = (unsigned)lrow * mld + (unsigned)(lcol >> 3), mstep = 16u * mld;
+        [[maybe_unused]] const unsigned mo = (unsigned)rrow * mld + (unsigned)(rcol >> 3), mstep = 16u * mld;                              // row order
         [[maybe_unused]] const size_t morg = (size_t)em0 * mld + (en0 >> 3);
         // (the loads and their counted waits are inline assembly: with LDS-DMA in flight hipcc waits vmcnt(0) at the first use
         // of any load result, which for half 1 would be exactly the wait on half 0's stores this order exists to avoid)
@@ -464,9 +495,13 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                  : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[0][3]), "+v"(raw[1][0]), "+v"(raw[1][1]), \
                    "+v"(raw[1][2]), "+v"(raw[1][3])                                                                   \
                  :: "memory")
-        // one (channel group, pixel block): accumulators -> the 8 packed outputs of this lane
-        auto value = [&](int pr, int j, const float (&bv)[8], u32x4 araw, u32x4 xraw, unsigned mbits = 0xffu) -> u32x4 {
+        // one (channel group, pixel block): accumulators -> 8 packed outputs.  Operands (araw / xraw / mbits) come in as loaded, in ROW
+        // ORDER, and are brought to the accumulator layout here; the result goes back in ROW ORDER (`acc_layout`: the same before the trip)
+        auto value = [&](int pr, int j, const float (&bv)[8], u32x4 araw, u32x4 xraw, unsigned mbits = 0xffu, u32x4* acc_layout = nullptr) -> u32x4 {
             float v[8];
+            if (has_add) araw = from_rows(araw);
+            if (aux_kind == 3) mbits = (unsigned)__builtin_amdgcn_ds_bpermute(from_rows_, (int)mbits);
+            else if (aux_kind) xraw = from_rows(xraw);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if constexpr (F8 != 0) { v[e] = acc[2 * pr][j][e] * deq + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] * deq + bv[4 + e]; }
@@ -512,15 +547,18 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     g8_gelu2((g8_f32x2){v[e], v[e + 1]}, uu, dd);
                     v[e] = uu[0]; v[e + 1] = uu[1]; dv[e] = dd[0]; dv[e + 1] = dd[1];
                 }
-                if (FULL > 0 || em0 + lrow + 16 * j < p.M)
-                    __builtin_nontemporal_store(pack8(dv), (u32x4*)((unsigned char*)(p.y2 + ((size_t)em0 * p.ldy + en0)) + (yo + j * ystep + 64 * pr)));
+                const u32x4 dvr = to_rows(pack8(dv));
+                if (FULL > 0 || em0 + rrow + 16 * j < p.M)
+                    G8_NT_STORE(dvr, (u32x4*)((unsigned char*)(p.y2 + ((size_t)em0 * p.ldy + en0)) + (yo + j * ystep + 64 * pr)));
             } else if (relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
             }
             acc[2 * pr][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[2 * pr + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const u32x4 pkv = pack8(v);
+            const u32x4 pka = pack8(v);
+            if (acc_layout) *acc_layout = pka;
+            const u32x4 pkv = to_rows(pka);
             if constexpr (QOUT) {
                 if (relu == 2 && p.mask_out) {         // ReLU6 mask of this row segment, from the STORED (bf16-rounded, clamped) values —
                     unsigned bits = 0u;                // the same 0 < u < 6 a backward pass reading the bf16 tensor would test
@@ -530,7 +568,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                         bits |= (r0 > 0.f && r0 < 6.f) ? (1u << (2 * e)) : 0u;
                         bits |= (r1 > 0.f && r1 < 6.f) ? (2u << (2 * e)) : 0u;
                     }
-                    if (FULL > 0 || em0 + lrow + 16 * j < p.M) p.mask_out[morg + (mo + j * mstep + 4 * pr)] = (unsigned char)bits;
+                    if (FULL > 0 || em0 + rrow + 16 * j < p.M) p.mask_out[morg + (mo + j * mstep + 4 * pr)] = (unsigned char)bits;
                 }
             }
             return pkv;
@@ -589,7 +627,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32x4 out = value(q, j, bv, raw0[q][j], raw0[q][j]);
-                    __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
+                    G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
                 }
             }
             G8_WAIT_HALF(8, raw1);                     // younger than half 1's loads: exactly the eight stores above
@@ -600,7 +638,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32x4 out = value(2 + q, j, bv, raw1[q][j], raw1[q][j]);
-                    __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
+                    G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
                 }
             }
         } else if constexpr (PRE) {
@@ -621,7 +659,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        __builtin_nontemporal_store(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
+                        G8_NT_STORE(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
                         quant_store(pk[q][j], q, j, true);
                     }
                 G8_WAIT_HALF(16, raw);
@@ -629,7 +667,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
+                    for (int j = 0; j < 4; ++j) G8_NT_STORE(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
                 G8_WAIT_HALF(8, raw);
             }
 #pragma unroll
@@ -639,7 +677,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32x4 out = value(2 + q, j, bv, raw[q][j], raw[q][j]);
-                    __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
+                    G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
                     if (has_q) quant_store(out, 2 + q, j, true);
                 }
             }
@@ -665,12 +703,13 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
-                    const u32x4 out = value(pr, j, bv, z, z, mb[pr][j]);
-                    if (p.y) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                    u32x4 oa;                          // (the column sums add the 16 pixel lanes of the accumulator layout)
+                    const u32x4 out = value(pr, j, bv, z, z, mb[pr][j], &oa);
+                    if (p.y) G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
                     if (has_q) quant_store(out, pr, j, true);
                     if (p.colpart) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { cs[2 * e] += __uint_as_float(out[e] << 16); cs[2 * e + 1] += __uint_as_float(out[e] & 0xffff0000u); }
+                        for (int e = 0; e < 4; ++e) { cs[2 * e] += __uint_as_float(oa[e] << 16); cs[2 * e + 1] += __uint_as_float(oa[e] & 0xffff0000u); }
                     }
                 }
                 if (p.colpart) {                       // the 16 pixel lanes of a column by DPP (fixed order), then this wave's 64-row sum to LDS
@@ -693,7 +732,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                 bias_of(pr, bv);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool ok = FULL > 0 || em0 + lrow + 16 * j < p.M;
+                    const bool ok = FULL > 0 || em0 + rrow + 16 * j < p.M;      // (of the row this lane loads and stores: row order)
                     u32x4 araw = (u32x4){0u, 0u, 0u, 0u}, xraw = (u32x4){0u, 0u, 0u, 0u};
                     unsigned mbits = 0xffu;
 #if defined(NKB_G8_NO_ASMLOADS)
@@ -708,10 +747,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
 #endif
                     const u32x4 out = value(pr, j, bv, araw, xraw, mbits);
 #if defined(NKB_G8_DIAG_NOSTORE)                  /* diagnostic builds only: how much of a tile is the store drain */
-                    if (ok && p.y && pr >= NKB_G8_DIAG_NOSTORE) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                    if (ok && p.y && pr >= NKB_G8_DIAG_NOSTORE) G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
                     else asm volatile("" :: "v"(out));
 #else
-                    if (ok && p.y) __builtin_nontemporal_store(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                    if (ok && p.y) G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
 #endif
                     if (has_q) quant_store(out, pr, j, ok);
                 }
