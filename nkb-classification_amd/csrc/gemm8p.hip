@@ -436,58 +436,75 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
         int lrow = wc * 64 + frow;
         const int lcol = wr * 128 + 8 * fgrp;
         asm volatile("" : "+v"(lrow));                 // the lane offsets are built here, per tile, not carried through the k-loop
-        // ROW ORDER (round 5, scripts/ubench/epi_probe.hip): the accumulator layout puts the 16 pixel rows of a fragment on CONSECUTIVE
-        // lanes (lane = 16 * chunk + row), so a 1 KB store instruction is 64 separate 16-byte requests: 128 KB leave an idle CU in
-        // 3.5 us, a crowded one in 6.8.  With lane = 4 * row + chunk (four consecutive lanes = 64 contiguous bytes) the same bytes
-        // take 1.0 / 3.5 us.  Every packed register crosses the lanes once through ds_bpermute (the LDS crossbar, no LDS memory);
-        // operand rows are loaded in row order and brought to the accumulator layout the same way; arithmetic stays where it was.
+        // ROW ORDER (round 5, scripts/ubench/store_probe.hip, epi_probe.hip).  The accumulator layout puts the 16 pixel rows of a
+        // fragment on CONSECUTIVE lanes (lane = 16 * chunk + row): a 1 KB store instruction is 64 separate 16-byte requests, and
+        // 128 KB leave an idle CU in 3.5 us, a crowded one in 6.8 (lanes in row order: 1.0 / 3.5).  And a non-temporal store of
+        // half a 128-byte line is a partial write all the way to memory (6.5 us in the crowd against 3.8 for whole lines).  So
+        // memory is addressed in ROW ORDER with whole lines: one instruction = 8 pixel rows x 128 bytes, lane = 8 * row + chunk,
+        // covering the 64 output channels of a channel-group PAIR (2 pp, 2 pp + 1).  Packed registers cross the lanes through
+        // one DPP half-row rotation + one ds_bpermute (the LDS crossbar, no LDS memory) per register; operand rows are loaded in
+        // row order and brought to the accumulator layout by the same two steps in reverse; the arithmetic stays where it was.
+        //   T(chunk g, row r) = r < 8 ? lo(g, r) : hi(g, r - 8)     rows 0-7  of both groups  -> instruction k = 0
+        //   U(g, r)          = r < 8 ? lo(g, r + 8) : hi(g, r)      rows 8-15 of both groups  -> instruction k = 1
+        //   row-order lane (row8, c) pulls T / U from accumulator lane (g = c & 3, r = row8 + 8 (c >> 2))
         int lane_ = lane;
         asm volatile("" : "+v"(lane_));
-        const int rrow = wc * 64 + (lane_ >> 2), rcol = wr * 128 + 8 * (lane_ & 3);   // this lane's pixel row / first column in row order
-        const int to_rows_ = (((lane_ & 3) << 4) | (lane_ >> 2)) << 2;                // row-order lane l takes the value of lane 16 * (l % 4) + l / 4
-        const int from_rows_ = ((4 * (lane_ & 15)) + (lane_ >> 4)) << 2;              // and back
-        auto to_rows = [&](u32x4 v) -> u32x4 {
-            u32x4 r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_ds_bpermute(to_rows_, (int)v[e]);
-            return r;
+        const int rrow = wc * 64 + (lane_ >> 3), rcol = wr * 128 + 8 * (lane_ & 7);   // this lane's pixel row / first column in row order (k = 0, pair 0)
+        const int to_rows_ = (16 * (lane_ & 3) + (lane_ >> 3) + 8 * ((lane_ >> 2) & 1)) << 2;
+        const int from_rows_ = (8 * (lane_ & 7) + 4 * ((lane_ >> 3) & 1) + (lane_ >> 4)) << 2;
+        constexpr int ROR8 = 0x128;                    // DPP row_ror:8 — lane r of a 16-lane row reads lane r ^ 8
+        auto pair_to_rows1 = [&](unsigned lo, unsigned hi, unsigned& r0, unsigned& r1) {
+            const int t_ = __builtin_amdgcn_update_dpp((int)lo, (int)hi, ROR8, 0xf, 0xc, false);
+            const int u_ = __builtin_amdgcn_update_dpp((int)hi, (int)lo, ROR8, 0xf, 0x3, false);
+            r0 = (unsigned)__builtin_amdgcn_ds_bpermute(to_rows_, t_);
+            r1 = (unsigned)__builtin_amdgcn_ds_bpermute(to_rows_, u_);
         };
-        auto from_rows = [&](u32x4 v) -> u32x4 {
-            u32x4 r;
+        auto pair_from_rows1 = [&](unsigned r0, unsigned r1, unsigned& lo, unsigned& hi) {
+            const int t_ = __builtin_amdgcn_ds_bpermute(from_rows_, (int)r0);
+            const int u_ = __builtin_amdgcn_ds_bpermute(from_rows_, (int)r1);
+            lo = (unsigned)__builtin_amdgcn_update_dpp(t_, u_, ROR8, 0xf, 0xc, false);
+            hi = (unsigned)__builtin_amdgcn_update_dpp(u_, t_, ROR8, 0xf, 0x3, false);
+        };
+        auto pair_to_rows = [&](const u32x4& lo, const u32x4& hi, u32x4& r0, u32x4& r1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_ds_bpermute(from_rows_, (int)v[e]);
-            return r;
+            for (int e = 0; e < 4; ++e) { unsigned a_, b_; pair_to_rows1(lo[e], hi[e], a_, b_); r0[e] = a_; r1[e] = b_; }
+        };
+        auto pair_from_rows = [&](const u32x4& r0, const u32x4& r1, u32x4& lo, u32x4& hi) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { unsigned a_, b_; pair_from_rows1(r0[e], r1[e], a_, b_); lo[e] = a_; hi[e] = b_; }
         };
         unsigned char* ybase = (unsigned char*)(p.y + ((size_t)em0 * p.ldy + en0));
         const unsigned char* xbase = (const unsigned char*)(p.aux + ((size_t)em0 * p.ldy + en0));
         const unsigned char* abase = (const unsigned char*)(p.add + ((size_t)em0 * p.ldadd + en0));
-        const unsigned yo = ((unsigned)rrow * (unsigned)p.ldy + rcol) * 2u, ao = ((unsigned)rrow * (unsigned)p.ldadd + rcol) * 2u;   // row order
+        // row-order offsets: instruction (pair pp, pixel block j, half k) is at  o + j * step + k * (step / 2) + 128 pp  (bytes, bf16 tensors)
+        const unsigned yo = ((unsigned)rrow * (unsigned)p.ldy + rcol) * 2u, ao = ((unsigned)rrow * (unsigned)p.ldadd + rcol) * 2u;
         const unsigned ystep = 32u * (unsigned)p.ldy, astep = 32u * (unsigned)p.ldadd;   // 16 rows, in bytes
         [[maybe_unused]] unsigned char* qbase = p.yq + ((size_t)em0 * p.ldq + en0);
-        [[maybe_unused]] const unsigned qo = (unsigned)rrow * (unsigned)p.ldq + rcol, qstep = 16u * (unsigned)p.ldq;                       // row order
+        [[maybe_unused]] const unsigned qo = (unsigned)rrow * (unsigned)p.ldq + rcol, qstep = 16u * (unsigned)p.ldq;      // + 64 pp  (one byte per element)
         [[maybe_unused]] const float qscale = QOUT ? g8_sload(p.q_state) : 1.f;
         [[maybe_unused]] const float qlim = p.q_kind == 0 ? 448.f : 57344.f;
         // vmcnt is in order: a load issued behind a store waits for that store's acknowledgement (microseconds), and a
         // wait for ANY load also drains the DMA stream.  So the compile-time variants with an operand (PRE) work in two
-        // halves of 8 rows: request half 0; compute it into packed registers (its accumulators and operand rows die);
-        // request half 1; only then store half 0; compute and store half 1.  No load is ever behind a store, and the plain
-        // variant has no vector-memory load at all (the bias comes from LDS).  The run-time variant (edge tiles, rare
+        // halves (channel-group pairs): request pair 0; compute it into packed registers (its accumulators and operand rows
+        // die); request pair 1; only then store pair 0; compute and store pair 1.  No load is ever behind a store, and the
+        // plain variant has no vector-memory load at all (the bias comes from LDS).  The run-time variant (edge tiles, rare
         // combinations) loads per row.
         constexpr bool PRE = (ADD > 0) != (AUX > 0 && AUX < 3);
         constexpr bool BITS = AUX == 3;                // ReLU6 mask as bits: 16 one-byte loads up front, nothing else to wait for
         [[maybe_unused]] const unsigned mld = (unsigned)p.N >> 3;
-        [[maybe_unused]] const unsigned mo = (unsigned)rrow * mld + (unsigned)(rcol >> 3), mstep = 16u * mld;                              // row order
+        [[maybe_unused]] const unsigned mo = (unsigned)rrow * mld + (unsigned)(rcol >> 3), mstep = 16u * mld;             // + 8 pp  (one byte per 8 channels)
         [[maybe_unused]] const size_t morg = (size_t)em0 * mld + (en0 >> 3);
+        auto row_ok = [&](int j, int k) -> bool { return FULL > 0 || em0 + rrow + 16 * j + 8 * k < p.M; };                // (of the row this lane loads and stores)
         // (the loads and their counted waits are inline assembly: with LDS-DMA in flight hipcc waits vmcnt(0) at the first use
-        // of any load result, which for half 1 would be exactly the wait on half 0's stores this order exists to avoid)
-        auto load_half = [&](int half, u32x4 (&raw)[2][4]) {
+        // of any load result, which for pair 1 would be exactly the wait on pair 0's stores this order exists to avoid)
+        auto load_half = [&](int pp, u32x4 (&raw)[2][4]) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned char* sb = ADD > 0 ? abase : xbase;
-                    const unsigned vo = ADD > 0 ? ao + j * astep + 64 * (2 * half + q) : yo + j * ystep + 64 * (2 * half + q);
-                    asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2" : "=v"(raw[q][j]) : "v"(vo), "s"(sb) : "memory");
+                    const unsigned vo = ADD > 0 ? ao + j * astep + k * (astep >> 1) + 128 * pp : yo + j * ystep + k * (ystep >> 1) + 128 * pp;
+                    asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2" : "=v"(raw[k][j]) : "v"(vo), "s"(sb) : "memory");
                 }
         };
 #define G8_WAIT_HALF(n, raw)                                                                                          \
@@ -495,13 +512,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                  : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[0][3]), "+v"(raw[1][0]), "+v"(raw[1][1]), \
                    "+v"(raw[1][2]), "+v"(raw[1][3])                                                                   \
                  :: "memory")
-        // one (channel group, pixel block): accumulators -> 8 packed outputs.  Operands (araw / xraw / mbits) come in as loaded, in ROW
-        // ORDER, and are brought to the accumulator layout here; the result goes back in ROW ORDER (`acc_layout`: the same before the trip)
-        auto value = [&](int pr, int j, const float (&bv)[8], u32x4 araw, u32x4 xraw, unsigned mbits = 0xffu, u32x4* acc_layout = nullptr) -> u32x4 {
+        // one (channel group, pixel block) in the ACCUMULATOR layout: accumulators + operands -> the 8 packed outputs of this lane
+        // (`dpk`: the GELU derivative, packed, where relu == 3)
+        auto value = [&](int pr, int j, const float (&bv)[8], u32x4 araw, u32x4 xraw, unsigned mbits, u32x4& dpk) -> u32x4 {
             float v[8];
-            if (has_add) araw = from_rows(araw);
-            if (aux_kind == 3) mbits = (unsigned)__builtin_amdgcn_ds_bpermute(from_rows_, (int)mbits);
-            else if (aux_kind) xraw = from_rows(xraw);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if constexpr (F8 != 0) { v[e] = acc[2 * pr][j][e] * deq + bv[e]; v[4 + e] = acc[2 * pr + 1][j][e] * deq + bv[4 + e]; }
@@ -547,35 +561,64 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     g8_gelu2((g8_f32x2){v[e], v[e + 1]}, uu, dd);
                     v[e] = uu[0]; v[e + 1] = uu[1]; dv[e] = dd[0]; dv[e + 1] = dd[1];
                 }
-                const u32x4 dvr = to_rows(pack8(dv));
-                if (FULL > 0 || em0 + rrow + 16 * j < p.M)
-                    G8_NT_STORE(dvr, (u32x4*)((unsigned char*)(p.y2 + ((size_t)em0 * p.ldy + en0)) + (yo + j * ystep + 64 * pr)));
+                dpk = pack8(dv);
             } else if (relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
             }
             acc[2 * pr][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[2 * pr + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const u32x4 pka = pack8(v);
-            if (acc_layout) *acc_layout = pka;
-            const u32x4 pkv = to_rows(pka);
+            return pack8(v);
+        };
+        auto bias_of = [&](int pr, float (&bv)[8]) {
+            if (p.bias) {                              // this wave's 128 bias values were DMA'd into LDS at the start of the tile
+                const float* bp = (const float*)(smem + 2 * BUF + wave * 512) + 32 * pr + 8 * fgrp;
+                const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+            }
+        };
+        // a channel-group PAIR of one pixel block: operand rows as loaded (row order, k = 0 / 1) -> the two packed 128-byte-row
+        // registers out[0] (rows 0-7) and out[1] (rows 8-15); the GELU derivative is stored from here (nothing waits behind it);
+        // `acc_lo / acc_hi`: the packed results still in the accumulator layout (the column sums of the mask variant)
+        auto pair_value = [&](int pp, int j, const float (&blo)[8], const float (&bhi)[8], const u32x4 (&a_)[2], const u32x4 (&x_)[2], unsigned m0, unsigned m1,
+                              u32x4 (&out)[2], u32x4* acc_lo = nullptr, u32x4* acc_hi = nullptr) {
+            u32x4 alo = {0u, 0u, 0u, 0u}, ahi = alo, xlo = alo, xhi = alo, dlo = alo, dhi = alo;
+            unsigned mlo = 0xffu, mhi = 0xffu;
+            if (has_add) pair_from_rows(a_[0], a_[1], alo, ahi);
+            if (aux_kind == 3) pair_from_rows1(m0, m1, mlo, mhi);
+            else if (aux_kind) pair_from_rows(x_[0], x_[1], xlo, xhi);
+            const u32x4 lo = value(2 * pp, j, blo, alo, xlo, mlo, dlo);
+            const u32x4 hi = value(2 * pp + 1, j, bhi, ahi, xhi, mhi, dhi);
+            if (acc_lo) { *acc_lo = lo; *acc_hi = hi; }
+            pair_to_rows(lo, hi, out[0], out[1]);
+            if (relu == 3) {
+                u32x4 d_[2];
+                pair_to_rows(dlo, dhi, d_[0], d_[1]);
+                unsigned char* y2b = (unsigned char*)(p.y2 + ((size_t)em0 * p.ldy + en0));
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (row_ok(j, k)) G8_NT_STORE(d_[k], (u32x4*)(y2b + (yo + j * ystep + k * (ystep >> 1) + 128 * pp)));
+            }
+        };
+        // the main output (+ the fp8 copy / the ReLU6 mask of the fp8 train step) of one row-order register
+        auto emit = [&](const u32x4& pk, int pp, int j, int k, bool ok, bool main_too) {
+            if (main_too && ok) G8_NT_STORE(pk, (u32x4*)(ybase + (yo + j * ystep + k * (ystep >> 1) + 128 * pp)));
             if constexpr (QOUT) {
                 if (relu == 2 && p.mask_out) {         // ReLU6 mask of this row segment, from the STORED (bf16-rounded, clamped) values —
                     unsigned bits = 0u;                // the same 0 < u < 6 a backward pass reading the bf16 tensor would test
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float r0 = __uint_as_float(pkv[e] << 16), r1 = __uint_as_float(pkv[e] & 0xffff0000u);
+                        const float r0 = __uint_as_float(pk[e] << 16), r1 = __uint_as_float(pk[e] & 0xffff0000u);
                         bits |= (r0 > 0.f && r0 < 6.f) ? (1u << (2 * e)) : 0u;
                         bits |= (r1 > 0.f && r1 < 6.f) ? (2u << (2 * e)) : 0u;
                     }
-                    if (FULL > 0 || em0 + rrow + 16 * j < p.M) p.mask_out[morg + (mo + j * mstep + 4 * pr)] = (unsigned char)bits;
+                    if (ok) p.mask_out[morg + (mo + j * mstep + k * (mstep >> 1) + 8 * pp)] = (unsigned char)bits;
                 }
-            }
-            return pkv;
-        };
-        // fp8 second output: the stored (bf16-rounded) row re-scaled and converted — the arithmetic of fp8_quantize_kernel
-        [[maybe_unused]] auto quant_store = [&](u32x4 pk, int pr, int j, bool ok) {
-            if constexpr (QOUT) {
+                // fp8 second output: the stored (bf16-rounded) row re-scaled and converted — the arithmetic of fp8_quantize_kernel
                 float q[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -592,132 +635,89 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w0, true);
                     w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], w1, true);
                 }
-                if (ok) *(u32x2*)(qbase + (qo + j * qstep + 32 * pr)) = (u32x2){w0, w1};
+                if (ok) *(u32x2*)(qbase + (qo + j * qstep + k * (qstep >> 1) + 64 * pp)) = (u32x2){w0, w1};
                 __builtin_amdgcn_sched_barrier(0);     // one row at a time: interleaved, 16 rows of temporaries do not fit
             }
         };
-        auto bias_of = [&](int pr, float (&bv)[8]) {
-            if (p.bias) {                              // this wave's 128 bias values were DMA'd into LDS at the start of the tile
-                const float* bp = (const float*)(smem + 2 * BUF + wave * 512) + 32 * pr + 8 * fgrp;
-                const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-            }
-        };
-        constexpr bool has_q = QOUT;
-#ifndef NKB_G8_PRE_ALL
-#define NKB_G8_PRE_ALL 0      // measured (round 5, scripts/gemm8p_epi_bench.py, same box, alternating builds): 105.0 vs 105.5 / 333.5 vs 334.7 us — no gain
-#endif
-        if constexpr (PRE && NKB_G8_PRE_ALL && !QOUT) {
-            // round 5: BOTH halves of the operand are requested up front — the fragment registers of the k-loop (64 of them) are dead
-            // between the last phase of a tile and the next phase 1, exactly the sixteen 16-byte rows of this lane.  One exposed
-            // memory round trip per tile instead of two: half 0 is multiplied and stored while half 1 is still landing, and the
-            // wait for half 1 counts half 0's eight stores as the youngest operations (no load ever waits behind a store).
-            u32x4 raw0[2][4], raw1[2][4];
-            load_half(0, raw0);
-            load_half(1, raw1);
-            G8_WAIT_HALF(8, raw0);                     // (also the DMA stream's youngest half-tiles, issued a k-tile ago)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float bv[8];
-                bias_of(q, bv);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32x4 out = value(q, j, bv, raw0[q][j], raw0[q][j]);
-                    G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
-                }
-            }
-            G8_WAIT_HALF(8, raw1);                     // younger than half 1's loads: exactly the eight stores above
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float bv[8];
-                bias_of(2 + q, bv);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32x4 out = value(2 + q, j, bv, raw1[q][j], raw1[q][j]);
-                    G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
-                }
-            }
-        } else if constexpr (PRE) {
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        if constexpr (PRE) {
             u32x4 raw[2][4], pk[2][4];
             load_half(0, raw);
             G8_WAIT_HALF(0, raw);                      // (also the DMA stream's three youngest half-tiles, issued a k-tile ago)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float bv[8];
-                bias_of(q, bv);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pk[q][j] = value(q, j, bv, raw[q][j], raw[q][j]);
-            }
-            load_half(1, raw);
-            // full tile: exactly the 8 (16 with the fp8 copy) stores of half 0 are younger than half 1's loads
-            if (has_q) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        G8_NT_STORE(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
-                        quant_store(pk[q][j], q, j, true);
-                    }
-                G8_WAIT_HALF(16, raw);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) G8_NT_STORE(pk[q][j], (u32x4*)(ybase + (yo + j * ystep + 64 * q)));
-                G8_WAIT_HALF(8, raw);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float bv[8];
-                bias_of(2 + q, bv);
+            {
+                float blo[8], bhi[8];
+                bias_of(0, blo); bias_of(1, bhi);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32x4 out = value(2 + q, j, bv, raw[q][j], raw[q][j]);
-                    G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * (2 + q))));
-                    if (has_q) quant_store(out, 2 + q, j, true);
+                    const u32x4 r_[2] = {raw[0][j], raw[1][j]};
+                    u32x4 o_[2];
+                    pair_value(0, j, blo, bhi, r_, r_, 0xffu, 0xffu, o_);
+                    pk[0][j] = o_[0]; pk[1][j] = o_[1];
+                }
+            }
+            load_half(1, raw);
+            // full tile: exactly the 8 (16 with the fp8 copy) stores of pair 0 are younger than pair 1's loads
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) emit(pk[k][j], 0, j, k, true, true);
+            if constexpr (QOUT) G8_WAIT_HALF(16, raw);
+            else G8_WAIT_HALF(8, raw);
+            {
+                float blo[8], bhi[8];
+                bias_of(2, blo); bias_of(3, bhi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 r_[2] = {raw[0][j], raw[1][j]};
+                    u32x4 o_[2];
+                    pair_value(1, j, blo, bhi, r_, r_, 0xffu, 0xffu, o_);
+                    emit(o_[0], 1, j, 0, true, true);
+                    emit(o_[1], 1, j, 1, true, true);
                 }
             }
         } else if constexpr (BITS) {
-            unsigned mb[4][4];
+            unsigned mb[2][2][4];                      // [pair][k][pixel block]
             const unsigned char* mb_base = p.mask_in + morg;
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr)
+            for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    asm volatile(G8_SGPR_SETTLE "global_load_ubyte %0, %1, %2" : "=v"(mb[pr][j]) : "v"(mo + j * mstep + 4 * pr), "s"(mb_base) : "memory");
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile(G8_SGPR_SETTLE "global_load_ubyte %0, %1, %2" : "=v"(mb[pp][k][j]) : "v"(mo + j * mstep + k * (mstep >> 1) + 8 * pp), "s"(mb_base) : "memory");
             asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(mb[0][0]), "+v"(mb[0][1]), "+v"(mb[0][2]), "+v"(mb[0][3]), "+v"(mb[1][0]), "+v"(mb[1][1]), "+v"(mb[1][2]),
-                           "+v"(mb[1][3]), "+v"(mb[2][0]), "+v"(mb[2][1]), "+v"(mb[2][2]), "+v"(mb[2][3]), "+v"(mb[3][0]), "+v"(mb[3][1]),
-                           "+v"(mb[3][2]), "+v"(mb[3][3])
+                         : "+v"(mb[0][0][0]), "+v"(mb[0][0][1]), "+v"(mb[0][0][2]), "+v"(mb[0][0][3]), "+v"(mb[0][1][0]), "+v"(mb[0][1][1]), "+v"(mb[0][1][2]),
+                           "+v"(mb[0][1][3]), "+v"(mb[1][0][0]), "+v"(mb[1][0][1]), "+v"(mb[1][0][2]), "+v"(mb[1][0][3]), "+v"(mb[1][1][0]), "+v"(mb[1][1][1]),
+                           "+v"(mb[1][1][2]), "+v"(mb[1][1][3])
                          :: "memory");
             float* cred = (float*)(smem + 2 * BUF + 4096 + 64);           // [4 pixel quarters][256 columns]
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                float bv[8];
-                bias_of(pr, bv);
-                float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int pp = 0; pp < 2; ++pp) {
+                float blo[8], bhi[8];
+                bias_of(2 * pp, blo); bias_of(2 * pp + 1, bhi);
+                float cs[2][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
-                    u32x4 oa;                          // (the column sums add the 16 pixel lanes of the accumulator layout)
-                    const u32x4 out = value(pr, j, bv, z, z, mb[pr][j], &oa);
-                    if (p.y) G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
-                    if (has_q) quant_store(out, pr, j, true);
+                    const u32x4 zz[2] = {z4, z4};
+                    u32x4 o_[2], oa[2];                // (the column sums add the 16 pixel lanes of the accumulator layout)
+                    pair_value(pp, j, blo, bhi, zz, zz, mb[pp][0][j], mb[pp][1][j], o_, &oa[0], &oa[1]);
+                    emit(o_[0], pp, j, 0, true, p.y != nullptr);
+                    emit(o_[1], pp, j, 1, true, p.y != nullptr);
                     if (p.colpart) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { cs[2 * e] += __uint_as_float(oa[e] << 16); cs[2 * e + 1] += __uint_as_float(oa[e] & 0xffff0000u); }
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { cs[h][2 * e] += __uint_as_float(oa[h][e] << 16); cs[h][2 * e + 1] += __uint_as_float(oa[h][e] & 0xffff0000u); }
                     }
                 }
                 if (p.colpart) {                       // the 16 pixel lanes of a column by DPP (fixed order), then this wave's 64-row sum to LDS
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float t_ = g8_row16_sum(cs[e]);
-                        if (frow == 0) cred[wc * 256 + lcol + 32 * pr + e] = t_;
-                    }
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float t_ = g8_row16_sum(cs[h][e]);
+                            if (frow == 0) cred[wc * 256 + lcol + 32 * (2 * pp + h) + e] = t_;
+                        }
                 }
             }
             if (p.colpart) {                           // (both wave groups are in the epilogue together: align_epi is forced on)
@@ -727,32 +727,32 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             }
         } else {
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                float bv[8];
-                bias_of(pr, bv);
+            for (int pp = 0; pp < 2; ++pp) {
+                float blo[8], bhi[8];
+                bias_of(2 * pp, blo); bias_of(2 * pp + 1, bhi);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool ok = FULL > 0 || em0 + rrow + 16 * j < p.M;      // (of the row this lane loads and stores: row order)
-                    u32x4 araw = (u32x4){0u, 0u, 0u, 0u}, xraw = (u32x4){0u, 0u, 0u, 0u};
-                    unsigned mbits = 0xffu;
-#if defined(NKB_G8_NO_ASMLOADS)
-                    if (has_add && ok) araw = *(const u32x4*)(abase + (ao + j * astep + 64 * pr));
-                    if (aux_kind == 3) { if (ok) mbits = p.mask_in[morg + (mo + j * mstep + 4 * pr)]; }
-                    else if (aux_kind && ok) xraw = *(const u32x4*)(xbase + (yo + j * ystep + 64 * pr));
-#else
-                    if (has_add && ok) asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(araw) : "v"(ao + j * astep + 64 * pr), "s"(abase) : "memory");
-                    if (aux_kind == 3) { if (ok) asm volatile(G8_SGPR_SETTLE "global_load_ubyte %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(mbits) : "v"(mo + j * mstep + 4 * pr), "s"(p.mask_in + morg) : "memory"); }
-                    else if (aux_kind && ok) asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(xraw) : "v"(yo + j * ystep + 64 * pr), "s"(xbase) : "memory");
+                    const bool ok[2] = {row_ok(j, 0), row_ok(j, 1)};
+                    u32x4 ar[2] = {z4, z4}, xr[2] = {z4, z4};
+                    unsigned mr[2] = {0xffu, 0xffu};
                     // (each load is waited for inside its own statement: the run-time form serves rare tiles, one row at a time)
-#endif
-                    const u32x4 out = value(pr, j, bv, araw, xraw, mbits);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        if (has_add && ok[k]) asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(ar[k]) : "v"(ao + j * astep + k * (astep >> 1) + 128 * pp), "s"(abase) : "memory");
+                        if (aux_kind == 3) { if (ok[k]) asm volatile(G8_SGPR_SETTLE "global_load_ubyte %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(mr[k]) : "v"(mo + j * mstep + k * (mstep >> 1) + 8 * pp), "s"(p.mask_in + morg) : "memory"); }
+                        else if (aux_kind && ok[k]) asm volatile(G8_SGPR_SETTLE "global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(xr[k]) : "v"(yo + j * ystep + k * (ystep >> 1) + 128 * pp), "s"(xbase) : "memory");
+                    }
+                    u32x4 o_[2];
+                    pair_value(pp, j, blo, bhi, ar, xr, mr[0], mr[1], o_);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
 #if defined(NKB_G8_DIAG_NOSTORE)                  /* diagnostic builds only: how much of a tile is the store drain */
-                    if (ok && p.y && pr >= NKB_G8_DIAG_NOSTORE) G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
-                    else asm volatile("" :: "v"(out));
+                        asm volatile("" :: "v"(o_[k]));
+                        emit(o_[k], pp, j, k, ok[k], p.y != nullptr && 2 * pp >= NKB_G8_DIAG_NOSTORE);
 #else
-                    if (ok && p.y) G8_NT_STORE(out, (u32x4*)(ybase + (yo + j * ystep + 64 * pr)));
+                        emit(o_[k], pp, j, k, ok[k], p.y != nullptr);
 #endif
-                    if (has_q) quant_store(out, pr, j, ok);
+                    }
                 }
             }
         }
