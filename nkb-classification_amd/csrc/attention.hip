@@ -130,16 +130,19 @@ __global__ __launch_bounds__(512, WPS) void attn_fwd_kernel(const bf16_t* __rest
     const long long rs = 3ll * D;
     const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    // (13 query blocks on 8 waves: logical waves 0-4 take two — both waves of ONE SIMD among them; the logical numbering rotates with
+    // the workgroup index so that the two workgroups sharing a CU do not put their fourth block on the same SIMD)
+    const int lwave = (wave + (blockIdx.x & 3)) & 7;
     // this wave's first query rows are requested before the K / V staging so that their latency hides behind it
     auto qrow = [&](int qb) { const int q = qb * 16 + fr; return base + (size_t)(q < T ? q : T - 1) * rs; };
-    bf16x8 q0 = *(const bf16x8*)(qrow(wave) + g * 8), q1 = *(const bf16x8*)(qrow(wave) + (4 + g) * 8);
+    bf16x8 q0 = *(const bf16x8*)(qrow(lwave) + g * 8), q1 = *(const bf16x8*)(qrow(lwave) + (4 + g) * 8);
     load_kv<512>(Ks, Vs, base + D, base + 2 * D, rs, T, TK, NKS * 32);
     __syncthreads();
 
     const float sl2 = scale * 1.4426950408889634f;   // exp(x) = exp2(x log2 e): the hardware exponential is base 2
     const float qscale = outq ? q_state[0] : 1.f;
     attn_u16x2 amax2 = {0, 0};
-    for (int qb = wave; qb * 16 < T; qb += 8) {            // 8 waves per workgroup, 2 workgroups per CU: 4 waves per SIMD
+    for (int qb = lwave; qb * 16 < T; qb += 8) {           // 8 waves per workgroup, 2 workgroups per CU: 4 waves per SIMD
         const int q = qb * 16 + fr;
         f32x4 acc[NKB];
         score_tile<NKB>(Ks, q0, q1, acc);
@@ -199,6 +202,8 @@ __global__ __launch_bounds__(512, WPS) void attn_fwd_kernel(const bf16_t* __rest
             }
             if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
+        // (measured, round 5: the row-order store of the backward kernel — permlane16_swap + ds_bpermute — buys 2.5 % here at 197 tokens and
+        // costs 3.7 % at 256: the forward kernel is vector-issue bound and does not wait for its stores; not kept)
         if (q < T) {
             bf16_t* orow = out + ((size_t)b * T + q) * D + h * DH;
 #pragma unroll
@@ -424,6 +429,36 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
         }
     };
 
+    // One finished 16-row x 128-byte block (pk[i] = this lane's row fr, columns 16 i + 4 g ... + 3: eight bytes) goes to memory in
+    // ROW ORDER (round 5, scripts/ubench/store_probe.hip: in the accumulator layout a store instruction is 64 scattered 8-byte
+    // requests, and 156 of them per head queue in front of the next head's loads).  permlane16_swap on the register pairs
+    // (2 m, 2 m + 1) leaves lane g of a row with two whole 16-byte chunks — chunk {0, 2, 1, 3}[g] of the 64-byte half m — and one
+    // ds_bpermute per register puts (row l >> 2, chunk l & 3) on lane l: four consecutive lanes = 64 contiguous bytes.
+    const int rr_ = lane >> 2, rp_ = lane & 3;
+    const int rsrc_ = (16 * ((rp_ >> 1) | ((rp_ & 1) << 1)) + rr_) << 2;
+    auto store_block = [&](const u32x2 (&pk)[4], int row0, size_t col0) {     // rows row0 .. row0 + 15 of d_qkv, columns col0 .. col0 + 63
+        u32x4 ch[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[2 * m][0], pk[2 * m + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[2 * m][1], pk[2 * m + 1][1], false, false);
+            const u32x4 mine = {s0[0], s1[0], s0[1], s1[1]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ch[m][e] = (unsigned)__builtin_amdgcn_ds_bpermute(rsrc_, (int)mine[e]);
+        }
+        if (row0 + rr_ < T) {
+            const size_t off = ((size_t)b * T + row0 + rr_) * rs + col0 + 8 * rp_;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                *(u32x4*)(dqkv + off + 32 * m) = ch[m];
+                if (dqkv_q) {
+                    store_q4<1>(dqkv_q + off + 32 * m, (u32x2){ch[m][0], ch[m][1]}, qscale, amax2);
+                    store_q4<1>(dqkv_q + off + 32 * m + 4, (u32x2){ch[m][2], ch[m][3]}, qscale, amax2);
+                }
+            }
+        }
+    };
+
     // ---- pass A: dQ, one query block per wave at a time --------------------------------------------------------------
     for (int qb = wave; qb < NKB; qb += NW) {
         const int q = qb * 16 + fr;
@@ -439,6 +474,7 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 const int kb = 2 * t + hb;               // a block past T: zero K / V rows, masked below
+                if ((NKB & 1) && kb == NKB) { pd[hb] = (u32x2){0u, 0u}; continue; }   // the padding half of the last 32-key step: dS = 0
                 const bf16x8 ka = *(const bf16x8*)(Ks + 2048 * kb + o0), kc = *(const bf16x8*)(Ks + 2048 * kb + o1);
                 const bf16x8 va = *(const bf16x8*)(Vs + 2048 * kb + o0), vc = *(const bf16x8*)(Vs + 2048 * kb + o1);
                 f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, q0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -461,19 +497,15 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
         u32x2 pkq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) pkq[i] = (u32x2){pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
-        if (q < T) {
-            bf16_t* orow = dqkv + ((size_t)b * T + q) * rs + h * DH;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *(u32x2*)(orow + 16 * i + 4 * g) = pkq[i];
-                if (dqkv_q) store_q4<1>(dqkv_q + ((size_t)b * T + q) * rs + h * DH + 16 * i + 4 * g, pkq[i], qscale, amax2);
-            }
-        }
+        store_block(pkq, qb * 16, (size_t)h * DH);
         if (colpart) add_colsum(0, pkq, q < T);
     }
 
     // ---- pass B: dK and dV, one key block per wave at a time ---------------------------------------------------------
-    for (int kb = wave; kb < NKB; kb += NW) {
+    // (key block kb belongs to wave kb + 1: with 13 blocks on 16 waves — four per SIMD, wave w on SIMD w & 3 — pass A's extra block
+    // sits on SIMD 0 (blocks 0, 4, 8, 12), so pass B's goes to SIMD 1: the busiest SIMD issues 3 x 84 + 4 x 112 = 700 MFMAs and
+    // their vector work instead of 4 x 196 = 784)
+    for (int kb = (wave + NW - 1) % NW; kb < NKB; kb += NW) {
         const bf16x8 kf0 = *(const bf16x8*)(Ks + 2048 * kb + o0), kf1 = *(const bf16x8*)(Ks + 2048 * kb + o1);
         const bf16x8 vf0 = *(const bf16x8*)(Vs + 2048 * kb + o0), vf1 = *(const bf16x8*)(Vs + 2048 * kb + o1);
         f32x4 ov[4], ok[4];
@@ -485,6 +517,7 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 const int qb = 2 * t + hb;              // rows of a block past T are zero images with lse = +inf: P = dS = 0
+                if ((NKB & 1) && qb == NKB) { pkp[hb] = (u32x2){0u, 0u}; pks[hb] = (u32x2){0u, 0u}; continue; }   // (not computed)
                 const bf16x8 qa0 = *(const bf16x8*)(Qs + 2048 * qb + o0), qa1 = *(const bf16x8*)(Qs + 2048 * qb + o1);
                 const bf16x8 da0 = *(const bf16x8*)(Ds + 2048 * qb + o0), da1 = *(const bf16x8*)(Ds + 2048 * qb + o1);
                 f32x4 S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -516,19 +549,8 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
             pkk[i] = (u32x2){pack_bf2(ok[i][0], ok[i][1]), pack_bf2(ok[i][2], ok[i][3])};
             pkv[i] = (u32x2){pack_bf2(ov[i][0], ov[i][1]), pack_bf2(ov[i][2], ov[i][3])};
         }
-        if (key < T) {
-            bf16_t* krow = dqkv + ((size_t)b * T + key) * rs + D + h * DH;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *(u32x2*)(krow + 16 * i + 4 * g) = pkk[i];
-                *(u32x2*)(krow + D + 16 * i + 4 * g) = pkv[i];
-                if (dqkv_q) {
-                    unsigned char* kq = dqkv_q + ((size_t)b * T + key) * rs + D + h * DH + 16 * i + 4 * g;
-                    store_q4<1>(kq, pkk[i], qscale, amax2);
-                    store_q4<1>(kq + D, pkv[i], qscale, amax2);
-                }
-            }
-        }
+        store_block(pkk, kb * 16, (size_t)D + h * DH);
+        store_block(pkv, kb * 16, (size_t)2 * D + h * DH);
         if (colpart) { add_colsum(1, pkk, key < T); add_colsum(2, pkv, key < T); }
     }
     if (colpart) {
