@@ -12,6 +12,16 @@
 // (k-slot (g, j): j < 4 -> key 16*(2t) + 4g + j, j >= 4 -> key 16*(2t+1) + 4g + j - 4), so P never leaves registers.
 #include "common.h"
 
+#ifdef NKB_ATTN_STAMPS
+// diagnostic build only (scripts/attn_stamps.py): s_memtime of every wave of the LAST 256 workgroups (steady state: the CUs are no longer in
+// step) at the start, behind the prologue, behind pass A, behind pass B
+__device__ unsigned long long attn_stamps[256 * 16 * 4];
+extern "C" int nkb_attn_read_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(attn_stamps), sizeof(attn_stamps)); }
+#define ATTN_STAMP(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x + 256 >= gridDim.x) attn_stamps[((blockIdx.x + 256 - gridDim.x) * 16 + (threadIdx.x >> 6)) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTN_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 // Waves per SIMD the forward kernel is compiled for (the second __launch_bounds__ argument is waves per execution unit, not
@@ -337,16 +347,19 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
     unsigned char* __restrict__ dqkv_q, float* __restrict__ q_state, float* __restrict__ colpart) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NKS = (NKB + 1) / 2, ROWS = NKS * 32, IMG = ROWS * 128;
+    ATTN_STAMP(0);
     const float qscale = dqkv_q ? q_state[0] : 1.f;
     attn_u16x2 amax2 = {0, 0};
     constexpr int NT = NKB_ATTN_BWD_THREADS, NW = NT / 64;
     constexpr int IT = (ROWS * 8 + NT - 1) / NT;
     const int D = H * DH;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    // (Q next to dO, K next to V: the pairs each pass reads in its inner loop are one 16-bit instruction offset apart, so a pair
+    // shares its address registers — pass B: 30 -> 18 address additions per 32-row step)
     unsigned char* Qs = smem;
-    unsigned char* Ks = smem + IMG;
-    unsigned char* Vs = smem + 2 * IMG;
-    unsigned char* Ds = smem + 3 * IMG;
+    unsigned char* Ds = smem + IMG;
+    unsigned char* Ks = smem + 2 * IMG;
+    unsigned char* Vs = smem + 3 * IMG;
     float* l2s = (float*)(smem + 4 * IMG);
     float* dls = l2s + ROWS;
     // colpart (optional): column sums of the stored dQ / dK / dV rows of this (image, head) — the qkv projection's bias gradient,
@@ -357,15 +370,15 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
     const bf16_t* base = qkv + (size_t)b * T * rs + h * DH;
     const bf16_t* dbase = dout + (size_t)b * T * D + h * DH;
     const bf16_t* obase = out + (size_t)b * T * D + h * DH;
-    for (int r = threadIdx.x; r < ROWS; r += NT) {
-        l2s[r] = r < T ? lse[((size_t)b * H + h) * T + r] * 1.4426950408889634f : INFINITY;
-        dls[r] = 0.f;
-    }
-    if (colpart)
-        for (int r = threadIdx.x; r < 3 * NW * 64; r += NT) cs[r] = 0.f;
-    __syncthreads();
+    // Prologue, ONE memory round trip and one barrier (round 5: the stamps of scripts/attn_stamps.py put 7.7 of a head's 21.8 us here
+    // when the lse rows were fetched, stored and fenced by a barrier BEFORE the five operand tensors were even requested, and the
+    // row sums of dO o O went through 8 LDS float atomics per row): every global load is issued first, delta is reduced over the 8
+    // lanes that hold a row's chunks by DPP (a fixed order — the atomics' was not) and stored once.
+    static_assert(ROWS <= NT, "one lse row per thread");
     {
         u32x4 rq[IT], rk[IT], rv[IT], rd[IT], ro[IT];
+        float lv = 0.f;
+        if ((int)threadIdx.x < T) lv = lse[((size_t)b * H + h) * T + threadIdx.x];
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int c = threadIdx.x + NT * i, row = c >> 3, ch = c & 7;
@@ -379,26 +392,31 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
                 ro[i] = *(const u32x4*)(obase + (size_t)row * D + ch * 8);
             }
         }
+        if ((int)threadIdx.x < ROWS) l2s[threadIdx.x] = (int)threadIdx.x < T ? lv * 1.4426950408889634f : INFINITY;
+        if (colpart)
+            for (int r = threadIdx.x; r < 3 * NW * 64; r += NT) cs[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int c = threadIdx.x + NT * i, row = c >> 3, ch = c & 7;
-            if (row >= ROWS) break;
+            if (row >= ROWS) break;                            // (whole waves: ROWS * 8 is a multiple of 256)
             *(u32x4*)(Qs + kswz(row, ch)) = rq[i];
             *(u32x4*)(Ks + kswz(row, ch)) = rk[i];
             *(u32x4*)(Vs + kswz(row, ch)) = rv[i];
             *(u32x4*)(Ds + kswz(row, ch)) = rd[i];
-            if (row < T) {
-                float fd[8], fo[8], t = 0.f;
-                unpack8(rd[i], fd);
-                unpack8(ro[i], fo);
+            float fd[8], fo[8], t = 0.f;                       // rows >= T hold zeros
+            unpack8(rd[i], fd);
+            unpack8(ro[i], fo);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t += fd[e] * fo[e];
-                atomicAdd(dls + row, t);                       // 8 chunk partials per row
-            }
+            for (int e = 0; e < 8; ++e) t += fd[e] * fo[e];
+            t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+            t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+            t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, true));   // row_half_mirror: the other quad of the 8
+            if (ch == 0) dls[row] = t;
         }
     }
     __syncthreads();
 
+    ATTN_STAMP(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
     const float sl2 = scale * 1.4426950408889634f;
     const int o0 = kswz(fr, g), o1 = kswz(fr, 4 + g);          // fragment offsets of row fr; +2048 per 16-row block
@@ -481,13 +499,17 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
                 f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, d0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, q1, s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc, d1, dp, 0, 0, 0);
-                float d[4];
+                // dS / scale = P (dP - delta): 4 vector instructions per element (fma, exp2, sub, mul) — the 1 / sqrt(dh) factor is
+                // applied to the finished dQ block instead of every element, the key mask only where a block can hold keys >= T
+                float pe[4], d[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float p = __builtin_amdgcn_exp2f(s[e] * sl2 - l2);
-                    if (kb >= NKB - 1 && kb * 16 + 4 * g + e >= T) p = 0.f;
-                    d[e] = p * (dp[e] - delta) * scale;
+                for (int e = 0; e < 4; ++e) pe[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sl2, -l2));
+                if (kb >= NKB - 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pe[e] = kb * 16 + 4 * g + e >= T ? 0.f : pe[e];
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = pe[e] * (dp[e] - delta);
                 pd[hb] = (u32x2){pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
             }
             const u32x4 pb = {pd[0][0], pd[0][1], pd[1][0], pd[1][1]};
@@ -496,11 +518,12 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
         }
         u32x2 pkq[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pkq[i] = (u32x2){pack_bf2(o[i][0], o[i][1]), pack_bf2(o[i][2], o[i][3])};
+        for (int i = 0; i < 4; ++i) pkq[i] = (u32x2){pack_bf2(o[i][0] * scale, o[i][1] * scale), pack_bf2(o[i][2] * scale, o[i][3] * scale)};
         store_block(pkq, qb * 16, (size_t)h * DH);
         if (colpart) add_colsum(0, pkq, q < T);
     }
 
+    ATTN_STAMP(2);
     // ---- pass B: dK and dV, one key block per wave at a time ---------------------------------------------------------
     // (key block kb belongs to wave kb + 1: with 13 blocks on 16 waves — four per SIMD, wave w on SIMD w & 3 — pass A's extra block
     // sits on SIMD 0 (blocks 0, 4, 8, 12), so pass B's goes to SIMD 1: the busiest SIMD issues 3 x 84 + 4 x 112 = 700 MFMAs and
@@ -528,8 +551,8 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
                 float pv[4], dv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pv[e] = __builtin_amdgcn_exp2f(S[e] * sl2 - l4[e]);
-                    dv[e] = pv[e] * (dP[e] - d4[e]) * scale;
+                    pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[e], sl2, -l4[e]));
+                    dv[e] = pv[e] * (dP[e] - d4[e]);     // dS / scale: the factor goes on the finished dK block
                 }
                 pkp[hb] = (u32x2){pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
                 pks[hb] = (u32x2){pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3])};
@@ -546,13 +569,14 @@ __global__ __launch_bounds__(NKB_ATTN_BWD_THREADS, 1) void attn_bwd_fused_kernel
         u32x2 pkk[4], pkv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            pkk[i] = (u32x2){pack_bf2(ok[i][0], ok[i][1]), pack_bf2(ok[i][2], ok[i][3])};
+            pkk[i] = (u32x2){pack_bf2(ok[i][0] * scale, ok[i][1] * scale), pack_bf2(ok[i][2] * scale, ok[i][3] * scale)};
             pkv[i] = (u32x2){pack_bf2(ov[i][0], ov[i][1]), pack_bf2(ov[i][2], ov[i][3])};
         }
         store_block(pkk, kb * 16, (size_t)D + h * DH);
         store_block(pkv, kb * 16, (size_t)2 * D + h * DH);
         if (colpart) { add_colsum(1, pkk, key < T); add_colsum(2, pkv, key < T); }
     }
+    ATTN_STAMP(3);
     if (colpart) {
         __syncthreads();
         if (threadIdx.x < 192) {
