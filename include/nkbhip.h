@@ -475,6 +475,9 @@ int nkb_gemm_fp8(int mode, const void* xq, const void* wq, void* y, const float*
 /* Envelope of the 256 x 256 eight-phase GEMM core that nkb_conv_gemm / nkb_linear_gelu use for wide plain 1x1 / Linear launches
  * (csrc/gemm8p.hip): on = 0 / 1; min_tiles, min_k > 0 replace the defaults (192 tiles, K >= 768).  Tests and A/B timing. */
 void nkb_gemm8p_config(int on, int min_tiles, int min_k);
+/* the ragged last row block (M % 256 rows) of a persistent 256 x 256 GEMM launch on its own small kernel where that saves the launch a
+ * round of tiles (csrc/gemm8p.hip, gemm8p_ragged_kernel): 1 (default) = on, 0 = every row block on the persistent kernel.  Tests / A-B timing. */
+void nkb_gemm8p_ragged(int on);
 
 /* Host replay of a recorded step (csrc/plan.hip).  The reference has no counterpart: its step is re-traced by the Python
  * interpreter every iteration (engine.py:36-75 -> torch dispatcher).  nkb_classification/hip.py records the entry points one

@@ -28,6 +28,7 @@
 #include "conv_params.h"
 #include "gemm8p.h"
 #include <type_traits>
+#include <atomic>
 
 #ifdef NKB_G8_STAMPS
 // diagnostic build only (scripts/g8_stamps.py): s_memtime of wave 0 / wave 4 of every workgroup at the top of a tile's first four
@@ -998,6 +999,174 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The RAGGED ROWS of a persistent launch as their own small kernel (round 5).  When M is no multiple of 256 the last row block's
+// tiles cost a whole tile time each — and where they are what pushes the tile count over a multiple of the CU count they cost
+// the launch a whole ROUND: unicom ViT-L/14 at batch 128 has M = 32 896 = 128.5 x 256, so each of its N = 1 024 launches walks
+// 516 = 2 x 256 + 4 tiles in three rounds (84 us against 62 for M = 32 768 at K = N = 1 024, 266 against 206 at K = 4 096).
+// nkb_launch_gemm8p then gives the persistent kernel the whole row blocks only and these R = M % 256 rows to this kernel:
+// grid = (N / 64 column blocks) x S splits of K, 8 waves; four of them multiply its R x 64 x (K / S) piece straight from global
+// memory (0.4 % of the launch's work: no LDS staging), stores it into an fp32 slab (write-through) and takes its column block's
+// ticket; the block's LAST arriver adds the S slabs in split order — the same sum whoever arrives last — and applies the epilogue of
+// gemm8p's `value()` (bias, residual, saved-derivative multiply / ReLU6 mask, ReLU / ReLU6 / GELU + GELU').  Hand-off as in
+// elementwise.hip (write-through stores, vmcnt(0), barrier, agent-scope ticket, the last arriver clears it and acquires once).
+constexpr int G8R_SLOTS = 2, G8R_MAXWG = 768, G8R_COLS = 64;
+__device__ float g8r_slabs[G8R_SLOTS * G8R_MAXWG * 256 * G8R_COLS / 2];   // R <= 128 per [split][block] piece in the common case; sized for R = 128
+__device__ unsigned g8r_tickets[G8R_SLOTS * 128];
+
+struct G8RParams {
+    const bf16_t* x; const bf16_t* w; bf16_t* y; bf16_t* y2;
+    const float* bias; const bf16_t* add; const bf16_t* aux;
+    int R, N, K, ldx, ldw, ldy, ldadd, relu, aux_kind, S;
+    float* slab; unsigned* ticket;
+};
+
+template <int RF>                                 // 16-row fragments per wave: the kernel covers 64 RF rows
+__global__ __launch_bounds__(512) void gemm8p_ragged_kernel(const G8RParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    const int cb = blockIdx.x, sp = blockIdx.y;
+    const int ks = p.K / p.S, k0 = sp * ks;       // (K % (32 S) == 0: checked by the host)
+    const int n0 = cb * G8R_COLS;
+    constexpr int PIECE = 4 * RF * 4 * 256;       // floats of one [split][column block] piece: [wave 0-3][i][j][lane][4]
+    // ---- waves 0-3: the R x 64 x (K / S) product straight from global memory.  D[n][m] = W rows x X rows^T: lane (fr, g) of
+    // fragment (i, j) holds row m = 16 (RF wave + i) + fr, columns n0 + 16 j + 4 g + e
+    if (wave < 4) {
+        f32x4 acc[RF][4];
+#pragma unroll
+        for (int i = 0; i < RF; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bf16_t* xr[RF];
+#pragma unroll
+        for (int i = 0; i < RF; ++i) { const int m = 16 * (RF * wave + i) + fr; xr[i] = p.x + (size_t)(m < p.R ? m : p.R - 1) * p.ldx + k0 + 8 * g; }
+        const bf16_t* wr_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr_[j] = p.w + (size_t)(n0 + 16 * j + fr) * p.ldw + k0 + 8 * g;
+#pragma unroll 4                                  // (four k-steps' loads in flight: the loop is latency-bound)
+        for (int k = 0; k < ks; k += 32) {
+            bf16x8 a[4], b[RF];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = *(const bf16x8*)(wr_[j] + k);
+#pragma unroll
+            for (int i = 0; i < RF; ++i) b[i] = *(const bf16x8*)(xr[i] + k);
+#pragma unroll
+            for (int i = 0; i < RF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[i][j], 0, 0, 0);
+        }
+        // the piece, lane-major (one 16-byte store per lane and fragment: 1 KB per instruction), write-through
+        float* mine = p.slab + ((size_t)sp * gridDim.x + cb) * PIECE + (size_t)wave * RF * 4 * 256;
+#pragma unroll
+        for (int i = 0; i < RF; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* d = mine + (i * 4 + j) * 256 + lane * 4;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(d), "v"(acc[i][j]) : "memory");
+            }
+    }
+    __shared__ unsigned last_flag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.ticket + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == (unsigned)p.S - 1u;
+        if (last) {
+            __hip_atomic_store(p.ticket + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        last_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    // ---- the column block's last arriver, all 8 waves: thread t = (row t >> 2, 16 columns = fragment j = t & 3 of that row): per
+    // split one 16-byte load for each of the 4 lane groups g; all S x 4 loads of a thread are in flight together
+    const int r = threadIdx.x >> 2, j = threadIdx.x & 3;
+    if (r >= 64 * RF || r >= p.R) return;
+    {
+        const int wv = r / (16 * RF), i = (r >> 4) % RF, frr = r & 15;
+        const float* src0 = p.slab + (size_t)cb * PIECE + (size_t)((wv * RF + i) * 4 + j) * 256 + frr * 4;
+        const size_t pstep = (size_t)gridDim.x * PIECE;
+        // (the epilogue's operands are requested in front of the pieces: one exposed round trip less)
+        const int c0 = 16 * j;
+        const size_t yo = (size_t)r * p.ldy + n0 + c0;
+        f32x4 bq[4];
+        u32x4 aq[2], xq[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[e] = p.bias ? *(const f32x4*)(p.bias + n0 + c0 + 4 * e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            aq[e] = p.add ? *(const u32x4*)(p.add + (size_t)r * p.ldadd + n0 + c0 + 8 * e) : (u32x4){0u, 0u, 0u, 0u};
+            xq[e] = p.aux_kind ? *(const u32x4*)(p.aux + yo + 8 * e) : (u32x4){0u, 0u, 0u, 0u};
+        }
+        f32x4 v4[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) v4[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int QB = 8;                       // splits per batch: 32 loads in flight per thread
+        for (int q0 = 0; q0 < p.S; q0 += QB) {
+            f32x4 t[QB][4];
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                {
+                    t[q][gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    // (coherent loads: the pieces were written by other CUs, possibly other dies, and these addresses were read before)
+                    if (q0 + q < p.S) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[q][gg]) : "v"(src0 + (size_t)(q0 + q) * pstep + gg * 64) : "memory");
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    asm volatile("" : "+v"(t[q][gg]));                         // (used only behind the wait above)
+                    v4[gg] += t[q][gg];                                        // split order: the same sum whoever arrived last
+                }
+        }
+        float v[16];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * gg + e] = v4[gg][e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += bq[e >> 2][e & 3];
+        if (p.add) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 8) {
+                float af[8];
+                unpack8(aq[e >> 3], af);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[e + u] += af[u];
+            }
+        }
+        if (p.aux_kind) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 8) {
+                float af[8];
+                unpack8(xq[e >> 3], af);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[e + u] = p.aux_kind == 1 ? v[e + u] * af[u] : ((af[u] > 0.f && af[u] < 6.f) ? v[e + u] : 0.f);
+            }
+        }
+        if (p.relu == 3) {
+            float dv[16];
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                g8_f32x2 uu, dd;
+                g8_gelu2((g8_f32x2){v[e], v[e + 1]}, uu, dd);
+                v[e] = uu[0]; v[e + 1] = uu[1]; dv[e] = dd[0]; dv[e + 1] = dd[1];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e += 8) *(u32x4*)(p.y2 + yo + e) = pack8(dv + e);
+        } else if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = p.relu == 2 ? fminf(fmaxf(v[e], 0.f), 6.f) : fmaxf(v[e], 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e += 8) *(u32x4*)(p.y + yo + e) = pack8(v + e);
+    }
+}
+
 }  // namespace
 
 static int g8_on = [] { const char* e = getenv("NKB_GEMM8P"); return e ? atoi(e) : 1; }();
@@ -1073,6 +1242,43 @@ static int g8_cus() {
     return cus;
 }
 
+// rounds of `tiles` whole tiles on `cus` workgroup slots
+static int g8_rounds(int tiles, int cus) { return (tiles + cus - 1) / cus; }
+#ifndef NKB_G8_RAGGED
+#define NKB_G8_RAGGED 1
+#endif
+static int g8_ragged_on = NKB_G8_RAGGED;
+// run-time switch (tests, A/B timing): 1 = the ragged rows of a persistent launch go to gemm8p_ragged_kernel where that saves a round
+extern "C" void nkb_gemm8p_ragged(int on) { g8_ragged_on = on; }
+// Launches the companion for rows [M0, M0 + R) of the problem in `p` (pointers of the FULL problem); false: shape not served.
+static bool g8_launch_ragged(const G8Params& p, int M0, int R, hipStream_t stream) {
+    if (R < 1 || R > 128 || p.N % G8R_COLS != 0 || p.row_scale || p.yq || p.mask_in || p.mask_out || p.colpart || p.stats) return false;
+    const int blocks = p.N / G8R_COLS;
+    if (blocks > 128) return false;
+    // splits of K: enough workgroups for every CU, pieces of at least 64 deep, K % (32 S) == 0
+    // pieces of 128 (K < 2 048) or 256 deep: one or two groups of four k-steps in flight per wave, S <= 16 pieces for the last arriver to read
+    int S = 1;
+    const int deep = p.K >= 2048 ? 256 : 128;
+    for (int c = 2; c <= 16; ++c)
+        if (p.K % (32 * c) == 0 && p.K / c >= deep && blocks * c <= G8R_MAXWG) S = c;
+    static std::atomic<unsigned> turn{0};
+    float* slabs = nullptr; unsigned* tickets = nullptr;
+    if (hipGetSymbolAddress((void**)&slabs, HIP_SYMBOL(g8r_slabs)) != hipSuccess || hipGetSymbolAddress((void**)&tickets, HIP_SYMBOL(g8r_tickets)) != hipSuccess ||
+        !slabs || !tickets)
+        return false;
+    const unsigned slot = turn.fetch_add(1u) % G8R_SLOTS;
+    G8RParams q;
+    q.x = p.x + (size_t)M0 * p.ldx; q.w = p.w; q.y = p.y + (size_t)M0 * p.ldy; q.y2 = p.y2 ? p.y2 + (size_t)M0 * p.ldy : nullptr;
+    q.bias = p.bias; q.add = p.add ? p.add + (size_t)M0 * p.ldadd : nullptr; q.aux = p.aux ? p.aux + (size_t)M0 * p.ldy : nullptr;
+    q.R = R; q.N = p.N; q.K = p.K; q.ldx = p.ldx; q.ldw = p.ldw; q.ldy = p.ldy; q.ldadd = p.ldadd; q.relu = p.relu;
+    q.aux_kind = p.aux ? 1 + p.aux_mode : 0; q.S = S;
+    q.slab = slabs + (size_t)slot * G8R_MAXWG * 128 * G8R_COLS; q.ticket = tickets + slot * 128;
+    const dim3 grid((unsigned)blocks, (unsigned)S);
+    if (R <= 64) hipLaunchKernelGGL(gemm8p_ragged_kernel<1>, grid, dim3(512), 0, stream, q);
+    else hipLaunchKernelGGL(gemm8p_ragged_kernel<2>, grid, dim3(512), 0, stream, q);
+    return true;
+}
+
 int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream, const float* row_scale, int rows_per_sample) {
     nkb_count_launch(0);
     G8Params p;
@@ -1104,9 +1310,19 @@ int nkb_launch_gemm8p(const ConvParams& cp, hipStream_t stream, const float* row
     // launches with BatchNorm statistics keep the one-tile-per-workgroup form (their partial sums go through LDS)
     constexpr int direct_on = 1;
     p.stagger = g8_stagger(tiles, cus, p.K / 64);
-    if (p.stats == nullptr && direct_on && p.K >= 128)
-        hipLaunchKernelGGL(gemm8p_kernel<true>, dim3((unsigned)g8_grid(tiles, cus)), dim3(512), lds, stream, p);
-    else
+    if (p.stats == nullptr && direct_on && p.K >= 128) {
+        // the ragged last row block to the companion kernel where the whole row blocks alone walk one round less
+        const int R = p.M % 256;
+        if (g8_ragged_on && R != 0 && p.tilesM >= 2 && g8_rounds((p.tilesM - 1) * p.tilesN, cus) < g8_rounds(tiles, cus)) {
+            G8Params full = p;
+            if (g8_launch_ragged(full, p.M - R, R, stream)) {
+                p.M -= R; p.tilesM -= 1;
+                p.group_m = (gm_env > 1 && wbytes > 3.0e6 && p.tilesN >= 6 && p.tilesM >= 2 * gm_env) ? gm_env : 0;
+            }
+        }
+        const int tiles1 = p.tilesM * p.tilesN;
+        hipLaunchKernelGGL(gemm8p_kernel<true>, dim3((unsigned)g8_grid(tiles1, cus)), dim3(512), lds, stream, p);
+    } else
         hipLaunchKernelGGL(gemm8p_kernel<false>, dim3((unsigned)tiles), dim3(512), lds, stream, p);
     return nkb_check_launch("gemm8p");
 }

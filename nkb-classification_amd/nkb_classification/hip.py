@@ -114,6 +114,7 @@ _SIGS = {
     "nkb_bucket_sum_bf16": (i32, [vp, i64, i32, vp, vp, i64, vp]),
     "nkb_segment_sumsq": (i32, [vp, vp, i32, vp, vp]),
     "nkb_gemm8p_config": (None, [i32, i32, i32]),
+    "nkb_gemm8p_ragged": (None, [i32]),
     "nkb_fp8_quantize": (i32, [i32, i32, vp, i64, vp, vp, vp]),
     "nkb_fp8_amax": (i32, [i32, vp, i64, vp, vp]),
     "nkb_fp8_scale_update": (i32, [vp, i32, vp]),
@@ -180,7 +181,7 @@ _PURE = frozenset({"nkb_kernel_launches", "nkb_linear_gelu_fused_ok", "nkb_versi
                    "nkb_bn_backward_workspace_floats", "nkb_wprep_block_elems", "nkb_wprep_job_blocks", "nkb_stem_weight_cols",
                    "nkb_bn_relu_maxpool_workspace_floats", "nkb_layernorm_workspace_floats", "nkb_loss_row_state_bytes",
                    "nkb_conv_wgrad_workspace_floats", "nkb_stem_wgrad_workspace_floats", "nkb_kernel_name",
-                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_convp_config", "nkb_rowres_reserve_cus", "nkb_rowres_reserved_cus",
+                   "nkb_prof_enable", "nkb_prof_collect", "nkb_prof_collect_raw", "nkb_gemm8p_config", "nkb_gemm8p_ragged", "nkb_convp_config", "nkb_rowres_reserve_cus", "nkb_rowres_reserved_cus",
                    "nkb_fp8_job_blocks", "nkb_wgrad_fp8_workspace_floats",
                    "nkb_fp8_quantize_colsum_workspace_floats",
                    "nkb_gram_bn_backward_workspace_floats", "nkb_bn_apply_gram_workspace_floats",
@@ -807,6 +808,11 @@ def segment_sumsq(x, offsets, nseg, out):
 
 def gemm8p_config(on: bool, min_tiles: int = 0, min_k: int = 0):
     load().nkb_gemm8p_config(int(on), min_tiles, min_k)
+
+
+def gemm8p_ragged(on: bool):
+    """The M % 256 ragged rows of a persistent GEMM launch on their own small kernel where that saves a round (tests / A-B timing)."""
+    load().nkb_gemm8p_ragged(int(on))
 
 
 # ---- fp8 (per-tensor scaled e4m3 / e5m2 operands, configs[4]) -----------------------------------------------------------

@@ -1419,6 +1419,85 @@ def test_gemm8p_matches_fp32_product(shape, epi, gemm8p_everywhere):
         assert torch.equal(st, outs[1][1])
 
 
+@pytest.mark.parametrize("epi", ["plain", "bias_add", "gelu2", "aux_mul", "mask6", "bias_relu"])
+@pytest.mark.parametrize("shape", [(256 * 64 + 128, 1024, 1024), (256 * 16 + 100, 4096, 1024), (256 * 21 + 40, 3072, 4096)],
+                         ids=lambda s: "M%d_N%d_K%d" % s)
+def test_gemm8p_ragged_rows_on_the_companion_kernel(shape, epi):
+    """M = whole row blocks + a ragged rest whose tiles would push the tile count over a multiple of 256 (unicom ViT-L/14 at batch 128:
+    516 = 2 x 256 + 4): the persistent kernel gets the whole blocks, the rest goes to gemm8p_ragged_kernel (K split over workgroups,
+    fp32 slabs, the column block's last arriver adds them in split order and applies the epilogue).  Against the fp32 product, bit-identical
+    between runs, and equal to the all-on-the-persistent-kernel schedule wherever the rows are not the ragged ones (those: within the
+    fp32 re-association of the k-range)."""
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the tile counts are chosen for 256 CUs")
+    M, N, K = shape
+    tiles, whole_tiles = ((M + 255) // 256) * (N // 256), (M // 256) * (N // 256)
+    assert (whole_tiles + 255) // 256 < (tiles + 255) // 256            # the whole row blocks alone walk one round less
+    torch.manual_seed(14)
+    d = hip.BF16
+    x = (torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV)
+    add = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    aux = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    u6 = (torch.randn(M, N, device=DEV) * 4).clamp(0, 6).to(torch.bfloat16)
+    geom = dict(N=M, H=1, W=1, Cin=K, ldx=K, P=1, Q=1, Cout=N, ldy=N)
+
+    def run():
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        y2 = None
+        if epi == "plain":
+            hip.conv_gemm(d, 0, x, w, y, **geom)
+        elif epi == "bias_relu":
+            hip.conv_gemm(d, 0, x, w, y, bias=bias, relu=True, **geom)
+        elif epi == "bias_add":
+            hip.conv_gemm(d, 0, x, w, y, bias=bias, add=add, ldadd=N, **geom)
+        elif epi == "aux_mul":
+            hip.linear_gelu(d, 4, x, w, None, aux, y, None, M, K, N)
+        elif epi == "mask6":
+            hip.linear_gelu(d, 3, x, w, None, u6, y, None, M, K, N)
+        else:
+            y2 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            hip.linear_gelu(d, 5, x, w, bias, None, y, y2, M, K, N)
+        torch.cuda.synchronize()
+        return y, y2
+
+    try:
+        hip.gemm8p_ragged(True)
+        a, a2 = run()
+        b, b2 = run()
+        hip.gemm8p_ragged(False)
+        whole, whole2 = run()
+    finally:
+        hip.gemm8p_ragged(True)
+    assert torch.equal(a, b) and (a2 is None or torch.equal(a2, b2))
+    assert not torch.isnan(a.float()).any() and (a2 is None or not torch.isnan(a2.float()).any())
+    M0 = M // 256 * 256
+    assert torch.equal(a[:M0], whole[:M0]) and (a2 is None or torch.equal(a2[:M0], whole2[:M0]))
+    pre = x.float() @ w.float().t()
+    ref2 = None
+    if epi == "bias_add":
+        ref = pre + bias + add.float()
+    elif epi == "bias_relu":
+        ref = torch.relu(pre + bias)
+    elif epi == "aux_mul":
+        ref = pre * aux.float()
+    elif epi == "mask6":
+        ref = torch.where((u6.float() > 0) & (u6.float() < 6), pre, torch.zeros_like(pre))
+    elif epi == "gelu2":
+        z = (pre + bias).double()
+        ref = torch.nn.functional.gelu(z).float()
+        ref2 = (0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)).float()
+    else:
+        ref = pre
+    torch.testing.assert_close(a.float(), ref, **tol(torch.bfloat16, K))
+    if ref2 is not None:
+        torch.testing.assert_close(a2.float(), ref2, **tol(torch.bfloat16, K))
+    # the ragged rows against the persistent kernel's own result for them: one bf16 unit at most
+    diff = (a[M0:].float() - whole[M0:].float()).abs()
+    assert (diff <= whole[M0:].float().abs() * 2 ** -7 + 1e-6).all()
+
+
 def test_gemm8p_envelope_falls_back_cleanly(gemm8p_everywhere):
     """Launches outside the kernel's envelope (Cout not a multiple of 256, K < 128, fp32 output) keep taking the 128 x 128
     kernel and still give the right answer."""
