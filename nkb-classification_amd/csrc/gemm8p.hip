@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     for (int e = 0; e < 8; ++e) v[e] = (af[e] > 0.f && af[e] < 6.f) ? v[e] : 0.f;
                 }
             }
-            if (relu == 3) {                           // GELU: u is the result, gelu'(pre) goes to the second output
+            if (!QOUT && relu == 3) {                  // GELU: u is the result, gelu'(pre) goes to the second output (bf16 kernels only)
                 float dv[8];
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
             const u32x4 hi = value(2 * pp + 1, j, bhi, ahi, xhi, mhi, dhi);
             if (acc_lo) { *acc_lo = lo; *acc_hi = hi; }
             pair_to_rows(lo, hi, out[0], out[1]);
-            if (relu == 3) {
+            if (!QOUT && relu == 3) {
                 u32x4 d_[2];
                 pair_to_rows(dlo, dhi, d_[0], d_[1]);
                 unsigned char* y2b = (unsigned char*)(p.y2 + ((size_t)em0 * p.ldy + en0));
@@ -882,6 +882,11 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const G8Params p) {
                     if (p.aux_mode == 0) epilogue(G8I<1>{}, G8I<0>{}, G8I<1>{}, G8I<0>{});
                     else epilogue(G8I<1>{}, G8I<0>{}, G8I<2>{}, G8I<0>{});
                 } else epilogue(G8I<1>{}, G8I<-1>{}, G8I<-1>{}, G8I<-1>{});
+                // The quantising kernels spill ~20 registers around their epilogues; hipcc's wait-count pass puts the wait for a spill
+                // RELOAD at the register's first use — for a loop constant that is the top of the k-loop, executed per k-tile
+                // (vmcnt(4) + vmcnt(0): the DMA stream drained every k-tile, +15 % on a K = 4 096 launch).  A wait the pass can SEE,
+                // once per tile behind the epilogue, tells it that nothing of the epilogue is pending when the loop is re-entered.
+                if constexpr (QOUT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
                 G8_STAMP(6);
                 if (p.align_epi && wr == 1) G8_BARRIER();
                 G8_STAMP(7);
